@@ -1,0 +1,535 @@
+# -*- coding: utf-8 -*-
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+
+Plain-PyTorch (CPU, fp32) restatement of the EMSANet forward path, i.e. of what
+`/root/reference/emsanet/model.py:27-233` and `/root/reference/emsanet/decoder.py:32-201`
+compose out of `nicr_mt_scene_analysis.model.*` (v0.3.1, README.md:665).
+
+* Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+  this file.  The product (`emsanet_amd/`) must never import it.
+* "PARITY UNPINNED": the arithmetic of the reference lives in an un-vendored git submodule
+  (`.gitmodules:1-3`, directory empty) and the reference's own tests assert shapes/types only
+  (`emsanet/tests/test_interface_model.py:96-101`, `test_interface_decoders.py:119-131`), so
+  there is no golden vector to pin this restatement against.  It follows SURVEY.md App. A;
+  every micro-detail that could not be read off `/root/reference` is a named constant in
+  `class Spec` below ([U] = unverified against upstream).
+* What IS pinned by the reference and honoured here:
+    - constructor / forward contract              emsanet/model.py:27-31,192-233
+    - decoder input layout + channel counts       emsanet/tests/test_interface_decoders.py:42-48,73-88
+    - input shapes                                emsanet/tests/test_interface_model.py:53-59
+    - default hyper-parameters                    emsanet/args.py (see emsanet_amd/args.py)
+    - state-dict key fragments                    emsanet/weights.py:22-26,39-56,82-119
+"""
+from collections import ChainMap, OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# [U] constants.  Flip here when upstream source becomes available.
+# --------------------------------------------------------------------------------------
+class Spec:
+    BLOCK_BN_EPS = 1e-3          # [U] ESANet's NonBottleneck1D hard-codes eps=1e-3
+    DEFAULT_BN_EPS = 1e-5        # torch default everywhere else
+    BN_MOMENTUM = 0.1            # torch default
+    SE_REDUCTION = 16            # [U]
+    PPM_BINS = (1, 5)            # [U] consistent with n_channels_reduction = 512 // 2
+    STEM_BIAS = False            # [U] torchvision ResNet stem
+    DW_UPSAMPLE_BIAS = True      # [U] ESANet 'learned-3x3-zeropad'
+    SIDE_OUTPUT_KERNEL = 1       # [U] 1x1 conv side heads
+    SKIP_FUSION_1X1 = True       # [U] 1x1 conv + BN + act on the rgb skip when channels differ
+    ORIENTATION_L2_NORMALIZE = False   # [U] raw 2-ch biternion
+    RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
+                     'resnet101': (3, 4, 23, 3)}   # NBt1D has expansion 1 -> 64/128/256/512
+
+
+# --------------------------------------------------------------------------------------
+# Counter-based Dropout2d mask (SURVEY.md §7 hard part (vii)): the build defines it, oracle
+# and HIP engine share the definition bit for bit.
+# --------------------------------------------------------------------------------------
+def _lowbias32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout2d_scale_mask(seed, layer_id, n, c, p):
+    """(n, c) float32 array: 0 where the channel is dropped else 1/(1-p)."""
+    nn_, cc = np.meshgrid(np.arange(n, dtype=np.uint64), np.arange(c, dtype=np.uint64),
+                          indexing='ij')
+    key = _lowbias32((np.uint64(seed) + np.uint64(layer_id) * np.uint64(0x9E3779B1)) & 0xFFFFFFFF)
+    h = _lowbias32((key + nn_ * np.uint64(0x85EBCA77) + cc * np.uint64(0xC2B2AE3D)) & 0xFFFFFFFF)
+    u = (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    keep = u >= np.float32(p)
+    return np.where(keep, np.float32(1.0 / (1.0 - p)), np.float32(0.0)).astype(np.float32)
+
+
+class HashDropout2d(nn.Module):
+    """Dropout2d whose channel mask is `dropout2d_scale_mask` (not torch's RNG)."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = float(p)
+        self.layer_id = -1      # assigned by the model
+        self.seed_fn = lambda: 0
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        m = dropout2d_scale_mask(self.seed_fn(), self.layer_id, x.shape[0], x.shape[1], self.p)
+        return x * torch.from_numpy(m).to(x.device)[:, :, None, None]
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+class ConvNormAct(nn.Sequential):
+    # [U] child names 'conv' / 'norm' (weights.py:39-47 shows '...shared_conv...norm...')
+    def __init__(self, cin, cout, kernel_size, stride=1, act=True, eps=Spec.DEFAULT_BN_EPS):
+        super().__init__()
+        self.add_module('conv', nn.Conv2d(cin, cout, kernel_size, stride=stride,
+                                          padding=kernel_size // 2, bias=False))
+        self.add_module('norm', nn.BatchNorm2d(cout, eps=eps, momentum=Spec.BN_MOMENTUM))
+        if act:
+            self.add_module('act', nn.ReLU())
+
+
+class NonBottleneck1D(nn.Module):
+    """conv3x1+b -> ReLU -> conv1x3+b -> BN -> ReLU -> conv3x1+b -> ReLU -> conv1x3+b -> BN
+    -> Dropout2d -> + identity -> ReLU   (figure doc/EMSANet-model.png)."""
+
+    def __init__(self, cin, cout, stride=1, dropout_p=0.0):
+        super().__init__()
+        self.conv3x1_1 = nn.Conv2d(cin, cout, (3, 1), stride=(stride, 1), padding=(1, 0), bias=True)
+        self.conv1x3_1 = nn.Conv2d(cout, cout, (1, 3), stride=(1, stride), padding=(0, 1), bias=True)
+        self.bn1 = nn.BatchNorm2d(cout, eps=Spec.BLOCK_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        self.conv3x1_2 = nn.Conv2d(cout, cout, (3, 1), padding=(1, 0), bias=True)
+        self.conv1x3_2 = nn.Conv2d(cout, cout, (1, 3), padding=(0, 1), bias=True)
+        self.bn2 = nn.BatchNorm2d(cout, eps=Spec.BLOCK_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        self.dropout = HashDropout2d(dropout_p)
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(cout, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        out = F.relu(self.conv3x1_1(x))
+        out = F.relu(self.bn1(self.conv1x3_1(out)))
+        out = F.relu(self.conv3x1_2(out))
+        out = self.bn2(self.conv1x3_2(out))
+        out = self.dropout(out)
+        identity = x if self.downsample is None else self.downsample(x)
+        return F.relu(out + identity)
+
+
+class ResNetNBt1D(nn.Module):
+    def __init__(self, name, n_input_channels, dropout_p):
+        super().__init__()
+        layers = Spec.RESNET_LAYERS[name]
+        self.conv1 = nn.Conv2d(n_input_channels, 64, 7, stride=2, padding=3, bias=Spec.STEM_BIAS)
+        self.bn1 = nn.BatchNorm2d(64, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        cin = 64
+        for i, (c, n) in enumerate(zip((64, 128, 256, 512), layers)):
+            blocks = []
+            for j in range(n):
+                blocks.append(NonBottleneck1D(cin, c, stride=2 if (i > 0 and j == 0) else 1,
+                                              dropout_p=dropout_p))
+                cin = c
+            setattr(self, f'layer{i + 1}', nn.Sequential(*blocks))
+        self.stage_channels = (64, 64, 128, 256, 512)
+        self.stage_downsamplings = (2, 4, 8, 16, 32)
+
+    def forward_stage(self, i, x):
+        if i == 0:
+            return F.relu(self.bn1(self.conv1(x)))
+        if i == 1:
+            x = F.max_pool2d(x, 3, stride=2, padding=1)
+        return getattr(self, f'layer{i}')(x)
+
+
+class SqueezeAndExcitation(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Conv2d(c, c // Spec.SE_REDUCTION, 1), nn.ReLU(),
+                                nn.Conv2d(c // Spec.SE_REDUCTION, c, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.fc(F.adaptive_avg_pool2d(x, 1))
+
+
+class SEAddUniRGB(nn.Module):
+    """'se-add-uni-rgb' (args.py:143-147): rgb <- SE(rgb) + SE(depth); depth unchanged."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.se_rgb = SqueezeAndExcitation(c)
+        self.se_depth = SqueezeAndExcitation(c)
+
+    def forward(self, rgb, depth):
+        return self.se_rgb(rgb) + self.se_depth(depth), depth
+
+
+class FusedEncoder(nn.Module):
+    def __init__(self, backbone_rgb, backbone_depth, fusion, skip_downsamplings):
+        super().__init__()
+        self.backbone_rgb = backbone_rgb
+        self.backbone_depth = backbone_depth
+        bb = backbone_rgb if backbone_rgb is not None else backbone_depth
+        self.two = backbone_rgb is not None and backbone_depth is not None
+        if self.two:
+            assert fusion == 'se-add-uni-rgb', fusion
+            self.fusion_modules = nn.ModuleList([SEAddUniRGB(c) for c in bb.stage_channels])
+        self.skip_downsamplings = tuple(skip_downsamplings)
+        self.downsampling = 32
+        self.n_channels_out = 512
+        ch = dict(zip(bb.stage_downsamplings, bb.stage_channels))
+        self.skips_n_channels = tuple(ch[d] for d in self.skip_downsamplings)
+
+    def forward(self, inputs):
+        rgb, depth = inputs.get('rgb'), inputs.get('depth')
+        skips = {}
+        bb = self.backbone_rgb if self.backbone_rgb is not None else self.backbone_depth
+        for i, ds in enumerate(bb.stage_downsamplings):
+            if rgb is not None:
+                rgb = self.backbone_rgb.forward_stage(i, rgb)
+            if depth is not None:
+                depth = self.backbone_depth.forward_stage(i, depth)
+            if self.two:
+                rgb, depth = self.fusion_modules[i](rgb, depth)
+            if ds in self.skip_downsamplings:
+                skips[str(ds)] = {k: v for k, v in (('rgb', rgb), ('depth', depth))
+                                  if v is not None}
+        outs = {k: v for k, v in (('rgb', rgb), ('depth', depth)) if v is not None}
+        return outs, skips
+
+
+class PyramidPoolingModule(nn.Module):
+    """'ppm' (args.py:243-256): bins (1,5), 1x1 conv+BN+ReLU per bin, bilinear up, concat, 1x1."""
+
+    def __init__(self, cin, cout, input_size):
+        super().__init__()
+        bins = Spec.PPM_BINS
+        self.n_channels_reduction = cin // len(bins)
+        self.features = nn.ModuleList([
+            nn.Sequential(nn.AdaptiveAvgPool2d(b), ConvNormAct(cin, self.n_channels_reduction, 1))
+            for b in bins])
+        self.final_conv = ConvNormAct(cin + self.n_channels_reduction * len(bins), cout, 1)
+
+    def forward(self, x):
+        h, w = x.shape[2:]
+        outs, feats = [x], []
+        for f in self.features:
+            y = f(x)
+            feats.append(y)
+            outs.append(F.interpolate(y, (h, w), mode='bilinear', align_corners=False))
+        return self.final_conv(torch.cat(outs, 1)), tuple(feats)
+
+
+class LearnedUpsampling(nn.Module):
+    """'learned-3x3-zeropad': nearest x2 then depth-wise 3x3 (zero pad) initialised to the
+    bilinear kernel [[1,2,1],[2,4,2],[1,2,1]]/16 (args.py:290-298)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1, groups=c, bias=Spec.DW_UPSAMPLE_BIAS)
+        w = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.
+        with torch.no_grad():
+            self.conv.weight.copy_(w.expand(c, 1, 3, 3))
+            if self.conv.bias is not None:
+                self.conv.bias.zero_()
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2, mode='nearest'))
+
+
+class DecoderModule(nn.Module):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, n_side):
+        super().__init__()
+        self.conv3x3 = ConvNormAct(cin, c, 3)
+        self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
+                                      for _ in range(n_blocks)])
+        self.side_output = nn.Conv2d(c, n_side, Spec.SIDE_OUTPUT_KERNEL)
+        self.upsampling = LearnedUpsampling(c)
+        if Spec.SKIP_FUSION_1X1 and skip_c != c:
+            self.skip_fusion = ConvNormAct(skip_c, c, 1)
+        else:
+            self.skip_fusion = None
+
+    def forward(self, x, skip):
+        x = self.blocks(self.conv3x3(x))
+        side = self.side_output(x) if self.training else None
+        x = self.upsampling(x)
+        if self.skip_fusion is not None:
+            skip = self.skip_fusion(skip)
+        return x + skip, side
+
+
+class DecoderBody(nn.Module):
+    def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
+                 fusion_downsamplings, n_side):
+        super().__init__()
+        mods, cin = [], n_channels_in
+        for c, sc in zip(n_channels, fusion_n_channels):
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, n_side))
+            cin = c
+        self.decoder_modules = nn.ModuleList(mods)
+        self.fusion_downsamplings = tuple(fusion_downsamplings)
+
+    def forward(self, x, skips):
+        sides = []
+        for m, ds in zip(self.decoder_modules, self.fusion_downsamplings):
+            x, s = m(x, skips[str(ds)]['rgb'])
+            sides.append(s)
+        return x, tuple(sides)
+
+
+class SemanticHead(nn.Module):
+    def __init__(self, c, n_classes):
+        super().__init__()
+        self.conv = nn.Conv2d(c, n_classes, 3, padding=1)
+        self.upsampling = nn.Sequential(LearnedUpsampling(n_classes), LearnedUpsampling(n_classes))
+
+    def forward(self, x):
+        return self.upsampling(self.conv(x))
+
+
+class SemanticDecoder(DecoderBody):
+    def __init__(self, n_classes, **kw):
+        super().__init__(n_side=n_classes, **kw)
+        self.head = SemanticHead(kw['n_channels'][-1], n_classes)
+        self.side_output_downscales = (32, 16, 8)     # module order (taken before each x2)
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        x, sides = DecoderBody.forward(self, x[0], skips)
+        out = self.head(x)
+        sides = sides if self.training else ()
+        if not do_postprocessing:
+            return out, sides
+        r = {'semantic_output': out, 'semantic_side_outputs': sides}
+        if not self.training:
+            score, idx = F.softmax(out, dim=1).max(dim=1)
+            r['semantic_segmentation_score'], r['semantic_segmentation_idx'] = score, idx
+        return r
+
+
+class InstanceHead(nn.Module):
+    """shared_conv 3x3 C->32*T (+norm+act), task_convs.{0,1,2} 3x3 32->1/2/2, shared DW
+    upsampling x2 x2 over the concatenated 5 channels (weights.py:39-56)."""
+
+    def __init__(self, c, with_orientation, n_per_task=32):
+        super().__init__()
+        outs = (1, 2, 2) if with_orientation else (1, 2)
+        self.n_per_task = n_per_task
+        self.shared_conv = ConvNormAct(c, n_per_task * len(outs), 3)
+        self.task_convs = nn.ModuleList([nn.Conv2d(n_per_task, o, 3, padding=1) for o in outs])
+        self.upsampling = nn.Sequential(LearnedUpsampling(sum(outs)), LearnedUpsampling(sum(outs)))
+
+    def forward(self, x):
+        x = self.shared_conv(x)
+        parts = torch.split(x, self.n_per_task, dim=1)
+        x = torch.cat([conv(p) for conv, p in zip(self.task_convs, parts)], dim=1)
+        return self.upsampling(x)
+
+
+class InstanceDecoder(DecoderBody):
+    def __init__(self, with_orientation, sigmoid_for_center, tanh_for_offset, **kw):
+        self.with_orientation = with_orientation
+        super().__init__(n_side=5 if with_orientation else 3, **kw)
+        self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
+        self.sigmoid_for_center = sigmoid_for_center
+        self.tanh_for_offset = tanh_for_offset
+        self.side_output_downscales = (32, 16, 8)
+
+    def _split(self, y):
+        center, offset = y[:, 0:1], y[:, 1:3]
+        if self.sigmoid_for_center:
+            center = torch.sigmoid(center)
+        if self.tanh_for_offset:
+            offset = torch.tanh(offset)
+        if not self.with_orientation:
+            return center, offset
+        orientation = y[:, 3:5]
+        if Spec.ORIENTATION_L2_NORMALIZE:
+            orientation = F.normalize(orientation, dim=1)
+        return center, offset, orientation
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        x, sides = DecoderBody.forward(self, x[0], skips)
+        out = self._split(self.head(x))
+        sides = tuple(self._split(s) for s in sides) if self.training else ()
+        if not do_postprocessing:
+            return out, sides
+        r = {'instance_output': out, 'instance_side_outputs': sides,
+             'instance_centers': out[0], 'instance_offsets': out[1]}
+        if self.with_orientation:
+            r['instance_orientation'] = out[2]
+        return r
+
+
+class SceneClassificationDecoder(nn.Module):
+    def __init__(self, cin, n_classes):
+        super().__init__()
+        self.head = nn.Linear(cin, n_classes)
+        self.side_output_downscales = ()
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        feat = x[1][0]                      # GAP branch of the context module (B,256,1,1)
+        out = self.head(torch.flatten(feat, 1))
+        if not do_postprocessing:
+            return out, ()
+        r = {'scene_output': out}
+        if not self.training:
+            score, idx = F.softmax(out, dim=1).max(dim=1)
+            r['scene_class_score'], r['scene_class_idx'] = score, idx
+        return r
+
+
+# --------------------------------------------------------------------------------------
+# the model (mirrors emsanet/model.py:27-233)
+# --------------------------------------------------------------------------------------
+class EMSANetOracle(nn.Module):
+    def __init__(self, args, dataset_config):
+        super().__init__()
+        self.args = args
+        self.dataset_config = dataset_config
+        n_sem = len(dataset_config.semantic_label_list_without_void)
+        n_scene = len(dataset_config.scene_label_list_without_void)
+        mods = tuple(args.input_modalities)
+        assert 'rgbd' not in mods, "rgbd single-encoder variant not restated"
+
+        def bb(name, block, cin):
+            assert block == 'nonbottleneck1d', block
+            return ResNetNBt1D(name, cin, args.dropout_p)
+
+        b_rgb = bb(args.rgb_encoder_backbone, args.rgb_encoder_backbone_resnet_block, 3) \
+            if 'rgb' in mods else None
+        b_d = bb(args.depth_encoder_backbone, args.depth_encoder_backbone_resnet_block, 1) \
+            if 'depth' in mods else None
+        self.encoder = FusedEncoder(b_rgb, b_d, args.encoder_fusion,
+                                    args.encoder_decoder_skip_downsamplings)
+        assert args.context_module == 'ppm'
+        self.context_module = PyramidPoolingModule(
+            512, 512, (args.input_height // 32, args.input_width // 32))
+
+        fus_c = self.encoder.skips_n_channels[::-1]
+        fus_d = tuple(args.encoder_decoder_skip_downsamplings)[::-1]
+        dec = OrderedDict()
+        if 'semantic' in args.tasks:
+            dec['semantic_decoder'] = SemanticDecoder(
+                n_classes=n_sem, n_channels_in=512,
+                n_channels=tuple(args.semantic_decoder_n_channels),
+                n_blocks=args.semantic_decoder_n_blocks,
+                dropout_p=args.semantic_decoder_block_dropout_p,
+                fusion_n_channels=fus_c, fusion_downsamplings=fus_d)
+        if 'instance' in args.tasks:
+            if args.instance_offset_encoding not in ('tanh', 'relative', 'deeplab'):
+                raise NotImplementedError
+            dec['instance_decoder'] = InstanceDecoder(
+                with_orientation='orientation' in args.tasks,
+                sigmoid_for_center=args.instance_center_encoding == 'sigmoid',
+                tanh_for_offset=args.instance_offset_encoding == 'tanh',
+                n_channels_in=512,
+                n_channels=tuple(args.instance_decoder_n_channels),
+                n_blocks=args.instance_decoder_n_blocks,
+                dropout_p=args.instance_decoder_block_dropout_p,
+                fusion_n_channels=fus_c, fusion_downsamplings=fus_d)
+        if 'scene' in args.tasks:
+            dec['scene_decoder'] = SceneClassificationDecoder(
+                self.context_module.n_channels_reduction, n_scene)
+        self.decoders = nn.ModuleDict(dec)
+
+        # reference init (model.py:162-190): He for encoder fusion, zero last BN gamma in decoders
+        if 'encoder-fusion' in args.he_init and self.encoder.two:
+            for m in self.encoder.fusion_modules.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                    if m.bias is not None:
+                        nn.init.zeros_(m.bias)
+        if not args.no_zero_init_decoder_residuals:
+            for m in self.decoders.modules():
+                if isinstance(m, NonBottleneck1D):
+                    nn.init.zeros_(m.bn2.weight)
+
+        # dropout bookkeeping (shared definition with the HIP engine)
+        self.dropout_seed = 0
+        self.dropout_step = 0
+        lid = 0
+        for m in self.modules():
+            if isinstance(m, HashDropout2d):
+                m.layer_id = lid
+                m.seed_fn = self._dropout_seed
+                lid += 1
+
+    def _dropout_seed(self):
+        return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF
+
+    def forward(self, batch, do_postprocessing=False):
+        enc_inputs = {k: batch[k] for k in ('rgb', 'depth') if k in self.args.input_modalities}
+        enc_outputs, skips = self.encoder(enc_inputs)
+        con_in = enc_outputs['rgb'] if len(enc_inputs) == 2 else list(enc_outputs.values())[0]
+        con_out, con_ctx = self.context_module(con_in)
+        outputs = [d((con_out, con_ctx), skips, batch, do_postprocessing=do_postprocessing)
+                   for d in self.decoders.values()]
+        if self.training:
+            self.dropout_step += 1
+        if do_postprocessing:
+            outputs = dict(ChainMap(*outputs))
+        return outputs
+
+
+# --------------------------------------------------------------------------------------
+# deterministic parameters (so container and GPU box regenerate identical weights)
+# --------------------------------------------------------------------------------------
+def deterministic_state_dict(model, seed=0):
+    """Every parameter/buffer from numpy default_rng(seed) in state_dict order.  Non-trivial
+    BN statistics and gammas (also the zero-initialised decoder gammas) so that parity tests
+    exercise every term."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for k, v in model.state_dict().items():
+        shp = tuple(v.shape)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith('running_mean'):
+            sd[k] = torch.from_numpy(rng.normal(0, 0.1, shp).astype(np.float32))
+        elif k.endswith('running_var'):
+            sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, shp).astype(np.float32))
+        elif v.dim() == 1 and (('bn' in k or 'norm' in k or k.split('.')[-2] == '1')
+                               and k.endswith('weight')):
+            sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, shp).astype(np.float32))
+        elif v.dim() == 1:
+            sd[k] = torch.from_numpy(rng.normal(0, 0.05, shp).astype(np.float32))
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            std = np.sqrt(2.0 / fan_in)
+            if 'upsampling' in k:            # keep DW kernels near the bilinear init
+                base = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.float32) / 16
+                sd[k] = torch.from_numpy(
+                    (base + rng.normal(0, 0.02, shp)).astype(np.float32))
+            else:
+                sd[k] = torch.from_numpy(rng.normal(0, std, shp).astype(np.float32))
+    return sd
+
+
+def synthetic_batch(batch_size, height, width, seed=1234, modalities=('rgb', 'depth')):
+    """The reference's own synthetic generator (inference_time_whole_model.py:519-545)."""
+    rng = np.random.default_rng(seed)
+    batch = {}
+    rgb = rng.integers(0, 255, (batch_size, height, width, 3), dtype=np.uint8)
+    depth = rng.integers(0, 40000, (batch_size, height, width), dtype=np.uint16)
+    if 'rgb' in modalities:
+        batch['rgb'] = torch.from_numpy(
+            (rgb.astype(np.float32) / 255).transpose(0, 3, 1, 2).copy())
+    if 'depth' in modalities:
+        batch['depth'] = torch.from_numpy((depth.astype(np.float32) / 20000)[:, None].copy())
+    return batch
