@@ -1,0 +1,112 @@
+# -*- coding: utf-8 -*-
+"""
+ctypes binding of libemsanet_hip.so -- exactly the symbols `include/emsanet_hip.h` declares.
+
+The library is built in-tree by `__graft_entry__.build()` (or `make -C emsanet_amd/csrc`) into
+`emsanet_amd/lib/libemsanet_hip.so`.  There is NO fallback: if the library is missing or a call
+is rejected, this module raises -- the product path never computes on the CPU or through torch
+operators instead.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int8, c_int32, c_int64, c_uint32, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libemsanet_hip.so')
+
+
+class EmsaConvGeom(Structure):
+    _fields_ = [
+        ('n_img', c_int32),
+        ('in_h', c_int32), ('in_w', c_int32),
+        ('out_h', c_int32), ('out_w', c_int32),
+        ('k_ch', c_int32), ('n_ch', c_int32),
+        ('kh', c_int32), ('kw', c_int32),
+        ('mul_h', c_int32), ('off_h', c_int32), ('step_h', c_int32), ('div_h', c_int32),
+        ('mul_w', c_int32), ('off_w', c_int32), ('step_w', c_int32), ('div_w', c_int32),
+        ('in_img_stride', c_int64), ('in_row_stride', c_int64),
+        ('in_px_stride', c_int32), ('ld_out', c_int32),
+    ]
+
+
+_P = c_void_p          # device pointers travel as integers (tensor.data_ptr())
+_GP = POINTER(EmsaConvGeom)
+
+# name -> (restype, argtypes); must stay in sync with include/emsanet_hip.h (tests check it)
+SIGNATURES = {
+    'emsa_arch': (c_char_p, []),
+    'emsa_version': (c_int, []),
+    'emsa_conv_igemm': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P]),
+    'emsa_conv_stats_rows': (c_int, [_GP]),
+    'emsa_conv_wgrad': (c_int, [_GP, _P, _P, _P, _P, _P]),
+    'emsa_pack_weight_fwd': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),
+    'emsa_pack_weight_dgrad': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),
+    'emsa_unpack_wgrad': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),
+    'emsa_stem_pack_input': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_stem_pack_weight': (c_int, [_P, _P, c_int32, c_int32, _P]),
+    'emsa_stem_unpack_wgrad': (c_int, [_P, _P, c_int32, c_int32, _P]),
+    'emsa_bn_finalize': (c_int, [_P, c_int32, c_int32, c_int64, _P, _P, c_float, c_float,
+                                 _P, _P, _P, _P, _P, _P, _P]),
+    'emsa_bn_fold': (c_int, [_P, _P, _P, _P, c_float, c_int32, _P, _P, _P, _P]),
+    'emsa_bn_act_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
+    'emsa_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32,
+                                   _P, _P]),
+    'emsa_bn_bwd_rows': (c_int, [c_int64]),
+    'emsa_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64,
+                                  c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    'emsa_dropout2d_mask': (c_int, [_P, c_int32, c_int32, c_float, c_uint32, c_uint32, _P]),
+    'emsa_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_channel_mean': (c_int, [_P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_se_mlp_fwd': (c_int, [_P] * 7 + [c_int32] * 3 + [_P]),
+    'emsa_se_mlp_bwd': (c_int, [_P] * 11 + [c_int32] * 3 + [_P]),
+    'emsa_se_scale_add_fwd': (c_int, [_P] * 5 + [c_int32, c_int64, c_int32, _P]),
+    'emsa_se_scale_bwd_reduce': (c_int, [_P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_se_scale_bwd_apply': (c_int, [_P] * 5 + [c_int32, c_int64, c_int32, _P]),
+    'emsa_up2x_dw3x3_fwd': (c_int, [_P] * 5 + [c_int32] * 4 + [_P]),
+    'emsa_up2x_dw3x3_bwd_data': (c_int, [_P] * 3 + [c_int32] * 4 + [_P]),
+    'emsa_up2x_dw3x3_bwd_weight': (c_int, [_P] * 4 + [c_int32] * 4 + [_P]),
+    'emsa_adaptive_avgpool_fwd': (c_int, [_P, _P] + [c_int32] * 5 + [_P]),
+    'emsa_adaptive_avgpool_bwd': (c_int, [_P, _P] + [c_int32] * 6 + [_P]),
+    'emsa_bilinear_fwd': (c_int, [_P, _P] + [c_int32] * 7 + [_P]),
+    'emsa_bilinear_bwd': (c_int, [_P, _P] + [c_int32] * 7 + [_P]),
+    'emsa_head_act_fwd': (c_int, [_P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
+    'emsa_head_act_bwd': (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
+    'emsa_copy_channels': (c_int, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_axpy': (c_int, [_P, _P, c_int64, c_float, _P]),
+}
+
+_ERR = {-1: 'EMSA_E_SHAPE (unsupported geometry)', -2: 'EMSA_E_ARG (bad argument)',
+        -3: 'EMSA_E_LAUNCH (HIP launch failed)'}
+
+
+class EmsaError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise EmsaError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C emsanet_amd/csrc). "
+            "There is no CPU / torch fallback for the EMSANet engine.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def check(status, name):
+    if status != 0:
+        raise EmsaError(f"{name} failed: {_ERR.get(status, status)}")

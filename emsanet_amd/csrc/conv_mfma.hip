@@ -1,0 +1,584 @@
+// Implicit-GEMM convolution on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   emsa_conv_igemm : out[m][n] = epi( sum_{tap,c} in[gather(m,tap)][c] * w[tap][n][c] )
+//                     forward conv and data gradient (same kernel, different gather geometry)
+//   emsa_conv_wgrad : dw[tap][n][c] += sum_m dout[m][n] * in[gather(m,tap)][c]
+//
+// Stands in for every nn.Conv2d / nn.Linear the reference model composes
+// (/root/reference/emsanet/model.py:47-119, /root/reference/emsanet/decoder.py:61-199), which
+// the reference runs as cuDNN eager kernels (/root/reference/main.py:23-24).
+//
+// Design (MI355X_MICROARCH.md / cdna_hip_programming.md):
+//   * NHWC activations: one GEMM row = one pixel = C contiguous floats -> every global access is
+//     a full 128-B line (8 lanes x float4), no im2col buffer in HBM.
+//   * K order inside a BK=32 chunk is permuted so that both MFMA operands are fetched from LDS
+//     with ds_read_b128: lane (i = l&31, h = l>>5) reads 4 consecutive k at 8t+4h and feeds
+//     them to 4 consecutive MFMAs; A and B use the same permutation so the product is exact.
+//   * LDS rows padded to 36 floats: the 16-lane groups of ds_read_b128 then cover all 64 banks
+//     (9*i mod 16 is a bijection) -> conflict-free reads; writes are 8 contiguous lanes per row.
+//   * register-staged double buffering, one barrier per K step; 2 workgroups per CU so one
+//     group's MFMA phase overlaps the other's global/LDS traffic.
+//   * epilogue fuses bias, BatchNorm batch-statistics partials (deterministic, no atomics),
+//     folded eval BatchNorm, residual add, ReLU and the ReLU-backward mask.
+#include "common.h"
+
+namespace {
+
+constexpr int kBK = 32;   // K chunk (channels) per step
+constexpr int kLD = 36;   // padded LDS row (floats)
+
+struct ConvArgs {
+  EmsaConvGeom g;
+  const float* in;
+  const float* w;
+  float* out;
+  const float* bias;
+  float* stats;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  const float* mask_src;
+  int ld_res, ld_mask, act;
+  int M, tiles_m, tiles_n, kchunks;
+};
+
+// gather helper: element offset of (row base, tap) or -1
+struct Gather {
+  int mul_h, off_h, step_h, div_h, mul_w, off_w, step_w, div_w, in_h, in_w;
+  int row_stride, px_stride;
+};
+
+__device__ __forceinline__ int gather_offset(const Gather& q, int img_off, int bh, int bw,
+                                             int kh, int kw) {
+  int hn = bh + kh * q.step_h, wn = bw + kw * q.step_w;
+  bool ok = true;
+  if (q.div_h > 1) {
+    ok = ok && (hn % q.div_h == 0);
+    hn /= q.div_h;
+  }
+  if (q.div_w > 1) {
+    ok = ok && (wn % q.div_w == 0);
+    wn /= q.div_w;
+  }
+  ok = ok && hn >= 0 && hn < q.in_h && wn >= 0 && wn < q.in_w;
+  return ok ? img_off + hn * q.row_stride + wn * q.px_stride : -1;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int AR = BM / 32, BR = BN / 32;            // float4 per thread per tile
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const As = smem;                  // [2][BM][kLD]
+  float* const Bs = smem + 2 * BM * kLD;   // [2][BN][kLD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const EmsaConvGeom& g = p.g;
+  Gather q;
+  q.mul_h = g.mul_h; q.off_h = g.off_h; q.step_h = g.step_h; q.div_h = g.div_h;
+  q.mul_w = g.mul_w; q.off_w = g.off_w; q.step_w = g.step_w; q.div_w = g.div_w;
+  q.in_h = g.in_h; q.in_w = g.in_w;
+  q.row_stride = (int)g.in_row_stride; q.px_stride = g.in_px_stride;
+
+  // ---- loader state -------------------------------------------------------------------
+  const int rl = tid >> 3, c4 = (tid & 7) * 4;
+  int a_bh[AR], a_bw[AR], a_img[AR], a_off[AR];
+  const int ohw = g.out_h * g.out_w;
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int m = m0 + rl + 32 * j;
+    if (m < p.M) {
+      const int img = m / ohw, rem = m - img * ohw;
+      const int oh = rem / g.out_w, ow = rem - oh * g.out_w;
+      a_bh[j] = oh * q.mul_h + q.off_h;
+      a_bw[j] = ow * q.mul_w + q.off_w;
+      a_img[j] = img * (int)g.in_img_stride;
+    } else {
+      a_bh[j] = -(1 << 29);
+      a_bw[j] = 0;
+      a_img[j] = 0;
+    }
+  }
+  const int taps = g.kh * g.kw;
+  const int steps = taps * p.kchunks;
+  int tap_n = 0, kc_n = 0;
+  float4 ra[AR], rb[BR];
+
+  auto load_regs = [&]() {
+    if (kc_n == 0) {
+      const int kh = tap_n / g.kw, kw = tap_n - kh * g.kw;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) a_off[j] = gather_offset(q, a_img[j], a_bh[j], a_bw[j], kh, kw);
+    }
+    const int k = kc_n * kBK + c4;
+    const bool kok = k < g.k_ch;
+#pragma unroll
+    for (int j = 0; j < AR; ++j)
+      ra[j] = (kok && a_off[j] >= 0) ? emsa_ld4(p.in + a_off[j] + k) : emsa_zero4();
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int n = n0 + rl + 32 * j;
+      rb[j] = (kok && n < g.n_ch)
+                  ? emsa_ld4(p.w + ((size_t)tap_n * g.n_ch + n) * g.k_ch + k)
+                  : emsa_zero4();
+    }
+    if (++kc_n == p.kchunks) {
+      kc_n = 0;
+      ++tap_n;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* a = As + buf * BM * kLD;
+    float* b = Bs + buf * BN * kLD;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) emsa_st4(a + (rl + 32 * j) * kLD + c4, ra[j]);
+#pragma unroll
+    for (int j = 0; j < BR; ++j) emsa_st4(b + (rl + 32 * j) * kLD + c4, rb[j]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_regs();
+  store_lds(0);
+  __syncthreads();
+
+  int cur = 0;
+  for (int s = 0; s < steps; ++s) {
+    const bool has_next = s + 1 < steps;
+    if (has_next) load_regs();
+
+    const float* a = As + cur * BM * kLD + (wm * TM * 32 + l31) * kLD + lh * 4;
+    const float* b = Bs + cur * BN * kLD + (wn * TN * 32 + l31) * kLD + lh * 4;
+#pragma unroll
+    for (int t = 0; t < kBK / 8; ++t) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = emsa_ld4(a + i * 32 * kLD + t * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = emsa_ld4(b + j * 32 * kLD + t * 8);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = kk == 0 ? fa[i].x : kk == 1 ? fa[i].y : kk == 2 ? fa[i].z : fa[i].w;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float bv = kk == 0 ? fb[j].x : kk == 1 ? fb[j].y : kk == 2 ? fb[j].z : fb[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (has_next) store_lds(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  const bool want_stats = p.stats != nullptr;
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + l31;
+    const bool nok = n < g.n_ch;
+    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + row;
+        if (m < p.M && nok) {
+          float v = acc[i][j][r] + bv;
+          s1[j] += v;
+          s2[j] += v * v;
+          v = v * sc + sh;
+          if (p.residual) v += p.residual[(size_t)m * p.ld_res + n];
+          if (p.mask_src) v = p.mask_src[(size_t)m * p.ld_mask + n] > 0.f ? v : 0.f;
+          if (p.act == EMSA_ACT_RELU) v = fmaxf(v, 0.f);
+          p.out[(size_t)m * g.ld_out + n] = v;
+        }
+      }
+    }
+  }
+
+  if (want_stats) {
+    // combine the two half-waves (rows r and r+4), then the WM waves through LDS
+    float* red = smem;   // [2][WM][BN]; all LDS reads of the main loop are behind a barrier
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+      if (lh == 0) {
+        const int col = (wn * TN + j) * 32 + l31;
+        red[(0 * WM + wm) * BN + col] = s1[j];
+        red[(1 * WM + wm) * BN + col] = s2[j];
+      }
+    }
+    __syncthreads();
+    for (int col = tid; col < BN; col += 256) {
+      const int n = n0 + col;
+      if (n < g.n_ch) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) {
+          a1 += red[(0 * WM + w_) * BN + col];
+          a2 += red[(1 * WM + w_) * BN + col];
+        }
+        p.stats[((size_t)0 * p.tiles_m + mt) * g.n_ch + n] = a1;
+        p.stats[((size_t)1 * p.tiles_m + mt) * g.n_ch + n] = a2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  EmsaConvGeom g;
+  const float* in;
+  const float* dout;
+  float* dw;
+  float* dbias;
+  int M, steps_total, steps_per_split;
+  int n_co_tiles, n_ci_tiles, n_tap_groups, n_tiles;
+  int dout_aligned;   // float4 loads of dout are legal
+};
+
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  static_assert(WCO * WCI * WT == 4, "4 waves");
+  constexpr int PK = 32;                       // pixels (GEMM K) per step
+  constexpr int TCO = BCO / 32 / WCO, TCI = BCI / 32 / WCI, TTW = (TT + WT - 1) / WT;
+  constexpr int DR = BCO / 32, XR = BCI / 32;   // float4 per thread per tile
+  constexpr int DTPR = BCO / 4, XTPR = BCI / 4; // threads per pixel row
+  constexpr int BUF = PK * BCO + TT * PK * BCI; // floats per LDS buffer
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wco = wave % WCO, wci = (wave / WCO) % WCI, wt = wave / (WCO * WCI);
+
+  const int tile = blockIdx.x % p.n_tiles, ks = blockIdx.x / p.n_tiles;
+  const int tg = tile % p.n_tap_groups;
+  const int ci_t = (tile / p.n_tap_groups) % p.n_ci_tiles;
+  const int co_t = tile / (p.n_tap_groups * p.n_ci_tiles);
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI, tap0 = tg * TT;
+
+  const EmsaConvGeom& g = p.g;
+  const int taps = g.kh * g.kw;
+  Gather q;
+  q.mul_h = g.mul_h; q.off_h = g.off_h; q.step_h = g.step_h; q.div_h = g.div_h;
+  q.mul_w = g.mul_w; q.off_w = g.off_w; q.step_w = g.step_w; q.div_w = g.div_w;
+  q.in_h = g.in_h; q.in_w = g.in_w;
+  q.row_stride = (int)g.in_row_stride; q.px_stride = g.in_px_stride;
+  const int ohw = g.out_h * g.out_w;
+
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(s_begin + p.steps_per_split, p.steps_total);
+
+  const int d_c4 = (tid % DTPR) * 4, d_r = tid / DTPR;
+  const int x_c4 = (tid % XTPR) * 4, x_r = tid / XTPR;
+  const bool do_bias = p.dbias != nullptr && ci_t == 0 && tg == 0;
+
+  float4 rd[DR], rx[TT][XR];
+  float4 bsum = emsa_zero4();
+
+  auto load_regs = [&](int s) {
+    const int mb = s * PK;
+#pragma unroll
+    for (int j = 0; j < DR; ++j) {
+      const int m = mb + d_r + j * (256 / DTPR);
+      const int co = co0 + d_c4;
+      float4 v = emsa_zero4();
+      if (m < p.M && co < g.n_ch) {
+        const float* src = p.dout + (size_t)m * g.ld_out + co;
+        if (p.dout_aligned && co + 3 < g.n_ch) {
+          v = emsa_ld4(src);
+        } else {
+          v.x = src[0];
+          if (co + 1 < g.n_ch) v.y = src[1];
+          if (co + 2 < g.n_ch) v.z = src[2];
+          if (co + 3 < g.n_ch) v.w = src[3];
+        }
+      }
+      rd[j] = v;
+      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int m = mb + x_r + j * (256 / XTPR);
+      const int ci = ci0 + x_c4;
+      int bh = -(1 << 29), bw = 0, img_off = 0;
+      if (m < p.M) {
+        const int img = m / ohw, rem = m - img * ohw;
+        const int oh = rem / g.out_w, ow = rem - oh * g.out_w;
+        bh = oh * q.mul_h + q.off_h;
+        bw = ow * q.mul_w + q.off_w;
+        img_off = img * (int)g.in_img_stride;
+      }
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int tap = tap0 + t;
+        float4 v = emsa_zero4();
+        if (tap < taps && ci < g.k_ch) {
+          const int kh = tap / g.kw, kw = tap - kh * g.kw;
+          const int off = gather_offset(q, img_off, bh, bw, kh, kw);
+          if (off >= 0) v = emsa_ld4(p.in + off + ci);
+        }
+        rx[t][j] = v;
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* d = smem + buf * BUF;
+    float* x = d + PK * BCO;
+#pragma unroll
+    for (int j = 0; j < DR; ++j) emsa_st4(d + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int j = 0; j < XR; ++j)
+        emsa_st4(x + t * PK * BCI + (x_r + j * (256 / XTPR)) * BCI + x_c4, rx[t][j]);
+  };
+
+  f32x16 acc[TCO][TCI][TTW];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int t = 0; t < TTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][t][r] = 0.f;
+
+  if (s_begin < s_end) {
+    load_regs(s_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool has_next = s + 1 < s_end;
+    if (has_next) load_regs(s + 1);
+
+    const float* d = smem + cur * BUF + lh * BCO + wco * TCO * 32 + l31;
+    const float* x = smem + cur * BUF + PK * BCO + lh * BCI + wci * TCI * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < PK / 2; ++kk) {
+      float fa[TCO];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) fa[i] = d[kk * 2 * BCO + i * 32];
+#pragma unroll
+      for (int t = 0; t < TTW; ++t) {
+        const int tl = wt * TTW + t;
+        if (tl < TT) {
+#pragma unroll
+          for (int j = 0; j < TCI; ++j) {
+            const float fb = x[tl * PK * BCI + kk * 2 * BCI + j * 32];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+              acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb, acc[i][j][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (has_next) store_lds(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: split-K partial -> atomic add ------------------------------------------
+#pragma unroll
+  for (int t = 0; t < TTW; ++t) {
+    const int tl = wt * TTW + t;
+    const int tap = tap0 + tl;
+    if (tl < TT && tap < taps) {
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) {
+          const int ci = ci0 + (wci * TCI + j) * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < g.n_ch && ci < g.k_ch)
+              unsafeAtomicAdd(p.dw + ((size_t)tap * g.n_ch + co) * g.k_ch + ci, acc[i][j][t][r]);
+          }
+        }
+    }
+  }
+
+  if (do_bias) {
+    float* red = smem;   // [256/DTPR][BCO]
+    red[d_r * BCO + d_c4 + 0] = bsum.x;
+    red[d_r * BCO + d_c4 + 1] = bsum.y;
+    red[d_r * BCO + d_c4 + 2] = bsum.z;
+    red[d_r * BCO + d_c4 + 3] = bsum.w;
+    __syncthreads();
+    if (tid < BCO && co0 + tid < g.n_ch) {
+      float a = 0.f;
+      for (int r = 0; r < 256 / DTPR; ++r) a += red[r * BCO + tid];
+      unsafeAtomicAdd(p.dbias + co0 + tid, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+enum ConvTile { TILE_128x128 = 0, TILE_128x64, TILE_64x64, TILE_128x32, TILE_COUNT };
+
+int tile_bm(ConvTile t) { return t == TILE_64x64 ? 64 : 128; }
+int tile_bn(ConvTile t) {
+  return t == TILE_128x128 ? 128 : t == TILE_128x32 ? 32 : 64;
+}
+
+// EMSA_CONV_TILE=0..3 forces a tile configuration (tests / tuning); read on every call
+int forced_tile() {
+  const char* e = getenv("EMSA_CONV_TILE");
+  const int v = (e && *e) ? atoi(e) : -1;
+  return (v >= 0 && v < TILE_COUNT) ? v : -1;
+}
+
+ConvTile pick_tile(long M, int n_ch) {
+  const int f = forced_tile();
+  if (f >= 0) return (ConvTile)f;
+  auto tiles = [&](ConvTile t) {
+    return ((M + tile_bm(t) - 1) / tile_bm(t)) * ((n_ch + tile_bn(t) - 1) / tile_bn(t));
+  };
+  if (n_ch <= 32) return tiles(TILE_128x32) >= 256 ? TILE_128x32 : TILE_64x64;
+  if (n_ch <= 64) return tiles(TILE_128x64) >= 512 ? TILE_128x64 : TILE_64x64;
+  if (tiles(TILE_128x128) >= 1024) return TILE_128x128;
+  if (tiles(TILE_128x64) >= 768) return TILE_128x64;
+  return TILE_64x64;
+}
+
+bool geom_ok(const EmsaConvGeom* g) {
+  if (!g) return false;
+  if (g->k_ch <= 0 || g->n_ch <= 0 || (g->k_ch & 3) || (g->in_px_stride & 3)) return false;
+  if ((g->in_row_stride & 3) || (g->in_img_stride & 3)) return false;
+  if (g->div_h < 1 || g->div_w < 1 || g->kh < 1 || g->kw < 1) return false;
+  const long in_elems = (long)g->n_img * g->in_img_stride;
+  const long out_elems = (long)g->n_img * g->out_h * g->out_w * (long)g->ld_out;
+  if (in_elems >= (1L << 31) || out_elems >= (1L << 31)) return false;
+  return true;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(const ConvArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (BM + BN) * kLD * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int grid = a.tiles_m * a.tiles_n;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, a);
+  return emsa_launch_status();
+}
+
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
+int launch_wgrad(WgradArgs a, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (32 * BCO + TT * 32 * BCI) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int taps = a.g.kh * a.g.kw;
+  a.n_co_tiles = (a.g.n_ch + BCO - 1) / BCO;
+  a.n_ci_tiles = (a.g.k_ch + BCI - 1) / BCI;
+  a.n_tap_groups = (taps + TT - 1) / TT;
+  a.n_tiles = a.n_co_tiles * a.n_ci_tiles * a.n_tap_groups;
+  a.steps_total = (a.M + 31) / 32;
+  int ksplit = 1024 / a.n_tiles;
+  const int max_split = (a.steps_total + 7) / 8;   // at least 8 steps (256 pixels) per block
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  a.steps_per_split = (a.steps_total + ksplit - 1) / ksplit;
+  ksplit = (a.steps_total + a.steps_per_split - 1) / a.steps_per_split;
+  hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>), dim3(a.n_tiles * ksplit),
+                     dim3(256), lds, st, a);
+  return emsa_launch_status();
+}
+
+}  // namespace
+
+extern "C" int emsa_conv_stats_rows(const EmsaConvGeom* g) {
+  if (!geom_ok(g)) return EMSA_E_SHAPE;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  const ConvTile t = pick_tile(M, g->n_ch);
+  return (int)((M + tile_bm(t) - 1) / tile_bm(t));
+}
+
+extern "C" int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const float* w, float* out,
+                               const float* bias, float* stats, const float* scale,
+                               const float* shift, const float* residual, int32_t ld_res,
+                               const float* mask_src, int32_t ld_mask, int32_t act,
+                               void* stream) {
+  if (!geom_ok(g)) return EMSA_E_SHAPE;
+  if (!in || !w || !out) return EMSA_E_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
+  ConvArgs a;
+  a.g = *g;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats;
+  a.scale = scale; a.shift = shift; a.residual = residual; a.mask_src = mask_src;
+  a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  a.M = (int)M;
+  const ConvTile t = pick_tile(M, g->n_ch);
+  a.tiles_m = (int)((M + tile_bm(t) - 1) / tile_bm(t));
+  a.tiles_n = (g->n_ch + tile_bn(t) - 1) / tile_bn(t);
+  a.kchunks = (g->k_ch + kBK - 1) / kBK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (t) {
+    case TILE_128x128: return launch_igemm<128, 128, 2, 2>(a, st);
+    case TILE_128x64: return launch_igemm<128, 64, 2, 2>(a, st);
+    case TILE_64x64: return launch_igemm<64, 64, 2, 2>(a, st);
+    default: return launch_igemm<128, 32, 4, 1>(a, st);
+  }
+}
+
+extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout,
+                               float* dw, float* dbias, void* stream) {
+  if (!geom_ok(g)) return EMSA_E_SHAPE;
+  if (!in || !dout || !dw) return EMSA_E_ARG;
+  if (g->div_h != 1 || g->div_w != 1) return EMSA_E_SHAPE;
+  WgradArgs a;
+  a.g = *g;
+  a.in = in; a.dout = dout; a.dw = dw; a.dbias = dbias;
+  a.M = g->n_img * g->out_h * g->out_w;
+  a.dout_aligned = ((g->ld_out & 3) == 0) && ((((uintptr_t)dout) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int taps = g->kh * g->kw;
+  if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2>(a, st);
+  if (taps == 1) {
+    if (g->n_ch >= 128 && g->k_ch >= 128) return launch_wgrad<128, 128, 1, 2, 2, 1>(a, st);
+    return launch_wgrad<64, 64, 1, 2, 2, 1>(a, st);
+  }
+  return launch_wgrad<64, 64, 3, 2, 2, 1>(a, st);
+}

@@ -1,0 +1,1193 @@
+// HBM-bound kernels of the EMSANet engine: BatchNorm (+ReLU/+Dropout2d/+residual), max pool,
+// squeeze-and-excitation fusion, nearest-x2 + depth-wise 3x3 upsampling, pyramid pooling,
+// head activations, weight packing.  All NHWC fp32, float4 per lane along channels so that a
+// wave touches whole 128-B lines; grids capped at ~8 blocks/CU with grid-stride loops
+// (cdna_hip_programming.md Guideline 11/13).
+//
+// Reference modules these stand in for are cited per entry point in include/emsanet_hip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 256 * 8;
+
+inline int grid_for(long work_items) {
+  long b = (work_items + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+// mode 0: OIHW -> [tap][cout_total][cin_total]; mode 1: OIHW -> [tap][cin_total][cout_total];
+// mode 2: [tap][cout_total][cin_total] -> OIHW
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout,
+                                   int cin, int kh, int kw, int cout_total, int cout_off,
+                                   int cin_total, int cin_off, int mode) {
+  const long total = (long)cout * cin * kh * kw;
+  const int taps = kh * kw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    // i enumerates OIHW
+    const int tap = (int)(i % taps);
+    const long r = i / taps;
+    const int ci = (int)(r % cin), co = (int)(r / cin);
+    if (mode == 0) {
+      dst[((long)tap * cout_total + cout_off + co) * cin_total + cin_off + ci] = src[i];
+    } else if (mode == 1) {
+      dst[((long)tap * cin_total + cin_off + ci) * cout_total + cout_off + co] = src[i];
+    } else {
+      dst[i] = src[((long)tap * cout_total + cout_off + co) * cin_total + cin_off + ci];
+    }
+  }
+}
+
+// stem: NCHW -> zero padded NHWC4 [n][h][w+8][4]
+__global__ void stem_pack_input_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                       int c, int h, int w) {
+  const int wp = w + 8;
+  const long total = (long)n * h * wp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % wp);
+    const long r = i / wp;
+    const int row = (int)(r % h), img = (int)(r / h);
+    const int sw = col - 3;
+    float4 v = emsa_zero4();
+    if (sw >= 0 && sw < w) {
+      const long base = ((long)img * c * h + row) * w + sw;
+      const long plane = (long)h * w;
+      v.x = x[base];
+      if (c > 1) v.y = x[base + plane];
+      if (c > 2) v.z = x[base + 2 * plane];
+      if (c > 3) v.w = x[base + 3 * plane];
+    }
+    emsa_st4(y + i * 4, v);
+  }
+}
+
+// stem weights: OIHW [cout][cin][7][7] <-> [7(kh)][cout][32 = 8(kw) x 4(c)]
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                        int cout, int cin, int unpack) {
+  const int total = 7 * cout * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i % 32, co = (i / 32) % cout, kh = i / (32 * cout);
+    const int kw = k / 4, c = k % 4;
+    const bool real = kw < 7 && c < cin;
+    if (!unpack) {
+      wp[i] = real ? w[((co * cin + c) * 7 + kh) * 7 + kw] : 0.f;
+    } else if (real) {
+      // here `w` is the packed gradient and `wp` the OIHW destination
+      wp[((co * cin + c) * 7 + kh) * 7 + kw] = w[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm
+// ------------------------------------------------------------------------------------------
+// reduce partial[2][rows][c] over rows in fp64: block = 32 channels x 8 row groups
+__device__ __forceinline__ void reduce_rows(const float* __restrict__ partial, int rows, int c,
+                                            double& o1, double& o2, int& ch_out, bool& leader) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (ch < c) {
+    for (int r = rg; r < rows; r += 8) {
+      a1 += (double)partial[((long)0 * rows + r) * c + ch];
+      a2 += (double)partial[((long)1 * rows + r) * c + ch];
+    }
+  }
+  red[0][rg][cl] = a1;
+  red[1][rg][cl] = a2;
+  __syncthreads();
+  leader = rg == 0 && ch < c;
+  ch_out = ch;
+  o1 = o2 = 0.0;
+  if (leader) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o1 += red[0][k][cl];
+      o2 += red[1][k][cl];
+    }
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int rows, int c, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* running_mean,
+                                   float* running_var, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+  double s1, s2;
+  int ch;
+  bool leader;
+  reduce_rows(stats, rows, c, s1, s2, ch, leader);
+  if (!leader) return;
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * invstd;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - (float)mean * sc;
+  save_mean[ch] = (float)mean;
+  save_invstd[ch] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm,
+                               const float* rv, float eps, int c, float* scale, float* shift,
+                               float* invstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c) {
+    const float is = 1.0f / sqrtf(rv[i] + eps);
+    const float sc = gamma[i] * is;
+    scale[i] = sc;
+    shift[i] = beta[i] - rm[i] * sc;
+    if (invstd) invstd[i] = is;
+  }
+}
+
+__global__ void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const float* __restrict__ drop,
+                                  const float* __restrict__ residual, long hw, int c4n, long total4,
+                                  int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const long pix = i / c4n;
+    float4 v = emsa_ld4(x + i * 4);
+    const float4 sc = emsa_ld4(scale + c4 * 4), sh = emsa_ld4(shift + c4 * 4);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+    v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (drop) {
+      const float4 d = emsa_ld4(drop + (pix / hw) * (long)c4n * 4 + c4 * 4);
+      v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+    }
+    if (residual) {
+      const float4 r = emsa_ld4(residual + i * 4);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (act == EMSA_ACT_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    emsa_st4(y + i * 4, v);
+  }
+}
+
+// generic "per-channel reduction of up to two float4 quantities over a pixel range":
+// block = (c4n columns) x (256/c4n row lanes); the functor returns the two float4 terms.
+template <typename F>
+__device__ __forceinline__ void column_reduce(long p0, long p1, int c4n, F f, float4& o1,
+                                              float4& o2, bool& leader, int& c4_out) {
+  extern __shared__ __attribute__((aligned(16))) float cred[];   // [2][lanes][c4n*4]
+  const int lanes = kThreads / c4n;
+  const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  float4 a1 = emsa_zero4(), a2 = emsa_zero4();
+  if (rl < lanes) {
+    for (long p = p0 + rl; p < p1; p += lanes) {
+      float4 t1, t2;
+      f(p, c4, t1, t2);
+      a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+      a2.x += t2.x; a2.y += t2.y; a2.z += t2.z; a2.w += t2.w;
+    }
+    emsa_st4(cred + ((0 * lanes + rl) * c4n + c4) * 4, a1);
+    emsa_st4(cred + ((1 * lanes + rl) * c4n + c4) * 4, a2);
+  }
+  __syncthreads();
+  leader = rl == 0;
+  c4_out = c4;
+  o1 = o2 = emsa_zero4();
+  if (leader) {
+    for (int k = 0; k < lanes; ++k) {
+      const float4 t1 = emsa_ld4(cred + ((0 * lanes + k) * c4n + c4) * 4);
+      const float4 t2 = emsa_ld4(cred + ((1 * lanes + k) * c4n + c4) * 4);
+      o1.x += t1.x; o1.y += t1.y; o1.z += t1.z; o1.w += t1.w;
+      o2.x += t2.x; o2.y += t2.y; o2.z += t2.z; o2.w += t2.w;
+    }
+  }
+}
+
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd,
+                                     const float* __restrict__ drop, long pixels, long hw, int c4n,
+                                     int act, int rows, float* __restrict__ partial) {
+  const long chunk = (pixels + rows - 1) / rows;
+  const long p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
+  float4 o1, o2;
+  bool leader;
+  int c4;
+  column_reduce(
+      p0, p1, c4n,
+      [&](long p, int cc, float4& t1, float4& t2) {
+        const long i = (p * c4n + cc) * 4;
+        float4 g = emsa_ld4(dy + i);
+        if (act == EMSA_ACT_RELU) {
+          const float4 yy = emsa_ld4(y + i);
+          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (drop) {
+          const float4 d = emsa_ld4(drop + ((p / hw) * c4n + cc) * 4);
+          g.x *= d.x; g.y *= d.y; g.z *= d.z; g.w *= d.w;
+        }
+        const float4 xx = emsa_ld4(x + i);
+        const float4 mu = emsa_ld4(mean + cc * 4), is = emsa_ld4(invstd + cc * 4);
+        t1 = g;
+        t2.x = g.x * (xx.x - mu.x) * is.x; t2.y = g.y * (xx.y - mu.y) * is.y;
+        t2.z = g.z * (xx.z - mu.z) * is.z; t2.w = g.w * (xx.w - mu.w) * is.w;
+      },
+      o1, o2, leader, c4);
+  if (leader) {
+    const int c = c4n * 4;
+    emsa_st4(partial + ((long)0 * rows + blockIdx.x) * c + c4 * 4, o1);
+    emsa_st4(partial + ((long)1 * rows + blockIdx.x) * c + c4 * 4, o2);
+  }
+}
+
+__global__ void bn_bwd_sum_kernel(const float* __restrict__ partial, int rows, int c,
+                                  float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  double s1, s2;
+  int ch;
+  bool leader;
+  reduce_rows(partial, rows, c, s1, s2, ch, leader);
+  if (leader) {
+    dbeta[ch] = (float)s1;
+    dgamma[ch] = (float)s2;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    const float* __restrict__ x, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean,
+                                    const float* __restrict__ invstd,
+                                    const float* __restrict__ drop,
+                                    const float* __restrict__ dbeta,
+                                    const float* __restrict__ dgamma, long hw, int c4n,
+                                    long total4, float inv_count, int act, int train,
+                                    float* __restrict__ dx, float* __restrict__ dres) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const long pix = i / c4n;
+    float4 g = emsa_ld4(dy + i * 4);
+    if (act == EMSA_ACT_RELU) {
+      const float4 yy = emsa_ld4(y + i * 4);
+      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    }
+    if (dres) emsa_st4(dres + i * 4, g);
+    if (drop) {
+      const float4 d = emsa_ld4(drop + (pix / hw) * (long)c4n * 4 + c4 * 4);
+      g.x *= d.x; g.y *= d.y; g.z *= d.z; g.w *= d.w;
+    }
+    const float4 ga = emsa_ld4(gamma + c4 * 4), is = emsa_ld4(invstd + c4 * 4);
+    float4 o;
+    if (train) {
+      const float4 xx = emsa_ld4(x + i * 4);
+      const float4 mu = emsa_ld4(mean + c4 * 4);
+      const float4 db = emsa_ld4(dbeta + c4 * 4), dg = emsa_ld4(dgamma + c4 * 4);
+      o.x = ga.x * is.x * (g.x - db.x * inv_count - (xx.x - mu.x) * is.x * dg.x * inv_count);
+      o.y = ga.y * is.y * (g.y - db.y * inv_count - (xx.y - mu.y) * is.y * dg.y * inv_count);
+      o.z = ga.z * is.z * (g.z - db.z * inv_count - (xx.z - mu.z) * is.z * dg.z * inv_count);
+      o.w = ga.w * is.w * (g.w - db.w * inv_count - (xx.w - mu.w) * is.w * dg.w * inv_count);
+    } else {
+      o.x = g.x * ga.x * is.x; o.y = g.y * ga.y * is.y;
+      o.z = g.z * ga.z * is.z; o.w = g.w * ga.w * is.w;
+    }
+    emsa_st4(dx + i * 4, o);
+  }
+}
+
+__global__ void dropout2d_mask_kernel(float* mask, int n, int c, float p, uint32_t seed,
+                                      uint32_t layer_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const uint32_t nn = i / c, cc = i % c;
+  const uint32_t key = emsa_lowbias32(seed + layer_id * 0x9E3779B1u);
+  const uint32_t h = emsa_lowbias32(key + nn * 0x85EBCA77u + cc * 0xC2B2AE3Du);
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  mask[i] = u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// max pool 3x3 s2 p1
+// ------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   int8_t* __restrict__ idx, int n, int h, int w, int c4n) {
+  const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;
+  const long total = (long)n * oh_n * ow_n * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long r = i / c4n;
+    const int ow = (int)(r % ow_n); r /= ow_n;
+    const int oh = (int)(r % oh_n);
+    const int img = (int)(r / oh_n);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bi[4] = {0, 0, 0, 0};
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+        if (ih < 0 || ih >= h || iw < 0 || iw >= w) continue;
+        const float4 v = emsa_ld4(x + (((long)img * h + ih) * w + iw) * c4n * 4 + c4 * 4);
+        const int t = kh * 3 + kw;
+        if (first || v.x > best.x) { best.x = v.x; bi[0] = t; }
+        if (first || v.y > best.y) { best.y = v.y; bi[1] = t; }
+        if (first || v.z > best.z) { best.z = v.z; bi[2] = t; }
+        if (first || v.w > best.w) { best.w = v.w; bi[3] = t; }
+        first = false;
+      }
+    emsa_st4(y + i * 4, best);
+    *reinterpret_cast<char4*>(idx + i * 4) = make_char4(bi[0], bi[1], bi[2], bi[3]);
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ idx,
+                                   float* __restrict__ dx, int n, int h, int w, int c4n) {
+  const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;
+  const long total = (long)n * h * w * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long r = i / c4n;
+    const int iw = (int)(r % w); r /= w;
+    const int ih = (int)(r % h);
+    const int img = (int)(r / h);
+    float4 a = emsa_zero4();
+    // windows oh with oh*2-1 <= ih <= oh*2+1
+    for (int oh = (ih >> 1); oh <= ((ih + 1) >> 1); ++oh) {
+      if (oh < 0 || oh >= oh_n) continue;
+      const int kh = ih - (oh * 2 - 1);
+      for (int ow = (iw >> 1); ow <= ((iw + 1) >> 1); ++ow) {
+        if (ow < 0 || ow >= ow_n) continue;
+        const int kw = iw - (ow * 2 - 1);
+        const int t = kh * 3 + kw;
+        const long o = (((long)img * oh_n + oh) * ow_n + ow) * c4n + c4;
+        const char4 k = *reinterpret_cast<const char4*>(idx + o * 4);
+        const float4 g = emsa_ld4(dy + o * 4);
+        if (k.x == t) a.x += g.x;
+        if (k.y == t) a.y += g.y;
+        if (k.z == t) a.z += g.z;
+        if (k.w == t) a.w += g.w;
+      }
+    }
+    emsa_st4(dx + i * 4, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// squeeze-and-excitation
+// ------------------------------------------------------------------------------------------
+// out[n][c] += scale * sum_{hw chunk} a*b (b may be NULL -> sum a)
+__global__ void channel_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                   float* __restrict__ out, long hw, int c4n, int splits,
+                                   float scale) {
+  const int img = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const long chunk = (hw + splits - 1) / splits;
+  const long p0 = img * hw + sp * chunk, p1 = min(img * hw + (sp + 1) * chunk, (img + 1) * hw);
+  float4 o1, o2;
+  bool leader;
+  int c4;
+  column_reduce(
+      p0, p1, c4n,
+      [&](long p, int cc, float4& t1, float4& t2) {
+        const long i = (p * c4n + cc) * 4;
+        t1 = emsa_ld4(a + i);
+        if (b) {
+          const float4 bb = emsa_ld4(b + i);
+          t1.x *= bb.x; t1.y *= bb.y; t1.z *= bb.z; t1.w *= bb.w;
+        }
+        t2 = emsa_zero4();
+      },
+      o1, o2, leader, c4);
+  if (leader) {
+    float* o = out + ((long)img * c4n + c4) * 4;
+    unsafeAtomicAdd(o + 0, o1.x * scale);
+    unsafeAtomicAdd(o + 1, o1.y * scale);
+    unsafeAtomicAdd(o + 2, o1.z * scale);
+    unsafeAtomicAdd(o + 3, o1.w * scale);
+  }
+}
+
+__global__ void se_mlp_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
+                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                  const float* __restrict__ b2, float* __restrict__ hid,
+                                  float* __restrict__ s, int c, int cr) {
+  extern __shared__ float sm[];   // [c] gap + [cr] hidden
+  float* g = sm;
+  float* hsh = sm + c;
+  const int img = blockIdx.x;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) g[i] = gap[(long)img * c + i];
+  __syncthreads();
+  for (int r = threadIdx.x; r < cr; r += blockDim.x) {
+    float a = b1[r];
+    for (int k = 0; k < c; ++k) a += w1[(long)r * c + k] * g[k];
+    a = fmaxf(a, 0.f);
+    hsh[r] = a;
+    hid[(long)img * cr + r] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    float a = b2[i];
+    for (int r = 0; r < cr; ++r) a += w2[(long)i * cr + r] * hsh[r];
+    s[(long)img * c + i] = 1.f / (1.f + expf(-a));
+  }
+}
+
+// grid = 8 blocks; every block recomputes dz1 [n][cr] in LDS, then owns 1/8 of the outputs
+__global__ void se_mlp_bwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
+                                  const float* __restrict__ w2, const float* __restrict__ hid,
+                                  const float* __restrict__ s, const float* __restrict__ ds,
+                                  float* __restrict__ dgap, float* __restrict__ dw1,
+                                  float* __restrict__ db1, float* __restrict__ dw2,
+                                  float* __restrict__ db2, int n, int c, int cr) {
+  extern __shared__ float dz1[];   // [n][cr]
+  const int tid = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
+  for (int i = tid; i < n * cr; i += blockDim.x) {
+    const int img = i / cr, r = i % cr;
+    float a = 0.f;
+    for (int k = 0; k < c; ++k) {
+      const float sv = s[(long)img * c + k];
+      a += ds[(long)img * c + k] * sv * (1.f - sv) * w2[(long)k * cr + r];
+    }
+    dz1[i] = hid[i] > 0.f ? a : 0.f;
+  }
+  __syncthreads();
+  // dw2 [c][cr], db2 [c]
+  for (int i = b * blockDim.x + tid; i < c * cr; i += nb * blockDim.x) {
+    const int k = i / cr, r = i % cr;
+    float a = 0.f;
+    for (int img = 0; img < n; ++img) {
+      const float sv = s[(long)img * c + k];
+      a += ds[(long)img * c + k] * sv * (1.f - sv) * hid[(long)img * cr + r];
+    }
+    dw2[i] = a;
+  }
+  for (int k = b * blockDim.x + tid; k < c; k += nb * blockDim.x) {
+    float a = 0.f;
+    for (int img = 0; img < n; ++img) {
+      const float sv = s[(long)img * c + k];
+      a += ds[(long)img * c + k] * sv * (1.f - sv);
+    }
+    db2[k] = a;
+  }
+  // dw1 [cr][c], db1 [cr]
+  for (int i = b * blockDim.x + tid; i < cr * c; i += nb * blockDim.x) {
+    const int r = i / c, k = i % c;
+    float a = 0.f;
+    for (int img = 0; img < n; ++img) a += dz1[img * cr + r] * gap[(long)img * c + k];
+    dw1[i] = a;
+  }
+  for (int r = b * blockDim.x + tid; r < cr; r += nb * blockDim.x) {
+    float a = 0.f;
+    for (int img = 0; img < n; ++img) a += dz1[img * cr + r];
+    db1[r] = a;
+  }
+  // dgap [n][c]
+  for (int i = b * blockDim.x + tid; i < n * c; i += nb * blockDim.x) {
+    const int img = i / c, k = i % c;
+    float a = 0.f;
+    for (int r = 0; r < cr; ++r) a += dz1[img * cr + r] * w1[(long)r * c + k];
+    dgap[i] = a;
+  }
+}
+
+__global__ void se_scale_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ sa,
+                                        const float* __restrict__ b, const float* __restrict__ sb,
+                                        float* __restrict__ out, long hw, int c4n, long total4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const long img = (i / c4n) / hw;
+    const float4 va = emsa_ld4(a + i * 4), ka = emsa_ld4(sa + (img * c4n + c4) * 4);
+    float4 o = make_float4(va.x * ka.x, va.y * ka.y, va.z * ka.z, va.w * ka.w);
+    if (b) {
+      const float4 vb = emsa_ld4(b + i * 4), kb = emsa_ld4(sb + (img * c4n + c4) * 4);
+      o.x += vb.x * kb.x; o.y += vb.y * kb.y; o.z += vb.z * kb.z; o.w += vb.w * kb.w;
+    }
+    emsa_st4(out + i * 4, o);
+  }
+}
+
+__global__ void se_scale_bwd_apply_kernel(const float* __restrict__ dout,
+                                          const float* __restrict__ s,
+                                          const float* __restrict__ dgap,
+                                          const float* __restrict__ extra, float* __restrict__ dx,
+                                          long hw, int c4n, long total4, float inv_hw) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    const long img = (i / c4n) / hw;
+    const float4 g = emsa_ld4(dout + i * 4), k = emsa_ld4(s + (img * c4n + c4) * 4);
+    const float4 dg = emsa_ld4(dgap + (img * c4n + c4) * 4);
+    float4 o = make_float4(g.x * k.x + dg.x * inv_hw, g.y * k.y + dg.y * inv_hw,
+                           g.z * k.z + dg.z * inv_hw, g.w * k.w + dg.w * inv_hw);
+    if (extra) {
+      const float4 e = emsa_ld4(extra + i * 4);
+      o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+    }
+    emsa_st4(dx + i * 4, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// nearest x2 + depth-wise 3x3 (zero pad)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c, int t) {
+  return make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t],
+                     w[(c + 3) * 9 + t]);
+}
+
+__global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
+                                   const float* __restrict__ bias, const float* __restrict__ skip,
+                                   float* __restrict__ y, int n, int h, int w, int c4n) {
+  const int oh_n = 2 * h, ow_n = 2 * w;
+  const long total = (long)n * oh_n * ow_n * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long r = i / c4n;
+    const int ow = (int)(r % ow_n); r /= ow_n;
+    const int oh = (int)(r % oh_n);
+    const int img = (int)(r / oh_n);
+    float4 a = bias ? emsa_ld4(bias + c4 * 4) : emsa_zero4();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int uh = oh + kh - 1;
+      if (uh < 0 || uh >= oh_n) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int uw = ow + kw - 1;
+        if (uw < 0 || uw >= ow_n) continue;
+        const float4 v =
+            emsa_ld4(x + ((((long)img * h + (uh >> 1)) * w + (uw >> 1)) * c4n + c4) * 4);
+        const float4 k = dw_weight4(wdw, c4 * 4, kh * 3 + kw);
+        a.x += v.x * k.x; a.y += v.y * k.y; a.z += v.z * k.z; a.w += v.w * k.w;
+      }
+    }
+    if (skip) {
+      const float4 sk = emsa_ld4(skip + i * 4);
+      a.x += sk.x; a.y += sk.y; a.z += sk.z; a.w += sk.w;
+    }
+    emsa_st4(y + i * 4, a);
+  }
+}
+
+__global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
+                                        const float* __restrict__ wdw, float* __restrict__ dx,
+                                        int n, int h, int w, int c4n) {
+  const int oh_n = 2 * h, ow_n = 2 * w;
+  const long total = (long)n * h * w * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % c4n);
+    long r = i / c4n;
+    const int iw = (int)(r % w); r /= w;
+    const int ih = (int)(r % h);
+    const int img = (int)(r / h);
+    float4 a = emsa_zero4();
+    // up-sampled positions (uh,uw) in {2ih,2ih+1}x{2iw,2iw+1}; tap (kh,kw) of output
+    // (uh+1-kh, uw+1-kw) reads it
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float4 k = dw_weight4(wdw, c4 * 4, kh * 3 + kw);
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+          const int oh = 2 * ih + dh + 1 - kh;
+          if (oh < 0 || oh >= oh_n) continue;
+#pragma unroll
+          for (int dw_ = 0; dw_ < 2; ++dw_) {
+            const int ow = 2 * iw + dw_ + 1 - kw;
+            if (ow < 0 || ow >= ow_n) continue;
+            const float4 g = emsa_ld4(dy + ((((long)img * oh_n + oh) * ow_n + ow) * c4n + c4) * 4);
+            a.x += g.x * k.x; a.y += g.y * k.y; a.z += g.z * k.z; a.w += g.w * k.w;
+          }
+        }
+      }
+    emsa_st4(dx + i * 4, a);
+  }
+}
+
+// dw[c][9] += sum dy*up(x) ; db[c] += sum dy.  block = c4n columns x lanes, pixel chunk per block
+__global__ void up2x_dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                          float* __restrict__ dwt, float* __restrict__ db, int n,
+                                          int h, int w, int c4n, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) float wred[];   // [lanes][10][c4n*4]
+  const int oh_n = 2 * h, ow_n = 2 * w;
+  const long pixels = (long)n * oh_n * ow_n;
+  const long chunk = (pixels + nblocks - 1) / nblocks;
+  const long p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
+  const int lanes = kThreads / c4n;
+  const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  float4 acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = emsa_zero4();
+  if (rl < lanes) {
+    for (long p = p0 + rl; p < p1; p += lanes) {
+      const int ow = (int)(p % ow_n);
+      const long r = p / ow_n;
+      const int oh = (int)(r % oh_n);
+      const int img = (int)(r / oh_n);
+      const float4 g = emsa_ld4(dy + (p * c4n + c4) * 4);
+      acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int uh = oh + kh - 1;
+        if (uh < 0 || uh >= oh_n) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int uw = ow + kw - 1;
+          if (uw < 0 || uw >= ow_n) continue;
+          const float4 v =
+              emsa_ld4(x + ((((long)img * h + (uh >> 1)) * w + (uw >> 1)) * c4n + c4) * 4);
+          float4& a = acc[kh * 3 + kw];
+          a.x += g.x * v.x; a.y += g.y * v.y; a.z += g.z * v.z; a.w += g.w * v.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) emsa_st4(wred + ((rl * 10 + t) * c4n + c4) * 4, acc[t]);
+  }
+  __syncthreads();
+  // 10 * c4n*4 outputs
+  const int c = c4n * 4;
+  for (int o = threadIdx.x; o < 10 * c; o += blockDim.x) {
+    const int t = o / c, ch = o % c;
+    float a = 0.f;
+    for (int k = 0; k < lanes; ++k) a += wred[(k * 10 + t) * c + ch];
+    if (t < 9)
+      unsafeAtomicAdd(dwt + ch * 9 + t, a);
+    else
+      unsafeAtomicAdd(db + ch, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pyramid pooling
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bin_range(int i, int size, int bins, int& b0, int& b1) {
+  b0 = (i * size) / bins;
+  b1 = ((i + 1) * size + bins - 1) / bins;
+}
+
+__global__ void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                            int n, int h, int w, int c, int bins) {
+  const long total = (long)n * bins * bins * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int bj = (int)(r % bins); r /= bins;
+    const int bi = (int)(r % bins);
+    const int img = (int)(r / bins);
+    int h0, h1, w0, w1;
+    bin_range(bi, h, bins, h0, h1);
+    bin_range(bj, w, bins, w0, w1);
+    float a = 0.f;
+    for (int hh = h0; hh < h1; ++hh)
+      for (int ww = w0; ww < w1; ++ww) a += x[(((long)img * h + hh) * w + ww) * c + ch];
+    y[i] = a / (float)((h1 - h0) * (w1 - w0));
+  }
+}
+
+__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                            int n, int h, int w, int c, int bins, int accumulate) {
+  const long total = (long)n * h * w * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int ww = (int)(r % w); r /= w;
+    const int hh = (int)(r % h);
+    const int img = (int)(r / h);
+    float a = 0.f;
+    for (int bi = 0; bi < bins; ++bi) {
+      int h0, h1;
+      bin_range(bi, h, bins, h0, h1);
+      if (hh < h0 || hh >= h1) continue;
+      for (int bj = 0; bj < bins; ++bj) {
+        int w0, w1;
+        bin_range(bj, w, bins, w0, w1);
+        if (ww < w0 || ww >= w1) continue;
+        a += dy[(((long)img * bins + bi) * bins + bj) * c + ch] /
+             (float)((h1 - h0) * (w1 - w0));
+      }
+    }
+    dx[i] = accumulate ? dx[i] + a : a;
+  }
+}
+
+__device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, int& i1, float& l) {
+  const float scale = (float)in / (float)out;
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l = s - (float)i0;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                    int ih, int iw, int oh, int ow, int c, int ld_y) {
+  const long total = (long)n * oh * ow * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int xo = (int)(r % ow); r /= ow;
+    const int yo = (int)(r % oh);
+    const int img = (int)(r / oh);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    bilinear_src(yo, ih, oh, h0, h1, lh);
+    bilinear_src(xo, iw, ow, w0, w1, lw);
+    const float* b = x + (long)img * ih * iw * c + ch;
+    const float v00 = b[((long)h0 * iw + w0) * c], v01 = b[((long)h0 * iw + w1) * c];
+    const float v10 = b[((long)h1 * iw + w0) * c], v11 = b[((long)h1 * iw + w1) * c];
+    y[(((long)img * oh + yo) * ow + xo) * ld_y + ch] =
+        (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+  }
+}
+
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n,
+                                    int ih, int iw, int oh, int ow, int c, int ld_dy) {
+  const long total = (long)n * oh * ow * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int xo = (int)(r % ow); r /= ow;
+    const int yo = (int)(r % oh);
+    const int img = (int)(r / oh);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    bilinear_src(yo, ih, oh, h0, h1, lh);
+    bilinear_src(xo, iw, ow, w0, w1, lw);
+    const float g = dy[(((long)img * oh + yo) * ow + xo) * ld_dy + ch];
+    float* b = dx + (long)img * ih * iw * c + ch;
+    unsafeAtomicAdd(b + ((long)h0 * iw + w0) * c, g * (1.f - lh) * (1.f - lw));
+    unsafeAtomicAdd(b + ((long)h0 * iw + w1) * c, g * (1.f - lh) * lw);
+    unsafeAtomicAdd(b + ((long)h1 * iw + w0) * c, g * lh * (1.f - lw));
+    unsafeAtomicAdd(b + ((long)h1 * iw + w1) * c, g * lh * lw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// head activations, copies
+// ------------------------------------------------------------------------------------------
+__global__ void head_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total,
+                                    int c, int n_sig, int n_tanh) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const float v = x[i];
+    y[i] = ch < n_sig ? 1.f / (1.f + expf(-v)) : ch < n_sig + n_tanh ? tanhf(v) : v;
+  }
+}
+
+__global__ void head_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    float* __restrict__ dx, long total, int c, int n_sig,
+                                    int n_tanh) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const float g = dy[i], v = y[i];
+    dx[i] = ch < n_sig ? g * v * (1.f - v) : ch < n_sig + n_tanh ? g * (1.f - v * v) : g;
+  }
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y,
+                                     int ld_y, long pixels, int c) {
+  const long total = pixels * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long p = i / c;
+    const int ch = (int)(i % c);
+    y[p * ld_y + ch] = x[p * ld_x + ch];
+  }
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                            float alpha) {
+  const long n4 = n / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    const float4 a = emsa_ld4(x + i * 4);
+    float4 b = emsa_ld4(y + i * 4);
+    b.x += alpha * a.x; b.y += alpha * a.y; b.z += alpha * a.z; b.w += alpha * a.w;
+    emsa_st4(y + i * 4, b);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = n4 * 4 + threadIdx.x;
+    y[i] += alpha * x[i];
+  }
+}
+
+inline bool c4_ok(int c) { return c >= 4 && (c & 3) == 0 && c <= 1024; }
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" const char* emsa_arch(void) { return "gfx950"; }
+extern "C" int emsa_version(void) { return 1; }
+
+static int pack_common(const float* src, float* dst, int cout, int cin, int kh, int kw,
+                       int cout_total, int cout_off, int cin_total, int cin_off, int mode,
+                       void* stream) {
+  if (!src || !dst) return EMSA_E_ARG;
+  if (cout_off + cout > cout_total || cin_off + cin > cin_total) return EMSA_E_SHAPE;
+  const long total = (long)cout * cin * kh * kw;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, src, dst, cout, cin, kh, kw, cout_total, cout_off,
+                     cin_total, cin_off, mode);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_pack_weight_fwd(const float* w, float* wp, int32_t cout, int32_t cin,
+                                    int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
+                                    int32_t cin_total, int32_t cin_off, void* stream) {
+  return pack_common(w, wp, cout, cin, kh, kw, cout_total, cout_off, cin_total, cin_off, 0,
+                     stream);
+}
+extern "C" int emsa_pack_weight_dgrad(const float* w, float* wp, int32_t cout, int32_t cin,
+                                      int32_t kh, int32_t kw, int32_t cout_total,
+                                      int32_t cout_off, int32_t cin_total, int32_t cin_off,
+                                      void* stream) {
+  return pack_common(w, wp, cout, cin, kh, kw, cout_total, cout_off, cin_total, cin_off, 1,
+                     stream);
+}
+extern "C" int emsa_unpack_wgrad(const float* dwp, float* dw, int32_t cout, int32_t cin,
+                                 int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
+                                 int32_t cin_total, int32_t cin_off, void* stream) {
+  return pack_common(dwp, dw, cout, cin, kh, kw, cout_total, cout_off, cin_total, cin_off, 2,
+                     stream);
+}
+
+extern "C" int emsa_stem_pack_input(const float* x, float* xp, int32_t n, int32_t c, int32_t h,
+                                    int32_t w, void* stream) {
+  if (!x || !xp) return EMSA_E_ARG;
+  if (c < 1 || c > 4) return EMSA_E_SHAPE;
+  const long total = (long)n * h * (w + 8);
+  hipLaunchKernelGGL(stem_pack_input_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, xp, n, c, h, w);
+  return emsa_launch_status();
+}
+extern "C" int emsa_stem_pack_weight(const float* w, float* wp, int32_t cout, int32_t cin,
+                                     void* stream) {
+  if (!w || !wp) return EMSA_E_ARG;
+  if (cin < 1 || cin > 4) return EMSA_E_SHAPE;
+  hipLaunchKernelGGL(stem_pack_weight_kernel, dim3(grid_for(7L * cout * 32)), dim3(kThreads), 0,
+                     (hipStream_t)stream, w, wp, cout, cin, 0);
+  return emsa_launch_status();
+}
+extern "C" int emsa_stem_unpack_wgrad(const float* dwp, float* dw, int32_t cout, int32_t cin,
+                                      void* stream) {
+  if (!dwp || !dw) return EMSA_E_ARG;
+  if (cin < 1 || cin > 4) return EMSA_E_SHAPE;
+  hipLaunchKernelGGL(stem_pack_weight_kernel, dim3(grid_for(7L * cout * 32)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dwp, dw, cout, cin, 1);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int64_t count,
+                                const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, float* scale,
+                                float* shift, float* save_mean, float* save_invstd,
+                                void* stream) {
+  if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd)
+    return EMSA_E_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     stats, rows, c, (double)count, gamma, beta, eps, momentum, running_mean,
+                     running_var, scale, shift, save_mean, save_invstd);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_bn_fold(const float* gamma, const float* beta, const float* rm,
+                            const float* rv, float eps, int32_t c, float* scale, float* shift,
+                            float* save_invstd, void* stream) {
+  if (!gamma || !beta || !rm || !rv || !scale || !shift) return EMSA_E_ARG;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     gamma, beta, rm, rv, eps, c, scale, shift, save_invstd);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift,
+                               const float* drop, const float* residual, int32_t n_img,
+                               int64_t hw, int32_t c, int32_t act, void* stream) {
+  if (!x || !y || !scale || !shift) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total4 = (long)n_img * hw * (c / 4);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, scale, shift, drop, residual, (long)hw, c / 4,
+                     total4, act);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_bn_bwd_rows(int64_t pixels) {
+  long r = (pixels + 255) / 256;
+  if (r < 1) r = 1;
+  if (r > 1024) r = 1024;
+  return (int)r;
+}
+
+extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x,
+                                  const float* save_mean, const float* save_invstd,
+                                  const float* drop, int32_t n_img, int64_t hw, int32_t c,
+                                  int32_t act, float* partial, void* stream) {
+  if (!dy || !x || !save_mean || !save_invstd || !partial) return EMSA_E_ARG;
+  if (act == EMSA_ACT_RELU && !y) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long pixels = (long)n_img * hw;
+  const int rows = emsa_bn_bwd_rows(pixels);
+  const int c4n = c / 4, lanes = kThreads / c4n;
+  const size_t lds = (size_t)2 * lanes * c * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
+                     dy, y, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act, rows,
+                     partial);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x,
+                                 const float* gamma, const float* save_mean,
+                                 const float* save_invstd, const float* drop,
+                                 const float* partial, int32_t rows, int32_t n_img, int64_t hw,
+                                 int32_t c, int32_t act, int32_t train, float* dx, float* dres,
+                                 float* dgamma, float* dbeta, void* stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
+    return EMSA_E_ARG;
+  if (act == EMSA_ACT_RELU && !y) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32), dim3(256), 0, st, partial, rows, c,
+                     dbeta, dgamma);
+  const long pixels = (long)n_img * hw;
+  const long total4 = pixels * (c / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads), 0, st, dy, y, x,
+                     gamma, save_mean, save_invstd, drop, dbeta, dgamma, (long)hw, c / 4, total4,
+                     1.0f / (float)pixels, act, train, dx, dres);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, uint32_t seed,
+                                   uint32_t layer_id, void* stream) {
+  if (!mask) return EMSA_E_ARG;
+  hipLaunchKernelGGL(dropout2d_mask_kernel, dim3((n * c + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, mask, n, c, p, seed, layer_id);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_maxpool3x3s2_fwd(const float* x, float* y, int8_t* idx, int32_t n, int32_t h,
+                                     int32_t w, int32_t c, void* stream) {
+  if (!x || !y || !idx) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, idx, n, h, w, c / 4);
+  return emsa_launch_status();
+}
+extern "C" int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t n,
+                                     int32_t h, int32_t w, int32_t c, void* stream) {
+  if (!dy || !dx || !idx) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total = (long)n * h * w * (c / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dy, idx, dx, n, h, w, c / 4);
+  return emsa_launch_status();
+}
+
+static int channel_dot(const float* a, const float* b, float* out, int n, long hw, int c,
+                       float scale, hipStream_t st) {
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  if (hipMemsetAsync(out, 0, (size_t)n * c * sizeof(float), st) != hipSuccess)
+    return EMSA_E_LAUNCH;
+  int splits = (int)((hw + 511) / 512);
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  const int c4n = c / 4, lanes = kThreads / c4n;
+  const size_t lds = (size_t)2 * lanes * c * sizeof(float);
+  hipLaunchKernelGGL(channel_dot_kernel, dim3(n * splits), dim3(kThreads), lds, st, a, b, out, hw,
+                     c4n, splits, scale);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_channel_mean(const float* x, float* gap, int32_t n, int64_t hw, int32_t c,
+                                 void* stream) {
+  if (!x || !gap) return EMSA_E_ARG;
+  return channel_dot(x, nullptr, gap, n, (long)hw, c, 1.0f / (float)hw, (hipStream_t)stream);
+}
+extern "C" int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, int32_t n,
+                                        int64_t hw, int32_t c, void* stream) {
+  if (!dout || !x || !ds) return EMSA_E_ARG;
+  return channel_dot(dout, x, ds, n, (long)hw, c, 1.0f, (hipStream_t)stream);
+}
+
+extern "C" int emsa_se_mlp_fwd(const float* gap, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* hid, float* s, int32_t n,
+                               int32_t c, int32_t cr, void* stream) {
+  if (!gap || !w1 || !b1 || !w2 || !b2 || !hid || !s) return EMSA_E_ARG;
+  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(n), dim3(256), (size_t)(c + cr) * sizeof(float),
+                     (hipStream_t)stream, gap, w1, b1, w2, b2, hid, s, c, cr);
+  return emsa_launch_status();
+}
+extern "C" int emsa_se_mlp_bwd(const float* gap, const float* w1, const float* w2,
+                               const float* hid, const float* s, const float* ds, float* dgap,
+                               float* dw1, float* db1, float* dw2, float* db2, int32_t n,
+                               int32_t c, int32_t cr, void* stream) {
+  if (!gap || !w1 || !w2 || !hid || !s || !ds || !dgap || !dw1 || !db1 || !dw2 || !db2)
+    return EMSA_E_ARG;
+  if ((size_t)n * cr * sizeof(float) > 60000) return EMSA_E_SHAPE;
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(8), dim3(256), (size_t)n * cr * sizeof(float),
+                     (hipStream_t)stream, gap, w1, w2, hid, s, ds, dgap, dw1, db1, dw2, db2, n, c,
+                     cr);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b,
+                                     const float* sb, float* out, int32_t n, int64_t hw,
+                                     int32_t c, void* stream) {
+  if (!a || !sa || !out || ((b == nullptr) != (sb == nullptr))) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total4 = (long)n * hw * (c / 4);
+  hipLaunchKernelGGL(se_scale_add_fwd_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
+                     (hipStream_t)stream, a, sa, b, sb, out, (long)hw, c / 4, total4);
+  return emsa_launch_status();
+}
+extern "C" int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap,
+                                       const float* dx_extra, float* dx, int32_t n, int64_t hw,
+                                       int32_t c, void* stream) {
+  if (!dout || !s || !dgap || !dx) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total4 = (long)n * hw * (c / 4);
+  hipLaunchKernelGGL(se_scale_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dout, s, dgap, dx_extra, dx, (long)hw, c / 4, total4,
+                     1.0f / (float)hw);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias,
+                                   const float* skip, float* y, int32_t n, int32_t h, int32_t w,
+                                   int32_t c, void* stream) {
+  if (!x || !wdw || !y) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total = (long)n * 4 * h * w * (c / 4);
+  hipLaunchKernelGGL(up2x_dw_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, wdw, bias, skip, y, n, h, w, c / 4);
+  return emsa_launch_status();
+}
+extern "C" int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float* dx, int32_t n,
+                                        int32_t h, int32_t w, int32_t c, void* stream) {
+  if (!dy || !wdw || !dx) return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const long total = (long)n * h * w * (c / 4);
+  hipLaunchKernelGGL(up2x_dw_bwd_data_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dy, wdw, dx, n, h, w, c / 4);
+  return emsa_launch_status();
+}
+extern "C" int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db,
+                                          int32_t n, int32_t h, int32_t w, int32_t c,
+                                          void* stream) {
+  if (!dy || !x || !dw || !db) return EMSA_E_ARG;
+  if (!c4_ok(c) || c > 512) return EMSA_E_SHAPE;
+  const long pixels = (long)n * 4 * h * w;
+  int nblocks = (int)((pixels + 511) / 512);
+  if (nblocks > 1024) nblocks = 1024;
+  if (nblocks < 1) nblocks = 1;
+  const int lanes = kThreads / (c / 4);
+  const size_t lds = (size_t)lanes * 10 * c * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_weight_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(up2x_dw_bwd_weight_kernel, dim3(nblocks), dim3(kThreads), lds,
+                     (hipStream_t)stream, dy, x, dw, db, n, h, w, c / 4, nblocks);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_adaptive_avgpool_fwd(const float* x, float* y, int32_t n, int32_t h,
+                                         int32_t w, int32_t c, int32_t bins, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  const long total = (long)n * bins * bins * c;
+  hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, n, h, w, c, bins);
+  return emsa_launch_status();
+}
+extern "C" int emsa_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t n, int32_t h,
+                                         int32_t w, int32_t c, int32_t bins, int32_t accumulate,
+                                         void* stream) {
+  if (!dy || !dx) return EMSA_E_ARG;
+  const long total = (long)n * h * w * c;
+  hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dy, dx, n, h, w, c, bins, accumulate);
+  return emsa_launch_status();
+}
+extern "C" int emsa_bilinear_fwd(const float* x, float* y, int32_t n, int32_t ih, int32_t iw,
+                                 int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  const long total = (long)n * oh * ow * c;
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, n, ih, iw, oh, ow, c, ld_y);
+  return emsa_launch_status();
+}
+extern "C" int emsa_bilinear_bwd(const float* dy, float* dx, int32_t n, int32_t ih, int32_t iw,
+                                 int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
+  if (!dy || !dx) return EMSA_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dx, 0, (size_t)n * ih * iw * c * sizeof(float), st) != hipSuccess)
+    return EMSA_E_LAUNCH;
+  const long total = (long)n * oh * ow * c;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, dy, dx, n,
+                     ih, iw, oh, ow, c, ld_dy);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_head_act_fwd(const float* x, float* y, int64_t pixels, int32_t c,
+                                 int32_t n_sig, int32_t n_tanh, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  const long total = (long)pixels * c;
+  hipLaunchKernelGGL(head_act_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, total, c, n_sig, n_tanh);
+  return emsa_launch_status();
+}
+extern "C" int emsa_head_act_bwd(const float* dy, const float* y, float* dx, int64_t pixels,
+                                 int32_t c, int32_t n_sig, int32_t n_tanh, void* stream) {
+  if (!dy || !y || !dx) return EMSA_E_ARG;
+  const long total = (long)pixels * c;
+  hipLaunchKernelGGL(head_act_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dy, y, dx, total, c, n_sig, n_tanh);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y,
+                                  int64_t pixels, int32_t c, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for((long)pixels * c)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, ld_x, y, ld_y, (long)pixels, c);
+  return emsa_launch_status();
+}
+extern "C" int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)n / 4 + 1)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, (long)n, alpha);
+  return emsa_launch_status();
+}

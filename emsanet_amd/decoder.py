@@ -1,0 +1,256 @@
+# -*- coding: utf-8 -*-
+"""
+Decoders of the EMSANet engine -- mirror of /root/reference/emsanet/decoder.py
+(`get_decoders(args, ...) -> nn.ModuleDict`, `KNOWN_DECODERS`; reference lines 26-48, 201) with
+the decoder classes the reference imports from `nicr_mt_scene_analysis.model.decoder`
+(reference lines 10-23) rebuilt on the HIP operators.
+
+Supported: the 'emsanet' decoder type for the semantic and instance(+orientation) tasks and the
+scene-classification head -- the full multi-task configuration of BASELINE.json.  The
+'segformermlp' decoders, the normal decoder and the eval-time panoptic merge are outside the hot
+path and raise NotImplementedError.
+"""
+from collections import OrderedDict
+from typing import Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .nn import ConvNormAct, LearnedUpsampling, NonBottleneck1D, make_plain_conv_rt, plain_conv
+
+KNOWN_DECODERS = (
+    'emsanet',         # decoder used in EMSANet publication
+    'segformermlp',    # MLP decoder used in SegFormer publication (not on the hot path)
+)
+
+
+class DecoderModule(nn.Module):
+    """conv3x3+BN+ReLU -> n_blocks x NBt1D -> [train: 1x1 side head] -> nearest x2 + DW3x3
+    -> + (1x1 conv+BN+ReLU of the rgb skip)          (figure doc/EMSANet-model.png)."""
+
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, n_side):
+        super().__init__()
+        self.conv3x3 = ConvNormAct(cin, c, 3)
+        self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
+                                      for _ in range(n_blocks)])
+        self.side_output = nn.Conv2d(c, n_side, 1)
+        self.upsampling = LearnedUpsampling(c)
+        self.skip_fusion = ConvNormAct(skip_c, c, 1) if skip_c != c else None
+        self.n_side = n_side
+        self._side_rt = make_plain_conv_rt(self.side_output)
+
+    def forward(self, x, skip):
+        x = self.blocks(self.conv3x3(x))
+        side = plain_conv(self._side_rt, x) if self.training else None   # padded to 4k channels
+        if self.skip_fusion is not None:
+            skip = self.skip_fusion(skip)
+        return self.upsampling(x, skip), side
+
+
+class DecoderBody(nn.Module):
+    def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
+                 fusion_downsamplings, n_side):
+        super().__init__()
+        mods, cin = [], n_channels_in
+        for c, sc in zip(n_channels, fusion_n_channels):
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, n_side))
+            cin = c
+        self.decoder_modules = nn.ModuleList(mods)
+        self.fusion_downsamplings = tuple(fusion_downsamplings)
+        self.side_output_downscales = (32, 16, 8)
+        self.postprocessing = None
+
+    def body(self, x, skips):
+        sides = []
+        for m, ds in zip(self.decoder_modules, self.fusion_downsamplings):
+            x, s = m(x, skips[str(ds)]['rgb'])
+            sides.append(s)
+        return x, tuple(sides)
+
+
+class SemanticHead(nn.Module):
+    def __init__(self, c, n_classes):
+        super().__init__()
+        self.conv = nn.Conv2d(c, n_classes, 3, padding=1)
+        cp = Fn.pad4(n_classes)
+        self.upsampling = nn.Sequential(LearnedUpsampling(n_classes, cp),
+                                        LearnedUpsampling(n_classes, cp))
+        self._rt = make_plain_conv_rt(self.conv)
+
+    def forward(self, x):
+        y = plain_conv(self._rt, x)
+        return self.upsampling[1](self.upsampling[0](y))
+
+
+class SemanticDecoder(DecoderBody):
+    """`SemanticDecoder(...)` of /root/reference/emsanet/decoder.py:63-91."""
+
+    def __init__(self, n_classes, **kw):
+        super().__init__(n_side=n_classes, **kw)
+        self.n_classes = n_classes
+        self.head = SemanticHead(kw['n_channels'][-1], n_classes)
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        x, sides = self.body(x[0], skips)
+        nc = self.n_classes
+        out = self.head(x)[:, :nc]
+        sides = tuple(s[:, :nc] for s in sides) if self.training else ()
+        if not do_postprocessing:
+            return out, sides
+        r = {'semantic_output': out, 'semantic_side_outputs': sides}
+        if not self.training:
+            score, idx = torch.softmax(out, dim=1).max(dim=1)
+            r['semantic_segmentation_score'], r['semantic_segmentation_idx'] = score, idx
+        return r
+
+
+class InstanceHead(nn.Module):
+    """shared_conv 3x3 C->32*T + norm + act; task_convs.{0,1,2} 3x3 32->1/2/2 evaluated as ONE
+    block-diagonal 96->8 convolution; shared DW upsampling x2 x2
+    (/root/reference/emsanet/weights.py:39-56)."""
+
+    def __init__(self, c, with_orientation, n_per_task=32):
+        super().__init__()
+        outs = (1, 2, 2) if with_orientation else (1, 2)
+        self.outs = outs
+        self.n_out = sum(outs)
+        cp = Fn.pad4(self.n_out)
+        self.shared_conv = ConvNormAct(c, n_per_task * len(outs), 3)
+        self.task_convs = nn.ModuleList([nn.Conv2d(n_per_task, o, 3, padding=1) for o in outs])
+        self.upsampling = nn.Sequential(LearnedUpsampling(self.n_out, cp),
+                                        LearnedUpsampling(self.n_out, cp))
+        placements, co = [], 0
+        for i, (conv, o) in enumerate(zip(self.task_convs, outs)):
+            placements.append((conv, co, i * n_per_task))
+            co += o
+        self._rt = ops.MultiConvRT(placements, cp, n_per_task * len(outs), 3, 1)
+
+    def forward(self, x):
+        x = self.shared_conv(x)
+        y = ops.MultiConvFunction.apply(x, self._rt, *self._rt.params())
+        return self.upsampling[1](self.upsampling[0](y))
+
+
+class InstanceDecoder(DecoderBody):
+    """`InstanceDecoder(...)` of /root/reference/emsanet/decoder.py:94-139."""
+
+    def __init__(self, with_orientation, sigmoid_for_center, tanh_for_offset, **kw):
+        self.with_orientation = with_orientation
+        super().__init__(n_side=5 if with_orientation else 3, **kw)
+        self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
+        self.sigmoid_for_center = sigmoid_for_center
+        self.tanh_for_offset = tanh_for_offset
+
+    def _split(self, y):
+        n_sig = 1 if self.sigmoid_for_center else 0
+        n_tanh = 2 if self.tanh_for_offset else 0
+        if n_sig or n_tanh:
+            if n_tanh and not n_sig:
+                raise NotImplementedError("tanh offsets without sigmoid centres")
+            y = ops.HeadActFunction.apply(y, n_sig, n_tanh)
+        center, offset = y[:, 0:1], y[:, 1:3]
+        if not self.with_orientation:
+            return center, offset
+        return center, offset, y[:, 3:5]
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        x, sides = self.body(x[0], skips)
+        out = self._split(self.head(x))
+        sides = tuple(self._split(s) for s in sides) if self.training else ()
+        if not do_postprocessing:
+            return out, sides
+        r = {'instance_output': out, 'instance_side_outputs': sides,
+             'instance_centers': out[0], 'instance_offsets': out[1]}
+        if self.with_orientation:
+            r['instance_orientation'] = out[2]
+        return r
+
+
+class SceneClassificationDecoder(nn.Module):
+    """`SceneClassificationDecoder(...)` of /root/reference/emsanet/decoder.py:191-199."""
+
+    def __init__(self, cin, n_classes):
+        super().__init__()
+        self.head = nn.Linear(cin, n_classes)
+        self.n_classes = n_classes
+        self.side_output_downscales = ()
+        self.postprocessing = None
+        self._rt = ops.MultiConvRT([(self.head, 0, 0)], Fn.pad4(n_classes), cin, 1, 0)
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        feat = x[1][0]                      # GAP branch of the context module (B, C, 1, 1)
+        y = ops.MultiConvFunction.apply(feat, self._rt, *self._rt.params())
+        out = y.flatten(1)[:, :self.n_classes]
+        if not do_postprocessing:
+            return out, ()
+        r = {'scene_output': out}
+        if not self.training:
+            score, idx = torch.softmax(out, dim=1).max(dim=1)
+            r['scene_class_score'], r['scene_class_idx'] = score, idx
+        return r
+
+
+def get_decoders(
+    args,
+    n_channels_in: int,
+    downsampling_in: int,
+    semantic_n_classes: int = 40,
+    instance_normalized_offset: bool = True,
+    instance_offset_distance_threshold: Union[None, int] = None,
+    instance_sigmoid_for_center: bool = True,
+    instance_tanh_for_offset: bool = True,
+    panoptic_semantic_classes_is_thing: Tuple[bool, ...] = (True, )*40,
+    panoptic_has_orientation: Tuple[bool, ...] = (True, )*40,
+    normal_n_channels_out: int = 3,
+    scene_n_channels_in: int = 512//2,
+    scene_n_classes: int = 10,
+    fusion_n_channels: Tuple[int, ...] = (512, 256, 128),
+    **kwargs
+) -> nn.ModuleDict:
+    """Same signature and defaults as /root/reference/emsanet/decoder.py:32-48."""
+    fusion_downsamplings = tuple(args.encoder_decoder_skip_downsamplings)[::-1]
+    if getattr(args, 'decoder_normalization', 'batchnorm') not in ('batchnorm', 'bn'):
+        raise NotImplementedError("only batchnorm decoders")
+    for a in ('upsampling_prediction', 'semantic_decoder_upsampling',
+              'instance_decoder_upsampling'):
+        if getattr(args, a, 'learned-3x3-zeropad') != 'learned-3x3-zeropad':
+            raise NotImplementedError(f"{a}={getattr(args, a)} (only learned-3x3-zeropad)")
+
+    decoders = OrderedDict()
+    if 'semantic' in args.tasks:
+        if args.semantic_decoder.lower() != 'emsanet':
+            raise NotImplementedError(f"semantic decoder '{args.semantic_decoder}'")
+        if args.semantic_encoder_decoder_fusion != 'add-rgb':
+            raise NotImplementedError(args.semantic_encoder_decoder_fusion)
+        decoders['semantic_decoder'] = SemanticDecoder(
+            n_classes=semantic_n_classes, n_channels_in=n_channels_in,
+            n_channels=tuple(args.semantic_decoder_n_channels),
+            n_blocks=args.semantic_decoder_n_blocks,
+            dropout_p=args.semantic_decoder_block_dropout_p,
+            fusion_n_channels=tuple(fusion_n_channels),
+            fusion_downsamplings=fusion_downsamplings)
+    if 'instance' in args.tasks:
+        if args.instance_decoder.lower() != 'emsanet':
+            raise NotImplementedError(f"instance decoder '{args.instance_decoder}'")
+        if args.instance_encoder_decoder_fusion != 'add-rgb':
+            raise NotImplementedError(args.instance_encoder_decoder_fusion)
+        decoders['instance_decoder'] = InstanceDecoder(
+            with_orientation='orientation' in args.tasks,
+            sigmoid_for_center=instance_sigmoid_for_center,
+            tanh_for_offset=instance_tanh_for_offset,
+            n_channels_in=n_channels_in,
+            n_channels=tuple(args.instance_decoder_n_channels),
+            n_blocks=args.instance_decoder_n_blocks,
+            dropout_p=args.instance_decoder_block_dropout_p,
+            fusion_n_channels=tuple(fusion_n_channels),
+            fusion_downsamplings=fusion_downsamplings)
+    if getattr(args, 'enable_panoptic', False):
+        raise NotImplementedError("PanopticHelper (eval-time merge) is a 'next' row, SURVEY §8f")
+    if 'normal' in args.tasks:
+        raise NotImplementedError("normal decoder is not part of the BASELINE.json configs")
+    if 'scene' in args.tasks:
+        decoders['scene_decoder'] = SceneClassificationDecoder(scene_n_channels_in,
+                                                               scene_n_classes)
+    return nn.ModuleDict(decoders)

@@ -1,0 +1,500 @@
+# -*- coding: utf-8 -*-
+"""
+Raw (no autograd) host wrappers around the C-ABI of libemsanet_hip.so.
+
+Tensor convention: an activation is a torch tensor of logical shape (N, C, H, W) whose memory is
+NHWC (torch "channels_last"), possibly a channel slice of a wider NHWC buffer (pixel stride
+`ld` >= C).  torch is used here for device memory and the current stream only; every byte of
+arithmetic happens in the HIP kernels.
+"""
+import torch
+
+from . import _lib
+from ._lib import EmsaConvGeom, check
+
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def act_empty(n, c, h, w, device, ld=None):
+    """(N,C,H,W) view over fresh NHWC memory (optionally a slice of an ld-wide buffer)."""
+    if ld is None or ld == c:
+        return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+    return torch.empty((n, h, w, ld), device=device, dtype=torch.float32)[..., :c].permute(0, 3, 1, 2)
+
+
+def act_zeros(n, c, h, w, device):
+    return torch.zeros((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def ld_of(t):
+    """pixel stride of an NHWC activation (validates the layout)."""
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    ld = sw if w > 1 else (sh // w if h > 1 else (sn // (h * w) if n > 1 else c))
+    if c > 1 and sc != 1:
+        raise _lib.EmsaError(f"activation is not NHWC: shape {tuple(t.shape)} stride {t.stride()}")
+    if (w > 1 and sw != ld) or (h > 1 and sh != w * ld) or (n > 1 and sn != h * w * ld) or ld < c:
+        raise _lib.EmsaError(f"activation is not NHWC: shape {tuple(t.shape)} stride {t.stride()}")
+    return ld
+
+
+def to_nhwc(t):
+    """Boundary helper: accept any layout of a logical NCHW tensor, return dense NHWC memory."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    n, c, h, w = t.shape
+    try:
+        if ld_of(t) == c:
+            return t
+    except _lib.EmsaError:
+        pass
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def as_act(t, dense=False):
+    """t itself when it already is an NHWC activation (dense if requested), else a dense copy."""
+    if t.dtype == torch.float32:
+        try:
+            ld = ld_of(t)
+            if not dense or ld == t.shape[1]:
+                return t
+        except _lib.EmsaError:
+            pass
+    return to_nhwc(t)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class ConvSpec:
+    """Geometry of one nn.Conv2d (OIHW parameter of shape [cout, cin, kh, kw])."""
+
+    __slots__ = ('cin', 'cout', 'kh', 'kw', 'sh', 'sw', 'ph', 'pw', '_geoms')
+
+    def __init__(self, cin, cout, kernel, stride=1, padding=0):
+        self.cin, self.cout = cin, cout
+        self.kh, self.kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+        self.sh, self.sw = (stride, stride) if isinstance(stride, int) else stride
+        self.ph, self.pw = (padding, padding) if isinstance(padding, int) else padding
+        self._geoms = {}
+
+    def out_hw(self, h, w):
+        return ((h + 2 * self.ph - self.kh) // self.sh + 1,
+                (w + 2 * self.pw - self.kw) // self.sw + 1)
+
+    def geom_fwd(self, n, h, w, ld_in, ld_out):
+        key = ('f', n, h, w, ld_in, ld_out)
+        g = self._geoms.get(key)
+        if g is None:
+            oh, ow = self.out_hw(h, w)
+            g = EmsaConvGeom(n, h, w, oh, ow, self.cin, self.cout, self.kh, self.kw,
+                             self.sh, -self.ph, 1, 1, self.sw, -self.pw, 1, 1,
+                             h * w * ld_in, w * ld_in, ld_in, ld_out)
+            self._geoms[key] = g
+        return g
+
+    def geom_dgrad(self, n, h, w, ld_dy, ld_dx):
+        """h, w = input (dx) size; gathers from dy (out_hw) with the transposed index map."""
+        key = ('d', n, h, w, ld_dy, ld_dx)
+        g = self._geoms.get(key)
+        if g is None:
+            oh, ow = self.out_hw(h, w)
+            g = EmsaConvGeom(n, oh, ow, h, w, self.cout, self.cin, self.kh, self.kw,
+                             1, self.ph, -1, self.sh, 1, self.pw, -1, self.sw,
+                             oh * ow * ld_dy, ow * ld_dy, ld_dy, ld_dx)
+            self._geoms[key] = g
+        return g
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+# ---------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------
+def pack_weight(w, mode, cout_total=None, cout_off=0, cin_total=None, cin_off=0, out=None):
+    """mode 'fwd' -> [tap][cout_total][cin_total]; 'dgrad' -> [tap][cin_total][cout_total]."""
+    cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+    cout_total = cout_total or cout
+    cin_total = cin_total or cin
+    if out is None:
+        if cout_total != cout or cin_total != cin:
+            out = torch.zeros(kh * kw * cout_total * cin_total, device=w.device, dtype=torch.float32)
+        else:
+            out = torch.empty(kh * kw * cout_total * cin_total, device=w.device, dtype=torch.float32)
+    fn = _lib.lib().emsa_pack_weight_fwd if mode == 'fwd' else _lib.lib().emsa_pack_weight_dgrad
+    check(fn(_p(w), _p(out), cout, cin, kh, kw, cout_total, cout_off, cin_total, cin_off,
+             _stream()), 'emsa_pack_weight_' + mode)
+    return out
+
+
+def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off=0):
+    cout, cin, kh, kw = like.shape if like.dim() == 4 else (like.shape[0], like.shape[1], 1, 1)
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    check(_lib.lib().emsa_unpack_wgrad(_p(dwp), _p(dw), cout, cin, kh, kw, cout_total or cout,
+                                       cout_off, cin_total or cin, cin_off, _stream()),
+          'emsa_unpack_wgrad')
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------
+def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
+             act=ACT_NONE, out=None):
+    n, c, h, w = x.shape
+    oh, ow = spec.out_hw(h, w)
+    if out is None:
+        out = act_empty(n, spec.cout, oh, ow, x.device)
+    g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(out))
+    L = _lib.lib()
+    stats = None
+    if want_stats:
+        rows = L.emsa_conv_stats_rows(g)
+        if rows <= 0:
+            check(rows or -1, 'emsa_conv_stats_rows')
+        stats = torch.empty((2, rows, spec.cout), device=x.device, dtype=torch.float32)
+    check(L.emsa_conv_igemm(g, _p(x), _p(wp), _p(out), _p(bias), _p(stats), _p(scale), _p(shift),
+                            _p(residual), ld_of(residual) if residual is not None else 0,
+                            None, 0, act, _stream()), 'emsa_conv_igemm')
+    return (out, stats) if want_stats else out
+
+
+def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None):
+    """dx = conv_transpose(dy); optional fused `* (mask_src > 0)` and `+ residual`."""
+    n = dy.shape[0]
+    h, w = in_hw
+    if out is None:
+        out = act_empty(n, spec.cin, h, w, dy.device)
+    g = spec.geom_dgrad(n, h, w, ld_of(dy), ld_of(out))
+    check(_lib.lib().emsa_conv_igemm(
+        g, _p(dy), _p(wpd), _p(out), None, None, None, None,
+        _p(residual), ld_of(residual) if residual is not None else 0,
+        _p(mask_src), ld_of(mask_src) if mask_src is not None else 0, ACT_NONE, _stream()),
+        'emsa_conv_igemm(dgrad)')
+    return out
+
+
+def conv_wgrad(x, dy, spec, want_bias):
+    """returns (dw packed [tap][cout][cin], dbias or None)"""
+    n, c, h, w = x.shape
+    g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(dy))
+    taps = spec.kh * spec.kw
+    dwp = torch.zeros(taps * spec.cout * spec.cin, device=x.device, dtype=torch.float32)
+    db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+    check(_lib.lib().emsa_conv_wgrad(g, _p(x), _p(dy), _p(dwp), _p(db), _stream()),
+          'emsa_conv_wgrad')
+    return dwp, db
+
+
+# ---------------------------------------------------------------------------------------------
+# stem (7x7 s2 p3 on NCHW input)
+# ---------------------------------------------------------------------------------------------
+class StemSpec:
+    """7x7/2 conv expressed as a 7x1 conv over the zero-padded NHWC4 image (k_ch = 32)."""
+
+    def __init__(self, cin, cout=64):
+        self.cin, self.cout = cin, cout
+        self._geoms = {}
+
+    def out_hw(self, h, w):
+        return (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+
+    def geom(self, n, h, w, ld_out):
+        key = (n, h, w, ld_out)
+        g = self._geoms.get(key)
+        if g is None:
+            oh, ow = self.out_hw(h, w)
+            wp = w + 8
+            g = EmsaConvGeom(n, h, wp, oh, ow, 32, self.cout, 7, 1,
+                             2, -3, 1, 1, 2, 0, 1, 1,
+                             h * wp * 4, wp * 4, 4, ld_out)
+            self._geoms[key] = g
+        return g
+
+
+def stem_pack_input(x_nchw):
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    xp = torch.empty((n, h, w + 8, 4), device=x.device, dtype=torch.float32)
+    check(_lib.lib().emsa_stem_pack_input(_p(x), _p(xp), n, c, h, w, _stream()),
+          'emsa_stem_pack_input')
+    return xp
+
+
+def stem_pack_weight(w):
+    cout, cin = w.shape[:2]
+    wp = torch.empty(7 * cout * 32, device=w.device, dtype=torch.float32)
+    check(_lib.lib().emsa_stem_pack_weight(_p(w), _p(wp), cout, cin, _stream()),
+          'emsa_stem_pack_weight')
+    return wp
+
+
+def stem_fwd(xp, wpk, spec, n, h, w, want_stats=True):
+    oh, ow = spec.out_hw(h, w)
+    out = act_empty(n, spec.cout, oh, ow, xp.device)
+    g = spec.geom(n, h, w, spec.cout)
+    L = _lib.lib()
+    stats = None
+    if want_stats:
+        rows = L.emsa_conv_stats_rows(g)
+        stats = torch.empty((2, rows, spec.cout), device=xp.device, dtype=torch.float32)
+    check(L.emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), None, _p(stats), None, None, None, 0,
+                            None, 0, ACT_NONE, _stream()), 'emsa_conv_igemm(stem)')
+    return out, stats
+
+
+def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift):
+    oh, ow = spec.out_hw(h, w)
+    out = act_empty(n, spec.cout, oh, ow, xp.device)
+    g = spec.geom(n, h, w, spec.cout)
+    check(_lib.lib().emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), None, None, _p(scale), _p(shift),
+                                     None, 0, None, 0, ACT_RELU, _stream()),
+          'emsa_conv_igemm(stem)')
+    return out
+
+
+def stem_wgrad(xp, dy, spec, n, h, w, like):
+    g = spec.geom(n, h, w, ld_of(dy))
+    dwp = torch.zeros(7 * spec.cout * 32, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), None, _stream()),
+          'emsa_conv_wgrad(stem)')
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
+          'emsa_stem_unpack_wgrad')
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# batch norm
+# ---------------------------------------------------------------------------------------------
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+    c = gamma.shape[0]
+    buf = torch.empty((4, c), device=gamma.device, dtype=torch.float32)
+    check(_lib.lib().emsa_bn_finalize(_p(stats), stats.shape[1], c, count, _p(gamma), _p(beta),
+                                      eps, momentum, _p(running_mean), _p(running_var),
+                                      _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream()),
+          'emsa_bn_finalize')
+    return buf[0], buf[1], buf[2], buf[3]      # scale, shift, mean, invstd
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps):
+    c = gamma.shape[0]
+    buf = torch.empty((3, c), device=gamma.device, dtype=torch.float32)
+    check(_lib.lib().emsa_bn_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, c,
+                                  _p(buf[0]), _p(buf[1]), _p(buf[2]), _stream()), 'emsa_bn_fold')
+    return buf[0], buf[1], buf[2]               # scale, shift, invstd
+
+
+def bn_act(x, scale, shift, drop=None, residual=None, act=ACT_NONE):
+    n, c, h, w = x.shape
+    assert ld_of(x) == c and (residual is None or ld_of(residual) == c)
+    y = act_empty(n, c, h, w, x.device)
+    check(_lib.lib().emsa_bn_act_fwd(_p(x), _p(y), _p(scale), _p(shift), _p(drop), _p(residual),
+                                     n, h * w, c, act, _stream()), 'emsa_bn_act_fwd')
+    return y
+
+
+def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
+    """returns dx, dres (or None), dgamma, dbeta"""
+    n, c, h, w = x.shape
+    assert ld_of(x) == c and ld_of(dy) == c
+    L = _lib.lib()
+    rows = L.emsa_bn_bwd_rows(n * h * w)
+    partial = torch.empty((2, rows, c), device=x.device, dtype=torch.float32)
+    check(L.emsa_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(drop), n, h * w, c,
+                               act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
+    dx = act_empty(n, c, h, w, x.device)
+    dres = act_empty(n, c, h, w, x.device) if want_dres else None
+    dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+    check(L.emsa_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(gamma), _p(mean), _p(invstd), _p(drop),
+                              _p(partial), rows, n, h * w, c, act, 1 if train else 0, _p(dx),
+                              _p(dres), _p(dgb[0]), _p(dgb[1]), _stream()), 'emsa_bn_bwd_apply')
+    return dx, dres, dgb[0], dgb[1]
+
+
+def dropout2d_mask(n, c, p, seed, layer_id, device):
+    m = torch.empty((n, c), device=device, dtype=torch.float32)
+    check(_lib.lib().emsa_dropout2d_mask(_p(m), n, c, p, seed & 0xFFFFFFFF, layer_id, _stream()),
+          'emsa_dropout2d_mask')
+    return m
+
+
+# ---------------------------------------------------------------------------------------------
+# pooling / SE / upsampling / PPM / heads
+# ---------------------------------------------------------------------------------------------
+def maxpool_fwd(x):
+    n, c, h, w = x.shape
+    assert ld_of(x) == c
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    y = act_empty(n, c, oh, ow, x.device)
+    idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.int8)
+    check(_lib.lib().emsa_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()),
+          'emsa_maxpool3x3s2_fwd')
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_hw):
+    n, c = dy.shape[:2]
+    h, w = in_hw
+    assert ld_of(dy) == c
+    dx = act_empty(n, c, h, w, dy.device)
+    check(_lib.lib().emsa_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, _stream()),
+          'emsa_maxpool3x3s2_bwd')
+    return dx
+
+
+def channel_mean(x):
+    n, c, h, w = x.shape
+    assert ld_of(x) == c
+    gap = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    check(_lib.lib().emsa_channel_mean(_p(x), _p(gap), n, h * w, c, _stream()),
+          'emsa_channel_mean')
+    return gap
+
+
+def se_mlp_fwd(gap, w1, b1, w2, b2):
+    n, c = gap.shape
+    cr = w1.shape[0]
+    hid = torch.empty((n, cr), device=gap.device, dtype=torch.float32)
+    s = torch.empty((n, c), device=gap.device, dtype=torch.float32)
+    check(_lib.lib().emsa_se_mlp_fwd(_p(gap), _p(w1), _p(b1), _p(w2), _p(b2), _p(hid), _p(s), n, c,
+                                     cr, _stream()), 'emsa_se_mlp_fwd')
+    return hid, s
+
+
+def se_mlp_bwd(gap, w1, w2, hid, s, ds):
+    n, c = gap.shape
+    cr = w1.shape[0]
+    dev = gap.device
+    dgap = torch.empty((n, c), device=dev, dtype=torch.float32)
+    dw1 = torch.empty((cr, c), device=dev, dtype=torch.float32)
+    db1 = torch.empty((cr,), device=dev, dtype=torch.float32)
+    dw2 = torch.empty((c, cr), device=dev, dtype=torch.float32)
+    db2 = torch.empty((c,), device=dev, dtype=torch.float32)
+    check(_lib.lib().emsa_se_mlp_bwd(_p(gap), _p(w1), _p(w2), _p(hid), _p(s), _p(ds), _p(dgap),
+                                     _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, _stream()),
+          'emsa_se_mlp_bwd')
+    return dgap, dw1, db1, dw2, db2
+
+
+def se_scale_add(a, sa, b=None, sb=None):
+    n, c, h, w = a.shape
+    out = act_empty(n, c, h, w, a.device)
+    check(_lib.lib().emsa_se_scale_add_fwd(_p(a), _p(sa), _p(b), _p(sb), _p(out), n, h * w, c,
+                                           _stream()), 'emsa_se_scale_add_fwd')
+    return out
+
+
+def se_scale_bwd_reduce(dout, x):
+    n, c, h, w = x.shape
+    ds = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    check(_lib.lib().emsa_se_scale_bwd_reduce(_p(dout), _p(x), _p(ds), n, h * w, c, _stream()),
+          'emsa_se_scale_bwd_reduce')
+    return ds
+
+
+def se_scale_bwd_apply(dout, s, dgap, extra=None):
+    n, c, h, w = dout.shape
+    dx = act_empty(n, c, h, w, dout.device)
+    check(_lib.lib().emsa_se_scale_bwd_apply(_p(dout), _p(s), _p(dgap), _p(extra), _p(dx), n,
+                                             h * w, c, _stream()), 'emsa_se_scale_bwd_apply')
+    return dx
+
+
+def up2x_dw_fwd(x, wdw, bias, skip=None):
+    n, c, h, w = x.shape
+    assert ld_of(x) == c and (skip is None or ld_of(skip) == c)
+    y = act_empty(n, c, 2 * h, 2 * w, x.device)
+    check(_lib.lib().emsa_up2x_dw3x3_fwd(_p(x), _p(wdw), _p(bias), _p(skip), _p(y), n, h, w, c,
+                                         _stream()), 'emsa_up2x_dw3x3_fwd')
+    return y
+
+
+def up2x_dw_bwd(dy, x, wdw, need_dx=True):
+    n, c, h, w = x.shape
+    assert ld_of(dy) == c
+    L = _lib.lib()
+    dx = None
+    if need_dx:
+        dx = act_empty(n, c, h, w, x.device)
+        check(L.emsa_up2x_dw3x3_bwd_data(_p(dy), _p(wdw), _p(dx), n, h, w, c, _stream()),
+              'emsa_up2x_dw3x3_bwd_data')
+    dwb = torch.zeros(c * 10, device=x.device, dtype=torch.float32)
+    dw, db = dwb[:c * 9], dwb[c * 9:]
+    check(L.emsa_up2x_dw3x3_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), n, h, w, c, _stream()),
+          'emsa_up2x_dw3x3_bwd_weight')
+    return dx, dw, db
+
+
+def adaptive_avgpool_fwd(x, bins):
+    n, c, h, w = x.shape
+    assert ld_of(x) == c
+    y = act_empty(n, c, bins, bins, x.device)
+    check(_lib.lib().emsa_adaptive_avgpool_fwd(_p(x), _p(y), n, h, w, c, bins, _stream()),
+          'emsa_adaptive_avgpool_fwd')
+    return y
+
+
+def adaptive_avgpool_bwd(dy, dx, bins, accumulate):
+    n, c, h, w = dx.shape
+    check(_lib.lib().emsa_adaptive_avgpool_bwd(_p(dy), _p(dx), n, h, w, c, bins,
+                                               1 if accumulate else 0, _stream()),
+          'emsa_adaptive_avgpool_bwd')
+    return dx
+
+
+def bilinear_fwd(x, out):
+    """x (N,C,ih,iw) dense -> out (N,C,oh,ow) possibly a channel slice"""
+    n, c, ih, iw = x.shape
+    oh, ow = out.shape[2:]
+    assert ld_of(x) == c
+    check(_lib.lib().emsa_bilinear_fwd(_p(x), _p(out), n, ih, iw, oh, ow, c, ld_of(out),
+                                       _stream()), 'emsa_bilinear_fwd')
+    return out
+
+
+def bilinear_bwd(dy, in_hw):
+    n, c, oh, ow = dy.shape
+    ih, iw = in_hw
+    dx = act_empty(n, c, ih, iw, dy.device)
+    check(_lib.lib().emsa_bilinear_bwd(_p(dy), _p(dx), n, ih, iw, oh, ow, c, ld_of(dy),
+                                       _stream()), 'emsa_bilinear_bwd')
+    return dx
+
+
+def head_act_fwd(x, n_sig, n_tanh):
+    n, c, h, w = x.shape
+    assert ld_of(x) == c
+    y = act_empty(n, c, h, w, x.device)
+    check(_lib.lib().emsa_head_act_fwd(_p(x), _p(y), n * h * w, c, n_sig, n_tanh, _stream()),
+          'emsa_head_act_fwd')
+    return y
+
+
+def head_act_bwd(dy, y, n_sig, n_tanh):
+    n, c, h, w = y.shape
+    assert ld_of(dy) == c
+    dx = act_empty(n, c, h, w, y.device)
+    check(_lib.lib().emsa_head_act_bwd(_p(dy), _p(y), _p(dx), n * h * w, c, n_sig, n_tanh,
+                                       _stream()), 'emsa_head_act_bwd')
+    return dx
+
+
+def copy_channels(src, dst):
+    """copy an activation (possibly a channel slice) into another (possibly a slice)."""
+    n, c, h, w = src.shape
+    check(_lib.lib().emsa_copy_channels(_p(src), ld_of(src), _p(dst), ld_of(dst), n * h * w, c,
+                                        _stream()), 'emsa_copy_channels')
+    return dst
+
+
+def axpy_(y, x, alpha=1.0):
+    check(_lib.lib().emsa_axpy(_p(x), _p(y), y.numel(), alpha, _stream()), 'emsa_axpy')
+    return y

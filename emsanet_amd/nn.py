@@ -1,0 +1,246 @@
+# -*- coding: utf-8 -*-
+"""
+nn.Module building blocks of the EMSANet engine.
+
+torch's nn.Conv2d / nn.BatchNorm2d / nn.Linear objects are used ONLY as parameter and buffer
+containers (so that `state_dict()` has the reference's OIHW shapes and BatchNorm buffers and
+`load_state_dict(strict=True)` of a reference checkpoint layout works, /root/reference/emsanet/
+weights.py:162); their `forward` is never called -- every module's forward dispatches to the
+fused HIP operators in `emsanet_amd/ops.py`.
+
+The modules stand in for `nicr_mt_scene_analysis.model.*` v0.3.1 as composed by
+/root/reference/emsanet/model.py:47-160 and /root/reference/emsanet/decoder.py:61-199 (the
+library itself is an un-vendored submodule; structure per SURVEY.md App. A, micro-details tagged
+[U] there are the constants of `Spec`).
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import ops
+from .functional import ACT_NONE, ACT_RELU
+
+
+class Spec:
+    """[U] constants of SURVEY.md App. A (same values as the oracle's Spec)."""
+    BLOCK_BN_EPS = 1e-3
+    DEFAULT_BN_EPS = 1e-5
+    BN_MOMENTUM = 0.1
+    SE_REDUCTION = 16
+    PPM_BINS = (1, 5)
+    RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
+                     'resnet101': (3, 4, 23, 3)}
+
+
+def _fast_eval(module):
+    """eval-mode, no autograd graph wanted -> folded-BatchNorm fast path."""
+    return (not module.training) and (not torch.is_grad_enabled())
+
+
+class ConvNormAct(nn.Module):
+    """conv (no bias) + BatchNorm + optional ReLU; children named 'conv' / 'norm'."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, act=True, eps=Spec.DEFAULT_BN_EPS):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=kernel_size // 2,
+                              bias=False)
+        self.norm = nn.BatchNorm2d(cout, eps=eps, momentum=Spec.BN_MOMENTUM)
+        self.act = ACT_RELU if act else ACT_NONE
+        self._crt, self._brt = ops.ConvRT(self.conv), ops.BNRT(self.norm)
+
+    def forward(self, x):
+        if _fast_eval(self):
+            return ops.conv_bn_act_eval(Fn.as_act(x), self._crt, self._brt, self.act)
+        return ops.ConvBNActFunction.apply(x, self._crt, self._brt, self.act, self.conv.weight,
+                                           self.norm.weight, self.norm.bias)
+
+
+class Dropout2dHash(nn.Module):
+    """Dropout2d with the counter-based channel mask shared with the oracle."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = float(p)
+        self.layer_id = -1
+        self.seed_fn = lambda: 0
+
+    def mask(self, n, c, device):
+        if not self.training or self.p == 0.0:
+            return None
+        return Fn.dropout2d_mask(n, c, self.p, self.seed_fn(), self.layer_id, device)
+
+
+class NonBottleneck1D(nn.Module):
+    def __init__(self, cin, cout, stride=1, dropout_p=0.0):
+        super().__init__()
+        self.conv3x1_1 = nn.Conv2d(cin, cout, (3, 1), stride=(stride, 1), padding=(1, 0))
+        self.conv1x3_1 = nn.Conv2d(cout, cout, (1, 3), stride=(1, stride), padding=(0, 1))
+        self.bn1 = nn.BatchNorm2d(cout, eps=Spec.BLOCK_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        self.conv3x1_2 = nn.Conv2d(cout, cout, (3, 1), padding=(1, 0))
+        self.conv1x3_2 = nn.Conv2d(cout, cout, (1, 3), padding=(0, 1))
+        self.bn2 = nn.BatchNorm2d(cout, eps=Spec.BLOCK_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        self.dropout = Dropout2dHash(dropout_p)
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(cout, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM))
+        else:
+            self.downsample = None
+        self._rt = ops.NBt1DRT(self)
+
+    def forward(self, x):
+        if _fast_eval(self):
+            return ops.nbt1d_eval(Fn.as_act(x, dense=True), self._rt)
+        drop = self.dropout.mask(x.shape[0], self.conv1x3_2.out_channels, x.device)
+        return ops.NBt1DFunction.apply(x, self._rt, drop, *self._rt.params())
+
+
+class ResNetNBt1D(nn.Module):
+    """ResNet-18/34/101 layout with NonBottleneck1D blocks (expansion 1)."""
+
+    def __init__(self, name, n_input_channels, dropout_p):
+        super().__init__()
+        if name not in Spec.RESNET_LAYERS:
+            raise NotImplementedError(f"backbone '{name}' (only NBt1D ResNet-18/34/101)")
+        layers = Spec.RESNET_LAYERS[name]
+        self.conv1 = nn.Conv2d(n_input_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        cin = 64
+        for i, (c, n) in enumerate(zip((64, 128, 256, 512), layers)):
+            blocks = []
+            for j in range(n):
+                blocks.append(NonBottleneck1D(cin, c, stride=2 if (i > 0 and j == 0) else 1,
+                                              dropout_p=dropout_p))
+                cin = c
+            setattr(self, f'layer{i + 1}', nn.Sequential(*blocks))
+        self.stage_channels = (64, 64, 128, 256, 512)
+        self.stage_downsamplings = (2, 4, 8, 16, 32)
+        self._stem = ops.StemRT(self.conv1, self.bn1)
+
+    def forward_stage(self, i, x):
+        if i == 0:
+            if _fast_eval(self):
+                return ops.stem_eval(x, self._stem)
+            return ops.StemFunction.apply(x, self._stem, self.conv1.weight, self.bn1.weight,
+                                          self.bn1.bias)
+        if i == 1:
+            x = ops.MaxPoolFunction.apply(x)
+        return getattr(self, f'layer{i}')(x)
+
+
+class SqueezeAndExcitation(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Conv2d(c, c // Spec.SE_REDUCTION, 1), nn.ReLU(),
+                                nn.Conv2d(c // Spec.SE_REDUCTION, c, 1), nn.Sigmoid())
+
+
+class SEAddUniRGB(nn.Module):
+    """'se-add-uni-rgb' (/root/reference/emsanet/args.py:143-147)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.se_rgb = SqueezeAndExcitation(c)
+        self.se_depth = SqueezeAndExcitation(c)
+
+    def forward(self, rgb, depth):
+        ps = ops._se_params(self.se_rgb) + ops._se_params(self.se_depth)
+        return ops.SEAddFunction.apply(rgb, depth, *ps), depth
+
+
+class FusedEncoder(nn.Module):
+    """dual ResNet-NBt1D with SE-add fusion after the stem and after every layer
+    (`get_encoder(...)`, /root/reference/emsanet/model.py:95-106)."""
+
+    def __init__(self, backbone_rgb, backbone_depth, fusion, skip_downsamplings):
+        super().__init__()
+        self.backbone_rgb = backbone_rgb
+        self.backbone_depth = backbone_depth
+        bb = backbone_rgb if backbone_rgb is not None else backbone_depth
+        self.two = backbone_rgb is not None and backbone_depth is not None
+        if self.two:
+            if fusion != 'se-add-uni-rgb':
+                raise NotImplementedError(f"encoder fusion '{fusion}'")
+            self.fusion_modules = nn.ModuleList([SEAddUniRGB(c) for c in bb.stage_channels])
+        self.skip_downsamplings = tuple(skip_downsamplings)
+        self.downsampling = 32
+        self.n_channels_out = 512
+        ch = dict(zip(bb.stage_downsamplings, bb.stage_channels))
+        self.skips_n_channels = tuple(ch[d] for d in self.skip_downsamplings)
+
+    def forward(self, inputs):
+        rgb, depth = inputs.get('rgb'), inputs.get('depth')
+        skips = {}
+        bb = self.backbone_rgb if self.backbone_rgb is not None else self.backbone_depth
+        for i, ds in enumerate(bb.stage_downsamplings):
+            if rgb is not None:
+                rgb = self.backbone_rgb.forward_stage(i, rgb)
+            if depth is not None:
+                depth = self.backbone_depth.forward_stage(i, depth)
+            if self.two:
+                rgb, depth = self.fusion_modules[i](rgb, depth)
+            if ds in self.skip_downsamplings:
+                skips[str(ds)] = {k: v for k, v in (('rgb', rgb), ('depth', depth))
+                                  if v is not None}
+        outs = {k: v for k, v in (('rgb', rgb), ('depth', depth)) if v is not None}
+        return outs, skips
+
+
+class PyramidPoolingModule(nn.Module):
+    """'ppm' context module (/root/reference/emsanet/args.py:243-256)."""
+
+    def __init__(self, cin, cout, input_size):
+        super().__init__()
+        bins = Spec.PPM_BINS
+        self.bins = bins
+        self.n_channels_reduction = cin // len(bins)
+        # child layout mirrors nn.Sequential(AdaptiveAvgPool2d, ConvNormAct): index '1' is the conv
+        self.features = nn.ModuleList([
+            nn.Sequential(nn.Identity(), ConvNormAct(cin, self.n_channels_reduction, 1))
+            for _ in bins])
+        self.final_conv = ConvNormAct(cin + self.n_channels_reduction * len(bins), cout, 1)
+
+    def forward(self, x):
+        feats = []
+        for b, f in zip(self.bins, self.features):
+            feats.append(f[1](ops.AdaptiveAvgPoolFunction.apply(x, b)))
+        cat = ops.PPMConcatFunction.apply(x, *feats)
+        return self.final_conv(cat), tuple(feats)
+
+
+class LearnedUpsampling(nn.Module):
+    """'learned-3x3-zeropad' (/root/reference/emsanet/args.py:290-298); `c_pad` >= c is the
+    channel count of the (zero padded) tensor the kernel runs on."""
+
+    def __init__(self, c, c_pad=None):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1, groups=c, bias=True)
+        w = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.
+        with torch.no_grad():
+            self.conv.weight.copy_(w.expand(c, 1, 3, 3))
+            self.conv.bias.zero_()
+        self.c, self.c_pad = c, c_pad or c
+
+    def _padded(self):
+        w, b = self.conv.weight, self.conv.bias
+        if self.c_pad != self.c:
+            # parameter-sized glue (a few hundred floats); autograd routes the slice back
+            w = torch.cat([w, w.new_zeros(self.c_pad - self.c, 1, 3, 3)], 0)
+            b = torch.cat([b, b.new_zeros(self.c_pad - self.c)], 0)
+        return w, b
+
+    def forward(self, x, skip=None):
+        w, b = self._padded()
+        return ops.UpsampleDWFunction.apply(x, w, b, skip)
+
+
+def make_plain_conv_rt(conv):
+    """runtime for an nn.Conv2d (+bias) evaluated by the MFMA kernel with its output channels
+    zero-padded to a multiple of 4; `plain_conv` returns the PADDED tensor (callers slice)."""
+    k = conv.kernel_size[0]
+    return ops.MultiConvRT([(conv, 0, 0)], Fn.pad4(conv.out_channels), conv.in_channels, k,
+                           conv.padding[0])
+
+
+def plain_conv(rt, x):
+    return ops.MultiConvFunction.apply(x, rt, *rt.params())

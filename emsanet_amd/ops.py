@@ -1,0 +1,537 @@
+# -*- coding: utf-8 -*-
+"""
+Fused forward/backward operators of the EMSANet engine as torch.autograd.Functions.
+
+Granularity follows the fusion plan of DESIGN.md, not the reference's module list: one Function
+per NonBottleneck1D block (4 MFMA convs + 2 BatchNorms + Dropout2d + residual, hand-written
+backward with the ReLU masks and the residual add fused into the data-gradient epilogues), one
+per conv+BN+act, per SE fusion, per learned upsampling ...  Every Function only sequences calls
+into libemsanet_hip.so (emsanet_amd/functional.py); autograd is used for graph bookkeeping only.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import functional as Fn
+from .functional import ACT_NONE, ACT_RELU
+
+
+# ---------------------------------------------------------------------------------------------
+# runtime views of parameter containers
+# ---------------------------------------------------------------------------------------------
+class ConvRT:
+    """nn.Conv2d used as a parameter container + cached packed weights."""
+
+    def __init__(self, conv):
+        self.conv = conv
+        self.spec = Fn.ConvSpec(conv.in_channels, conv.out_channels, tuple(conv.kernel_size),
+                                tuple(conv.stride), tuple(conv.padding))
+        self._key = None
+        self._wp = None
+
+    def packed(self):
+        w = self.conv.weight
+        key = (w._version, w.data_ptr())
+        if key != self._key:
+            self._wp = Fn.pack_weight(w.detach(), 'fwd')
+            self._key = key
+        return self._wp
+
+
+class BNRT:
+    """nn.BatchNorm2d used as a parameter/buffer container."""
+
+    def __init__(self, bn):
+        self.bn = bn
+
+    def batch_stats(self):
+        # torch semantics: batch statistics in training mode or when no running stats exist
+        return self.bn.training or self.bn.running_mean is None
+
+    def running(self):
+        bn = self.bn
+        if bn.training and bn.track_running_stats and bn.running_mean is not None:
+            return bn.running_mean, bn.running_var
+        return None, None
+
+    def forward_stats(self, stats, count):
+        """-> scale, shift, mean, invstd for this call (updates running stats in train mode)."""
+        bn = self.bn
+        g, b = bn.weight.detach(), bn.bias.detach()
+        if self.batch_stats():
+            rm, rv = self.running()
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            return Fn.bn_finalize(stats, count, g, b, bn.eps, mom, rm, rv)
+        scale, shift, invstd = Fn.bn_fold(g, b, bn.running_mean, bn.running_var, bn.eps)
+        return scale, shift, bn.running_mean, invstd
+
+    def folded(self):
+        bn = self.bn
+        s, t, _ = Fn.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                             bn.eps)
+        return s, t
+
+
+def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
+    """conv (+bias) -> BN (batch or frozen statistics) -> *drop -> +residual -> act.
+    returns out, y_raw, (mean, invstd)"""
+    bias = crt.conv.bias.detach() if crt.conv.bias is not None else None
+    if brt.batch_stats():
+        y, stats = Fn.conv_fwd(x, crt.packed(), crt.spec, bias=bias, want_stats=True)
+        count = y.shape[0] * y.shape[2] * y.shape[3]
+    else:
+        y, stats, count = Fn.conv_fwd(x, crt.packed(), crt.spec, bias=bias), None, 0
+    scale, shift, mean, invstd = brt.forward_stats(stats, count)
+    out = Fn.bn_act(y, scale, shift, drop, residual, act)
+    return out, y, mean, invstd
+
+
+def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
+    """-> dx (or None), dw (OIHW), dbias (or None)"""
+    conv = crt.conv
+    dwp, db = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None)
+    dw = Fn.unpack_wgrad(dwp, conv.weight)
+    dx = None
+    if need_dx:
+        wpd = Fn.pack_weight(conv.weight.detach(), 'dgrad')
+        dx = Fn.conv_dgrad(dy, wpd, crt.spec, x.shape[2:], mask_src=mask_src, residual=residual)
+    return dx, dw, db
+
+
+# ---------------------------------------------------------------------------------------------
+# NonBottleneck1D block
+# ---------------------------------------------------------------------------------------------
+class NBt1DRT:
+    def __init__(self, block):
+        self.c31_1, self.c13_1 = ConvRT(block.conv3x1_1), ConvRT(block.conv1x3_1)
+        self.c31_2, self.c13_2 = ConvRT(block.conv3x1_2), ConvRT(block.conv1x3_2)
+        self.bn1, self.bn2 = BNRT(block.bn1), BNRT(block.bn2)
+        if block.downsample is not None:
+            self.cds, self.bnds = ConvRT(block.downsample[0]), BNRT(block.downsample[1])
+        else:
+            self.cds = self.bnds = None
+
+    def params(self):
+        ps = []
+        for c in (self.c31_1, self.c13_1):
+            ps += [c.conv.weight, c.conv.bias]
+        ps += [self.bn1.bn.weight, self.bn1.bn.bias]
+        for c in (self.c31_2, self.c13_2):
+            ps += [c.conv.weight, c.conv.bias]
+        ps += [self.bn2.bn.weight, self.bn2.bn.bias]
+        if self.cds is not None:
+            ps += [self.cds.conv.weight, self.bnds.bn.weight, self.bnds.bn.bias]
+        return ps
+
+
+class NBt1DFunction(Function):
+    """conv3x1+b,ReLU -> conv1x3+b,BN,ReLU -> conv3x1+b,ReLU -> conv1x3+b,BN -> Dropout2d
+    -> + identity -> ReLU   (reference block: SURVEY.md §8 a3)."""
+
+    @staticmethod
+    def forward(ctx, x, rt, drop, *params):
+        x = Fn.as_act(x, dense=True)
+        b = lambda c: c.conv.bias.detach()   # noqa: E731
+        y1 = Fn.conv_fwd(x, rt.c31_1.packed(), rt.c31_1.spec, bias=b(rt.c31_1), act=ACT_RELU)
+        a2, y2, m1, is1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
+        y3 = Fn.conv_fwd(a2, rt.c31_2.packed(), rt.c31_2.spec, bias=b(rt.c31_2), act=ACT_RELU)
+        if rt.cds is not None:
+            idn, yd, md, isd = _conv_bn_forward(x, rt.cds, rt.bnds, ACT_NONE)
+        else:
+            idn, yd, md, isd = x, None, None, None
+        out, y4, m2, is2 = _conv_bn_forward(y3, rt.c13_2, rt.bn2, ACT_RELU, drop=drop,
+                                            residual=idn)
+        ctx.rt, ctx.drop = rt, drop
+        ctx.save_for_backward(x, out)
+        ctx.saved = (y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd)
+        ctx.bn_train = (rt.bn1.batch_stats(), rt.bn2.batch_stats(),
+                        rt.bnds.batch_stats() if rt.bnds is not None else False)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        rt, drop = ctx.rt, ctx.drop
+        x, out = ctx.saved_tensors
+        y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd = ctx.saved
+        ctx.saved = None
+        dout = Fn.as_act(dout, dense=True)
+        t1, t2, tds = ctx.bn_train
+        need_dx = ctx.needs_input_grad[0]
+
+        # out = relu(bn2(y4)*drop + idn)
+        dy4, dres, dg2, db2 = Fn.bn_bwd(dout, out, y4, rt.bn2.bn.weight.detach(), m2, is2, drop,
+                                        ACT_RELU, t2, want_dres=True)
+        # conv1x3_2 (input y3 = relu(.)): ReLU mask fused into the dgrad epilogue
+        dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3)
+        # conv3x1_2 (input a2 = relu(bn1(y2)))
+        da2, dw3, dbias3 = _conv_backward(a2, dz3, rt.c31_2, True)
+        dy2, _, dg1, db1 = Fn.bn_bwd(da2, a2, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
+                                     ACT_RELU, t1, want_dres=False)
+        dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1)
+        grads = []
+        if rt.cds is None:
+            # identity skip: dx = dgrad(conv3x1_1) + dres, add fused into the epilogue
+            dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dres)
+        else:
+            dyd, _, dgd, dbd = Fn.bn_bwd(dres, None, yd, rt.bnds.bn.weight.detach(), md, isd,
+                                         None, ACT_NONE, tds, want_dres=False)
+            dxd, dwd, _ = _conv_backward(x, dyd, rt.cds, need_dx)
+            dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dxd)
+        grads = [dw1, dbias1, dw2, dbias2, dg1, db1, dw3, dbias3, dw4, dbias4, dg2, db2]
+        if rt.cds is not None:
+            grads += [dwd, dgd, dbd]
+        return (dx, None, None) + tuple(grads)
+
+
+def nbt1d_eval(x, rt):
+    """no-grad / eval fast path: both BatchNorms folded into the conv epilogues (4 launches)."""
+    b = lambda c: c.conv.bias.detach()   # noqa: E731
+    y1 = Fn.conv_fwd(x, rt.c31_1.packed(), rt.c31_1.spec, bias=b(rt.c31_1), act=ACT_RELU)
+    s1, t1 = rt.bn1.folded()
+    a2 = Fn.conv_fwd(y1, rt.c13_1.packed(), rt.c13_1.spec, bias=b(rt.c13_1), scale=s1, shift=t1,
+                     act=ACT_RELU)
+    y3 = Fn.conv_fwd(a2, rt.c31_2.packed(), rt.c31_2.spec, bias=b(rt.c31_2), act=ACT_RELU)
+    if rt.cds is not None:
+        sd, td = rt.bnds.folded()
+        idn = Fn.conv_fwd(x, rt.cds.packed(), rt.cds.spec, scale=sd, shift=td)
+    else:
+        idn = x
+    s2, t2 = rt.bn2.folded()
+    return Fn.conv_fwd(y3, rt.c13_2.packed(), rt.c13_2.spec, bias=b(rt.c13_2), scale=s2, shift=t2,
+                       residual=idn, act=ACT_RELU)
+
+
+# ---------------------------------------------------------------------------------------------
+# conv + BN (+ReLU)
+# ---------------------------------------------------------------------------------------------
+class ConvBNActFunction(Function):
+    @staticmethod
+    def forward(ctx, x, crt, brt, act, weight, gamma, beta):
+        x = Fn.as_act(x)
+        out, y, mean, invstd = _conv_bn_forward(x, crt, brt, act)
+        ctx.crt, ctx.brt, ctx.act = crt, brt, act
+        ctx.save_for_backward(x, out)
+        ctx.saved = (y, mean, invstd)
+        ctx.bn_train = brt.batch_stats()
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        x, out = ctx.saved_tensors
+        y, mean, invstd = ctx.saved
+        ctx.saved = None
+        dout = Fn.as_act(dout, dense=True)
+        dy, _, dg, db = Fn.bn_bwd(dout, out, y, ctx.brt.bn.weight.detach(), mean, invstd, None,
+                                  ctx.act, ctx.bn_train, want_dres=False)
+        dx, dw, _ = _conv_backward(x, dy, ctx.crt, ctx.needs_input_grad[0])
+        return dx, None, None, None, dw, dg, db
+
+
+def conv_bn_act_eval(x, crt, brt, act):
+    s, t = brt.folded()
+    return Fn.conv_fwd(x, crt.packed(), crt.spec, scale=s, shift=t, act=act)
+
+
+# ---------------------------------------------------------------------------------------------
+# plain conv (+bias) whose packed weight may host several parameters (padding / block-diagonal)
+# ---------------------------------------------------------------------------------------------
+class MultiConvRT:
+    """One GEMM-level convolution assembled from several nn.Conv2d / nn.Linear parameters.
+    `placements` = [(module, cout_off, cin_off)], total (cout_total, cin_total) multiples of 4."""
+
+    def __init__(self, placements, cout_total, cin_total, kernel, padding):
+        self.placements = placements
+        self.spec = Fn.ConvSpec(cin_total, cout_total, kernel, 1, padding)
+        self._key = None
+        self._wp = None
+        self._bias = None
+        self.has_bias = any(m.bias is not None for m, _, _ in placements)
+
+    def _w4(self, m):
+        w = m.weight
+        return w if w.dim() == 4 else w[:, :, None, None]
+
+    def packed(self):
+        key = tuple((m.weight._version, m.weight.data_ptr(),
+                     m.bias._version if m.bias is not None else 0) for m, _, _ in self.placements)
+        if key != self._key:
+            s = self.spec
+            wp = torch.zeros(s.kh * s.kw * s.cout * s.cin, device=self.placements[0][0].weight.device,
+                             dtype=torch.float32)
+            bias = torch.zeros(s.cout, device=wp.device, dtype=torch.float32) if self.has_bias else None
+            for m, co, ci in self.placements:
+                Fn.pack_weight(self._w4(m).detach(), 'fwd', s.cout, co, s.cin, ci, out=wp)
+                if m.bias is not None:
+                    bias[co:co + m.bias.shape[0]].copy_(m.bias.detach())
+            self._wp, self._bias, self._key = wp, bias, key
+        return self._wp, self._bias
+
+    def packed_dgrad(self):
+        s = self.spec
+        wp = torch.zeros(s.kh * s.kw * s.cout * s.cin, device=self.placements[0][0].weight.device,
+                         dtype=torch.float32)
+        for m, co, ci in self.placements:
+            Fn.pack_weight(self._w4(m).detach(), 'dgrad', s.cout, co, s.cin, ci, out=wp)
+        return wp
+
+    def params(self):
+        ps = []
+        for m, _, _ in self.placements:
+            ps.append(m.weight)
+            if m.bias is not None:
+                ps.append(m.bias)
+        return ps
+
+
+class MultiConvFunction(Function):
+    @staticmethod
+    def forward(ctx, x, rt, *params):
+        x = Fn.as_act(x)
+        wp, bias = rt.packed()
+        y = Fn.conv_fwd(x, wp, rt.spec, bias=bias)
+        ctx.rt = rt
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        rt = ctx.rt
+        (x,) = ctx.saved_tensors
+        dy = Fn.as_act(dy)
+        s = rt.spec
+        dwp, db = Fn.conv_wgrad(x, dy, s, rt.has_bias)
+        grads = []
+        for m, co, ci in rt.placements:
+            w4 = rt._w4(m)
+            dw = Fn.unpack_wgrad(dwp, w4, s.cout, co, s.cin, ci)
+            grads.append(dw.reshape(m.weight.shape))
+            if m.bias is not None:
+                grads.append(db[co:co + m.bias.shape[0]].clone())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = Fn.conv_dgrad(dy, rt.packed_dgrad(), s, x.shape[2:])
+        return (dx, None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------
+# stem: 7x7/2 conv + BN + ReLU on the NCHW network input
+# ---------------------------------------------------------------------------------------------
+class StemRT:
+    def __init__(self, conv, bn):
+        self.conv, self.brt = conv, BNRT(bn)
+        self.spec = Fn.StemSpec(conv.in_channels, conv.out_channels)
+        self._key = None
+        self._wp = None
+
+    def packed(self):
+        w = self.conv.weight
+        key = (w._version, w.data_ptr())
+        if key != self._key:
+            self._wp = Fn.stem_pack_weight(w.detach())
+            self._key = key
+        return self._wp
+
+
+class StemFunction(Function):
+    @staticmethod
+    def forward(ctx, x_nchw, rt, weight, gamma, beta):
+        n, c, h, w = x_nchw.shape
+        xp = Fn.stem_pack_input(x_nchw.detach().float())
+        brt = rt.brt
+        if brt.batch_stats():
+            y, stats = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=True)
+            count = y.shape[0] * y.shape[2] * y.shape[3]
+        else:
+            y, _ = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=False)
+            stats, count = None, 0
+        scale, shift, mean, invstd = brt.forward_stats(stats, count)
+        out = Fn.bn_act(y, scale, shift, None, None, ACT_RELU)
+        ctx.rt = rt
+        ctx.hw = (n, h, w)
+        ctx.save_for_backward(out)
+        ctx.saved = (xp, y, mean, invstd)
+        ctx.bn_train = brt.batch_stats()
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        rt = ctx.rt
+        (out,) = ctx.saved_tensors
+        xp, y, mean, invstd = ctx.saved
+        ctx.saved = None
+        n, h, w = ctx.hw
+        dout = Fn.as_act(dout, dense=True)
+        dy, _, dg, db = Fn.bn_bwd(dout, out, y, rt.brt.bn.weight.detach(), mean, invstd, None,
+                                  ACT_RELU, ctx.bn_train, want_dres=False)
+        dw = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight)
+        # gradient w.r.t. the network input is not produced (the reference never needs it:
+        # /root/reference/main.py:597-599 back-propagates into parameters only)
+        return None, None, dw, dg, db
+
+
+def stem_eval(x_nchw, rt):
+    n, c, h, w = x_nchw.shape
+    xp = Fn.stem_pack_input(x_nchw.float())
+    s, t = rt.brt.folded()
+    return Fn.stem_fwd_folded(xp, rt.packed(), rt.spec, n, h, w, s, t)
+
+
+# ---------------------------------------------------------------------------------------------
+# max pool
+# ---------------------------------------------------------------------------------------------
+class MaxPoolFunction(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = Fn.as_act(x, dense=True)
+        y, idx = Fn.maxpool_fwd(x)
+        ctx.idx, ctx.hw = idx, tuple(x.shape[2:])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return Fn.maxpool_bwd(Fn.as_act(dy, dense=True), ctx.idx, ctx.hw)
+
+
+# ---------------------------------------------------------------------------------------------
+# SE-add fusion
+# ---------------------------------------------------------------------------------------------
+def _se_params(se):
+    f0, f2 = se.fc[0], se.fc[2]
+    return [f0.weight, f0.bias, f2.weight, f2.bias]
+
+
+class SEAddFunction(Function):
+    """out = rgb * SE_rgb(rgb) + depth * SE_depth(depth)   ('se-add-uni-rgb')"""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, w1r, b1r, w2r, b2r, w1d, b1d, w2d, b2d):
+        rgb, depth = Fn.as_act(rgb, dense=True), Fn.as_act(depth, dense=True)
+        flat = lambda w: w.detach().reshape(w.shape[0], -1)   # noqa: E731
+        gr, gd = Fn.channel_mean(rgb), Fn.channel_mean(depth)
+        hr, sr = Fn.se_mlp_fwd(gr, flat(w1r), b1r.detach(), flat(w2r), b2r.detach())
+        hd, sd = Fn.se_mlp_fwd(gd, flat(w1d), b1d.detach(), flat(w2d), b2d.detach())
+        out = Fn.se_scale_add(rgb, sr, depth, sd)
+        ctx.save_for_backward(rgb, depth)
+        ctx.saved = (gr, gd, hr, sr, hd, sd, flat(w1r), flat(w2r), flat(w1d), flat(w2d))
+        ctx.shapes = (w1r.shape, w2r.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        rgb, depth = ctx.saved_tensors
+        gr, gd, hr, sr, hd, sd, w1r, w2r, w1d, w2d = ctx.saved
+        ctx.saved = None
+        dout = Fn.as_act(dout, dense=True)
+        s1, s2 = ctx.shapes
+        res = []
+        for x, g, h, s, w1, w2 in ((rgb, gr, hr, sr, w1r, w2r), (depth, gd, hd, sd, w1d, w2d)):
+            ds = Fn.se_scale_bwd_reduce(dout, x)
+            dgap, dw1, db1, dw2, db2 = Fn.se_mlp_bwd(g, w1, w2, h, s, ds)
+            dx = Fn.se_scale_bwd_apply(dout, s, dgap)
+            res.append((dx, dw1.reshape(s1), db1, dw2.reshape(s2), db2))
+        (dr, a1, a2, a3, a4), (dd, e1, e2, e3, e4) = res
+        return dr, dd, a1, a2, a3, a4, e1, e2, e3, e4
+
+
+# ---------------------------------------------------------------------------------------------
+# learned upsampling (nearest x2 + depth-wise 3x3) with optional fused skip add
+# ---------------------------------------------------------------------------------------------
+class UpsampleDWFunction(Function):
+    """`wdw`/`bias` are the (possibly zero-padded) [c,1,3,3] / [c] tensors the kernel reads."""
+
+    @staticmethod
+    def forward(ctx, x, wdw, bias, skip):
+        x = Fn.as_act(x, dense=True)
+        if skip is not None:
+            skip = Fn.as_act(skip, dense=True)
+        w = wdw.detach().contiguous()
+        y = Fn.up2x_dw_fwd(x, w, bias.detach() if bias is not None else None, skip)
+        ctx.save_for_backward(x, w)
+        ctx.has = (bias is not None, skip is not None)
+        ctx.wshape = wdw.shape
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = Fn.as_act(dy, dense=True)
+        dx, dw, db = Fn.up2x_dw_bwd(dy, x, w, need_dx=ctx.needs_input_grad[0])
+        has_bias, has_skip = ctx.has
+        return dx, dw.reshape(ctx.wshape), (db if has_bias else None), (dy if has_skip else None)
+
+
+# ---------------------------------------------------------------------------------------------
+# pyramid pooling pieces
+# ---------------------------------------------------------------------------------------------
+class AdaptiveAvgPoolFunction(Function):
+    @staticmethod
+    def forward(ctx, x, bins):
+        x = Fn.as_act(x, dense=True)
+        ctx.bins, ctx.shape = bins, tuple(x.shape)
+        return Fn.adaptive_avgpool_fwd(x, bins)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dx = Fn.act_empty(n, c, h, w, dy.device)
+        Fn.adaptive_avgpool_bwd(Fn.as_act(dy, dense=True), dx, ctx.bins, accumulate=False)
+        return dx, None
+
+
+class PPMConcatFunction(Function):
+    """cat([x, bilinear(y_i) ...], dim=1) written straight into one NHWC buffer."""
+
+    @staticmethod
+    def forward(ctx, x, *ys):
+        x = Fn.as_act(x)
+        ys = [Fn.as_act(y, dense=True) for y in ys]
+        n, c, h, w = x.shape
+        total = c + sum(y.shape[1] for y in ys)
+        buf = Fn.act_empty(n, total, h, w, x.device)
+        Fn.copy_channels(x, buf[:, :c])
+        off = c
+        for y in ys:
+            Fn.bilinear_fwd(y, buf[:, off:off + y.shape[1]])
+            off += y.shape[1]
+        ctx.meta = (c, [tuple(y.shape) for y in ys])
+        return buf
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dbuf):
+        dbuf = Fn.as_act(dbuf)
+        c, yshapes = ctx.meta
+        n, _, h, w = dbuf.shape
+        dx = Fn.act_empty(n, c, h, w, dbuf.device)
+        Fn.copy_channels(dbuf[:, :c], dx)
+        off, dys = c, []
+        for ys in yshapes:
+            dys.append(Fn.bilinear_bwd(dbuf[:, off:off + ys[1]], ys[2:]))
+            off += ys[1]
+        return (dx,) + tuple(dys)
+
+
+# ---------------------------------------------------------------------------------------------
+# head activations
+# ---------------------------------------------------------------------------------------------
+class HeadActFunction(Function):
+    @staticmethod
+    def forward(ctx, x, n_sig, n_tanh):
+        y = Fn.head_act_fwd(Fn.as_act(x, dense=True), n_sig, n_tanh)
+        ctx.save_for_backward(y)
+        ctx.cfg = (n_sig, n_tanh)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return Fn.head_act_bwd(Fn.as_act(dy, dense=True), y, *ctx.cfg), None, None

@@ -1,0 +1,231 @@
+/*
+ * emsanet_hip.h -- C-ABI of libemsanet_hip.so (gfx950 / MI355X).
+ *
+ * The reference (TUI-NICR/EMSANet) has no FFI or plugin interface: its hot path is a Python
+ * nn.Module (`emsanet/model.py:27-233`, `emsanet/decoder.py:32-201`) whose layers come from the
+ * un-vendored `nicr_mt_scene_analysis.model.*` and run as cuDNN/ATen eager kernels
+ * (`main.py:23-24`).  This header is therefore the boundary the BUILD defines underneath that
+ * module surface (last bullet): one entry point per fused op, each citing the
+ * reference-side module call it stands in for.  `emsanet_amd/_lib.py` binds exactly these
+ * symbols with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all tensors are fp32, device memory, NHWC ("pixel rows" of C contiguous channels);
+ *     `ld*` = distance in elements between consecutive pixels (>= C; lets a kernel read or
+ *     write a channel slice of a wider tensor, i.e. concat/split without a copy)
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates
+ *     nothing, and is re-entrant per stream
+ *   - return value: 0 = launched, negative = rejected (EMSA_E_*)
+ */
+#ifndef EMSANET_HIP_H
+#define EMSANET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMSA_OK 0
+#define EMSA_E_SHAPE (-1)   /* unsupported geometry (e.g. channel count not a multiple of 4) */
+#define EMSA_E_ARG (-2)     /* null pointer / inconsistent arguments */
+#define EMSA_E_LAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch */
+
+#define EMSA_ACT_NONE 0
+#define EMSA_ACT_RELU 1
+
+/* library identity: returns the gfx arch string the kernels were compiled for ("gfx950") */
+const char* emsa_arch(void);
+int emsa_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (v_mfma_f32_32x32x2_f32).
+ * Stands in for every nn.Conv2d of the model: NBt1D 3x1/1x3 (`get_block_class('nonbottleneck1d')`,
+ * emsanet/model.py:49-52, decoder.py:69-72), decoder 3x3, 1x1 (downsample, skip fusion, PPM, side
+ * heads), the 7x7 stem (through emsa_stem_pack_input) and nn.Linear of the scene head
+ * (decoder.py:191-199).
+ *
+ * Gather geometry (shared by forward, data-gradient and weight-gradient):
+ *   GEMM row m  <-> pixel (img, oh, ow) of the "out" grid  [n_img x out_h x out_w]
+ *   tap (kh,kw) reads the "in" grid at
+ *        ih = (oh*mul_h + off_h + kh*step_h) / div_h   (tap skipped when not divisible or OOB)
+ *        iw = (ow*mul_w + off_w + kw*step_w) / div_w
+ *   forward conv:   mul=stride, off=-pad, step=dilation, div=1
+ *   data gradient:  mul=1, off=+pad, step=-dilation, div=stride  (in/out grids swapped)
+ *   element address of channel c of that pixel:
+ *        in + img*in_img_stride + ih*in_row_stride + iw*in_px_stride + c
+ * ------------------------------------------------------------------------------------------ */
+typedef struct EmsaConvGeom {
+  int32_t n_img;
+  int32_t in_h, in_w;          /* grid that is gathered from */
+  int32_t out_h, out_w;        /* grid that is produced (GEMM rows) */
+  int32_t k_ch;                /* channels gathered per tap (GEMM K per tap), multiple of 4 */
+  int32_t n_ch;                /* channels produced (GEMM N) */
+  int32_t kh, kw;
+  int32_t mul_h, off_h, step_h, div_h;
+  int32_t mul_w, off_w, step_w, div_w;
+  int64_t in_img_stride, in_row_stride;   /* elements */
+  int32_t in_px_stride;                   /* elements */
+  int32_t ld_out;                         /* pixel stride of the produced tensor */
+} EmsaConvGeom;
+
+/* out[m][n] = epilogue( sum_{tap,c} in[gather(m,tap)][c] * w[tap][n][c] )
+ *   w        packed [kh*kw][n_ch][k_ch]  (emsa_pack_weight_*)
+ *   bias     [n_ch] or NULL: v = acc + bias[n]
+ *   stats    NULL, or float[2][gridM][n_ch]: per-M-tile partial sum / sum of squares of v
+ *            (BatchNorm batch statistics; gridM = emsa_conv_stats_rows(geom)); reduce with
+ *            emsa_bn_finalize
+ *   scale/shift [n_ch] or NULL: v = v*scale[n] + shift[n]     (folded eval-mode BatchNorm)
+ *   residual NULL or tensor with pixel stride ld_res: v += residual[m][n]
+ *   mask_src NULL or tensor with pixel stride ld_mask: v = mask_src[m][n] > 0 ? v : 0
+ *            (ReLU backward fused into the data-gradient epilogue)
+ *   act      EMSA_ACT_*                                                                     */
+int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const float* w, float* out,
+                    const float* bias, float* stats, const float* scale, const float* shift,
+                    const float* residual, int32_t ld_res, const float* mask_src,
+                    int32_t ld_mask, int32_t act, void* stream);
+/* number of M tiles (rows of the stats partial buffer) emsa_conv_igemm will use for `g` */
+int emsa_conv_stats_rows(const EmsaConvGeom* g);
+
+/* dw[tap][n][c] += sum_m dout[m][n] * in[gather(m,tap)][c]     (dw must be zeroed by the caller)
+ *   dout     gradient of the produced tensor, pixel stride g->ld_out
+ *   dbias    NULL or [n_ch], += sum_m dout[m][n]               (must be zeroed by the caller) */
+int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout, float* dw,
+                    float* dbias, void* stream);
+
+/* weight layout transforms between the reference's OIHW parameters and the packed layouts.
+ * The packed buffer may be wider than the parameter (cout_total/cin_total >= cout/cin) and the
+ * parameter is placed at (cout_off, cin_off): used to zero-pad channel counts to a multiple of 4
+ * (instance head 5 -> 8, scene head 10 -> 12) and to lay the three `task_convs` of the instance
+ * head (emsanet/weights.py:49-52) out as one block-diagonal 96 -> 8 convolution.              */
+int emsa_pack_weight_fwd(const float* w_oihw, float* w_packed, int32_t cout, int32_t cin,
+                         int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
+                         int32_t cin_total, int32_t cin_off,
+                         void* stream);   /* -> [tap][cout_total][cin_total] */
+int emsa_pack_weight_dgrad(const float* w_oihw, float* w_packed, int32_t cout, int32_t cin,
+                           int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
+                           int32_t cin_total, int32_t cin_off,
+                           void* stream); /* -> [tap][cin_total][cout_total] */
+int emsa_unpack_wgrad(const float* dw_packed, float* dw_oihw, int32_t cout, int32_t cin,
+                      int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
+                      int32_t cin_total, int32_t cin_off,
+                      void* stream);      /* [tap][cout_total][cin_total] -> OIHW */
+
+/* 7x7 stride-2 stem (`get_backbone(... n_input_channels=3|1)`, emsanet/model.py:47-74):
+ * NCHW input -> zero-padded NHWC4 [n][h][w+8][4] (3 left, 5 right columns) so that the 7 kw taps
+ * x 4 channels of one kh row are 32 contiguous floats: the stem runs on emsa_conv_igemm as a
+ * 7x1 conv with k_ch = 32.  Weights: OIHW [64][c][7][7] <-> packed [7][64][32].               */
+int emsa_stem_pack_input(const float* x_nchw, float* x_pad, int32_t n, int32_t c, int32_t h,
+                         int32_t w, void* stream);
+int emsa_stem_pack_weight(const float* w_oihw, float* w_packed, int32_t cout, int32_t cin,
+                          void* stream);
+int emsa_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, int32_t cout, int32_t cin,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (+ReLU, +Dropout2d, +residual add)  -- nn.BatchNorm2d / activation / nn.Dropout2d /
+ * `out + identity` of the NBt1D block and of every ConvNormAct.
+ * ------------------------------------------------------------------------------------------ */
+/* reduce the conv's stats partials -> batch mean/var; writes scale = gamma*invstd,
+ * shift = beta - mean*scale, save_mean, save_invstd; updates running stats in place
+ * (momentum, unbiased variance) when running_mean != NULL.  count = pixels per channel.      */
+int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int64_t count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, float* scale, float* shift,
+                     float* save_mean, float* save_invstd, void* stream);
+/* eval mode: scale/shift (and optionally invstd, may be NULL) from running statistics */
+int emsa_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, int32_t c, float* scale, float* shift,
+                 float* save_invstd, void* stream);
+/* y = act( (x*scale[c] + shift[c]) * drop[n][c] + residual ), drop/residual may be NULL */
+int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift,
+                    const float* drop, const float* residual, int32_t n_img, int64_t hw,
+                    int32_t c, int32_t act, void* stream);
+/* backward, pass 1: g = dy * (y>0 if act) ; partial[2][rows][c] of  sum g*drop  and
+ * sum g*drop*xhat  with xhat = (x-mean)*invstd.  rows = emsa_bn_bwd_rows(n_img*hw)          */
+int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* save_mean,
+                       const float* save_invstd, const float* drop, int32_t n_img, int64_t hw,
+                       int32_t c, int32_t act, float* partial, void* stream);
+int emsa_bn_bwd_rows(int64_t pixels);
+/* backward, pass 2: reduces `partial` (dgamma, dbeta written), then
+ *   train: dx = gamma*invstd*(g*drop - dbeta/M - xhat*dgamma/M);  eval (train=0): dx = g*drop*scale
+ *   dres (may be NULL) = g                                                                  */
+int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* gamma,
+                      const float* save_mean, const float* save_invstd, const float* drop,
+                      const float* partial, int32_t rows, int32_t n_img, int64_t hw, int32_t c,
+                      int32_t act, int32_t train, float* dx, float* dres, float* dgamma,
+                      float* dbeta, void* stream);
+/* Dropout2d channel mask [n][c]: 0 or 1/(1-p); counter-based hash shared with the oracle */
+int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, uint32_t seed,
+                        uint32_t layer_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / squeeze-and-excitation fusion / upsampling
+ * ------------------------------------------------------------------------------------------ */
+/* 3x3 stride-2 pad-1 max pool of the ResNet stem; idx = int8 argmax tap per output element */
+int emsa_maxpool3x3s2_fwd(const float* x, float* y, int8_t* idx, int32_t n, int32_t h, int32_t w,
+                          int32_t c, void* stream);
+int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t n, int32_t h,
+                          int32_t w, int32_t c, void* stream);
+
+/* SE-add fusion ('se-add-uni-rgb', emsanet/args.py:143-147):
+ *   emsa_channel_mean: gap[n][c] = mean_hw x                      (F.adaptive_avg_pool2d(x,1))
+ *   emsa_se_mlp_fwd:   hid = relu(W1 gap + b1); s = sigmoid(W2 hid + b2)   (W1 [cr][c], W2 [c][cr])
+ *   emsa_se_scale_add_fwd: out = a*sa[n][c] + b*sb[n][c]          (b/sb NULL: plain SE)        */
+int emsa_channel_mean(const float* x, float* gap, int32_t n, int64_t hw, int32_t c,
+                      void* stream);
+int emsa_se_mlp_fwd(const float* gap, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* hid, float* s, int32_t n, int32_t c, int32_t cr,
+                    void* stream);
+int emsa_se_mlp_bwd(const float* gap, const float* w1, const float* w2, const float* hid,
+                    const float* s, const float* ds, float* dgap, float* dw1, float* db1,
+                    float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, void* stream);
+int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b, const float* sb,
+                          float* out, int32_t n, int64_t hw, int32_t c, void* stream);
+/* ds[n][c] = sum_hw dout*x   (gradient w.r.t. the SE weighting) */
+int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, int32_t n, int64_t hw,
+                             int32_t c, void* stream);
+/* dx = dout*s[n][c] + dgap[n][c]/hw  (+ dx_extra if not NULL: gradient arriving from another
+ * consumer of x, e.g. the depth stream that continues un-fused)                             */
+int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap,
+                            const float* dx_extra, float* dx, int32_t n, int64_t hw, int32_t c,
+                            void* stream);
+
+/* 'learned-3x3-zeropad' upsampling (emsanet/args.py:290-298): nearest x2 then depth-wise 3x3,
+ * zero padding, + bias, + optional skip tensor (encoder-decoder fusion 'add-rgb').
+ *   x [n][h][w][c] -> y [n][2h][2w][c];  wdw [c][3][3] (OIHW of a depth-wise conv), bias [c]  */
+int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias, const float* skip,
+                        float* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float* dx, int32_t n, int32_t h,
+                             int32_t w, int32_t c, void* stream);
+/* dw [c][9] and db [c] accumulated with atomics: zero them first */
+int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db, int32_t n,
+                               int32_t h, int32_t w, int32_t c, void* stream);
+
+/* pyramid pooling ('ppm', emsanet/args.py:243-256): adaptive average pool to bins x bins and
+ * bilinear (align_corners=False) upsampling back, written into a channel slice (ld_y)        */
+int emsa_adaptive_avgpool_fwd(const float* x, float* y, int32_t n, int32_t h, int32_t w,
+                              int32_t c, int32_t bins, void* stream);
+int emsa_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t n, int32_t h, int32_t w,
+                              int32_t c, int32_t bins, int32_t accumulate, void* stream);
+int emsa_bilinear_fwd(const float* x, float* y, int32_t n, int32_t ih, int32_t iw, int32_t oh,
+                      int32_t ow, int32_t c, int32_t ld_y, void* stream);
+int emsa_bilinear_bwd(const float* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh,
+                      int32_t ow, int32_t c, int32_t ld_dy, void* stream);
+
+/* instance head activations (sigmoid centre, tanh offset; emsanet/model.py:122-137):
+ * channels [0,n_sig) sigmoid, [n_sig, n_sig+n_tanh) tanh, rest identity                       */
+int emsa_head_act_fwd(const float* x, float* y, int64_t pixels, int32_t c, int32_t n_sig,
+                      int32_t n_tanh, void* stream);
+int emsa_head_act_bwd(const float* dy, const float* y, float* dx, int64_t pixels, int32_t c,
+                      int32_t n_sig, int32_t n_tanh, void* stream);
+
+/* plain copies with strides (channel slice <-> dense), and y += x */
+int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y, int64_t pixels,
+                       int32_t c, void* stream);
+int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMSANET_HIP_H */

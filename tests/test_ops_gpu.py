@@ -1,0 +1,345 @@
+"""GPU parity of every C-ABI kernel against a plain PyTorch CPU reference of the same op
+(fp64 reference, tolerance 1e-4 relative to the tensor's max magnitude: fp32 kernels with a
+different summation order than the reference)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import DEV, close, rnd, to_act
+
+pytestmark = pytest.mark.gpu
+
+
+def _fn():
+    from emsanet_amd import functional as Fn
+    return Fn
+
+
+CONVS = [
+    # cin, cout, kernel, stride, padding, n, h, w
+    (64, 64, (3, 1), (1, 1), (1, 0), 2, 12, 20),
+    (64, 64, (1, 3), (1, 1), (0, 1), 2, 12, 20),
+    (128, 128, (1, 3), (1, 1), (0, 1), 3, 9, 13),
+    (64, 128, (3, 1), (2, 1), (1, 0), 2, 12, 20),
+    (128, 128, (1, 3), (1, 2), (0, 1), 2, 6, 20),
+    (64, 128, (1, 1), (2, 2), (0, 0), 2, 12, 20),
+    (256, 128, (3, 3), (1, 1), (1, 1), 2, 8, 10),
+    (128, 40, (3, 3), (1, 1), (1, 1), 2, 8, 10),
+    (96, 8, (3, 3), (1, 1), (1, 1), 2, 8, 10),
+    (512, 256, (1, 1), (1, 1), (0, 0), 2, 5, 5),
+    (256, 12, (1, 1), (1, 1), (0, 0), 4, 1, 1),
+    (64, 64, (1, 3), (1, 1), (0, 1), 1, 30, 40),
+]
+
+
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv_fwd(cfg, tile, monkeypatch):
+    Fn = _fn()
+    if tile >= 0:
+        monkeypatch.setenv('EMSA_CONV_TILE', str(tile))
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    b = rnd(cout, seed=3)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=s, padding=p)
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    wp = Fn.pack_weight(wt.to(DEV), 'fwd')
+    y, stats = Fn.conv_fwd(to_act(x), wp, spec, bias=b.to(DEV), want_stats=True)
+    torch.cuda.synchronize()
+    close(y, ref, what='conv')
+    cnt = ref.numel() / cout
+    close(stats[0].sum(0) / cnt, ref.mean((0, 2, 3)), what='stats mean')
+    close(stats[1].sum(0) / cnt, (ref * ref).mean((0, 2, 3)), tol=2e-4, what='stats sq')
+    # fused epilogue: folded BN + residual + relu
+    sc, sh = rnd(cout, seed=4), rnd(cout, seed=5)
+    res = rnd(*ref.shape, seed=6)
+    y2 = Fn.conv_fwd(to_act(x), wp, spec, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV),
+                     residual=to_act(res), act=Fn.ACT_RELU)
+    ref2 = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res)
+    close(y2, ref2, what='conv epilogue')
+
+
+@pytest.mark.parametrize('tile', [-1, 0, 2])
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv_dgrad(cfg, tile, monkeypatch):
+    Fn = _fn()
+    if tile >= 0:
+        monkeypatch.setenv('EMSA_CONV_TILE', str(tile))
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    y = F.conv2d(x, wt.double(), None, stride=s, padding=p)
+    dy = rnd(*y.shape, seed=7)
+    y.backward(dy.double())
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    wpd = Fn.pack_weight(wt.to(DEV), 'dgrad')
+    dx = Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w))
+    torch.cuda.synchronize()
+    close(dx, x.grad, what='dgrad')
+    mask = rnd(n, cin, h, w, seed=8)
+    res = rnd(n, cin, h, w, seed=9)
+    dx2 = Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w), mask_src=to_act(mask))
+    close(dx2, x.grad * (mask > 0), what='dgrad mask')
+    dx3 = Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w), residual=to_act(res))
+    close(dx3, x.grad + res, what='dgrad residual')
+
+
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv_wgrad(cfg):
+    Fn = _fn()
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1).double().requires_grad_(True)
+    b = rnd(cout, seed=3).double().requires_grad_(True)
+    y = F.conv2d(x.double(), wt, b, stride=s, padding=p)
+    dy = rnd(*y.shape, seed=7)
+    y.backward(dy.double())
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    dwp, db = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True)
+    dw = Fn.unpack_wgrad(dwp, wt.detach().float().to(DEV))
+    torch.cuda.synchronize()
+    close(dw, wt.grad, what='wgrad')
+    close(db, b.grad, what='bgrad')
+
+
+def test_conv_wgrad_split_k_large():
+    """long pixel axis (split-K with atomics) at the 1-D conv shape of the /4 stage"""
+    Fn = _fn()
+    cin = cout = 64
+    n, h, w = 2, 120, 160
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 1, 3, seed=2, scale=0.1).double().requires_grad_(True)
+    y = F.conv2d(x.double(), wt, None, padding=(0, 1))
+    dy = rnd(*y.shape, seed=7, scale=0.1)
+    y.backward(dy.double())
+    spec = Fn.ConvSpec(cin, cout, (1, 3), 1, (0, 1))
+    dwp, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, False)
+    dw = Fn.unpack_wgrad(dwp, wt.detach().float().to(DEV))
+    close(dw, wt.grad, tol=2e-4, what='wgrad split-k')
+
+
+@pytest.mark.parametrize('cin', [3, 1])
+def test_stem(cin):
+    Fn = _fn()
+    n, h, w = 2, 32, 48
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(64, cin, 7, 7, seed=2, scale=0.1).double().requires_grad_(True)
+    y = F.conv2d(x.double(), wt, None, stride=2, padding=3)
+    dy = rnd(*y.shape, seed=3)
+    y.backward(dy.double())
+    spec = Fn.StemSpec(cin)
+    xp = Fn.stem_pack_input(x.to(DEV))
+    wp = Fn.stem_pack_weight(wt.detach().float().to(DEV))
+    out, stats = Fn.stem_fwd(xp, wp, spec, n, h, w)
+    close(out, y, what='stem fwd')
+    dw = Fn.stem_wgrad(xp, to_act(dy), spec, n, h, w, wt.detach().float().to(DEV))
+    close(dw, wt.grad, what='stem wgrad')
+
+
+def test_pack_roundtrip_and_blockdiag():
+    Fn = _fn()
+    w = rnd(5, 7, 3, 3, seed=1).to(DEV)
+    wp = Fn.pack_weight(w, 'fwd', 8, 2, 12, 4)
+    ref = torch.zeros(9, 8, 12)
+    ref[:, 2:7, 4:11] = w.cpu().permute(2, 3, 0, 1).reshape(9, 5, 7)
+    close(wp.view(9, 8, 12), ref, tol=0, what='pack fwd')
+    wd = Fn.pack_weight(w, 'dgrad', 8, 2, 12, 4)
+    close(wd.view(9, 12, 8), ref.transpose(1, 2), tol=0, what='pack dgrad')
+    back = Fn.unpack_wgrad(wp, w, 8, 2, 12, 4)
+    close(back, w, tol=0, what='unpack')
+
+
+@pytest.mark.parametrize('c', [64, 128, 512, 40])
+@pytest.mark.parametrize('act', [0, 1])
+@pytest.mark.parametrize('train', [True, False])
+def test_bn_fwd_bwd(c, act, train):
+    Fn = _fn()
+    n, h, w = 3, 7, 9
+    x = rnd(n, c, h, w, seed=1).double().requires_grad_(True)
+    res = rnd(n, c, h, w, seed=2).double().requires_grad_(True)
+    gamma = (rnd(c, seed=3) * 0.2 + 1).double().requires_grad_(True)
+    beta = rnd(c, seed=4).double().requires_grad_(True)
+    drop = (torch.rand(n, c, generator=torch.Generator().manual_seed(0)) > 0.3).double() / 0.7
+    rm, rv = rnd(c, seed=5) * 0.1, rnd(c, seed=6).abs() + 0.5
+    eps = 1e-3
+    rm_ref, rv_ref = rm.clone().double(), rv.clone().double()
+    yb = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=train, momentum=0.1, eps=eps)
+    out = yb * drop[:, :, None, None] + res
+    if act:
+        out = F.relu(out)
+    dy = rnd(n, c, h, w, seed=7)
+    out.backward(dy.double())
+
+    g, b = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    xa = to_act(x.detach().float())
+    rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
+    if train:
+        # statistics the way the conv epilogue delivers them: [2][rows][c] partial sums
+        xs = x.detach().float().permute(0, 2, 3, 1).reshape(-1, c)
+        rows = 5
+        chunks = torch.chunk(xs, rows, 0)
+        stats = torch.stack([torch.stack([ch.sum(0) for ch in chunks]),
+                             torch.stack([(ch * ch).sum(0) for ch in chunks])]).to(DEV)
+        scale, shift, mean, invstd = Fn.bn_finalize(stats, xs.shape[0], g, b, eps, 0.1, rmg, rvg)
+        close(rmg, rm_ref, what='running mean')
+        close(rvg, rv_ref, what='running var')
+    else:
+        scale, shift, invstd = Fn.bn_fold(g, b, rmg, rvg, eps)
+        mean = rmg
+    y = Fn.bn_act(xa, scale, shift, drop.float().to(DEV), to_act(res.detach().float()), act)
+    close(y, out, what='bn_act fwd')
+    dx, dres, dg, db = Fn.bn_bwd(to_act(dy), y, xa, g, mean, invstd, drop.float().to(DEV), act,
+                                 train, want_dres=True)
+    close(dx, x.grad, what='bn dx')
+    close(dres, res.grad, what='bn dres')
+    close(dg, gamma.grad, what='bn dgamma')
+    close(db, beta.grad, what='bn dbeta')
+
+
+def test_dropout_mask_matches_oracle():
+    Fn = _fn()
+    from oracle.emsanet_oracle import dropout2d_scale_mask
+    for seed, lid, p in ((0, 0, 0.1), (123456789, 7, 0.2), (0xFFFFFFFF, 49, 0.5)):
+        m = Fn.dropout2d_mask(32, 512, p, seed, lid, DEV)
+        ref = torch.from_numpy(dropout2d_scale_mask(seed, lid, 32, 512, p))
+        assert torch.equal(m.cpu(), ref)
+        assert 0.0 < (ref == 0).float().mean() < 2 * p + 0.05
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 12, 20), (1, 64, 7, 9)])
+def test_maxpool(shape):
+    Fn = _fn()
+    x = rnd(*shape, seed=1).double().requires_grad_(True)
+    y = F.max_pool2d(x, 3, stride=2, padding=1)
+    dy = rnd(*y.shape, seed=2)
+    y.backward(dy.double())
+    yg, idx = Fn.maxpool_fwd(to_act(x.detach().float()))
+    close(yg, y, tol=0, what='maxpool')
+    dx = Fn.maxpool_bwd(to_act(dy), idx, shape[2:])
+    close(dx, x.grad, tol=1e-6, what='maxpool bwd')
+
+
+@pytest.mark.parametrize('c', [64, 512])
+def test_se_fusion(c):
+    Fn = _fn()
+    from emsanet_amd import ops
+    from emsanet_amd.nn import SEAddUniRGB
+    torch.manual_seed(0)
+    n, h, w = 3, 6, 10
+    mod = SEAddUniRGB(c)
+    ref = mod.double()
+    rgb = rnd(n, c, h, w, seed=1).double().requires_grad_(True)
+    dep = rnd(n, c, h, w, seed=2).double().requires_grad_(True)
+
+    def se(m, x):
+        return x * m.fc(F.adaptive_avg_pool2d(x, 1))
+    out = se(ref.se_rgb, rgb) + se(ref.se_depth, dep)
+    dy = rnd(n, c, h, w, seed=3)
+    out.backward(dy.double())
+    ref_grads = [p.grad.clone() for p in ref.parameters()]
+
+    gm = SEAddUniRGB(c)
+    gm.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    gm.to(DEV)
+    r = to_act(rgb.detach().float()).requires_grad_(True)
+    d = to_act(dep.detach().float()).requires_grad_(True)
+    o, _ = gm(r, d)
+    close(o, out, what='se fwd')
+    o.backward(to_act(dy))
+    close(r.grad, rgb.grad, what='se d_rgb')
+    close(d.grad, dep.grad, what='se d_depth')
+    for (k, p), g in zip(gm.named_parameters(), ref_grads):
+        close(p.grad, g, tol=2e-4, what=f'se {k}')
+
+
+@pytest.mark.parametrize('c,cp', [(64, 64), (40, 40), (5, 8)])
+def test_upsample_dw(c, cp):
+    Fn = _fn()
+    from emsanet_amd import ops
+    n, h, w = 2, 5, 7
+    x = torch.zeros(n, cp, h, w)
+    x[:, :c] = rnd(n, c, h, w, seed=1)
+    x = x.double().requires_grad_(True)
+    wt = torch.zeros(cp, 1, 3, 3)
+    wt[:c] = rnd(c, 1, 3, 3, seed=2)
+    wt = wt.double().requires_grad_(True)
+    b = torch.zeros(cp)
+    b[:c] = rnd(c, seed=3)
+    b = b.double().requires_grad_(True)
+    skip = rnd(n, cp, 2 * h, 2 * w, seed=4).double().requires_grad_(True)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), wt, b, padding=1, groups=cp) + skip
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy.double())
+    xg = to_act(x.detach().float()).requires_grad_(True)
+    wg = wt.detach().float().to(DEV).requires_grad_(True)
+    bg = b.detach().float().to(DEV).requires_grad_(True)
+    sg = to_act(skip.detach().float()).requires_grad_(True)
+    yg = ops.UpsampleDWFunction.apply(xg, wg, bg, sg)
+    close(yg, y, what='up fwd')
+    yg.backward(to_act(dy))
+    close(xg.grad, x.grad, what='up dx')
+    close(wg.grad, wt.grad, what='up dw')
+    close(bg.grad, b.grad, what='up db')
+    close(sg.grad, skip.grad, what='up dskip')
+
+
+def test_ppm_pieces():
+    Fn = _fn()
+    from emsanet_amd import ops
+    n, c, h, w = 2, 32, 15, 20
+    x = rnd(n, c, h, w, seed=1).double().requires_grad_(True)
+    y1 = rnd(n, 16, 1, 1, seed=2).double().requires_grad_(True)
+    y5 = rnd(n, 16, 5, 5, seed=3).double().requires_grad_(True)
+    for bins in (1, 5, 4):
+        xx = x.detach().clone().requires_grad_(True)
+        p = F.adaptive_avg_pool2d(xx, bins)
+        dp = rnd(*p.shape, seed=4)
+        p.backward(dp.double())
+        xg = to_act(x.detach().float()).requires_grad_(True)
+        pg = ops.AdaptiveAvgPoolFunction.apply(xg, bins)
+        close(pg, p, what=f'pool{bins}')
+        pg.backward(to_act(dp))
+        close(xg.grad, xx.grad, what=f'pool{bins} bwd')
+    cat = torch.cat([x, F.interpolate(y1, (h, w), mode='bilinear', align_corners=False),
+                     F.interpolate(y5, (h, w), mode='bilinear', align_corners=False)], 1)
+    dc = rnd(*cat.shape, seed=5)
+    cat.backward(dc.double())
+    xg = to_act(x.detach().float()).requires_grad_(True)
+    y1g = to_act(y1.detach().float()).requires_grad_(True)
+    y5g = to_act(y5.detach().float()).requires_grad_(True)
+    cg = ops.PPMConcatFunction.apply(xg, y1g, y5g)
+    close(cg, cat, what='ppm cat')
+    cg.backward(to_act(dc))
+    close(xg.grad, x.grad, what='ppm dx')
+    close(y1g.grad, y1.grad, what='ppm dy1')
+    close(y5g.grad, y5.grad, what='ppm dy5')
+
+
+def test_head_act():
+    from emsanet_amd import ops
+    x = rnd(2, 8, 6, 7, seed=1).double().requires_grad_(True)
+    y = torch.cat([torch.sigmoid(x[:, :1]), torch.tanh(x[:, 1:3]), x[:, 3:]], 1)
+    dy = rnd(*y.shape, seed=2)
+    y.backward(dy.double())
+    xg = to_act(x.detach().float()).requires_grad_(True)
+    yg = ops.HeadActFunction.apply(xg, 1, 2)
+    close(yg, y, what='head act')
+    yg.backward(to_act(dy))
+    close(xg.grad, x.grad, what='head act bwd')
+
+
+def test_copy_axpy():
+    Fn = _fn()
+    x = rnd(2, 12, 3, 5, seed=1)
+    xa = to_act(x)
+    dst = Fn.act_zeros(2, 20, 3, 5, DEV)
+    Fn.copy_channels(xa[:, 4:12], dst[:, 2:10])
+    ref = torch.zeros(2, 20, 3, 5)
+    ref[:, 2:10] = x[:, 4:12]
+    close(dst, ref, tol=0, what='copy')
+    a = rnd(1003, seed=2).to(DEV)
+    b = rnd(1003, seed=3).to(DEV)
+    b0 = b.clone()
+    Fn.axpy_(b, a, 0.5)
+    close(b, b0.cpu() + 0.5 * a.cpu(), tol=1e-6, what='axpy')
