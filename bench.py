@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""
+bench.py -- EMSANet forward+backward throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one training step of the full RGB-D multi-task EMSANet-R34-NBt1D on a synthetic
+bs=32/GPU batch at 640x480, fp32: forward, backward driven by fixed output cotangents
+(the task losses live in an un-vendored library), gradient all-reduce across ranks
+(N>1, overlapped with backward) and the SGD-nesterov update of /root/reference/emsanet/
+optimizer.py:29-36.  Inputs are resident in HBM before the timed region.  Weights: deterministic
+random init; data: the reference's own synthetic generator (inference_time_whole_model.py:519-545).
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of
+the MFMA convolution kernels inside the timed steps (emsa_prof_* C-ABI); `cpu_baseline` times the
+oracle (plain PyTorch CPU restatement, tests infrastructure) on the host cores for a bounded
+sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np    # noqa: E402
+import torch          # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FWD_GFLOP_PER_IMAGE = 119.672609792    # FlopCounterMode on the oracle at 480x640
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-size', type=int, default=32, help='per GPU')
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true',
+                    help='do not bracket conv launches with HIP events (A/B of the overhead)')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
+    return ap.parse_args()
+
+
+def synthetic_batch_device(bs, h, w, seed, device):
+    # same generator as oracle.synthetic_batch / the reference's timing script
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 255, (bs, h, w, 3), dtype=np.uint8)
+    depth = rng.integers(0, 40000, (bs, h, w), dtype=np.uint16)
+    return {
+        'rgb': torch.from_numpy((rgb.astype(np.float32) / 255).transpose(0, 3, 1, 2).copy()).to(device),
+        'depth': torch.from_numpy((depth.astype(np.float32) / 20000)[:, None].copy()).to(device),
+    }
+
+
+def deterministic_init_(model, seed=0):
+    """random-init weights of the architecture (no checkpoints available): keep the reference's
+    constructor init but give BatchNorm non-trivial statistics and the decoder residual gammas a
+    non-zero value so that no branch of the backward pass is multiplied by exact zeros."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('bn2.weight'):
+                p.copy_(torch.empty(p.shape).uniform_(0.2, 0.4, generator=g))
+
+
+def flatten_outputs(outs):
+    flat = []
+    for o, sides in outs:
+        flat += list(o) if isinstance(o, tuple) else [o]
+        for s in sides:
+            flat += list(s) if isinstance(s, tuple) else [s]
+    return flat
+
+
+def cpu_baseline(args):
+    """oracle (port of the reference path) fwd+bwd on the host cores, bounded sample"""
+    from emsanet_amd import full_args, nyuv2_config
+    from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
+    cores = torch.get_num_threads()
+    a = full_args(input_height=args.height, input_width=args.width)
+    o = EMSANetOracle(a, nyuv2_config())
+    o.load_state_dict(deterministic_state_dict(o, 0))
+    o.train()
+    bs = 1
+    batch = synthetic_batch(bs, args.height, args.width)
+
+    def step():
+        for p in o.parameters():
+            p.grad = None
+        flat = flatten_outputs(o(batch))
+        torch.autograd.backward(flat, [torch.full_like(t, 1e-3) for t in flat])
+    t0 = time.time()
+    step()                      # warm-up (allocator, oneDNN primitive cache)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 >= args.cpu_seconds or n >= 10:
+            break
+    dt = time.time() - t0
+    return {'value': round(n * bs / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} fwd+bwd iteration(s) of the PyTorch-CPU oracle, bs={bs}, '
+                      f'{args.width}x{args.height} RGB-D, all heads, train mode, fp32 oneDNN, '
+                      f'after 1 warm-up iteration ({warm:.1f}s)'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL over xGMI
+
+    from emsanet_amd import _lib, full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.parallel import GradientBuckets, broadcast_parameters
+
+    L = _lib.lib()
+    a = full_args(input_height=args.height, input_width=args.width)
+    torch.manual_seed(0)
+    model = EMSANet(a, nyuv2_config())
+    deterministic_init_(model)
+    model.to(dev)
+    broadcast_parameters(model)
+    bs = args.batch_size
+    batch = synthetic_batch_device(bs, args.height, args.width, 1234 + rank, dev)
+
+    if args.eval:
+        model.eval()
+    else:
+        model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    buckets = GradientBuckets(params)
+    # LR rule of the reference: 0.01 * batch/8 (args.py:1338-1344); tiny here so that the random
+    # net stays finite over the benchmark steps
+    opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    cots = None
+
+    def step():
+        nonlocal cots
+        if args.eval:
+            with torch.no_grad():
+                model(batch)
+            return
+        buckets.reset()
+        flat = flatten_outputs(model(batch))
+        if cots is None:
+            g = torch.Generator(device='cpu').manual_seed(4321)
+            cots = [(torch.randn(t.shape, generator=g) * 1e-3).to(dev).contiguous(
+                memory_format=torch.channels_last if t.dim() == 4 else torch.contiguous_format)
+                for t in flat]
+        torch.autograd.backward(flat, cots)
+        buckets.finish()
+        opt.step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timing = not args.no_kernel_timing
+    L.emsa_prof_reset()
+    L.emsa_prof_enable(1 if timing else 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    L.emsa_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    images = bs * world * args.steps
+    value = images / dt
+    # ---- roofline of the dominant kernel --------------------------------------------------
+    kernels = []
+    if timing:
+        for cls in range(8):
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+            _lib.check(L.emsa_prof_read(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)),
+                       'emsa_prof_read')
+            if n.value:
+                kernels.append({'kernel': L.emsa_prof_name(cls).decode(), 'launches': n.value,
+                                'total_ms': round(ms.value, 3),
+                                'avg_us': round(1e3 * ms.value / n.value, 2),
+                                'algo_gflop_per_launch': round(fl.value / n.value / 1e9, 4),
+                                'tflops': round(fl.value / ms.value / 1e9, 2)})
+    kernels.sort(key=lambda k: -k['total_ms'])
+    roofline = None
+    if kernels:
+        k = kernels[0]
+        roofline = {'bound': 'mfma', 'kernel': k['kernel'], 'achieved': k['tflops'],
+                    'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(k['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'launches': k['launches'], 'avg_us': k['avg_us'],
+                    'algo_gflop_per_launch': k['algo_gflop_per_launch'],
+                    'share_of_step': round(k['total_ms'] / (dt * 1e3), 4)}
+    conv_ms = sum(k['total_ms'] for k in kernels)
+    conv_fl = sum(k['total_ms'] * k['tflops'] for k in kernels)     # ms * TFLOP/s = GFLOP
+    step_gflop = (1 if args.eval else 3) * FWD_GFLOP_PER_IMAGE * bs \
+        if (args.height, args.width) == (480, 640) else None
+
+    out = {
+        'metric': 'images/sec (640x480 RGB-D, bs=32/GPU) fwd+bwd',
+        'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: full EMSANet RGB-D (ResNet-34-NBt1D x2, '
+                               'SE-add fusion, PPM, semantic+instance+orientation+scene heads), '
+                               f'{args.width}x{args.height}, bs={bs}/GPU, fp32, train mode '
+                               '(BN batch stats, Dropout2d), step = fwd + bwd (fixed output '
+                               'cotangents) + grad all-reduce + SGD-nesterov update',
+                   'global_batch': bs * world, 'parallelism': f'dp{world}',
+                   'weights': 'random init (deterministic)', 'mode': 'eval-fwd' if args.eval else 'train'},
+        'roofline': roofline,
+        'conv_kernels': kernels,
+        'conv_mfma_time_share': round(conv_ms / (dt * 1e3), 4) if kernels else None,
+        'conv_mfma_tflops_overall': round(conv_fl / conv_ms, 2) if conv_ms else None,
+        'model_tflops_effective': round(step_gflop * world * args.steps / dt / 1e3, 2)
+        if step_gflop else None,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args)
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -56,11 +56,12 @@ SIGNATURES = {
     'emsa_dropout2d_mask': (c_int, [_P, c_int32, c_int32, c_float, c_uint32, c_uint32, _P]),
     'emsa_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
-    'emsa_channel_mean': (c_int, [_P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_channel_ws_floats': (c_int, [c_int32, c_int64, c_int32]),
+    'emsa_channel_mean': (c_int, [_P, _P, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_se_mlp_fwd': (c_int, [_P] * 7 + [c_int32] * 3 + [_P]),
     'emsa_se_mlp_bwd': (c_int, [_P] * 11 + [c_int32] * 3 + [_P]),
     'emsa_se_scale_add_fwd': (c_int, [_P] * 5 + [c_int32, c_int64, c_int32, _P]),
-    'emsa_se_scale_bwd_reduce': (c_int, [_P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_se_scale_bwd_reduce': (c_int, [_P, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_se_scale_bwd_apply': (c_int, [_P] * 5 + [c_int32, c_int64, c_int32, _P]),
     'emsa_up2x_dw3x3_fwd': (c_int, [_P] * 5 + [c_int32] * 4 + [_P]),
     'emsa_up2x_dw3x3_bwd_data': (c_int, [_P] * 3 + [c_int32] * 4 + [_P]),
@@ -73,6 +74,11 @@ SIGNATURES = {
     'emsa_head_act_bwd': (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
     'emsa_copy_channels': (c_int, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_axpy': (c_int, [_P, _P, c_int64, c_float, _P]),
+    'emsa_prof_enable': (c_int, [c_int32]),
+    'emsa_prof_reset': (c_int, []),
+    'emsa_prof_name': (c_char_p, [c_int32]),
+    'emsa_prof_read': (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                               POINTER(c_int32)]),
 }
 
 _ERR = {-1: 'EMSA_E_SHAPE (unsupported geometry)', -2: 'EMSA_E_ARG (bad argument)',

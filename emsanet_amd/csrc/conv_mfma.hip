@@ -22,7 +22,51 @@
 //     folded eval BatchNorm, residual add, ReLU and the ReLU-backward mask.
 #include "common.h"
 
+#include <vector>
+
 namespace {
+
+// ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream ---------
+struct ProfSlot {
+  hipEvent_t a, b;
+  int cls;
+  double flops;
+};
+std::vector<ProfSlot> g_prof_pool;
+size_t g_prof_used = 0;
+bool g_prof_on = false;
+const char* const kProfNames[8] = {
+    "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,2,2>",
+    "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
+    "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1>",
+    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>"};
+
+ProfSlot* prof_begin(int cls, double flops, hipStream_t st) {
+  if (!g_prof_on) return nullptr;
+  if (g_prof_used == g_prof_pool.size()) {
+    ProfSlot s;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return nullptr;
+    g_prof_pool.push_back(s);
+  }
+  ProfSlot* s = &g_prof_pool[g_prof_used++];
+  s->cls = cls;
+  s->flops = flops;
+  (void)hipEventRecord(s->a, st);
+  return s;
+}
+void prof_end(ProfSlot* s, hipStream_t st) {
+  if (s) (void)hipEventRecord(s->b, st);
+}
+
+// algorithmic (direct-convolution) FLOPs of one launch: 2 * pixels * k_ch * n_ch * taps, pixels
+// counted on the grid of the FORWARD conv's output (for a strided data gradient that is the
+// gathered grid), no discount for padding taps
+double algo_flops(const EmsaConvGeom& g) {
+  const bool transposed = g.div_h > 1 || g.div_w > 1;
+  const double px = (double)g.n_img * (transposed ? (double)g.in_h * g.in_w
+                                                  : (double)g.out_h * g.out_w);
+  return 2.0 * px * g.k_ch * g.n_ch * g.kh * g.kw;
+}
 
 constexpr int kBK = 32;   // K chunk (channels) per step
 constexpr int kLD = 36;   // padded LDS row (floats)
@@ -210,7 +254,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (m < p.M && nok) {
           float v = acc[i][j][r] + bv;
           s1[j] += v;
-          s2[j] += v * v;
           v = v * sc + sh;
           if (p.residual) v += p.residual[(size_t)m * p.ld_res + n];
           if (p.mask_src) v = p.mask_src[(size_t)m * p.ld_mask + n] > 0.f ? v : 0.f;
@@ -222,29 +265,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 
   if (want_stats) {
-    // combine the two half-waves (rows r and r+4), then the WM waves through LDS
-    float* red = smem;   // [2][WM][BN]; all LDS reads of the main loop are behind a barrier
+    // Per-tile (count, sum, M2 about the tile mean) -> merged with Chan's formula in
+    // emsa_bn_finalize: no E[x^2]-mean^2 cancellation.  Deterministic (no atomics).
+    float* red = smem;            // [WM][BN]; main-loop LDS reads are all behind a barrier
+    float* tmean = smem + WM * BN;  // [BN]
+    const int cnt = min(BM, p.M - m0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 32);
-      if (lh == 0) {
-        const int col = (wn * TN + j) * 32 + l31;
-        red[(0 * WM + wm) * BN + col] = s1[j];
-        red[(1 * WM + wm) * BN + col] = s2[j];
+      if (lh == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s1[j];
+    }
+    __syncthreads();
+    for (int col = tid; col < BN; col += 256) {
+      float a1 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WM; ++w_) a1 += red[w_ * BN + col];
+      tmean[col] = a1 / (float)cnt;
+      const int n = n0 + col;
+      if (n < g.n_ch) {
+        p.stats[((size_t)0 * p.tiles_m + mt) * g.n_ch + n] = a1;
+        p.stats[((size_t)2 * p.tiles_m + mt) * g.n_ch + n] = (float)cnt;
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = (wn * TN + j) * 32 + l31;
+      const int n = n0 + col;
+      const float bv = (n < g.n_ch && p.bias) ? p.bias[n] : 0.f;
+      const float mu = tmean[col];
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m0 + row < p.M) {
+            const float d = acc[i][j][r] + bv - mu;
+            q2 += d * d;
+          }
+        }
+      s2[j] = q2 + __shfl_xor(q2, 32);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (lh == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s2[j];
     __syncthreads();
     for (int col = tid; col < BN; col += 256) {
       const int n = n0 + col;
       if (n < g.n_ch) {
-        float a1 = 0.f, a2 = 0.f;
+        float a2 = 0.f;
 #pragma unroll
-        for (int w_ = 0; w_ < WM; ++w_) {
-          a1 += red[(0 * WM + w_) * BN + col];
-          a2 += red[(1 * WM + w_) * BN + col];
-        }
-        p.stats[((size_t)0 * p.tiles_m + mt) * g.n_ch + n] = a1;
+        for (int w_ = 0; w_ < WM; ++w_) a2 += red[w_ * BN + col];
         p.stats[((size_t)1 * p.tiles_m + mt) * g.n_ch + n] = a2;
       }
     }
@@ -496,7 +569,10 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
     attr = true;
   }
   const int grid = a.tiles_m * a.tiles_n;
+  constexpr int cls = BN == 128 ? 0 : BN == 32 ? 3 : BM == 128 ? 1 : 2;
+  ProfSlot* ps = prof_begin(cls, algo_flops(a.g), st);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, a);
+  prof_end(ps, st);
   return emsa_launch_status();
 }
 
@@ -521,8 +597,11 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   if (ksplit < 1) ksplit = 1;
   a.steps_per_split = (a.steps_total + ksplit - 1) / ksplit;
   ksplit = (a.steps_total + a.steps_per_split - 1) / a.steps_per_split;
+  constexpr int cls = TT == 7 ? 4 : TT == 3 ? 7 : BCO == 128 ? 5 : 6;
+  ProfSlot* ps = prof_begin(cls, algo_flops(a.g), st);
   hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>), dim3(a.n_tiles * ksplit),
                      dim3(256), lds, st, a);
+  prof_end(ps, st);
   return emsa_launch_status();
 }
 
@@ -581,4 +660,37 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     return launch_wgrad<64, 64, 1, 2, 2, 1>(a, st);
   }
   return launch_wgrad<64, 64, 3, 2, 2, 1>(a, st);
+}
+
+// ---- profiling C-ABI -------------------------------------------------------------------------
+extern "C" int emsa_prof_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return EMSA_OK;
+}
+extern "C" int emsa_prof_reset(void) {
+  g_prof_used = 0;
+  return EMSA_OK;
+}
+extern "C" const char* emsa_prof_name(int32_t cls) {
+  return (cls >= 0 && cls < 8) ? kProfNames[cls] : "";
+}
+// call after the stream has been synchronised; sums over the launches recorded since reset
+extern "C" int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops,
+                              int32_t* launches) {
+  if (!total_ms || !total_flops || !launches) return EMSA_E_ARG;
+  double ms = 0.0, fl = 0.0;
+  int n = 0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    const ProfSlot& s = g_prof_pool[i];
+    if (s.cls != cls) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) return EMSA_E_LAUNCH;
+    ms += t;
+    fl += s.flops;
+    ++n;
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = n;
+  return EMSA_OK;
 }

@@ -117,20 +117,45 @@ __device__ __forceinline__ void reduce_rows(const float* __restrict__ partial, i
   }
 }
 
+// stats = float[3][rows][c]: per-tile sum, M2 (about the tile mean), count.  Chan et al. merge in
+// fp64: block = 32 channels x 8 row groups, groups merged through LDS.
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int rows, int c, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean,
                                    float* running_var, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-  double s1, s2;
-  int ch;
-  bool leader;
-  reduce_rows(stats, rows, c, s1, s2, ch, leader);
-  if (!leader) return;
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;
-  if (var < 0.0) var = 0.0;
+  __shared__ double sn[8][32], sm[8][32], sq[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  if (ch < c) {
+    for (int r = rg; r < rows; r += 8) {
+      const double nb = (double)stats[((long)2 * rows + r) * c + ch];
+      if (nb <= 0.0) continue;
+      const double mb = (double)stats[((long)0 * rows + r) * c + ch] / nb;
+      const double qb = (double)stats[((long)1 * rows + r) * c + ch];
+      const double nn = n + nb, d = mb - mean;
+      mean += d * nb / nn;
+      m2 += qb + d * d * n * nb / nn;
+      n = nn;
+    }
+  }
+  sn[rg][cl] = n; sm[rg][cl] = mean; sq[rg][cl] = m2;
+  __syncthreads();
+  if (rg != 0 || ch >= c) return;
+  n = 0.0; mean = 0.0; m2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double nb = sn[k][cl];
+    if (nb <= 0.0) continue;
+    const double nn = n + nb, d = sm[k][cl] - mean;
+    mean += d * nb / nn;
+    m2 += sq[k][cl] + d * d * n * nb / nn;
+    n = nn;
+  }
+  (void)count;
+  const double var = n > 0.0 ? m2 / n : 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[ch] * invstd;
   scale[ch] = sc;
@@ -138,7 +163,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int rows, in
   save_mean[ch] = (float)mean;
   save_invstd[ch] = invstd;
   if (running_mean) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
     running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
     running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
   }
@@ -393,10 +418,11 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* _
 // ------------------------------------------------------------------------------------------
 // squeeze-and-excitation
 // ------------------------------------------------------------------------------------------
-// out[n][c] += scale * sum_{hw chunk} a*b (b may be NULL -> sum a)
+// stage 1: ws[n][split][c] = sum_{hw chunk} a*b (b may be NULL -> sum a); stage 2 sums the splits
+// in a fixed order -> bit-reproducible (no atomics: the SE weighting feeds every later layer, and
+// run-to-run noise there flips ReLU masks downstream)
 __global__ void channel_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                   float* __restrict__ out, long hw, int c4n, int splits,
-                                   float scale) {
+                                   float* __restrict__ ws, long hw, int c4n, int splits) {
   const int img = blockIdx.x / splits, sp = blockIdx.x % splits;
   const long chunk = (hw + splits - 1) / splits;
   const long p0 = img * hw + sp * chunk, p1 = min(img * hw + (sp + 1) * chunk, (img + 1) * hw);
@@ -415,13 +441,17 @@ __global__ void channel_dot_kernel(const float* __restrict__ a, const float* __r
         t2 = emsa_zero4();
       },
       o1, o2, leader, c4);
-  if (leader) {
-    float* o = out + ((long)img * c4n + c4) * 4;
-    unsafeAtomicAdd(o + 0, o1.x * scale);
-    unsafeAtomicAdd(o + 1, o1.y * scale);
-    unsafeAtomicAdd(o + 2, o1.z * scale);
-    unsafeAtomicAdd(o + 3, o1.w * scale);
-  }
+  if (leader) emsa_st4(ws + ((long)blockIdx.x * c4n + c4) * 4, o1);
+}
+
+__global__ void channel_dot_finish_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                          int n, int c, int splits, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const int img = i / c, ch = i % c;
+  float a = 0.f;
+  for (int sp = 0; sp < splits; ++sp) a += ws[((long)img * splits + sp) * c + ch];
+  out[i] = a * scale;
 }
 
 __global__ void se_mlp_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
@@ -1014,30 +1044,38 @@ extern "C" int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* 
   return emsa_launch_status();
 }
 
-static int channel_dot(const float* a, const float* b, float* out, int n, long hw, int c,
-                       float scale, hipStream_t st) {
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
-  if (hipMemsetAsync(out, 0, (size_t)n * c * sizeof(float), st) != hipSuccess)
-    return EMSA_E_LAUNCH;
+static int channel_splits(long hw) {
   int splits = (int)((hw + 511) / 512);
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
+  return splits;
+}
+
+static int channel_dot(const float* a, const float* b, float* out, float* ws, int n, long hw,
+                       int c, float scale, hipStream_t st) {
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  const int splits = channel_splits(hw);
   const int c4n = c / 4, lanes = kThreads / c4n;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
-  hipLaunchKernelGGL(channel_dot_kernel, dim3(n * splits), dim3(kThreads), lds, st, a, b, out, hw,
-                     c4n, splits, scale);
+  hipLaunchKernelGGL(channel_dot_kernel, dim3(n * splits), dim3(kThreads), lds, st, a, b, ws, hw,
+                     c4n, splits);
+  hipLaunchKernelGGL(channel_dot_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, ws,
+                     out, n, c, splits, scale);
   return emsa_launch_status();
 }
 
-extern "C" int emsa_channel_mean(const float* x, float* gap, int32_t n, int64_t hw, int32_t c,
-                                 void* stream) {
-  if (!x || !gap) return EMSA_E_ARG;
-  return channel_dot(x, nullptr, gap, n, (long)hw, c, 1.0f / (float)hw, (hipStream_t)stream);
+extern "C" int emsa_channel_ws_floats(int32_t n, int64_t hw, int32_t c) {
+  return n * channel_splits((long)hw) * c;
 }
-extern "C" int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, int32_t n,
-                                        int64_t hw, int32_t c, void* stream) {
-  if (!dout || !x || !ds) return EMSA_E_ARG;
-  return channel_dot(dout, x, ds, n, (long)hw, c, 1.0f, (hipStream_t)stream);
+extern "C" int emsa_channel_mean(const float* x, float* gap, float* ws, int32_t n, int64_t hw,
+                                 int32_t c, void* stream) {
+  if (!x || !gap || !ws) return EMSA_E_ARG;
+  return channel_dot(x, nullptr, gap, ws, n, (long)hw, c, 1.0f / (float)hw, (hipStream_t)stream);
+}
+extern "C" int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, float* ws,
+                                        int32_t n, int64_t hw, int32_t c, void* stream) {
+  if (!dout || !x || !ds || !ws) return EMSA_E_ARG;
+  return channel_dot(dout, x, ds, ws, n, (long)hw, c, 1.0f, (hipStream_t)stream);
 }
 
 extern "C" int emsa_se_mlp_fwd(const float* gap, const float* w1, const float* b1,

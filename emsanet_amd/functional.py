@@ -7,6 +7,8 @@ NHWC (torch "channels_last"), possibly a channel slice of a wider NHWC buffer (p
 `ld` >= C).  torch is used here for device memory and the current stream only; every byte of
 arithmetic happens in the HIP kernels.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -19,11 +21,23 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_POISON = bool(os.environ.get('EMSA_POISON'))
+
+
+def _empty(shape, device, dtype=torch.float32):
+    """scratch/output allocation; EMSA_POISON=1 fills it with NaN (debug: finds reads of
+    memory a kernel was supposed to write)"""
+    t = torch.empty(shape, device=device, dtype=dtype)
+    if _POISON:
+        t.fill_(float('nan') if dtype.is_floating_point else 111)
+    return t
+
+
 def act_empty(n, c, h, w, device, ld=None):
     """(N,C,H,W) view over fresh NHWC memory (optionally a slice of an ld-wide buffer)."""
     if ld is None or ld == c:
-        return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
-    return torch.empty((n, h, w, ld), device=device, dtype=torch.float32)[..., :c].permute(0, 3, 1, 2)
+        return _empty((n, h, w, c), device).permute(0, 3, 1, 2)
+    return _empty((n, h, w, ld), device)[..., :c].permute(0, 3, 1, 2)
 
 
 def act_zeros(n, c, h, w, device):
@@ -127,7 +141,7 @@ def pack_weight(w, mode, cout_total=None, cout_off=0, cin_total=None, cin_off=0,
         if cout_total != cout or cin_total != cin:
             out = torch.zeros(kh * kw * cout_total * cin_total, device=w.device, dtype=torch.float32)
         else:
-            out = torch.empty(kh * kw * cout_total * cin_total, device=w.device, dtype=torch.float32)
+            out = _empty(kh * kw * cout_total * cin_total, w.device)
     fn = _lib.lib().emsa_pack_weight_fwd if mode == 'fwd' else _lib.lib().emsa_pack_weight_dgrad
     check(fn(_p(w), _p(out), cout, cin, kh, kw, cout_total, cout_off, cin_total, cin_off,
              _stream()), 'emsa_pack_weight_' + mode)
@@ -136,7 +150,7 @@ def pack_weight(w, mode, cout_total=None, cout_off=0, cin_total=None, cin_off=0,
 
 def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off=0):
     cout, cin, kh, kw = like.shape if like.dim() == 4 else (like.shape[0], like.shape[1], 1, 1)
-    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    dw = _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_unpack_wgrad(_p(dwp), _p(dw), cout, cin, kh, kw, cout_total or cout,
                                        cout_off, cin_total or cin, cin_off, _stream()),
           'emsa_unpack_wgrad')
@@ -159,7 +173,7 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
         rows = L.emsa_conv_stats_rows(g)
         if rows <= 0:
             check(rows or -1, 'emsa_conv_stats_rows')
-        stats = torch.empty((2, rows, spec.cout), device=x.device, dtype=torch.float32)
+        stats = _empty((3, rows, spec.cout), x.device)
     check(L.emsa_conv_igemm(g, _p(x), _p(wp), _p(out), _p(bias), _p(stats), _p(scale), _p(shift),
                             _p(residual), ld_of(residual) if residual is not None else 0,
                             None, 0, act, _stream()), 'emsa_conv_igemm')
@@ -222,7 +236,7 @@ class StemSpec:
 def stem_pack_input(x_nchw):
     x = x_nchw.contiguous()
     n, c, h, w = x.shape
-    xp = torch.empty((n, h, w + 8, 4), device=x.device, dtype=torch.float32)
+    xp = _empty((n, h, w + 8, 4), x.device)
     check(_lib.lib().emsa_stem_pack_input(_p(x), _p(xp), n, c, h, w, _stream()),
           'emsa_stem_pack_input')
     return xp
@@ -230,7 +244,7 @@ def stem_pack_input(x_nchw):
 
 def stem_pack_weight(w):
     cout, cin = w.shape[:2]
-    wp = torch.empty(7 * cout * 32, device=w.device, dtype=torch.float32)
+    wp = _empty(7 * cout * 32, w.device)
     check(_lib.lib().emsa_stem_pack_weight(_p(w), _p(wp), cout, cin, _stream()),
           'emsa_stem_pack_weight')
     return wp
@@ -244,7 +258,7 @@ def stem_fwd(xp, wpk, spec, n, h, w, want_stats=True):
     stats = None
     if want_stats:
         rows = L.emsa_conv_stats_rows(g)
-        stats = torch.empty((2, rows, spec.cout), device=xp.device, dtype=torch.float32)
+        stats = _empty((3, rows, spec.cout), xp.device)
     check(L.emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), None, _p(stats), None, None, None, 0,
                             None, 0, ACT_NONE, _stream()), 'emsa_conv_igemm(stem)')
     return out, stats
@@ -265,7 +279,7 @@ def stem_wgrad(xp, dy, spec, n, h, w, like):
     dwp = torch.zeros(7 * spec.cout * 32, device=dy.device, dtype=torch.float32)
     check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), None, _stream()),
           'emsa_conv_wgrad(stem)')
-    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    dw = _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
           'emsa_stem_unpack_wgrad')
     return dw
@@ -276,7 +290,7 @@ def stem_wgrad(xp, dy, spec, n, h, w, like):
 # ---------------------------------------------------------------------------------------------
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
     c = gamma.shape[0]
-    buf = torch.empty((4, c), device=gamma.device, dtype=torch.float32)
+    buf = _empty((4, c), gamma.device)
     check(_lib.lib().emsa_bn_finalize(_p(stats), stats.shape[1], c, count, _p(gamma), _p(beta),
                                       eps, momentum, _p(running_mean), _p(running_var),
                                       _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream()),
@@ -286,7 +300,7 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
 
 def bn_fold(gamma, beta, running_mean, running_var, eps):
     c = gamma.shape[0]
-    buf = torch.empty((3, c), device=gamma.device, dtype=torch.float32)
+    buf = _empty((3, c), gamma.device)
     check(_lib.lib().emsa_bn_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, c,
                                   _p(buf[0]), _p(buf[1]), _p(buf[2]), _stream()), 'emsa_bn_fold')
     return buf[0], buf[1], buf[2]               # scale, shift, invstd
@@ -307,12 +321,12 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
     assert ld_of(x) == c and ld_of(dy) == c
     L = _lib.lib()
     rows = L.emsa_bn_bwd_rows(n * h * w)
-    partial = torch.empty((2, rows, c), device=x.device, dtype=torch.float32)
+    partial = _empty((2, rows, c), x.device)
     check(L.emsa_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(drop), n, h * w, c,
                                act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
     dx = act_empty(n, c, h, w, x.device)
     dres = act_empty(n, c, h, w, x.device) if want_dres else None
-    dgb = torch.empty((2, c), device=x.device, dtype=torch.float32)
+    dgb = _empty((2, c), x.device)
     check(L.emsa_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(gamma), _p(mean), _p(invstd), _p(drop),
                               _p(partial), rows, n, h * w, c, act, 1 if train else 0, _p(dx),
                               _p(dres), _p(dgb[0]), _p(dgb[1]), _stream()), 'emsa_bn_bwd_apply')
@@ -320,7 +334,7 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
 
 
 def dropout2d_mask(n, c, p, seed, layer_id, device):
-    m = torch.empty((n, c), device=device, dtype=torch.float32)
+    m = _empty((n, c), device)
     check(_lib.lib().emsa_dropout2d_mask(_p(m), n, c, p, seed & 0xFFFFFFFF, layer_id, _stream()),
           'emsa_dropout2d_mask')
     return m
@@ -334,7 +348,7 @@ def maxpool_fwd(x):
     assert ld_of(x) == c
     oh, ow = (h + 1) // 2, (w + 1) // 2
     y = act_empty(n, c, oh, ow, x.device)
-    idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.int8)
+    idx = _empty((n, oh, ow, c), x.device, torch.int8)
     check(_lib.lib().emsa_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()),
           'emsa_maxpool3x3s2_fwd')
     return y, idx
@@ -353,8 +367,9 @@ def maxpool_bwd(dy, idx, in_hw):
 def channel_mean(x):
     n, c, h, w = x.shape
     assert ld_of(x) == c
-    gap = torch.empty((n, c), device=x.device, dtype=torch.float32)
-    check(_lib.lib().emsa_channel_mean(_p(x), _p(gap), n, h * w, c, _stream()),
+    gap = _empty((n, c), x.device)
+    ws = _empty((_lib.lib().emsa_channel_ws_floats(n, h * w, c),), x.device)
+    check(_lib.lib().emsa_channel_mean(_p(x), _p(gap), _p(ws), n, h * w, c, _stream()),
           'emsa_channel_mean')
     return gap
 
@@ -362,8 +377,8 @@ def channel_mean(x):
 def se_mlp_fwd(gap, w1, b1, w2, b2):
     n, c = gap.shape
     cr = w1.shape[0]
-    hid = torch.empty((n, cr), device=gap.device, dtype=torch.float32)
-    s = torch.empty((n, c), device=gap.device, dtype=torch.float32)
+    hid = _empty((n, cr), gap.device)
+    s = _empty((n, c), gap.device)
     check(_lib.lib().emsa_se_mlp_fwd(_p(gap), _p(w1), _p(b1), _p(w2), _p(b2), _p(hid), _p(s), n, c,
                                      cr, _stream()), 'emsa_se_mlp_fwd')
     return hid, s
@@ -373,11 +388,11 @@ def se_mlp_bwd(gap, w1, w2, hid, s, ds):
     n, c = gap.shape
     cr = w1.shape[0]
     dev = gap.device
-    dgap = torch.empty((n, c), device=dev, dtype=torch.float32)
-    dw1 = torch.empty((cr, c), device=dev, dtype=torch.float32)
-    db1 = torch.empty((cr,), device=dev, dtype=torch.float32)
-    dw2 = torch.empty((c, cr), device=dev, dtype=torch.float32)
-    db2 = torch.empty((c,), device=dev, dtype=torch.float32)
+    dgap = _empty((n, c), dev)
+    dw1 = _empty((cr, c), dev)
+    db1 = _empty((cr,), dev)
+    dw2 = _empty((c, cr), dev)
+    db2 = _empty((c,), dev)
     check(_lib.lib().emsa_se_mlp_bwd(_p(gap), _p(w1), _p(w2), _p(hid), _p(s), _p(ds), _p(dgap),
                                      _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, _stream()),
           'emsa_se_mlp_bwd')
@@ -394,9 +409,10 @@ def se_scale_add(a, sa, b=None, sb=None):
 
 def se_scale_bwd_reduce(dout, x):
     n, c, h, w = x.shape
-    ds = torch.empty((n, c), device=x.device, dtype=torch.float32)
-    check(_lib.lib().emsa_se_scale_bwd_reduce(_p(dout), _p(x), _p(ds), n, h * w, c, _stream()),
-          'emsa_se_scale_bwd_reduce')
+    ds = _empty((n, c), x.device)
+    ws = _empty((_lib.lib().emsa_channel_ws_floats(n, h * w, c),), x.device)
+    check(_lib.lib().emsa_se_scale_bwd_reduce(_p(dout), _p(x), _p(ds), _p(ws), n, h * w, c,
+                                              _stream()), 'emsa_se_scale_bwd_reduce')
     return ds
 
 

@@ -15,6 +15,28 @@ from torch.autograd.function import once_differentiable
 from . import functional as Fn
 from .functional import ACT_NONE, ACT_RELU
 
+# debug: set to a list to record (tag, tensor clone) for every backward's inputs and outputs
+TRACE = None
+
+
+def _traced(fn):
+    """wrap a Function.backward: with ops.TRACE = [] every incoming / outgoing gradient is cloned
+    into the list (tools/determinism.py uses it to find the first diverging tensor)."""
+    def wrapper(ctx, *grads):
+        if TRACE is None:
+            return fn(ctx, *grads)
+        tag = fn.__qualname__.split('.')[0]
+        for i, g in enumerate(grads):
+            if torch.is_tensor(g):
+                TRACE.append((f'{tag}.in{i}', g.detach().clone()))
+        out = fn(ctx, *grads)
+        for i, g in enumerate(out if isinstance(out, tuple) else (out,)):
+            if torch.is_tensor(g):
+                TRACE.append((f'{tag}.out{i}', g.detach().clone()))
+        return out
+    wrapper.__qualname__ = fn.__qualname__
+    return wrapper
+
 
 # ---------------------------------------------------------------------------------------------
 # runtime views of parameter containers
@@ -150,6 +172,7 @@ class NBt1DFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dout):
         rt, drop = ctx.rt, ctx.drop
         x, out = ctx.saved_tensors
@@ -218,6 +241,7 @@ class ConvBNActFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dout):
         x, out = ctx.saved_tensors
         y, mean, invstd = ctx.saved
@@ -297,6 +321,7 @@ class MultiConvFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dy):
         rt = ctx.rt
         (x,) = ctx.saved_tensors
@@ -358,6 +383,7 @@ class StemFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dout):
         rt = ctx.rt
         (out,) = ctx.saved_tensors
@@ -393,6 +419,7 @@ class MaxPoolFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dy):
         return Fn.maxpool_bwd(Fn.as_act(dy, dense=True), ctx.idx, ctx.hw)
 
@@ -423,6 +450,7 @@ class SEAddFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dout):
         rgb, depth = ctx.saved_tensors
         gr, gd, hr, sr, hd, sd, w1r, w2r, w1d, w2d = ctx.saved
@@ -459,6 +487,7 @@ class UpsampleDWFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = Fn.as_act(dy, dense=True)
@@ -479,6 +508,7 @@ class AdaptiveAvgPoolFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dy):
         n, c, h, w = ctx.shape
         dx = Fn.act_empty(n, c, h, w, dy.device)
@@ -506,6 +536,7 @@ class PPMConcatFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dbuf):
         dbuf = Fn.as_act(dbuf)
         c, yshapes = ctx.meta
@@ -532,6 +563,7 @@ class HeadActFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @_traced
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         return Fn.head_act_bwd(Fn.as_act(dy, dense=True), y, *ctx.cfg), None, None

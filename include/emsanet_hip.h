@@ -72,9 +72,9 @@ typedef struct EmsaConvGeom {
 /* out[m][n] = epilogue( sum_{tap,c} in[gather(m,tap)][c] * w[tap][n][c] )
  *   w        packed [kh*kw][n_ch][k_ch]  (emsa_pack_weight_*)
  *   bias     [n_ch] or NULL: v = acc + bias[n]
- *   stats    NULL, or float[2][gridM][n_ch]: per-M-tile partial sum / sum of squares of v
- *            (BatchNorm batch statistics; gridM = emsa_conv_stats_rows(geom)); reduce with
- *            emsa_bn_finalize
+ *   stats    NULL, or float[3][gridM][n_ch]: per-M-tile sum of v, M2 = sum (v - tile mean)^2 and
+ *            row count (BatchNorm batch statistics; gridM = emsa_conv_stats_rows(geom));
+ *            merged by emsa_bn_finalize (Chan et al., fp64) -- no E[x^2]-mean^2 cancellation
  *   scale/shift [n_ch] or NULL: v = v*scale[n] + shift[n]     (folded eval-mode BatchNorm)
  *   residual NULL or tensor with pixel stride ld_res: v += residual[m][n]
  *   mask_src NULL or tensor with pixel stride ld_mask: v = mask_src[m][n] > 0 ? v : 0
@@ -126,7 +126,7 @@ int emsa_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, int32_t cout,
  * BatchNorm (+ReLU, +Dropout2d, +residual add)  -- nn.BatchNorm2d / activation / nn.Dropout2d /
  * `out + identity` of the NBt1D block and of every ConvNormAct.
  * ------------------------------------------------------------------------------------------ */
-/* reduce the conv's stats partials -> batch mean/var; writes scale = gamma*invstd,
+/* merge the conv's stats partials [3][rows][c] -> batch mean/var; writes scale = gamma*invstd,
  * shift = beta - mean*scale, save_mean, save_invstd; updates running stats in place
  * (momentum, unbiased variance) when running_mean != NULL.  count = pixels per channel.      */
 int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int64_t count,
@@ -172,7 +172,10 @@ int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t
  *   emsa_channel_mean: gap[n][c] = mean_hw x                      (F.adaptive_avg_pool2d(x,1))
  *   emsa_se_mlp_fwd:   hid = relu(W1 gap + b1); s = sigmoid(W2 hid + b2)   (W1 [cr][c], W2 [c][cr])
  *   emsa_se_scale_add_fwd: out = a*sa[n][c] + b*sb[n][c]          (b/sb NULL: plain SE)        */
-int emsa_channel_mean(const float* x, float* gap, int32_t n, int64_t hw, int32_t c,
+/* `ws` = caller-provided scratch of emsa_channel_ws_floats(n, hw, c) floats (two-stage,
+ * atomics-free, bit-reproducible reduction) */
+int emsa_channel_ws_floats(int32_t n, int64_t hw, int32_t c);
+int emsa_channel_mean(const float* x, float* gap, float* ws, int32_t n, int64_t hw, int32_t c,
                       void* stream);
 int emsa_se_mlp_fwd(const float* gap, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* hid, float* s, int32_t n, int32_t c, int32_t cr,
@@ -183,8 +186,8 @@ int emsa_se_mlp_bwd(const float* gap, const float* w1, const float* w2, const fl
 int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b, const float* sb,
                           float* out, int32_t n, int64_t hw, int32_t c, void* stream);
 /* ds[n][c] = sum_hw dout*x   (gradient w.r.t. the SE weighting) */
-int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, int32_t n, int64_t hw,
-                             int32_t c, void* stream);
+int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, float* ws, int32_t n,
+                             int64_t hw, int32_t c, void* stream);
 /* dx = dout*s[n][c] + dgap[n][c]/hw  (+ dx_extra if not NULL: gradient arriving from another
  * consumer of x, e.g. the depth stream that continues un-fused)                             */
 int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap,
@@ -224,6 +227,18 @@ int emsa_head_act_bwd(const float* dy, const float* y, float* dx, int64_t pixels
 int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y, int64_t pixels,
                        int32_t c, void* stream);
 int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every
+ * emsa_conv_igemm / emsa_conv_wgrad launch is bracketed by HIP events on its own stream.
+ * cls 0..3 = conv_igemm_kernel tile configs, 4..7 = conv_wgrad_kernel configs
+ * (emsa_prof_name).  emsa_prof_read: call after synchronising; sums since emsa_prof_reset;
+ * total_flops = ALGORITHMIC direct-convolution FLOPs (2*pixels*k_ch*n_ch*taps).
+ * ------------------------------------------------------------------------------------------ */
+int emsa_prof_enable(int32_t on);
+int emsa_prof_reset(void);
+const char* emsa_prof_name(int32_t cls);
+int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops, int32_t* launches);
 
 #ifdef __cplusplus
 }

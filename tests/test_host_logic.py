@@ -21,6 +21,8 @@ class _FakeLib:
             self.calls[name] += 1
             if name in ('emsa_conv_stats_rows', 'emsa_bn_bwd_rows'):
                 return 3
+            if name == 'emsa_channel_ws_floats':
+                return 64
             return 0
         return fn
 

@@ -49,8 +49,12 @@ def test_conv_fwd(cfg, tile, monkeypatch):
     torch.cuda.synchronize()
     close(y, ref, what='conv')
     cnt = ref.numel() / cout
-    close(stats[0].sum(0) / cnt, ref.mean((0, 2, 3)), what='stats mean')
-    close(stats[1].sum(0) / cnt, (ref * ref).mean((0, 2, 3)), tol=2e-4, what='stats sq')
+    assert float(stats[2][:, 0].sum()) == cnt
+    mean = stats[0].sum(0) / cnt
+    close(mean, ref.mean((0, 2, 3)), what='stats mean')
+    tile_mean = stats[0] / stats[2]
+    m2 = stats[1].sum(0) + (stats[2] * (tile_mean - mean[None]) ** 2).sum(0)
+    close(m2 / cnt, ref.var((0, 2, 3), unbiased=False), tol=2e-4, what='stats var')
     # fused epilogue: folded BN + residual + relu
     sc, sh = rnd(cout, seed=4), rnd(cout, seed=5)
     res = rnd(*ref.shape, seed=6)
@@ -180,7 +184,9 @@ def test_bn_fwd_bwd(c, act, train):
         rows = 5
         chunks = torch.chunk(xs, rows, 0)
         stats = torch.stack([torch.stack([ch.sum(0) for ch in chunks]),
-                             torch.stack([(ch * ch).sum(0) for ch in chunks])]).to(DEV)
+                             torch.stack([((ch - ch.mean(0)) ** 2).sum(0) for ch in chunks]),
+                             torch.stack([torch.full((c,), float(ch.shape[0])) for ch in chunks])
+                             ]).to(DEV)
         scale, shift, mean, invstd = Fn.bn_finalize(stats, xs.shape[0], g, b, eps, 0.1, rmg, rvg)
         close(rmg, rm_ref, what='running mean')
         close(rvg, rv_ref, what='running var')
