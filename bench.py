@@ -92,7 +92,7 @@ def cpu_baseline(args):
     o = EMSANetOracle(a, nyuv2_config())
     o.load_state_dict(deterministic_state_dict(o, 0))
     o.train()
-    bs = 1
+    bs = 2      # train-mode BatchNorm of the PPM 1x1 branch needs > 1 sample per channel
     batch = synthetic_batch(bs, args.height, args.width)
 
     def step():
