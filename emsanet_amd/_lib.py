@@ -11,7 +11,8 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int8, c_int32, c_int64, c_uint32, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libemsanet_hip.so')
+LIB_PATH = os.environ.get('EMSA_LIB') or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), 'lib', 'libemsanet_hip.so')   # EMSA_LIB: tuning builds
 
 
 class EmsaConvGeom(Structure):
@@ -41,11 +42,13 @@ SIGNATURES = {
     'emsa_pack_weight_fwd': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),
     'emsa_pack_weight_dgrad': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),
     'emsa_unpack_wgrad': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),
+    'emsa_pack_weight_pair': (c_int, [_P, _P, _P] + [c_int32] * 4 + [_P]),
     'emsa_stem_pack_input': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_stem_pack_weight': (c_int, [_P, _P, c_int32, c_int32, _P]),
     'emsa_stem_unpack_wgrad': (c_int, [_P, _P, c_int32, c_int32, _P]),
     'emsa_bn_finalize': (c_int, [_P, c_int32, c_int32, c_int64, _P, _P, c_float, c_float,
-                                 _P, _P, _P, _P, _P, _P, _P]),
+                                 _P, _P, _P, _P, _P, _P, _P, _P]),
+    'emsa_bn_finalize_ws_bytes': (c_int, [c_int32]),
     'emsa_bn_fold': (c_int, [_P, _P, _P, _P, c_float, c_int32, _P, _P, _P, _P]),
     'emsa_bn_act_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
     'emsa_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32,

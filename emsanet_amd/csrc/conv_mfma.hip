@@ -68,8 +68,29 @@ double algo_flops(const EmsaConvGeom& g) {
   return 2.0 * px * g.k_ch * g.n_ch * g.kh * g.kw;
 }
 
+#ifndef EMSA_ABL
+#define EMSA_ABL 0   // tuning only (tools/conv_bench.py): 1 = no global loads, 2 = no stores, 4 = no MFMA
+#endif
 constexpr int kBK = 32;   // K chunk (channels) per step
 constexpr int kLD = 36;   // padded LDS row (floats)
+
+
+// unsigned division by a launch-time constant (n < 2^31): q = (mulhi(n, mul) + n) >> shift
+struct FastDiv {
+  uint32_t mul, shift, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.mul = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f) {
+  return (__umulhi(n, f.mul) + n) >> f.shift;
+}
 
 struct ConvArgs {
   EmsaConvGeom g;
@@ -84,19 +105,33 @@ struct ConvArgs {
   const float* mask_src;
   int ld_res, ld_mask, act;
   int M, tiles_m, tiles_n, kchunks;
+  uint32_t in_bytes, w_bytes;
+  int vec_epilogue;          // float4 epilogue legal (n_ch, ld's, pointers 16-B aligned)
+  FastDiv div_ohw, div_ow;
 };
 
-// gather helper: element offset of (row base, tap) or -1
+// Hardware bounds-checked 16-byte load: an offset >= num_records returns 0, which IS the zero
+// padding / tail predication of the implicit GEMM -- no exec-mask branches around the loads.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOOB = 0x80000000u;   // every buffer is < 2 GiB (checked by the launcher)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+// gather helper: BYTE offset of (row base, tap) or kOOB
 struct Gather {
   int mul_h, off_h, step_h, div_h, mul_w, off_w, step_w, div_w, in_h, in_w;
   int row_stride, px_stride;
 };
 
-__device__ __forceinline__ int gather_offset(const Gather& q, int img_off, int bh, int bw,
-                                             int kh, int kw) {
+__device__ __forceinline__ uint32_t gather_offset(const Gather& q, int img_off, int bh, int bw,
+                                                  int kh, int kw) {
   int hn = bh + kh * q.step_h, wn = bw + kw * q.step_w;
   bool ok = true;
-  if (q.div_h > 1) {
+  if (q.div_h > 1) {      // strided data gradient only (wave-uniform branch)
     ok = ok && (hn % q.div_h == 0);
     hn /= q.div_h;
   }
@@ -105,7 +140,7 @@ __device__ __forceinline__ int gather_offset(const Gather& q, int img_off, int b
     wn /= q.div_w;
   }
   ok = ok && hn >= 0 && hn < q.in_h && wn >= 0 && wn < q.in_w;
-  return ok ? img_off + hn * q.row_stride + wn * q.px_stride : -1;
+  return ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * 4u : kOOB;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -133,15 +168,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   q.row_stride = (int)g.in_row_stride; q.px_stride = g.in_px_stride;
 
   // ---- loader state -------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
   const int rl = tid >> 3, c4 = (tid & 7) * 4;
-  int a_bh[AR], a_bw[AR], a_img[AR], a_off[AR];
-  const int ohw = g.out_h * g.out_w;
+  int a_bh[AR], a_bw[AR], a_img[AR];
+  uint32_t a_off[AR], b_off[BR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
     const int m = m0 + rl + 32 * j;
     if (m < p.M) {
-      const int img = m / ohw, rem = m - img * ohw;
-      const int oh = rem / g.out_w, ow = rem - oh * g.out_w;
+      const int img = (int)fast_div((uint32_t)m, p.div_ohw);
+      const int rem = m - img * (int)p.div_ohw.d;
+      const int oh = (int)fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
       a_bh[j] = oh * q.mul_h + q.off_h;
       a_bw[j] = ow * q.mul_w + q.off_w;
       a_img[j] = img * (int)g.in_img_stride;
@@ -151,8 +189,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       a_img[j] = 0;
     }
   }
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + rl + 32 * j;
+    b_off[j] = n < g.n_ch ? (uint32_t)(n * g.k_ch + c4) * 4u : kOOB;
+  }
   const int taps = g.kh * g.kw;
   const int steps = taps * p.kchunks;
+  const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 4u;
   int tap_n = 0, kc_n = 0;
   float4 ra[AR], rb[BR];
 
@@ -163,17 +207,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int j = 0; j < AR; ++j) a_off[j] = gather_offset(q, a_img[j], a_bh[j], a_bw[j], kh, kw);
     }
     const int k = kc_n * kBK + c4;
-    const bool kok = k < g.k_ch;
+    // k >= k_ch (partial last chunk) -> out of range; kOOB + small stays out of range
+    const uint32_t kb = k < g.k_ch ? (uint32_t)k * 4u : kOOB;
+    const uint32_t wb = k < g.k_ch ? (uint32_t)tap_n * w_tap_bytes + (uint32_t)(kc_n * kBK) * 4u
+                                   : kOOB;
+#if EMSA_ABL & 1
+#pragma unroll
+    for (int j = 0; j < AR; ++j) ra[j] = make_float4(a_off[j], kb, 1.f, 2.f);
+#pragma unroll
+    for (int j = 0; j < BR; ++j) rb[j] = make_float4(b_off[j], wb, 2.f, 1.f);
+#else
 #pragma unroll
     for (int j = 0; j < AR; ++j)
-      ra[j] = (kok && a_off[j] >= 0) ? emsa_ld4(p.in + a_off[j] + k) : emsa_zero4();
+      ra[j] = buf_ld4(rs_in, ((a_off[j] | kb) & kOOB) ? kOOB : a_off[j] + kb);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const int n = n0 + rl + 32 * j;
-      rb[j] = (kok && n < g.n_ch)
-                  ? emsa_ld4(p.w + ((size_t)tap_n * g.n_ch + n) * g.k_ch + k)
-                  : emsa_zero4();
-    }
+    for (int j = 0; j < BR; ++j)
+      rb[j] = buf_ld4(rs_w, ((b_off[j] | wb) & kOOB) ? kOOB : b_off[j] + wb);
+#endif
     if (++kc_n == p.kchunks) {
       kc_n = 0;
       ++tap_n;
@@ -222,7 +272,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const float bv = kk == 0 ? fb[j].x : kk == 1 ? fb[j].y : kk == 2 ? fb[j].z : fb[j].w;
+#if EMSA_ABL & 4
+            acc[i][j][kk] += av * bv;
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+#endif
           }
         }
       }
@@ -234,34 +288,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
   // ---- epilogue -------------------------------------------------------------------------
   const bool want_stats = p.stats != nullptr;
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
-
+  float s1[TN], s2[TN], bvv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + l31;
-    const bool nok = n < g.n_ch;
-    const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
-    const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-    const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+    bvv[j] = (n < g.n_ch && p.bias) ? p.bias[n] : 0.f;
+    s1[j] = s2[j] = 0.f;
+  }
+  if (want_stats) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + row;
-        if (m < p.M && nok) {
-          float v = acc[i][j][r] + bv;
-          s1[j] += v;
-          v = v * sc + sh;
-          if (p.residual) v += p.residual[(size_t)m * p.ld_res + n];
-          if (p.mask_src) v = p.mask_src[(size_t)m * p.ld_mask + n] > 0.f ? v : 0.f;
-          if (p.act == EMSA_ACT_RELU) v = fmaxf(v, 0.f);
-          p.out[(size_t)m * g.ld_out + n] = v;
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m0 + row < p.M) s1[j] += acc[i][j][r] + bvv[j];
         }
-      }
-    }
   }
 
   if (want_stats) {
@@ -322,6 +365,84 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       }
     }
   }
+
+  // ---- output pass --------------------------------------------------------------------------
+  if (p.vec_epilogue) {
+    // stage (acc + bias) through LDS so that global stores, residual and mask accesses are
+    // 16 B per lane along channels (whole 128-B lines per 8 lanes) instead of 4-B scalars
+    constexpr int SLD = BN + 4;
+    float* stage = smem;                 // [BM][SLD] <= LDS of the main loop
+    __syncthreads();                     // statistics (if any) are done with LDS
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          stage[row * SLD + (wn * TN + j) * 32 + l31] = acc[i][j][r] + bvv[j];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    const int col4 = tid % C4, row0 = tid / C4;
+    const int n = n0 + col4 * 4;
+    if (n < g.n_ch) {
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = emsa_zero4();
+      if (p.scale) {
+        sc = emsa_ld4(p.scale + n);
+        sh = emsa_ld4(p.shift + n);
+      }
+#pragma unroll 4
+      for (int row = row0; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        float4 v = emsa_ld4(stage + row * SLD + col4 * 4);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+        v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        if (p.residual) {
+          const float4 rr = emsa_ld4(p.residual + (size_t)m * p.ld_res + n);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.mask_src) {
+          const float4 mm = emsa_ld4(p.mask_src + (size_t)m * p.ld_mask + n);
+          v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
+          v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+        }
+        if (p.act == EMSA_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+#if EMSA_ABL & 2
+        if (v.x == 1.2345e30f) emsa_st4(p.out + (size_t)m * g.ld_out + n, v);
+#else
+        emsa_st4(p.out + (size_t)m * g.ld_out + n, v);
+#endif
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + l31;
+      const bool nok = n < g.n_ch;
+      const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+      const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int m = m0 + row;
+          if (m < p.M && nok) {
+            float v = (acc[i][j][r] + bvv[j]) * sc + sh;
+            if (p.residual) v += p.residual[(size_t)m * p.ld_res + n];
+            if (p.mask_src) v = p.mask_src[(size_t)m * p.ld_mask + n] > 0.f ? v : 0.f;
+            if (p.act == EMSA_ACT_RELU) v = fmaxf(v, 0.f);
+            p.out[(size_t)m * g.ld_out + n] = v;
+          }
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,6 +457,8 @@ struct WgradArgs {
   int M, steps_total, steps_per_split;
   int n_co_tiles, n_ci_tiles, n_tap_groups, n_tiles;
   int dout_aligned;   // float4 loads of dout are legal
+  uint32_t in_bytes, dout_bytes;
+  FastDiv div_ohw, div_ow;
 };
 
 template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
@@ -365,7 +488,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   q.mul_w = g.mul_w; q.off_w = g.off_w; q.step_w = g.step_w; q.div_w = g.div_w;
   q.in_h = g.in_h; q.in_w = g.in_w;
   q.row_stride = (int)g.in_row_stride; q.px_stride = g.in_px_stride;
-  const int ohw = g.out_h * g.out_w;
 
   const int s_begin = ks * p.steps_per_split;
   const int s_end = min(s_begin + p.steps_per_split, p.steps_total);
@@ -377,6 +499,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   float4 rd[DR], rx[TT][XR];
   float4 bsum = emsa_zero4();
 
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
   auto load_regs = [&](int s) {
     const int mb = s * PK;
 #pragma unroll
@@ -384,17 +508,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const int m = mb + d_r + j * (256 / DTPR);
       const int co = co0 + d_c4;
       float4 v = emsa_zero4();
-      if (m < p.M && co < g.n_ch) {
+#if !(EMSA_ABL & 1)
+      if (p.dout_aligned) {
+        v = buf_ld4(rs_dy, (m < p.M && co < g.n_ch) ? (uint32_t)(m * g.ld_out + co) * 4u : kOOB);
+      } else if (m < p.M && co < g.n_ch) {
         const float* src = p.dout + (size_t)m * g.ld_out + co;
-        if (p.dout_aligned && co + 3 < g.n_ch) {
-          v = emsa_ld4(src);
-        } else {
-          v.x = src[0];
-          if (co + 1 < g.n_ch) v.y = src[1];
-          if (co + 2 < g.n_ch) v.z = src[2];
-          if (co + 3 < g.n_ch) v.w = src[3];
-        }
+        v.x = src[0];
+        if (co + 1 < g.n_ch) v.y = src[1];
+        if (co + 2 < g.n_ch) v.z = src[2];
+        if (co + 3 < g.n_ch) v.w = src[3];
       }
+#endif
       rd[j] = v;
       bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
     }
@@ -404,22 +528,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const int ci = ci0 + x_c4;
       int bh = -(1 << 29), bw = 0, img_off = 0;
       if (m < p.M) {
-        const int img = m / ohw, rem = m - img * ohw;
-        const int oh = rem / g.out_w, ow = rem - oh * g.out_w;
+        const int img = (int)fast_div((uint32_t)m, p.div_ohw);
+        const int rem = m - img * (int)p.div_ohw.d;
+        const int oh = (int)fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
         bh = oh * q.mul_h + q.off_h;
         bw = ow * q.mul_w + q.off_w;
         img_off = img * (int)g.in_img_stride;
       }
+      const uint32_t cb = ci < g.k_ch ? (uint32_t)ci * 4u : kOOB;
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
         const int tap = tap0 + t;
-        float4 v = emsa_zero4();
-        if (tap < taps && ci < g.k_ch) {
-          const int kh = tap / g.kw, kw = tap - kh * g.kw;
-          const int off = gather_offset(q, img_off, bh, bw, kh, kw);
-          if (off >= 0) v = emsa_ld4(p.in + off + ci);
-        }
-        rx[t][j] = v;
+        const int kh = tap / g.kw, kw = tap - kh * g.kw;
+        uint32_t off = tap < taps ? gather_offset(q, img_off, bh, bw, kh, kw) : kOOB;
+        off = ((off | cb) & kOOB) ? kOOB : off + cb;
+#if EMSA_ABL & 1
+        rx[t][j] = make_float4(off, 1.f, 2.f, 3.f);
+#else
+        rx[t][j] = buf_ld4(rs_in, off);
+#endif
       }
     }
   };
@@ -535,16 +662,15 @@ int forced_tile() {
   return (v >= 0 && v < TILE_COUNT) ? v : -1;
 }
 
+// Measured on MI355X (tools/conv_bench.py, profiles/r01_b_conv_tiles.md): with the slow fp32 MFMA
+// (64 cycles per 32x32x2) operand reuse is not the limiter -- phase overlap is.  The 64x64 tile
+// (36 KiB LDS -> 4 workgroups = 16 waves per CU) beats 128x64 / 128x128 on every layer shape of
+// the model (c64: 80 vs 60 TF, c128: 94 vs 81, c256/c512: 95 vs 90), so it is the default;
+// 128x32 only serves the narrow heads.
 ConvTile pick_tile(long M, int n_ch) {
   const int f = forced_tile();
   if (f >= 0) return (ConvTile)f;
-  auto tiles = [&](ConvTile t) {
-    return ((M + tile_bm(t) - 1) / tile_bm(t)) * ((n_ch + tile_bn(t) - 1) / tile_bn(t));
-  };
-  if (n_ch <= 32) return tiles(TILE_128x32) >= 256 ? TILE_128x32 : TILE_64x64;
-  if (n_ch <= 64) return tiles(TILE_128x64) >= 512 ? TILE_128x64 : TILE_64x64;
-  if (tiles(TILE_128x128) >= 1024) return TILE_128x128;
-  if (tiles(TILE_128x64) >= 768) return TILE_128x64;
+  if (n_ch <= 32 && M >= 128 * 256) return TILE_128x32;
   return TILE_64x64;
 }
 
@@ -555,7 +681,9 @@ bool geom_ok(const EmsaConvGeom* g) {
   if (g->div_h < 1 || g->div_w < 1 || g->kh < 1 || g->kw < 1) return false;
   const long in_elems = (long)g->n_img * g->in_img_stride;
   const long out_elems = (long)g->n_img * g->out_h * g->out_w * (long)g->ld_out;
-  if (in_elems >= (1L << 31) || out_elems >= (1L << 31)) return false;
+  // buffer descriptors address < 2 GiB (kOOB = 2^31 must be out of range); outputs int32-indexed
+  if (in_elems >= (1L << 29) || out_elems >= (1L << 31)) return false;
+  if ((long)g->kh * g->kw * g->n_ch * g->k_ch >= (1L << 29)) return false;
   return true;
 }
 
@@ -633,6 +761,15 @@ extern "C" int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const flo
   a.tiles_m = (int)((M + tile_bm(t) - 1) / tile_bm(t));
   a.tiles_n = (g->n_ch + tile_bn(t) - 1) / tile_bn(t);
   a.kchunks = (g->k_ch + kBK - 1) / kBK;
+  a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
+  a.w_bytes = (uint32_t)((size_t)g->kh * g->kw * g->n_ch * g->k_ch * sizeof(float));
+  a.div_ohw = make_fastdiv((uint32_t)(g->out_h * g->out_w));
+  a.div_ow = make_fastdiv((uint32_t)g->out_w);
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  a.vec_epilogue = (g->n_ch % 4 == 0) && (g->ld_out % 4 == 0) && al16(out) && al16(bias) &&
+                   al16(scale) && al16(shift) && (!residual || (ld_res % 4 == 0 && al16(residual))) &&
+                   (!mask_src || (ld_mask % 4 == 0 && al16(mask_src)));
+  if (getenv("EMSA_SCALAR_EPILOGUE")) a.vec_epilogue = 0;
   hipStream_t st = (hipStream_t)stream;
   switch (t) {
     case TILE_128x128: return launch_igemm<128, 128, 2, 2>(a, st);
@@ -651,7 +788,12 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   a.g = *g;
   a.in = in; a.dout = dout; a.dw = dw; a.dbias = dbias;
   a.M = g->n_img * g->out_h * g->out_w;
-  a.dout_aligned = ((g->ld_out & 3) == 0) && ((((uintptr_t)dout) & 15) == 0);
+  a.dout_aligned = ((g->ld_out & 3) == 0) && ((g->n_ch & 3) == 0) &&
+                   ((((uintptr_t)dout) & 15) == 0);
+  a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
+  a.dout_bytes = (uint32_t)((size_t)a.M * g->ld_out * sizeof(float));
+  a.div_ohw = make_fastdiv((uint32_t)(g->out_h * g->out_w));
+  a.div_ow = make_fastdiv((uint32_t)g->out_w);
   hipStream_t st = (hipStream_t)stream;
   const int taps = g->kh * g->kw;
   if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2>(a, st);

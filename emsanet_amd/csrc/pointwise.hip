@@ -24,9 +24,11 @@ inline int grid_for(long work_items) {
 // ------------------------------------------------------------------------------------------
 // mode 0: OIHW -> [tap][cout_total][cin_total]; mode 1: OIHW -> [tap][cin_total][cout_total];
 // mode 2: [tap][cout_total][cin_total] -> OIHW
+// mode 3: OIHW -> both packed layouts (dst = forward, dst2 = data gradient)
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout,
                                    int cin, int kh, int kw, int cout_total, int cout_off,
-                                   int cin_total, int cin_off, int mode) {
+                                   int cin_total, int cin_off, int mode,
+                                   float* __restrict__ dst2 = nullptr) {
   const long total = (long)cout * cin * kh * kw;
   const int taps = kh * kw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -35,7 +37,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
     const int tap = (int)(i % taps);
     const long r = i / taps;
     const int ci = (int)(r % cin), co = (int)(r / cin);
-    if (mode == 0) {
+    if (mode == 3) {
+      const float v = src[i];
+      dst[((long)tap * cout_total + cout_off + co) * cin_total + cin_off + ci] = v;
+      dst2[((long)tap * cin_total + cin_off + ci) * cout_total + cout_off + co] = v;
+    } else if (mode == 0) {
       dst[((long)tap * cout_total + cout_off + co) * cin_total + cin_off + ci] = src[i];
     } else if (mode == 1) {
       dst[((long)tap * cin_total + cin_off + ci) * cout_total + cout_off + co] = src[i];
@@ -117,44 +123,59 @@ __device__ __forceinline__ void reduce_rows(const float* __restrict__ partial, i
   }
 }
 
-// stats = float[3][rows][c]: per-tile sum, M2 (about the tile mean), count.  Chan et al. merge in
-// fp64: block = 32 channels x 8 row groups, groups merged through LDS.
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int rows, int c, double count,
+// stats = float[3][rows][c]: per-tile sum, M2 (about the tile mean), count.
+// Two-level merge in fp64.  Level 1 (grid = channel groups x row slices): per slice
+//   S0 = sum n_t, S1 = sum sum_t, Q = sum (M2_t + sum_t^2 / n_t)        [= sum of squares]
+// Level 2: var = (Q - S1^2/S0) / S0.  The tile-local M2 keeps the fp32 partials exact to fp32
+// roundoff; the cross-tile combination runs entirely in fp64 (53-bit mantissa over 24-bit
+// inputs), so the textbook cancellation costs nothing measurable for mean^2/var up to ~1e8.
+constexpr int kBnSlices = 64;
+__global__ void bn_partial_kernel(const float* __restrict__ stats, int rows, int c,
+                                  double* __restrict__ ws) {
+  __shared__ double sh[3][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  const int slices = gridDim.y, sl = blockIdx.y;
+  const int per = (rows + slices - 1) / slices;
+  const int r0 = sl * per, r1 = min(r0 + per, rows);
+  double s0 = 0.0, s1 = 0.0, q = 0.0;
+  if (ch < c)
+    for (int r = r0 + rg; r < r1; r += 8) {
+      const double nb = (double)stats[((long)2 * rows + r) * c + ch];
+      if (nb > 0.0) {
+        const double sb = (double)stats[((long)0 * rows + r) * c + ch];
+        s0 += nb;
+        s1 += sb;
+        q += (double)stats[((long)1 * rows + r) * c + ch] + sb * sb / nb;
+      }
+    }
+  sh[0][rg][cl] = s0; sh[1][rg][cl] = s1; sh[2][rg][cl] = q;
+  __syncthreads();
+  if (rg == 0 && ch < c) {
+    s0 = s1 = q = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s0 += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
+    double* o = ws + ((long)sl * c + ch) * 3;
+    o[0] = s0; o[1] = s1; o[2] = q;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, int slices, int c,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean,
                                    float* running_var, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-  __shared__ double sn[8][32], sm[8][32], sq[8][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + cl;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  if (ch < c) {
-    for (int r = rg; r < rows; r += 8) {
-      const double nb = (double)stats[((long)2 * rows + r) * c + ch];
-      if (nb <= 0.0) continue;
-      const double mb = (double)stats[((long)0 * rows + r) * c + ch] / nb;
-      const double qb = (double)stats[((long)1 * rows + r) * c + ch];
-      const double nn = n + nb, d = mb - mean;
-      mean += d * nb / nn;
-      m2 += qb + d * d * n * nb / nn;
-      n = nn;
-    }
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double n = 0.0, s1 = 0.0, q = 0.0;
+  for (int sl = 0; sl < slices; ++sl) {
+    const double* o = ws + ((long)sl * c + ch) * 3;
+    n += o[0]; s1 += o[1]; q += o[2];
   }
-  sn[rg][cl] = n; sm[rg][cl] = mean; sq[rg][cl] = m2;
-  __syncthreads();
-  if (rg != 0 || ch >= c) return;
-  n = 0.0; mean = 0.0; m2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const double nb = sn[k][cl];
-    if (nb <= 0.0) continue;
-    const double nn = n + nb, d = sm[k][cl] - mean;
-    mean += d * nb / nn;
-    m2 += sq[k][cl] + d * d * n * nb / nn;
-    n = nn;
-  }
-  (void)count;
+  const double mean = n > 0.0 ? s1 / n : 0.0;
+  double m2 = q - s1 * mean;
+  if (m2 < 0.0) m2 = 0.0;
   const double var = n > 0.0 ? m2 / n : 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[ch] * invstd;
@@ -583,41 +604,65 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
                      w[(c + 3) * 9 + t]);
 }
 
+// One thread = (input pixel (ih,iw), 4 channels): it owns the 2x2 output quad (2ih+a, 2iw+b).
+// Output (2ih+a, 2iw+b) reads up-sampled rows 2ih+a-1 .. 2ih+a+1, i.e. input rows
+// ih-1+ (a+kh)/2 ... : with r = (a + kh + 1) >> 1 in {0,1,2} selecting input row ih-1+r.  So the
+// quad needs the 3x3 input neighbourhood once (9 float4 loads for 4 outputs) and per output the
+// 9 taps collapse onto 2x2 / 2x3 / 3x2 / ... neighbourhood entries.
 __global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const float* __restrict__ skip,
                                    float* __restrict__ y, int n, int h, int w, int c4n) {
-  const int oh_n = 2 * h, ow_n = 2 * w;
-  const long total = (long)n * oh_n * ow_n * c4n;
+  const long total = (long)n * h * w * c4n;
+  const int ow_n = 2 * w;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
     long r = i / c4n;
-    const int ow = (int)(r % ow_n); r /= ow_n;
-    const int oh = (int)(r % oh_n);
-    const int img = (int)(r / oh_n);
-    float4 a = bias ? emsa_ld4(bias + c4 * 4) : emsa_zero4();
+    const int iw = (int)(r % w); r /= w;
+    const int ih = (int)(r % h);
+    const int img = (int)(r / h);
+    float4 nb[3][3];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int uh = oh + kh - 1;
-      if (uh < 0 || uh >= oh_n) continue;
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int uw = ow + kw - 1;
-        if (uw < 0 || uw >= ow_n) continue;
-        const float4 v =
-            emsa_ld4(x + ((((long)img * h + (uh >> 1)) * w + (uw >> 1)) * c4n + c4) * 4);
-        const float4 k = dw_weight4(wdw, c4 * 4, kh * 3 + kw);
-        a.x += v.x * k.x; a.y += v.y * k.y; a.z += v.z * k.z; a.w += v.w * k.w;
+      for (int b = 0; b < 3; ++b) {
+        const int hh = ih - 1 + a, ww = iw - 1 + b;
+        nb[a][b] = (hh >= 0 && hh < h && ww >= 0 && ww < w)
+                       ? emsa_ld4(x + ((((long)img * h + hh) * w + ww) * c4n + c4) * 4)
+                       : emsa_zero4();
       }
-    }
-    if (skip) {
-      const float4 sk = emsa_ld4(skip + i * 4);
-      a.x += sk.x; a.y += sk.y; a.z += sk.z; a.w += sk.w;
-    }
-    emsa_st4(y + i * 4, a);
+    float4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = dw_weight4(wdw, c4 * 4, t);
+    const float4 bv = bias ? emsa_ld4(bias + c4 * 4) : emsa_zero4();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float4 acc = bv;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            // up-sampled coordinate 2ih+a+kh-1 -> input row ih-1 + ((a+kh+1)>>1); rows outside
+            // the UP-SAMPLED image (zero padding) are exactly the nb entries already zeroed,
+            // except that up-row -1 / 2h map to input rows -1 / h which are zero as well
+            const float4 v = nb[(a + kh + 1) >> 1][(b + kw + 1) >> 1];
+            const float4 kk = k[kh * 3 + kw];
+            acc.x += v.x * kk.x; acc.y += v.y * kk.y; acc.z += v.z * kk.z; acc.w += v.w * kk.w;
+          }
+        const long o = ((((long)img * 2 * h + 2 * ih + a) * ow_n + 2 * iw + b) * c4n + c4) * 4;
+        if (skip) {
+          const float4 sk = emsa_ld4(skip + o);
+          acc.x += sk.x; acc.y += sk.y; acc.z += sk.z; acc.w += sk.w;
+        }
+        emsa_st4(y + o, acc);
+      }
   }
 }
 
+// dx(ih,iw) = sum over the 4x4 output neighbourhood (2ih-1 .. 2ih+2) of dy * (collapsed taps):
+// output (oh,ow) touches input row ih through taps kh with ((oh+kh-1)>>1) == ih.
 __global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
                                         const float* __restrict__ wdw, float* __restrict__ dx,
                                         int n, int h, int w, int c4n) {
@@ -630,38 +675,47 @@ __global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
     const int iw = (int)(r % w); r /= w;
     const int ih = (int)(r % h);
     const int img = (int)(r / h);
+    float4 k[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k[t] = dw_weight4(wdw, c4 * 4, t);
     float4 a = emsa_zero4();
-    // up-sampled positions (uh,uw) in {2ih,2ih+1}x{2iw,2iw+1}; tap (kh,kw) of output
-    // (uh+1-kh, uw+1-kw) reads it
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int p = 0; p < 4; ++p) {
+      const int oh = 2 * ih - 1 + p;
+      if (oh < 0 || oh >= oh_n) continue;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const float4 k = dw_weight4(wdw, c4 * 4, kh * 3 + kw);
+      for (int q = 0; q < 4; ++q) {
+        const int ow = 2 * iw - 1 + q;
+        if (ow < 0 || ow >= ow_n) continue;
+        const float4 g = emsa_ld4(dy + ((((long)img * oh_n + oh) * ow_n + ow) * c4n + c4) * 4);
+        // taps kh with oh+kh-1 in {2ih, 2ih+1}  <=>  kh in {2-p, 3-p} intersect [0,2]
+        float4 ws = emsa_zero4();
 #pragma unroll
-        for (int dh = 0; dh < 2; ++dh) {
-          const int oh = 2 * ih + dh + 1 - kh;
-          if (oh < 0 || oh >= oh_n) continue;
+        for (int kh = 0; kh < 3; ++kh) {
+          if (kh != 2 - p && kh != 3 - p) continue;
 #pragma unroll
-          for (int dw_ = 0; dw_ < 2; ++dw_) {
-            const int ow = 2 * iw + dw_ + 1 - kw;
-            if (ow < 0 || ow >= ow_n) continue;
-            const float4 g = emsa_ld4(dy + ((((long)img * oh_n + oh) * ow_n + ow) * c4n + c4) * 4);
-            a.x += g.x * k.x; a.y += g.y * k.y; a.z += g.z * k.z; a.w += g.w * k.w;
+          for (int kw = 0; kw < 3; ++kw) {
+            if (kw != 2 - q && kw != 3 - q) continue;
+            const float4 kk = k[kh * 3 + kw];
+            ws.x += kk.x; ws.y += kk.y; ws.z += kk.z; ws.w += kk.w;
           }
         }
+        a.x += g.x * ws.x; a.y += g.y * ws.y; a.z += g.z * ws.z; a.w += g.w * ws.w;
       }
+    }
     emsa_st4(dx + i * 4, a);
   }
 }
 
-// dw[c][9] += sum dy*up(x) ; db[c] += sum dy.  block = c4n columns x lanes, pixel chunk per block
+// dw[c][9] += sum dy*up(x) ; db[c] += sum dy.  block = c4n columns x lanes over a chunk of INPUT
+// pixels; one thread visits an input pixel, loads its 3x3 neighbourhood once and the 2x2 output
+// quad's dy, and accumulates all 9 taps of the 4 outputs (13 loads per 36x4 FMAs).
 __global__ void up2x_dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                           float* __restrict__ dwt, float* __restrict__ db, int n,
                                           int h, int w, int c4n, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float wred[];   // [lanes][10][c4n*4]
   const int oh_n = 2 * h, ow_n = 2 * w;
-  const long pixels = (long)n * oh_n * ow_n;
+  const long pixels = (long)n * h * w;
   const long chunk = (pixels + nblocks - 1) / nblocks;
   const long p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
   const int lanes = kThreads / c4n;
@@ -671,32 +725,41 @@ __global__ void up2x_dw_bwd_weight_kernel(const float* __restrict__ dy, const fl
   for (int t = 0; t < 10; ++t) acc[t] = emsa_zero4();
   if (rl < lanes) {
     for (long p = p0 + rl; p < p1; p += lanes) {
-      const int ow = (int)(p % ow_n);
-      const long r = p / ow_n;
-      const int oh = (int)(r % oh_n);
-      const int img = (int)(r / oh_n);
-      const float4 g = emsa_ld4(dy + (p * c4n + c4) * 4);
-      acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+      const int iw = (int)(p % w);
+      const long r = p / w;
+      const int ih = (int)(r % h);
+      const int img = (int)(r / h);
+      float4 nb[3][3];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int uh = oh + kh - 1;
-        if (uh < 0 || uh >= oh_n) continue;
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int uw = ow + kw - 1;
-          if (uw < 0 || uw >= ow_n) continue;
-          const float4 v =
-              emsa_ld4(x + ((((long)img * h + (uh >> 1)) * w + (uw >> 1)) * c4n + c4) * 4);
-          float4& a = acc[kh * 3 + kw];
-          a.x += g.x * v.x; a.y += g.y * v.y; a.z += g.z * v.z; a.w += g.w * v.w;
+        for (int b = 0; b < 3; ++b) {
+          const int hh = ih - 1 + a, ww = iw - 1 + b;
+          nb[a][b] = (hh >= 0 && hh < h && ww >= 0 && ww < w)
+                         ? emsa_ld4(x + ((((long)img * h + hh) * w + ww) * c4n + c4) * 4)
+                         : emsa_zero4();
         }
-      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float4 g = emsa_ld4(
+              dy + ((((long)img * oh_n + 2 * ih + a) * ow_n + 2 * iw + b) * c4n + c4) * 4);
+          acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float4 v = nb[(a + kh + 1) >> 1][(b + kw + 1) >> 1];
+              float4& t = acc[kh * 3 + kw];
+              t.x += g.x * v.x; t.y += g.y * v.y; t.z += g.z * v.z; t.w += g.w * v.w;
+            }
+        }
     }
 #pragma unroll
     for (int t = 0; t < 10; ++t) emsa_st4(wred + ((rl * 10 + t) * c4n + c4) * 4, acc[t]);
   }
   __syncthreads();
-  // 10 * c4n*4 outputs
   const int c = c4n * 4;
   for (int o = threadIdx.x; o < 10 * c; o += blockDim.x) {
     const int t = o / c, ch = o % c;
@@ -888,7 +951,7 @@ static int pack_common(const float* src, float* dst, int cout, int cin, int kh, 
   const long total = (long)cout * cin * kh * kw;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, src, dst, cout, cin, kh, kw, cout_total, cout_off,
-                     cin_total, cin_off, mode);
+                     cin_total, cin_off, mode, (float*)nullptr);
   return emsa_launch_status();
 }
 
@@ -904,6 +967,15 @@ extern "C" int emsa_pack_weight_dgrad(const float* w, float* wp, int32_t cout, i
                                       void* stream) {
   return pack_common(w, wp, cout, cin, kh, kw, cout_total, cout_off, cin_total, cin_off, 1,
                      stream);
+}
+extern "C" int emsa_pack_weight_pair(const float* w, float* wp_fwd, float* wp_dgrad, int32_t cout,
+                                     int32_t cin, int32_t kh, int32_t kw, void* stream) {
+  if (!w || !wp_fwd || !wp_dgrad) return EMSA_E_ARG;
+  const long total = (long)cout * cin * kh * kw;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, w, wp_fwd, cout, cin, kh, kw, cout, 0, cin, 0, 3,
+                     wp_dgrad);
+  return emsa_launch_status();
 }
 extern "C" int emsa_unpack_wgrad(const float* dwp, float* dw, int32_t cout, int32_t cin,
                                  int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
@@ -938,15 +1010,26 @@ extern "C" int emsa_stem_unpack_wgrad(const float* dwp, float* dw, int32_t cout,
   return emsa_launch_status();
 }
 
+extern "C" int emsa_bn_finalize_ws_bytes(int32_t c) {
+  return (int)(kBnSlices * (size_t)c * 3 * sizeof(double));
+}
+
 extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int64_t count,
                                 const float* gamma, const float* beta, float eps, float momentum,
                                 float* running_mean, float* running_var, float* scale,
-                                float* shift, float* save_mean, float* save_invstd,
+                                float* shift, float* save_mean, float* save_invstd, void* ws,
                                 void* stream) {
-  if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd)
+  if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd || !ws)
     return EMSA_E_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                     stats, rows, c, (double)count, gamma, beta, eps, momentum, running_mean,
+  (void)count;
+  int slices = (rows + 31) / 32;
+  if (slices > kBnSlices) slices = kBnSlices;
+  if (slices < 1) slices = 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3((c + 31) / 32, slices), dim3(256), 0, st, stats, rows,
+                     c, (double*)ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, st,
+                     (const double*)ws, slices, c, gamma, beta, eps, momentum, running_mean,
                      running_var, scale, shift, save_mean, save_invstd);
   return emsa_launch_status();
 }
@@ -1145,9 +1228,9 @@ extern "C" int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float
                                           void* stream) {
   if (!dy || !x || !dw || !db) return EMSA_E_ARG;
   if (!c4_ok(c) || c > 512) return EMSA_E_SHAPE;
-  const long pixels = (long)n * 4 * h * w;
-  int nblocks = (int)((pixels + 511) / 512);
-  if (nblocks > 1024) nblocks = 1024;
+  const long pixels = (long)n * h * w;
+  int nblocks = (int)((pixels + 255) / 256);
+  if (nblocks > 2048) nblocks = 2048;
   if (nblocks < 1) nblocks = 1;
   const int lanes = kThreads / (c / 4);
   const size_t lds = (size_t)lanes * 10 * c * sizeof(float);

@@ -148,6 +148,15 @@ def pack_weight(w, mode, cout_total=None, cout_off=0, cin_total=None, cin_off=0,
     return out
 
 
+def pack_weight_pair(w):
+    """both packed layouts ([tap][cout][cin], [tap][cin][cout]) in one launch"""
+    cout, cin, kh, kw = w.shape
+    buf = _empty((2, kh * kw * cout * cin), w.device)
+    check(_lib.lib().emsa_pack_weight_pair(_p(w), _p(buf[0]), _p(buf[1]), cout, cin, kh, kw,
+                                           _stream()), 'emsa_pack_weight_pair')
+    return buf[0], buf[1]
+
+
 def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off=0):
     cout, cin, kh, kw = like.shape if like.dim() == 4 else (like.shape[0], like.shape[1], 1, 1)
     dw = _empty(tuple(like.shape), like.device)
@@ -291,10 +300,11 @@ def stem_wgrad(xp, dy, spec, n, h, w, like):
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
     c = gamma.shape[0]
     buf = _empty((4, c), gamma.device)
+    ws = _empty((_lib.lib().emsa_bn_finalize_ws_bytes(c) // 8,), gamma.device, torch.float64)
     check(_lib.lib().emsa_bn_finalize(_p(stats), stats.shape[1], c, count, _p(gamma), _p(beta),
                                       eps, momentum, _p(running_mean), _p(running_var),
-                                      _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _stream()),
-          'emsa_bn_finalize')
+                                      _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _p(ws),
+                                      _stream()), 'emsa_bn_finalize')
     return buf[0], buf[1], buf[2], buf[3]      # scale, shift, mean, invstd
 
 

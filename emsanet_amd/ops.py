@@ -50,14 +50,29 @@ class ConvRT:
                                 tuple(conv.stride), tuple(conv.padding))
         self._key = None
         self._wp = None
+        self._keyd = None
+        self._wpd = None
 
     def packed(self):
         w = self.conv.weight
         key = (w._version, w.data_ptr())
         if key != self._key:
-            self._wp = Fn.pack_weight(w.detach(), 'fwd')
+            if w.requires_grad:
+                # trainable: the data-gradient layout will be needed too -> one launch for both
+                self._wp, self._wpd = Fn.pack_weight_pair(w.detach())
+                self._keyd = key
+            else:
+                self._wp = Fn.pack_weight(w.detach(), 'fwd')
             self._key = key
         return self._wp
+
+    def packed_dgrad(self):
+        w = self.conv.weight
+        key = (w._version, w.data_ptr())
+        if key != self._keyd:
+            self._wpd = Fn.pack_weight(w.detach(), 'dgrad')
+            self._keyd = key
+        return self._wpd
 
 
 class BNRT:
@@ -115,8 +130,8 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
     dw = Fn.unpack_wgrad(dwp, conv.weight)
     dx = None
     if need_dx:
-        wpd = Fn.pack_weight(conv.weight.detach(), 'dgrad')
-        dx = Fn.conv_dgrad(dy, wpd, crt.spec, x.shape[2:], mask_src=mask_src, residual=residual)
+        dx = Fn.conv_dgrad(dy, crt.packed_dgrad(), crt.spec, x.shape[2:], mask_src=mask_src,
+                           residual=residual)
     return dx, dw, db
 
 

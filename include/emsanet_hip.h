@@ -106,6 +106,9 @@ int emsa_pack_weight_dgrad(const float* w_oihw, float* w_packed, int32_t cout, i
                            int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
                            int32_t cin_total, int32_t cin_off,
                            void* stream); /* -> [tap][cin_total][cout_total] */
+/* both packed layouts of one parameter in a single launch (training: forward + data gradient) */
+int emsa_pack_weight_pair(const float* w_oihw, float* w_packed_fwd, float* w_packed_dgrad,
+                          int32_t cout, int32_t cin, int32_t kh, int32_t kw, void* stream);
 int emsa_unpack_wgrad(const float* dw_packed, float* dw_oihw, int32_t cout, int32_t cin,
                       int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
                       int32_t cin_total, int32_t cin_off,
@@ -132,7 +135,9 @@ int emsa_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, int32_t cout,
 int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int64_t count,
                      const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, float* scale, float* shift,
-                     float* save_mean, float* save_invstd, void* stream);
+                     float* save_mean, float* save_invstd, void* ws, void* stream);
+/* bytes of the fp64 scratch `ws` emsa_bn_finalize needs for c channels */
+int emsa_bn_finalize_ws_bytes(int32_t c);
 /* eval mode: scale/shift (and optionally invstd, may be NULL) from running statistics */
 int emsa_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, int32_t c, float* scale, float* shift,

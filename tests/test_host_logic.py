@@ -21,7 +21,7 @@ class _FakeLib:
             self.calls[name] += 1
             if name in ('emsa_conv_stats_rows', 'emsa_bn_bwd_rows'):
                 return 3
-            if name == 'emsa_channel_ws_floats':
+            if name in ('emsa_channel_ws_floats', 'emsa_bn_finalize_ws_bytes'):
                 return 64
             return 0
         return fn
