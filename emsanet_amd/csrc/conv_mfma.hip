@@ -71,8 +71,20 @@ double algo_flops(const EmsaConvGeom& g) {
 #ifndef EMSA_ABL
 #define EMSA_ABL 0   // tuning only (tools/conv_bench.py): 1 = no global loads, 2 = no stores, 4 = no MFMA
 #endif
-constexpr int kBK = 32;   // K chunk (channels) per step
-constexpr int kLD = 36;   // padded LDS row (floats)
+// Single LDS buffer + register prefetch (two barriers per step) beats double buffering on
+// MI355X for both kernels (profiles/r01_c_*): half the LDS -> twice the resident workgroups, and
+// with the 64-cycle fp32 MFMA it is resident waves, not barrier count, that keeps the matrix
+// pipe fed.  EMSA_SB: bit0 = igemm single buffer, bit1 = wgrad single buffer.
+#ifndef EMSA_SB
+#define EMSA_SB 3
+#endif
+#ifndef EMSA_BK
+#define EMSA_BK 32
+#endif
+constexpr int kBK = EMSA_BK;      // K chunk (channels) per step
+constexpr int kLD = kBK + 4;      // padded LDS row (floats): conflict-free ds_read_b128
+constexpr int kRowLanes = kBK / 4;          // lanes (float4) per staged row
+constexpr int kRowsPerPass = 256 / kRowLanes;
 
 
 // unsigned division by a launch-time constant (n < 2^31): q = (mulhi(n, mul) + n) >> shift
@@ -146,11 +158,12 @@ __device__ __forceinline__ uint32_t gather_offset(const Gather& q, int img_off, 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(WM * WN == 4, "4 waves");
-  constexpr int AR = BM / 32, BR = BN / 32;            // float4 per thread per tile
+  constexpr int AR = BM / kRowsPerPass, BR = BN / kRowsPerPass;   // float4 per thread per tile
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const As = smem;                  // [2][BM][kLD]
-  float* const Bs = smem + 2 * BM * kLD;   // [2][BN][kLD]
+  constexpr int NBUF = (EMSA_SB & 1) ? 1 : 2;
+  float* const As = smem;                     // [NBUF][BM][kLD]
+  float* const Bs = smem + NBUF * BM * kLD;   // [NBUF][BN][kLD]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -170,12 +183,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // ---- loader state -------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
-  const int rl = tid >> 3, c4 = (tid & 7) * 4;
+  const int rl = tid / kRowLanes, c4 = (tid % kRowLanes) * 4;
   int a_bh[AR], a_bw[AR], a_img[AR];
   uint32_t a_off[AR], b_off[BR];
 #pragma unroll
   for (int j = 0; j < AR; ++j) {
-    const int m = m0 + rl + 32 * j;
+    const int m = m0 + rl + kRowsPerPass * j;
     if (m < p.M) {
       const int img = (int)fast_div((uint32_t)m, p.div_ohw);
       const int rem = m - img * (int)p.div_ohw.d;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
-    const int n = n0 + rl + 32 * j;
+    const int n = n0 + rl + kRowsPerPass * j;
     b_off[j] = n < g.n_ch ? (uint32_t)(n * g.k_ch + c4) * 4u : kOOB;
   }
   const int taps = g.kh * g.kw;
@@ -233,9 +246,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     float* a = As + buf * BM * kLD;
     float* b = Bs + buf * BN * kLD;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) emsa_st4(a + (rl + 32 * j) * kLD + c4, ra[j]);
+    for (int j = 0; j < AR; ++j) emsa_st4(a + (rl + kRowsPerPass * j) * kLD + c4, ra[j]);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) emsa_st4(b + (rl + 32 * j) * kLD + c4, rb[j]);
+    for (int j = 0; j < BR; ++j) emsa_st4(b + (rl + kRowsPerPass * j) * kLD + c4, rb[j]);
   };
 
   f32x16 acc[TM][TN];
@@ -281,9 +294,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
       }
     }
-    if (has_next) store_lds(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (NBUF == 2) {
+      if (has_next) store_lds(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();                 // every wave is done reading the buffer
+      if (has_next) store_lds(0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue -------------------------------------------------------------------------
@@ -469,6 +488,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   constexpr int DR = BCO / 32, XR = BCI / 32;   // float4 per thread per tile
   constexpr int DTPR = BCO / 4, XTPR = BCI / 4; // threads per pixel row
   constexpr int BUF = PK * BCO + TT * PK * BCI; // floats per LDS buffer
+  constexpr int NBUF = (EMSA_SB & 2) ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -604,9 +624,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         }
       }
     }
-    if (has_next) store_lds(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (NBUF == 2) {
+      if (has_next) store_lds(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();                 // every wave is done reading the buffer
+      if (has_next) store_lds(0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: split-K partial -> atomic add ------------------------------------------
@@ -689,7 +715,9 @@ bool geom_ok(const EmsaConvGeom* g) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(const ConvArgs& a, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * kLD * sizeof(float);
+  constexpr size_t lds_main = (size_t)((EMSA_SB & 1) ? 1 : 2) * (BM + BN) * kLD * sizeof(float);
+  constexpr size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);   // staged epilogue
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN>,
@@ -706,7 +734,7 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
 
 template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
 int launch_wgrad(WgradArgs a, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * (32 * BCO + TT * 32 * BCI) * sizeof(float);
+  constexpr size_t lds = (size_t)((EMSA_SB & 2) ? 1 : 2) * (32 * BCO + TT * 32 * BCI) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>,
