@@ -13,8 +13,9 @@ bs=32/GPU batch at 640x480, fp32: forward, backward driven by fixed output cotan
 optimizer.py:29-36.  Inputs are resident in HBM before the timed region.  Weights: deterministic
 random init; data: the reference's own synthetic generator (inference_time_whole_model.py:519-545).
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of
-the MFMA convolution kernels inside the timed steps (emsa_prof_* C-ABI); `cpu_baseline` times the
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every 4th launch
+(per kernel class) of the MFMA convolution kernels inside the timed steps (emsa_prof_* C-ABI;
+bracketing every launch costs 3 % of the step, every 4th < 1 %); `cpu_baseline` times the
 oracle (plain PyTorch CPU restatement, tests infrastructure) on the host cores for a bounded
 sample of the same workload.
 """
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='do not bracket conv launches with HIP events (A/B of the overhead)')
+    ap.add_argument('--timing-every', type=int, default=4,
+                    help='bracket every n-th launch of each conv kernel class with HIP events')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
     return ap.parse_args()
@@ -184,7 +187,7 @@ def main():
         step()
     timing = not args.no_kernel_timing
     L.emsa_prof_reset()
-    L.emsa_prof_enable(1 if timing else 0)
+    L.emsa_prof_enable(args.timing_every if timing else 0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -212,18 +215,33 @@ def main():
             _lib.check(L.emsa_prof_read(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)),
                        'emsa_prof_read')
             if n.value:
-                kernels.append({'kernel': L.emsa_prof_name(cls).decode(), 'launches': n.value,
-                                'total_ms': round(ms.value, 3),
+                seen = L.emsa_prof_seen(cls)
+                scale = seen / n.value            # sampled -> all launches of the class
+                kernels.append({'kernel': L.emsa_prof_name(cls).decode(), 'launches': seen,
+                                'timed_launches': n.value,
+                                'total_ms': round(ms.value * scale, 3),
                                 'avg_us': round(1e3 * ms.value / n.value, 2),
                                 'algo_gflop_per_launch': round(fl.value / n.value / 1e9, 4),
                                 'tflops': round(fl.value / ms.value / 1e9, 2)})
     kernels.sort(key=lambda k: -k['total_ms'])
     roofline = None
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+    except Exception:
+        pmc = None
     if kernels:
         k = kernels[0]
+        if pmc and (args.height, args.width, bs) == (480, 640, 32) and not args.eval:
+            ent = pmc['kernels'].get(k['kernel'].replace(' ', ''))
+            if ent:
+                traffic = ent['hbm_bytes_per_launch']
+                traffic_src = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / ' \
+                              'WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)'
         roofline = {'bound': 'mfma', 'kernel': k['kernel'], 'achieved': k['tflops'],
                     'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(k['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(k['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,
                     'launches': k['launches'], 'avg_us': k['avg_us'],
                     'algo_gflop_per_launch': k['algo_gflop_per_launch'],
                     'share_of_step': round(k['total_ms'] / (dt * 1e3), 4)}

@@ -79,6 +79,7 @@ SIGNATURES = {
     'emsa_axpy': (c_int, [_P, _P, c_int64, c_float, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
     'emsa_prof_reset': (c_int, []),
+    'emsa_prof_seen': (c_int, [c_int32]),
     'emsa_prof_name': (c_char_p, [c_int32]),
     'emsa_prof_read': (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                POINTER(c_int32)]),

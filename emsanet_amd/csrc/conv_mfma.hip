@@ -34,7 +34,8 @@ struct ProfSlot {
 };
 std::vector<ProfSlot> g_prof_pool;
 size_t g_prof_used = 0;
-bool g_prof_on = false;
+int g_prof_every = 0;          // 0 = off, n = bracket every n-th launch of each kernel class
+int g_prof_seen[8] = {0};
 const char* const kProfNames[8] = {
     "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,2,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
@@ -42,7 +43,8 @@ const char* const kProfNames[8] = {
     "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>"};
 
 ProfSlot* prof_begin(int cls, double flops, hipStream_t st) {
-  if (!g_prof_on) return nullptr;
+  if (g_prof_every <= 0) return nullptr;
+  if ((g_prof_seen[cls]++ % g_prof_every) != 0) return nullptr;
   if (g_prof_used == g_prof_pool.size()) {
     ProfSlot s;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return nullptr;
@@ -155,8 +157,12 @@ __device__ __forceinline__ uint32_t gather_offset(const Gather& q, int img_off, 
   return ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * 4u : kOOB;
 }
 
+#ifndef EMSA_WPE
+#define EMSA_WPE 6     // min waves per SIMD requested for the 64x64 tile (register cap)
+#endif
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? EMSA_WPE : 2) void conv_igemm_kernel(
+    const ConvArgs p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int AR = BM / kRowsPerPass, BR = BN / kRowsPerPass;   // float4 per thread per tile
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -833,14 +839,16 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
 }
 
 // ---- profiling C-ABI -------------------------------------------------------------------------
-extern "C" int emsa_prof_enable(int32_t on) {
-  g_prof_on = on != 0;
+extern "C" int emsa_prof_enable(int32_t every) {
+  g_prof_every = every > 0 ? every : 0;
   return EMSA_OK;
 }
 extern "C" int emsa_prof_reset(void) {
   g_prof_used = 0;
+  for (int i = 0; i < 8; ++i) g_prof_seen[i] = 0;
   return EMSA_OK;
 }
+extern "C" int emsa_prof_seen(int32_t cls) { return (cls >= 0 && cls < 8) ? g_prof_seen[cls] : 0; }
 extern "C" const char* emsa_prof_name(int32_t cls) {
   return (cls >= 0 && cls < 8) ? kProfNames[cls] : "";
 }

@@ -209,8 +209,10 @@ def conv_wgrad(x, dy, spec, want_bias):
     n, c, h, w = x.shape
     g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(dy))
     taps = spec.kh * spec.kw
-    dwp = torch.zeros(taps * spec.cout * spec.cin, device=x.device, dtype=torch.float32)
-    db = torch.zeros(spec.cout, device=x.device, dtype=torch.float32) if want_bias else None
+    nw = taps * spec.cout * spec.cin
+    buf = torch.zeros(nw + (spec.cout if want_bias else 0), device=x.device, dtype=torch.float32)
+    dwp = buf[:nw]
+    db = buf[nw:] if want_bias else None
     check(_lib.lib().emsa_conv_wgrad(g, _p(x), _p(dy), _p(dwp), _p(db), _stream()),
           'emsa_conv_wgrad')
     return dwp, db

@@ -234,14 +234,16 @@ int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y, int
 int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every
- * emsa_conv_igemm / emsa_conv_wgrad launch is bracketed by HIP events on its own stream.
+ * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every n-th
+ * emsa_conv_igemm / emsa_conv_wgrad launch of each class is bracketed by HIP events on its own
+ * stream (bracketing EVERY launch costs ~3 % of a training step, every 4th < 1 %).
  * cls 0..3 = conv_igemm_kernel tile configs, 4..7 = conv_wgrad_kernel configs
  * (emsa_prof_name).  emsa_prof_read: call after synchronising; sums since emsa_prof_reset;
  * total_flops = ALGORITHMIC direct-convolution FLOPs (2*pixels*k_ch*n_ch*taps).
  * ------------------------------------------------------------------------------------------ */
-int emsa_prof_enable(int32_t on);
+int emsa_prof_enable(int32_t every);   /* 0 = off; n = bracket every n-th launch per class */
 int emsa_prof_reset(void);
+int emsa_prof_seen(int32_t cls);       /* launches of the class since reset (sampled or not) */
 const char* emsa_prof_name(int32_t cls);
 int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops, int32_t* launches);
 

@@ -244,6 +244,46 @@ def test_full_res_eval_bs1():
     _argmax_check(fo[-1], f64[-1], 'scene')
 
 
+def test_config4_r101_highres_eval():
+    """BASELINE config 4 shape: ResNet-101-NBt1D dual encoder at 960x736 (json says 960x720,
+    which is not divisible by 32 -- SURVEY.md 0.3), bs=1, eval"""
+    from emsanet_amd import full_args
+    from oracle.emsanet_oracle import synthetic_batch
+    args = full_args(input_height=736, input_width=960, rgb_encoder_backbone='resnet101',
+                     depth_encoder_backbone='resnet101')
+    model, o32, o64 = _triple(args)
+    del o64
+    model.eval(), o32.eval()
+    batch = synthetic_batch(1, 736, 960)
+    with torch.no_grad():
+        ref = o32(batch)
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+    fr, fo = _flatten(ref), _flatten(out)
+    for i, (a, b) in enumerate(zip(fo, fr)):
+        close(a, b, tol=TOL, what=f'output {i}')
+    _argmax_check(fo[0], fr[0].double(), 'semantic')
+
+
+def test_resnet18_rgbd_train_step():
+    """smaller backbone variant (reference test matrix uses resnet18, test_interface_model.py)"""
+    from emsanet_amd import full_args
+    from oracle.emsanet_oracle import synthetic_batch
+    args = full_args(input_height=64, input_width=96, rgb_encoder_backbone='resnet18',
+                     depth_encoder_backbone='resnet18')
+    model, o32, o64 = _triple(args)
+    for m in (model, o32, o64):
+        m.train()
+        m.dropout_seed = 7
+    batch = synthetic_batch(4, 64, 96)
+    r32, r64 = o32(batch), o64({k: v.double() for k, v in batch.items()})
+    out = model({k: v.to(DEV) for k, v in batch.items()})
+    for i, (a, b, c) in enumerate(zip(_flatten(out), _flatten(r32), _flatten(r64))):
+        lim = max(TOL, 4 * _rel(b, c))
+        assert _rel(a, c) <= lim, f"output {i}: {_rel(a, c):.3e} > {lim:.3e}"
+    sum((t * t).mean() for t in _flatten(out)).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 def test_missing_gpu_input_fails_loudly():
     from emsanet_amd import _lib, full_args, nyuv2_config
     from emsanet_amd.model import EMSANet

@@ -52,6 +52,9 @@ def _worker(rank, world, port, bucket_bytes, ret):
         buckets.finish()
     if rank == 0:
         ret['grads'] = [p.grad.clone() for p in net.parameters()]
+        flat = buckets.buckets[0][0]
+        ret['views'] = all(p.grad.data_ptr() >= buckets.buckets[buckets._bucket_of[p]][0].data_ptr()
+                           for p in net.parameters())
         ret['n_buckets'] = len(buckets.buckets)
     dist.destroy_process_group()
 
@@ -74,17 +77,23 @@ def test_gradient_buckets_average_like_single_process(bucket_bytes):
     assert ret['n_buckets'] == (1 if bucket_bytes > 4096 else ret['n_buckets'])
     if bucket_bytes == 256:
         assert ret['n_buckets'] > 1
+    assert ret['views']      # after finish() the gradients live in the reduced flat buffers
 
 
-def test_single_process_buckets_are_views():
+def test_single_process_is_passthrough():
+    """world size 1: no copies, no collectives -- gradients are what autograd produced"""
     sys.path.insert(0, ROOT)
     from emsanet_amd.parallel import GradientBuckets
     net = _net()
     b = GradientBuckets(list(net.parameters()), bucket_bytes=1 << 20)
-    b.reset()
-    net(torch.randn(2, 3, 6, 6)).sum().backward()
-    b.finish()
-    flat = b.buckets[0][0]
+    x = torch.randn(2, 3, 6, 6)
+    for _ in range(2):
+        b.reset()
+        assert all(p.grad is None for p in net.parameters())
+        net(x).sum().backward()
+        b.finish()
+    ref = _net()
+    ref(x).sum().backward()
     assert b.n_bytes() == sum(p.numel() for p in net.parameters()) * 4
-    assert flat.abs().sum() > 0
-    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in net.parameters())
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(p.grad, q.grad)

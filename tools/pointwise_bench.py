@@ -1,0 +1,80 @@
+"""Micro-benchmark of the HBM-bound kernels at the bs=32 640x480 shapes (GPU box): algorithmic
+GB/s = (tensors read + written once each) / time."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from emsanet_amd import functional as Fn      # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    n = 32
+    for c, h, w in ((64, 240, 320), (64, 120, 160), (128, 60, 80), (256, 30, 40), (512, 15, 20)):
+        x = Fn.act_empty(n, c, h, w, DEV).normal_()
+        y = Fn.act_empty(n, c, h, w, DEV).normal_()
+        dy = Fn.act_empty(n, c, h, w, DEV).normal_()
+        res = Fn.act_empty(n, c, h, w, DEV).normal_()
+        sc = torch.rand(c, device=DEV) + 0.5
+        sh = torch.randn(c, device=DEV)
+        mean, inv = torch.randn(c, device=DEV), torch.rand(c, device=DEV) + 0.5
+        drop = (torch.rand(n, c, device=DEV) > 0.1).float()
+        mb = x.numel() * 4 / 1e6
+        t = timeit(lambda: Fn.bn_act(x, sc, sh, None, None, 1))
+        row = f"c{c} {h}x{w} ({mb:6.0f} MB/tensor) | bn_act {2 * mb / t:5.2f} TB/s"
+        t = timeit(lambda: Fn.bn_act(x, sc, sh, drop, res, 1))
+        row += f" | bn_act+drop+res {3 * mb / t:5.2f}"
+        L = Fn._lib.lib()
+        rows = L.emsa_bn_bwd_rows(n * h * w)
+        part = torch.empty((2, rows, c), device=DEV)
+        p = Fn._p
+        t = timeit(lambda: L.emsa_bn_bwd_reduce(p(dy), p(y), p(x), p(mean), p(inv), None, n, h * w, c, 1, p(part), Fn._stream()))
+        row += f" | bwd_reduce {3 * mb / t:5.2f}"
+        t = timeit(lambda: Fn.bn_bwd(dy, y, x, sc, mean, inv, None, 1, True, True))
+        row += f" | bwd(reduce+apply+dres) {8 * mb / t:5.2f}"
+        if h <= 120:
+            wdw = torch.randn(c, 1, 3, 3, device=DEV)
+            b = torch.randn(c, device=DEV)
+            skip = Fn.act_empty(n, c, 2 * h, 2 * w, DEV).normal_()
+            t = timeit(lambda: Fn.up2x_dw_fwd(x, wdw, b, skip))
+            row += f" | up2x fwd {9 * mb / t:5.2f}"
+            t = timeit(lambda: Fn.up2x_dw_bwd(skip, x, wdw))
+            row += f" | up2x bwd(data+weight) {10 * mb / t:5.2f}"
+        print(row, flush=True)
+    # 40-channel full-resolution prediction upsampling
+    x = Fn.act_empty(n, 40, 240, 320, DEV).normal_()
+    wdw = torch.randn(40, 1, 3, 3, device=DEV)
+    b = torch.randn(40, device=DEV)
+    mb = x.numel() * 4 / 1e6
+    t = timeit(lambda: Fn.up2x_dw_fwd(x, wdw, b, None))
+    print(f"c40 240x320->480x640 up2x fwd {5 * mb / t:5.2f} TB/s ({t:.0f} us)")
+    xs = Fn.act_empty(n, 64, 240, 320, DEV).normal_()
+    t = timeit(lambda: Fn.maxpool_fwd(xs))
+    print(f"maxpool fwd {1.25 * xs.numel() * 4 / 1e6 / t:5.2f} TB/s")
+    t = timeit(lambda: Fn.channel_mean(xs))
+    print(f"channel_mean {xs.numel() * 4 / 1e6 / t:5.2f} TB/s")
+    a = torch.empty(xs.numel(), device=DEV)
+    bq = torch.empty(xs.numel(), device=DEV)
+    t = timeit(lambda: bq.copy_(a))
+    print(f"torch copy (reference) {2 * xs.numel() * 4 / 1e6 / t:5.2f} TB/s")
+
+
+if __name__ == '__main__':
+    main()
