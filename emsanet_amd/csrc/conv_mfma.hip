@@ -37,10 +37,10 @@ size_t g_prof_used = 0;
 int g_prof_every = 0;          // 0 = off, n = bracket every n-th launch of each kernel class
 int g_prof_seen[8] = {0};
 const char* const kProfNames[8] = {
-    "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,2,2>",
+    "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,4,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
     "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1>",
-    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>"};
+    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_kernel<64,64>"};
 
 ProfSlot* prof_begin(int cls, double flops, hipStream_t st) {
   if (g_prof_every <= 0) return nullptr;
@@ -86,7 +86,6 @@ double algo_flops(const EmsaConvGeom& g) {
 constexpr int kBK = EMSA_BK;      // K chunk (channels) per step
 constexpr int kLD = kBK + 4;      // padded LDS row (floats): conflict-free ds_read_b128
 constexpr int kRowLanes = kBK / 4;          // lanes (float4) per staged row
-constexpr int kRowsPerPass = 256 / kRowLanes;
 
 
 // unsigned division by a launch-time constant (n < 2^31): q = (mulhi(n, mul) + n) >> shift
@@ -161,9 +160,11 @@ __device__ __forceinline__ uint32_t gather_offset(const Gather& q, int img_off, 
 #define EMSA_WPE 6     // min waves per SIMD requested for the 64x64 tile (register cap)
 #endif
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? EMSA_WPE : 2) void conv_igemm_kernel(
-    const ConvArgs p) {
-  static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(WM * WN * 64, (BM * BN <= 64 * 64) ? EMSA_WPE : 2) void
+conv_igemm_kernel(const ConvArgs p) {
+  constexpr int NT = WM * WN * 64;                 // threads per workgroup (4 or 8 waves)
+  constexpr int kRowsPerPass = NT / kRowLanes;
+  static_assert(BM % kRowsPerPass == 0 && BN % kRowsPerPass == 0, "loader mapping");
   constexpr int AR = BM / kRowsPerPass, BR = BN / kRowsPerPass;   // float4 per thread per tile
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? EMSA_WPE : 2) void conv
       if (lh == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s1[j];
     }
     __syncthreads();
-    for (int col = tid; col < BN; col += 256) {
+    for (int col = tid; col < BN; col += NT) {
       float a1 = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < WM; ++w_) a1 += red[w_ * BN + col];
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? EMSA_WPE : 2) void conv
     for (int j = 0; j < TN; ++j)
       if (lh == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s2[j];
     __syncthreads();
-    for (int col = tid; col < BN; col += 256) {
+    for (int col = tid; col < BN; col += NT) {
       const int n = n0 + col;
       if (n < g.n_ch) {
         float a2 = 0.f;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? EMSA_WPE : 2) void conv
           stage[row * SLD + (wn * TN + j) * 32 + l31] = acc[i][j][r] + bvv[j];
         }
     __syncthreads();
-    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    constexpr int C4 = BN / 4, RPP = NT / C4;
     const int col4 = tid % C4, row0 = tid / C4;
     const int n = n0 + col4 * 4;
     if (n < g.n_ch) {
@@ -655,7 +656,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#if EMSA_ABL & 2
+            if (co < g.n_ch && ci < g.k_ch && acc[i][j][t][r] == 1.2345e30f)
+#else
             if (co < g.n_ch && ci < g.k_ch)
+#endif
               unsafeAtomicAdd(p.dw + ((size_t)tap * g.n_ch + co) * g.k_ch + ci, acc[i][j][t][r]);
           }
         }
@@ -670,6 +675,184 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     red[d_r * BCO + d_c4 + 3] = bsum.w;
     __syncthreads();
     if (tid < BCO && co0 + tid < g.n_ch) {
+      float a = 0.f;
+      for (int r = 0; r < 256 / DTPR; ++r) a += red[r * BCO + tid];
+      unsafeAtomicAdd(p.dbias + co0 + tid, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of the stride-1 3-tap 1-D convolutions (3x1 / 1x3: 79 % of the model's MACs)
+// ------------------------------------------------------------------------------------------
+// Pixels (GEMM K) are enumerated ALONG the convolution direction (b fastest, length L), so the
+// three taps of output pixel k read input pixels k-1, k, k+1: one halo'd x tile [PK+2][BCI] in
+// LDS serves all taps as row shifts (the generic kernel loads one x tile per tap).  Taps that
+// would cross a line end are masked per k with two ballot masks.  Half the global loads, LDS
+// writes and LDS footprint of conv_wgrad_kernel<64,64,3>.
+struct Wgrad1dArgs {
+  const float* in;
+  const float* dout;
+  float* dw;
+  float* dbias;
+  int M, L, n_ch, k_ch;              // M = n_img*A*L pixels, L = line length along the conv
+  int in_sa, in_sb, in_simg;         // element strides of x for (a, b, img)
+  int dy_sa, dy_sb, dy_simg;         // element strides of dy
+  int steps_total, steps_per_split, n_co_tiles, n_ci_tiles, n_tiles;
+  uint32_t in_bytes, dout_bytes;
+  FastDiv div_al, div_l;
+};
+
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const Wgrad1dArgs p) {
+  constexpr int PK = 32, XROWS = PK + 2;
+  constexpr int TCO = BCO / 64, TCI = BCI / 64;     // 32x32 tiles per wave (2x2 waves)
+  constexpr int DTPR = BCO / 4, XTPR = BCI / 4;
+  constexpr int DR = PK * DTPR / 256;
+  constexpr int XR = (XROWS * XTPR + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const dS = smem;                  // [PK][BCO]
+  float* const xS = smem + PK * BCO;       // [XROWS][BCI]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int tile = blockIdx.x % p.n_tiles, ks = blockIdx.x / p.n_tiles;
+  const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(s_begin + p.steps_per_split, p.steps_total);
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
+  const int d_c4 = (tid % DTPR) * 4, d_r = tid / DTPR;
+  const int x_c4 = (tid % XTPR) * 4, x_r = tid / XTPR;
+  const bool do_bias = p.dbias != nullptr && ci_t == 0;
+
+  auto pixel_off = [&](int k, int sa, int sb, int simg) -> uint32_t {
+    if (k < 0 || k >= p.M) return kOOB;
+    const int img = (int)fast_div((uint32_t)k, p.div_al);
+    const int rem = k - img * (int)p.div_al.d;
+    const int a = (int)fast_div((uint32_t)rem, p.div_l), b = rem - a * p.L;
+    return (uint32_t)(img * simg + a * sa + b * sb) * 4u;
+  };
+
+  float4 rd[DR], rx[XR];
+  float4 bsum = emsa_zero4();
+  auto load_regs = [&](int s) {
+    const int k0 = s * PK;
+    const uint32_t cob = (co0 + d_c4) < p.n_ch ? (uint32_t)(co0 + d_c4) * 4u : kOOB;
+    const uint32_t cib = (ci0 + x_c4) < p.k_ch ? (uint32_t)(ci0 + x_c4) * 4u : kOOB;
+#pragma unroll
+    for (int j = 0; j < DR; ++j) {
+      const uint32_t o = pixel_off(k0 + d_r + j * (256 / DTPR), p.dy_sa, p.dy_sb, p.dy_simg);
+#if EMSA_ABL & 1
+      rd[j] = make_float4(o, cob, 1.f, 2.f);
+#else
+      rd[j] = buf_ld4(rs_dy, ((o | cob) & kOOB) ? kOOB : o + cob);
+#endif
+      bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int r = x_r + j * (256 / XTPR);
+      const uint32_t o = r < XROWS ? pixel_off(k0 - 1 + r, p.in_sa, p.in_sb, p.in_simg) : kOOB;
+#if EMSA_ABL & 1
+      rx[j] = make_float4(o, cib, 1.f, 2.f);
+#else
+      rx[j] = buf_ld4(rs_in, ((o | cib) & kOOB) ? kOOB : o + cib);
+#endif
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int j = 0; j < DR; ++j) emsa_st4(dS + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int r = x_r + j * (256 / XTPR);
+      if (r < XROWS) emsa_st4(xS + r * BCI + x_c4, rx[j]);
+    }
+  };
+
+  f32x16 acc[TCO][TCI][3];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][t][r] = 0.f;
+
+  if (s_begin < s_end) {
+    load_regs(s_begin);
+    store_lds();
+  }
+  __syncthreads();
+
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool has_next = s + 1 < s_end;
+    if (has_next) load_regs(s + 1);
+    // line-end masks of this step's 32 pixels: bit r set = tap 0 (left) / tap 2 (right) invalid
+    const int k0 = s * PK;
+    const int kk0 = k0 + (lane & 31);
+    const int a_ = (int)fast_div((uint32_t)kk0, p.div_l);
+    const int pos = kk0 - a_ * p.L;          // (img*A + a)*L + b  ->  b (L divides A*L)
+    const uint32_t mleft = (uint32_t)__ballot(lane < 32 && pos == 0);
+    const uint32_t mright = (uint32_t)__ballot(lane < 32 && pos == p.L - 1);
+
+    const float* d = dS + lh * BCO + wco * TCO * 32 + l31;
+    const float* x = xS + lh * BCI + wci * TCI * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < PK / 2; ++kk) {
+      const int r = 2 * kk + lh;
+      float fa[TCO];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) fa[i] = d[kk * 2 * BCO + i * 32];
+      const bool okl = !((mleft >> r) & 1u), okr = !((mright >> r) & 1u);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) {
+          float fb = x[(kk * 2 + t) * BCI + j * 32];
+          if (t == 0) fb = okl ? fb : 0.f;
+          if (t == 2) fb = okr ? fb : 0.f;
+#pragma unroll
+          for (int i = 0; i < TCO; ++i)
+            acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb, acc[i][j][t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (has_next) store_lds();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < TCI; ++j) {
+        const int ci = ci0 + (wci * TCI + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#if EMSA_ABL & 2
+          if (co < p.n_ch && ci < p.k_ch && acc[i][j][t][r] == 1.2345e30f)
+#else
+          if (co < p.n_ch && ci < p.k_ch)
+#endif
+            unsafeAtomicAdd(p.dw + ((size_t)t * p.n_ch + co) * p.k_ch + ci, acc[i][j][t][r]);
+        }
+      }
+  if (do_bias) {
+    float* red = smem;   // [256/DTPR][BCO]
+    red[d_r * BCO + d_c4 + 0] = bsum.x;
+    red[d_r * BCO + d_c4 + 1] = bsum.y;
+    red[d_r * BCO + d_c4 + 2] = bsum.z;
+    red[d_r * BCO + d_c4 + 3] = bsum.w;
+    __syncthreads();
+    if (tid < BCO && co0 + tid < p.n_ch) {
       float a = 0.f;
       for (int r = 0; r < 256 / DTPR; ++r) a += red[r * BCO + tid];
       unsafeAtomicAdd(p.dbias + co0 + tid, a);
@@ -733,7 +916,8 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
   const int grid = a.tiles_m * a.tiles_n;
   constexpr int cls = BN == 128 ? 0 : BN == 32 ? 3 : BM == 128 ? 1 : 2;
   ProfSlot* ps = prof_begin(cls, algo_flops(a.g), st);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st,
+                     a);
   prof_end(ps, st);
   return emsa_launch_status();
 }
@@ -807,7 +991,7 @@ extern "C" int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const flo
   hipStream_t st = (hipStream_t)stream;
   switch (t) {
     case TILE_128x128: return launch_igemm<128, 128, 2, 2>(a, st);
-    case TILE_128x64: return launch_igemm<128, 64, 2, 2>(a, st);
+    case TILE_128x64: return launch_igemm<128, 64, 4, 2>(a, st);   // 8 waves of 32x32
     case TILE_64x64: return launch_igemm<64, 64, 2, 2>(a, st);
     default: return launch_igemm<128, 32, 4, 1>(a, st);
   }
@@ -830,6 +1014,48 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   a.div_ow = make_fastdiv((uint32_t)g->out_w);
   hipStream_t st = (hipStream_t)stream;
   const int taps = g->kh * g->kw;
+  // stride-1 3-tap 1-D convolution with "same" padding -> halo kernel
+  const bool along_w = g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0;
+  const bool along_h = g->kh == 3 && g->kw == 1 && g->off_h == -1 && g->off_w == 0;
+  if ((along_w || along_h) && g->mul_h == 1 && g->mul_w == 1 && g->step_h == 1 &&
+      g->step_w == 1 && g->in_h == g->out_h && g->in_w == g->out_w && a.dout_aligned &&
+      !getenv("EMSA_WGRAD_GENERIC")) {
+    Wgrad1dArgs w;
+    w.in = in; w.dout = dout; w.dw = dw; w.dbias = dbias;
+    w.M = a.M; w.n_ch = g->n_ch; w.k_ch = g->k_ch;
+    const int H = g->out_h, W = g->out_w;
+    w.L = along_w ? W : H;
+    const int A = along_w ? H : W;
+    w.in_simg = (int)g->in_img_stride;
+    w.dy_simg = H * W * g->ld_out;
+    if (along_w) {
+      w.in_sa = (int)g->in_row_stride; w.in_sb = g->in_px_stride;
+      w.dy_sa = W * g->ld_out; w.dy_sb = g->ld_out;
+    } else {
+      w.in_sa = g->in_px_stride; w.in_sb = (int)g->in_row_stride;
+      w.dy_sa = g->ld_out; w.dy_sb = W * g->ld_out;
+    }
+    w.in_bytes = a.in_bytes; w.dout_bytes = a.dout_bytes;
+    w.div_al = make_fastdiv((uint32_t)(A * w.L));
+    w.div_l = make_fastdiv((uint32_t)w.L);
+    constexpr int BCO = 64, BCI = 64;
+    w.n_co_tiles = (g->n_ch + BCO - 1) / BCO;
+    w.n_ci_tiles = (g->k_ch + BCI - 1) / BCI;
+    w.n_tiles = w.n_co_tiles * w.n_ci_tiles;
+    w.steps_total = (w.M + 31) / 32;
+    int ksplit = 1536 / w.n_tiles;
+    const int max_split = (w.steps_total + 7) / 8;
+    if (ksplit > max_split) ksplit = max_split;
+    if (ksplit < 1) ksplit = 1;
+    w.steps_per_split = (w.steps_total + ksplit - 1) / ksplit;
+    ksplit = (w.steps_total + w.steps_per_split - 1) / w.steps_per_split;
+    constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
+    ProfSlot* ps = prof_begin(7, algo_flops(a.g), st);
+    hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * ksplit), dim3(256), lds,
+                       st, w);
+    prof_end(ps, st);
+    return emsa_launch_status();
+  }
   if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2>(a, st);
   if (taps == 1) {
     if (g->n_ch >= 128 && g->k_ch >= 128) return launch_wgrad<128, 128, 1, 2, 2, 1>(a, st);

@@ -252,16 +252,21 @@ def test_config4_r101_highres_eval():
     args = full_args(input_height=736, input_width=960, rgb_encoder_backbone='resnet101',
                      depth_encoder_backbone='resnet101')
     model, o32, o64 = _triple(args)
-    del o64
-    model.eval(), o32.eval()
+    model.eval(), o32.eval(), o64.eval()
     batch = synthetic_batch(1, 736, 960)
     with torch.no_grad():
         ref = o32(batch)
+        ref64 = o64({k: v.double() for k, v in batch.items()})
         out = model({k: v.to(DEV) for k, v in batch.items()})
-    fr, fo = _flatten(ref), _flatten(out)
-    for i, (a, b) in enumerate(zip(fo, fr)):
-        close(a, b, tol=TOL, what=f'output {i}')
-    _argmax_check(fo[0], fr[0].double(), 'semantic')
+    fr, f64, fo = _flatten(ref), _flatten(ref64), _flatten(out)
+    # 2 x 33 NBt1D blocks deep: fp32 roundoff of BOTH fp32 paths reaches the 1e-3 class on the
+    # tanh/sigmoid-bounded outputs, so the fp64 oracle is the reference and the CPU fp32 path
+    # the yardstick (same rule as the train-mode outputs)
+    for i, (a, b, c) in enumerate(zip(fo, fr, f64)):
+        lim = max(TOL, 4 * _rel(b, c))
+        assert _rel(a, c) <= lim, f"output {i}: err vs fp64 {_rel(a, c):.3e} > {lim:.3e}"
+        close(a, b, tol=2 * TOL, what=f'output {i} vs fp32 oracle')
+    _argmax_check(fo[0], f64[0], 'semantic')
 
 
 def test_resnet18_rgbd_train_step():
