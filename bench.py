@@ -52,6 +52,8 @@ def parse():
                     help='bracket every n-th launch of each conv kernel class with HIP events')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
+    ap.add_argument('--graph', action='store_true',
+                    help='with --eval: replay the whole-model hipGraph (BASELINE config 5 shape)')
     return ap.parse_args()
 
 
@@ -160,9 +162,17 @@ def main():
     opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
     cots = None
 
+    graphed = None
+    if args.eval and args.graph:
+        from emsanet_amd.graph import GraphedInference
+        graphed = GraphedInference(model, batch)
+
     def step():
         nonlocal cots
         if args.eval:
+            if graphed is not None:
+                graphed(batch)
+                return
             with torch.no_grad():
                 model(batch)
             return
@@ -262,7 +272,8 @@ def main():
                                '(BN batch stats, Dropout2d), step = fwd + bwd (fixed output '
                                'cotangents) + grad all-reduce + SGD-nesterov update',
                    'global_batch': bs * world, 'parallelism': f'dp{world}',
-                   'weights': 'random init (deterministic)', 'mode': 'eval-fwd' if args.eval else 'train'},
+                   'weights': 'random init (deterministic)',
+                   'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval else 'train'},
         'roofline': roofline,
         'conv_kernels': kernels,
         'conv_mfma_time_share': round(conv_ms / (dt * 1e3), 4) if kernels else None,

@@ -289,6 +289,29 @@ def test_resnet18_rgbd_train_step():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_hipgraph_inference_matches_eager():
+    """BASELINE config 5 shape (640x480, bs=1): whole-model hipGraph replay == eager forward"""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.graph import GraphedInference
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import synthetic_batch
+    model = EMSANet(full_args(), nyuv2_config()).to(DEV).eval()
+    b1 = {k: v.to(DEV) for k, v in synthetic_batch(1, 480, 640, seed=1).items()}
+    b2 = {k: v.to(DEV) for k, v in synthetic_batch(1, 480, 640, seed=2).items()}
+    g = GraphedInference(model, b1)
+    with torch.no_grad():
+        e1 = [t.clone() for t in _flatten(model(b1))]
+        e2 = [t.clone() for t in _flatten(model(b2))]
+    o1 = [t.clone() for t in _flatten(g(b1))]
+    o2 = [t.clone() for t in _flatten(g(b2))]
+    torch.cuda.synchronize()
+    for a, b in zip(o1, e1):
+        assert torch.equal(a, b)
+    for a, b in zip(o2, e2):
+        assert torch.equal(a, b)
+    assert not torch.equal(o1[0], o2[0])
+
+
 def test_missing_gpu_input_fails_loudly():
     from emsanet_amd import _lib, full_args, nyuv2_config
     from emsanet_amd.model import EMSANet
