@@ -83,6 +83,9 @@ double algo_flops(const EmsaConvGeom& g) {
 #ifndef EMSA_BK
 #define EMSA_BK 32
 #endif
+#ifndef EMSA_SCHED
+#define EMSA_SCHED 1   // tuning: bit0 = s_setprio(1) around the MFMA cluster, bit1 = issue the
+#endif                 // next-step global loads after the first MFMA group
 constexpr int kBK = EMSA_BK;      // K chunk (channels) per step
 constexpr int kLD = kBK + 4;      // padded LDS row (floats): conflict-free ds_read_b128
 constexpr int kRowLanes = kBK / 4;          // lanes (float4) per staged row
@@ -273,7 +276,7 @@ conv_igemm_kernel(const ConvArgs p) {
   int cur = 0;
   for (int s = 0; s < steps; ++s) {
     const bool has_next = s + 1 < steps;
-    if (has_next) load_regs();
+    if (!(EMSA_SCHED & 2) && has_next) load_regs();
 
     const float* a = As + cur * BM * kLD + (wm * TM * 32 + l31) * kLD + lh * 4;
     const float* b = Bs + cur * BN * kLD + (wn * TN * 32 + l31) * kLD + lh * 4;
@@ -284,6 +287,7 @@ conv_igemm_kernel(const ConvArgs p) {
       for (int i = 0; i < TM; ++i) fa[i] = emsa_ld4(a + i * 32 * kLD + t * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = emsa_ld4(b + j * 32 * kLD + t * 8);
+      if (EMSA_SCHED & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -300,6 +304,8 @@ conv_igemm_kernel(const ConvArgs p) {
           }
         }
       }
+      if (EMSA_SCHED & 1) __builtin_amdgcn_s_setprio(0);
+      if ((EMSA_SCHED & 2) && t == 0 && has_next) load_regs();
     }
     if (NBUF == 2) {
       if (has_next) store_lds(cur ^ 1);
@@ -703,10 +709,16 @@ struct Wgrad1dArgs {
   FastDiv div_al, div_l;
 };
 
+// (tried: A operand by ds_read_b64 over even/odd channel tiles, waves splitting K -- halves the LDS
+//  read instructions but needs 96 accumulator registers -> 2 waves/SIMD -> 57 vs 77 TFLOP/s;
+//  occupancy beats instruction count with the 64-cycle fp32 MFMA.)
+#ifndef EMSA_W1D_WPE
+#define EMSA_W1D_WPE 4
+#endif
 template <int BCO, int BCI>
-__global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const Wgrad1dArgs p) {
+__global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(const Wgrad1dArgs p) {
+  static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
   constexpr int PK = 32, XROWS = PK + 2;
-  constexpr int TCO = BCO / 64, TCI = BCI / 64;     // 32x32 tiles per wave (2x2 waves)
   constexpr int DTPR = BCO / 4, XTPR = BCI / 4;
   constexpr int DR = PK * DTPR / 256;
   constexpr int XR = (XROWS * XTPR + 255) / 256;
@@ -717,6 +729,7 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const Wgrad1dArgs p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int wco = wave & 1, wci = wave >> 1;
+  constexpr int NQ = 1;
   const int tile = blockIdx.x % p.n_tiles, ks = blockIdx.x / p.n_tiles;
   const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
@@ -773,15 +786,13 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const Wgrad1dArgs p) 
     }
   };
 
-  f32x16 acc[TCO][TCI][3];
+  f32x16 acc[NQ][3];
 #pragma unroll
-  for (int i = 0; i < TCO; ++i)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int j = 0; j < TCI; ++j)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
 
   if (s_begin < s_end) {
     load_regs(s_begin);
@@ -800,26 +811,19 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const Wgrad1dArgs p) 
     const uint32_t mleft = (uint32_t)__ballot(lane < 32 && pos == 0);
     const uint32_t mright = (uint32_t)__ballot(lane < 32 && pos == p.L - 1);
 
-    const float* d = dS + lh * BCO + wco * TCO * 32 + l31;
-    const float* x = xS + lh * BCI + wci * TCI * 32 + l31;
+    const float* d = dS + lh * BCO + wco * 32 + l31;
+    const float* x = xS + lh * BCI + wci * 32 + l31;
 #pragma unroll
     for (int kk = 0; kk < PK / 2; ++kk) {
       const int r = 2 * kk + lh;
-      float fa[TCO];
-#pragma unroll
-      for (int i = 0; i < TCO; ++i) fa[i] = d[kk * 2 * BCO + i * 32];
+      const float fa = d[kk * 2 * BCO];
       const bool okl = !((mleft >> r) & 1u), okr = !((mright >> r) & 1u);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-#pragma unroll
-        for (int j = 0; j < TCI; ++j) {
-          float fb = x[(kk * 2 + t) * BCI + j * 32];
-          if (t == 0) fb = okl ? fb : 0.f;
-          if (t == 2) fb = okr ? fb : 0.f;
-#pragma unroll
-          for (int i = 0; i < TCO; ++i)
-            acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb, acc[i][j][t], 0, 0, 0);
-        }
+        float fb = x[(kk * 2 + t) * BCI];
+        if (t == 0) fb = okl ? fb : 0.f;
+        if (t == 2) fb = okr ? fb : 0.f;
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0][t], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -830,21 +834,20 @@ __global__ __launch_bounds__(256) void conv_wgrad1d_kernel(const Wgrad1dArgs p) 
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int i = 0; i < TCO; ++i)
+    for (int q = 0; q < NQ; ++q) {
+      const int ci = ci0 + wci * 32 + l31;
 #pragma unroll
-      for (int j = 0; j < TCI; ++j) {
-        const int ci = ci0 + (wci * TCI + j) * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = co0 + wco * 32 + row;
 #if EMSA_ABL & 2
-          if (co < p.n_ch && ci < p.k_ch && acc[i][j][t][r] == 1.2345e30f)
+        if (co < p.n_ch && ci < p.k_ch && acc[q][t][r] == 1.2345e30f)
 #else
-          if (co < p.n_ch && ci < p.k_ch)
+        if (co < p.n_ch && ci < p.k_ch)
 #endif
-            unsafeAtomicAdd(p.dw + ((size_t)t * p.n_ch + co) * p.k_ch + ci, acc[i][j][t][r]);
-        }
+          unsafeAtomicAdd(p.dw + ((size_t)t * p.n_ch + co) * p.k_ch + ci, acc[q][t][r]);
       }
+    }
   if (do_bias) {
     float* red = smem;   // [256/DTPR][BCO]
     red[d_r * BCO + d_c4 + 0] = bsum.x;

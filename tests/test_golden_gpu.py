@@ -35,9 +35,9 @@ def _inputs(bs, h, w, modalities=('rgb', 'depth')):
 
 
 def _weights(model, seed=0):
-    # same generator as oracle.deterministic_state_dict, restated here so that this test does not
-    # touch oracle/ (state-dict order and shapes are identical by construction)
-    from oracle.emsanet_oracle import deterministic_state_dict
+    # same generator as oracle.deterministic_state_dict, restated in tests/util.py so that this
+    # test does not touch oracle/ (state-dict order and shapes are identical by construction)
+    from util import deterministic_state_dict
     model.load_state_dict(deterministic_state_dict(model, seed))
     return model.to(DEV)
 
