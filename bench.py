@@ -52,6 +52,8 @@ def parse():
                     help='bracket every n-th launch of each conv kernel class with HIP events')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='validation: RCCL process group + bucketed all-reduce path with ONE rank')
     ap.add_argument('--graph', action='store_true',
                     help='with --eval: replay the whole-model hipGraph (BASELINE config 5 shape)')
     return ap.parse_args()
@@ -132,9 +134,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL over xGMI
 
     from emsanet_amd import _lib, full_args, nyuv2_config
@@ -156,7 +159,7 @@ def main():
     else:
         model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    buckets = GradientBuckets(params)
+    buckets = GradientBuckets(params, force_collectives=args.force_dist)
     # LR rule of the reference: 0.01 * batch/8 (args.py:1338-1344); tiny here so that the random
     # net stays finite over the benchmark steps
     opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
@@ -211,8 +214,7 @@ def main():
         dt = float(t.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     images = bs * world * args.steps
@@ -286,7 +288,7 @@ def main():
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -53,7 +53,7 @@ SIGNATURES = {
     'emsa_bn_act_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
     'emsa_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32,
                                    _P, _P]),
-    'emsa_bn_bwd_rows': (c_int, [c_int64]),
+    'emsa_bn_bwd_rows': (c_int, [c_int64, c_int32]),
     'emsa_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64,
                                   c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'emsa_dropout2d_mask': (c_int, [_P, c_int32, c_int32, c_float, c_uint32, c_uint32, _P]),
@@ -77,6 +77,9 @@ SIGNATURES = {
     'emsa_head_act_bwd': (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
     'emsa_copy_channels': (c_int, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_axpy': (c_int, [_P, _P, c_int64, c_float, _P]),
+    'emsa_ce_semantic_blocks': (c_int, [c_int64]),
+    'emsa_ce_semantic_fwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, _P, _P, _P]),
+    'emsa_ce_semantic_bwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, _P, _P, _P, c_int32, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
     'emsa_prof_reset': (c_int, []),
     'emsa_prof_seen': (c_int, [c_int32]),

@@ -1055,11 +1055,18 @@ extern "C" int emsa_bn_act_fwd(const float* x, float* y, const float* scale, con
   return emsa_launch_status();
 }
 
-extern "C" int emsa_bn_bwd_rows(int64_t pixels) {
-  long r = (pixels + 255) / 256;
+// number of partial rows (= blocks of the reduce kernel) for `pixels` pixels of `c` channels:
+// ~8 K floats per block so that also the low-resolution, wide tensors (C=256/512 at /16, /32)
+// fill the chip (they ran at 0.7-2.7 TB/s with one block per 256 pixels)
+static int bn_bwd_rows_for(long pixels, int c) {
+  long r = (pixels * c + 8191) / 8192;
+  if (r > pixels) r = pixels;
   if (r < 1) r = 1;
   if (r > 1024) r = 1024;
   return (int)r;
+}
+extern "C" int emsa_bn_bwd_rows(int64_t pixels, int32_t c) {
+  return bn_bwd_rows_for((long)pixels, c);
 }
 
 extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x,
@@ -1070,7 +1077,7 @@ extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* 
   if (act == EMSA_ACT_RELU && !y) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long pixels = (long)n_img * hw;
-  const int rows = emsa_bn_bwd_rows(pixels);
+  const int rows = bn_bwd_rows_for(pixels, c);
   const int c4n = c / 4, lanes = kThreads / c4n;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,

@@ -332,7 +332,7 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
     n, c, h, w = x.shape
     assert ld_of(x) == c and ld_of(dy) == c
     L = _lib.lib()
-    rows = L.emsa_bn_bwd_rows(n * h * w)
+    rows = L.emsa_bn_bwd_rows(n * h * w, c)
     partial = _empty((2, rows, c), x.device)
     check(L.emsa_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(drop), n, h * w, c,
                                act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')

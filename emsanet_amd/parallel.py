@@ -23,9 +23,12 @@ import torch.distributed as dist
 class GradientBuckets:
     """usage per step:  buckets.reset(); loss.backward(); buckets.finish(); optimizer.step()"""
 
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True,
+                 force_collectives=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collectives: run the gather + all-reduce path even with one rank (validation)
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.average = average
         params = [p for p in params if p.requires_grad]
         self.params = params
@@ -47,7 +50,7 @@ class GradientBuckets:
         for bi, (_, ps, _) in enumerate(self.buckets):
             for p in ps:
                 self._bucket_of[p] = bi
-                if self.world > 1:
+                if self.active:
                     p.register_post_accumulate_grad_hook(self._hook)
         self.reset()
 
@@ -93,13 +96,13 @@ class GradientBuckets:
 
     def finish(self):
         """call after backward: wait for the collectives; gradients become the world average"""
-        if self.world > 1:
+        if self.active:
             for bi in range(len(self.buckets)):
                 if self._pending[bi] >= 0:      # some parameter received no gradient this step
                     self._launch(bi)
             for h in self._handles:
                 h.wait()
-            if self.average:
+            if self.average and self.world > 1:
                 torch._foreach_mul_([f for f, _, _ in self.buckets], 1.0 / self.world)
         self._handles = []
 

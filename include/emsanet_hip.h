@@ -147,11 +147,11 @@ int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* s
                     const float* drop, const float* residual, int32_t n_img, int64_t hw,
                     int32_t c, int32_t act, void* stream);
 /* backward, pass 1: g = dy * (y>0 if act) ; partial[2][rows][c] of  sum g*drop  and
- * sum g*drop*xhat  with xhat = (x-mean)*invstd.  rows = emsa_bn_bwd_rows(n_img*hw)          */
+ * sum g*drop*xhat  with xhat = (x-mean)*invstd.  rows = emsa_bn_bwd_rows(n_img*hw, c)          */
 int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* save_mean,
                        const float* save_invstd, const float* drop, int32_t n_img, int64_t hw,
                        int32_t c, int32_t act, float* partial, void* stream);
-int emsa_bn_bwd_rows(int64_t pixels);
+int emsa_bn_bwd_rows(int64_t pixels, int32_t c);
 /* backward, pass 2: reduces `partial` (dgamma, dbeta written), then
  *   train: dx = gamma*invstd*(g*drop - dbeta/M - xhat*dgamma/M);  eval (train=0): dx = g*drop*scale
  *   dres (may be NULL) = g                                                                  */
@@ -232,6 +232,25 @@ int emsa_head_act_bwd(const float* dy, const float* y, float* dx, int64_t pixels
 int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y, int64_t pixels,
                        int32_t c, void* stream);
 int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Class-weighted semantic cross-entropy (`task_helper.training_step`,
+ * main.py:131-141; numerics pinned by emsanet/tests/test_semantic_loss.py:15-48):
+ *   loss = sum_p w[t_p-1] * -log softmax(x_p)[t_p-1] / sum_p w[t_p-1],   target 0 = void.
+ * logits NHWC with pixel stride ld (>= n_classes rounded up to 4), target int64 [pixels].
+ *   partial  float[2 * emsa_ce_semantic_blocks(pixels)] scratch
+ *   out      float[2]: out[0] = loss, out[1] = divisor (kept for backward)
+ *   backward: dlogits = grad_out[0] * w[t] / divisor * (softmax - onehot), 0 for void pixels and
+ *             for padding channels; grad_out is a DEVICE scalar (no host sync)
+ * ------------------------------------------------------------------------------------------ */
+int emsa_ce_semantic_blocks(int64_t pixels);
+int emsa_ce_semantic_fwd(const float* logits, int32_t ld, const int64_t* target,
+                         const float* weights, int32_t n_classes, int64_t pixels, float* partial,
+                         float* out, void* stream);
+int emsa_ce_semantic_bwd(const float* logits, int32_t ld, const int64_t* target,
+                         const float* weights, int32_t n_classes, int64_t pixels,
+                         const float* sums, const float* grad_out, float* dlogits, int32_t ld_d,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every n-th

@@ -91,6 +91,29 @@ def main():
         d['grad:' + k] = dict(o.named_parameters())[k].grad.numpy().copy()
     d['running_mean:encoder.backbone_rgb.bn1'] = o.encoder.backbone_rgb.bn1.running_mean.numpy().copy()
     np.savez_compressed(os.path.join(HERE, 'full_rgbd_96x64_train.npz'), **d)
+    # ---- semantic cross-entropy: outputs of the REFERENCE's own in-tree oracle class -----------
+    # (executed from /root/reference, nothing of it is copied into the repo)
+    import ast
+    ref_file = '/root/reference/emsanet/tests/test_semantic_loss.py'
+    src = open(ref_file).read()
+    cls = [n for n in ast.parse(src).body
+           if isinstance(n, ast.ClassDef) and n.name == 'CrossEntropyLossPrevious'][0]
+    ns = {'torch': torch, 'np': np, 'nn': torch.nn}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), ref_file, 'exec'), ns)
+    from oracle.semantic_loss_oracle import NYUV2_TEST_CLASS_WEIGHTS
+    ref_loss = ns['CrossEntropyLossPrevious'](device='cpu', weight=list(NYUV2_TEST_CLASS_WEIGHTS))
+    g = torch.Generator().manual_seed(2024)
+    shapes = [(2, 40, 48, 64), (2, 40, 6, 8), (2, 40, 3, 4), (3, 40, 30, 41)]
+    preds = tuple(torch.randn(sh, generator=g) * 3 for sh in shapes)
+    # targets 0..40: 0 = void (the reference's test only draws 0..39; void is the edge case)
+    tgts = tuple(torch.randint(0, 41, (sh[0], sh[2], sh[3]), generator=g) for sh in shapes)
+    tgts[1][0] = 0                                   # an all-void image
+    losses = ref_loss(preds, tgts)
+    d = {f'pred{i}': p.numpy() for i, p in enumerate(preds)}
+    d.update({f'target{i}': t.numpy().astype(np.uint8) for i, t in enumerate(tgts)})
+    d['loss'] = np.array([float(x) for x in losses], np.float64)
+    np.savez_compressed(os.path.join(HERE, 'semantic_ce.npz'), **d)
+    print('semantic_ce losses (reference class):', d['loss'])
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -42,7 +42,7 @@ def main():
         t = timeit(lambda: Fn.bn_act(x, sc, sh, drop, res, 1))
         row += f" | bn_act+drop+res {3 * mb / t:5.2f}"
         L = Fn._lib.lib()
-        rows = L.emsa_bn_bwd_rows(n * h * w)
+        rows = L.emsa_bn_bwd_rows(n * h * w, c)
         part = torch.empty((2, rows, c), device=DEV)
         p = Fn._p
         t = timeit(lambda: L.emsa_bn_bwd_reduce(p(dy), p(y), p(x), p(mean), p(inv), None, n, h * w, c, 1, p(part), Fn._stream()))
@@ -76,5 +76,29 @@ def main():
     print(f"torch copy (reference) {2 * xs.numel() * 4 / 1e6 / t:5.2f} TB/s")
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def loss_bench():
+    from emsanet_amd.loss import CrossEntropyLossSemantic
+    n = 32
+    x = Fn.act_empty(n, 40, 480, 640, DEV).normal_().requires_grad_(True)
+    t = torch.randint(0, 41, (n, 480, 640), device=DEV)
+    crit = CrossEntropyLossSemantic(torch.rand(40) + 0.5).to(DEV)
+    mb = x.numel() * 4 / 1e6
+    tf = timeit(lambda: crit([x.detach()], [t]))
+    loss = crit([x], [t])[0][0]
+    tb = timeit(lambda: torch.autograd.grad(loss, x, retain_graph=True))
+    print(f"semantic CE 40ch 480x640 bs32: fwd {tf:.0f} us ({(mb + t.numel() * 8 / 1e6) / tf:.2f} TB/s), "
+          f"bwd {tb:.0f} us ({(2 * mb + t.numel() * 8 / 1e6) / tb:.2f} TB/s)")
+    ref = torch.nn.CrossEntropyLoss(weight=crit.weights, ignore_index=-1)
+    xr = x.detach().clone().requires_grad_(True)
+    tt = timeit(lambda: ref(xr, t - 1))
+    lr = ref(xr, t - 1)
+    ttb = timeit(lambda: torch.autograd.grad(lr, xr, retain_graph=True))
+    print(f"torch.nn.CrossEntropyLoss (reference of the same op): fwd {tt:.0f} us, bwd {ttb:.0f} us")
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'loss':
+    loss_bench()
