@@ -125,6 +125,20 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line (rank 0): everything libraries print to fd 1 while the
+    # benchmark runs (RCCL prints its version banner there) is routed to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    line = run(args)
+    sys.stdout.flush()
+    if line is not None:
+        # fd 1 stays redirected (RCCL also prints at library teardown); the JSON line goes
+        # straight to the original stdout
+        os.write(real_stdout, (line + '\n').encode())
+
+
+def run(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -214,8 +228,9 @@ def main():
         dt = float(t.item())
 
     if rank != 0:
-        dist.destroy_process_group()
-        return
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return None
 
     images = bs * world * args.steps
     value = images / dt
@@ -287,9 +302,9 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args)
     else:
         out['cpu_baseline'] = None
-    print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    return json.dumps(out)
 
 
 if __name__ == '__main__':
