@@ -26,24 +26,52 @@ KNOWN_DECODERS = (
 )
 
 
+class SemanticSideHead(nn.Module):
+    """1x1 side-output head; key fragments ('semantic_decoder', 'head', 'conv') -- the ones the
+    reference's checkpoint surgery resizes (/root/reference/emsanet/weights.py:95-119)."""
+
+    def __init__(self, c, n_classes):
+        super().__init__()
+        self.conv = nn.Conv2d(c, n_classes, 1)
+        self._rt = make_plain_conv_rt(self.conv)
+
+    def forward(self, x):
+        return plain_conv(self._rt, x)                 # channels padded to a multiple of 4
+
+
+class InstanceSideHead(nn.Module):
+    """per-task 1x1 side heads ('...head...task_convs.{0,1,2}', weights.py:28-52) evaluated as
+    ONE C -> 8 GEMM (output channel offsets 0, 1, 3)."""
+
+    def __init__(self, c, with_orientation):
+        super().__init__()
+        outs = (1, 2, 2) if with_orientation else (1, 2)
+        self.task_convs = nn.ModuleList([nn.Conv2d(c, o, 1) for o in outs])
+        placements, co = [], 0
+        for conv, o in zip(self.task_convs, outs):
+            placements.append((conv, co, 0))
+            co += o
+        self._rt = ops.MultiConvRT(placements, Fn.pad4(sum(outs)), c, 1, 0)
+
+    def forward(self, x):
+        return ops.MultiConvFunction.apply(x, self._rt, *self._rt.params())
+
+
 class DecoderModule(nn.Module):
     """conv3x3+BN+ReLU -> n_blocks x NBt1D -> [train: 1x1 side head] -> nearest x2 + DW3x3
     -> + (1x1 conv+BN+ReLU of the rgb skip)          (figure doc/EMSANet-model.png)."""
 
-    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, n_side):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c):
         super().__init__()
         self.conv3x3 = ConvNormAct(cin, c, 3)
         self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
                                       for _ in range(n_blocks)])
-        self.side_output = nn.Conv2d(c, n_side, 1)
         self.upsampling = LearnedUpsampling(c)
         self.skip_fusion = ConvNormAct(skip_c, c, 1) if skip_c != c else None
-        self.n_side = n_side
-        self._side_rt = make_plain_conv_rt(self.side_output)
 
-    def forward(self, x, skip):
+    def forward(self, x, skip, side_head):
         x = self.blocks(self.conv3x3(x))
-        side = plain_conv(self._side_rt, x) if self.training else None   # padded to 4k channels
+        side = side_head(x) if self.training else None
         if self.skip_fusion is not None:
             skip = self.skip_fusion(skip)
         return self.upsampling(x, skip), side
@@ -51,21 +79,23 @@ class DecoderModule(nn.Module):
 
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
-                 fusion_downsamplings, n_side):
+                 fusion_downsamplings, side_head_factory):
         super().__init__()
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
-            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, n_side))
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc))
             cin = c
         self.decoder_modules = nn.ModuleList(mods)
+        self.side_output_heads = nn.ModuleList([side_head_factory(c) for c in n_channels])
         self.fusion_downsamplings = tuple(fusion_downsamplings)
         self.side_output_downscales = (32, 16, 8)
         self.postprocessing = None
 
     def body(self, x, skips):
         sides = []
-        for m, ds in zip(self.decoder_modules, self.fusion_downsamplings):
-            x, s = m(x, skips[str(ds)]['rgb'])
+        for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
+                            self.fusion_downsamplings):
+            x, s = m(x, skips[str(ds)]['rgb'], h)
             sides.append(s)
         return x, tuple(sides)
 
@@ -88,7 +118,7 @@ class SemanticDecoder(DecoderBody):
     """`SemanticDecoder(...)` of /root/reference/emsanet/decoder.py:63-91."""
 
     def __init__(self, n_classes, **kw):
-        super().__init__(n_side=n_classes, **kw)
+        super().__init__(side_head_factory=lambda c: SemanticSideHead(c, n_classes), **kw)
         self.n_classes = n_classes
         self.head = SemanticHead(kw['n_channels'][-1], n_classes)
 
@@ -138,7 +168,7 @@ class InstanceDecoder(DecoderBody):
 
     def __init__(self, with_orientation, sigmoid_for_center, tanh_for_offset, **kw):
         self.with_orientation = with_orientation
-        super().__init__(n_side=5 if with_orientation else 3, **kw)
+        super().__init__(side_head_factory=lambda c: InstanceSideHead(c, with_orientation), **kw)
         self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
         self.sigmoid_for_center = sigmoid_for_center
         self.tanh_for_offset = tanh_for_offset

@@ -1,0 +1,92 @@
+# -*- coding: utf-8 -*-
+"""
+Checkpoint loading with the reference's state-dict surgery.
+
+`load_weights(args, model, state_dict)` stands in for /root/reference/emsanet/weights.py:11-162:
+the same cases, decided on the same key fragments, ending in `load_state_dict(strict=True)`
+(:162).  Cases (reference lines in brackets):
+  1. renamed prefix `fused_encoders.*` -> `encoder.*`                                   [22-26]
+  2. checkpoint trained WITH orientation, model without: drop `task_convs.2`, cut the shared
+     conv / its norm from 96 to 64 channels, keep the first 3 of 5 shared depth-wise upsampling
+     channels                                                                            [28-56]
+  3. semantic-only model fed a panoptic checkpoint: `decoders.panoptic_helper.semantic_decoder.`
+     -> `decoders.semantic_decoder.`                                                     [58-66]
+  4. keys the model does not have are dropped                                            [68-78]
+  5. scene head with a different number of classes keeps the model's own weights         [80-91]
+  6. semantic head 37 (SUNRGB-D) <-> 40 (NYUv2/ScanNet/Hypersim) classes: copy / keep the
+     first 37 channels; any remaining shape mismatch keeps the model's weights   [93-119,147-160]
+The ScanNet 20/200-class benchmark remapping (:121-145) needs the un-vendored datasets package
+and raises NotImplementedError.
+"""
+import torch
+
+
+def _has(key, *fragments):
+    return all(f in key for f in fragments)
+
+
+def load_weights(args, model, state_dict, verbose=True):
+    log = print if verbose else (lambda *a, **k: None)
+    own = model.state_dict()
+    sd = {k.replace('fused_encoders.', 'encoder.'): v for k, v in state_dict.items()}   # case 1
+
+    tasks = tuple(args.tasks)
+    if 'instance' in tasks and 'orientation' not in tasks:                               # case 2
+        if any(_has(k, 'instance_decoder', 'head', 'task_convs.2') for k in sd):
+            log("Detected pretrained weights with orientation, removing orientation weights "
+                "in instance head.")
+            for k in list(sd):
+                v = sd[k]
+                if _has(k, 'instance_decoder', 'head', 'shared_conv'):
+                    if v.dim() > 0 and v.shape[0] == 96:
+                        sd[k] = v[:-32]
+                elif _has(k, 'instance_decoder', 'head', 'task_convs.2'):
+                    del sd[k]
+                elif _has(k, 'instance_decoder', 'head', 'upsampling'):
+                    sd[k] = v[:3]
+
+    if len(tasks) == 1 and tasks[0] == 'semantic':                                       # case 3
+        sd = {k.replace('decoders.panoptic_helper.semantic_decoder.',
+                        'decoders.semantic_decoder.'): v for k, v in sd.items()}
+
+    if len(sd) != len(own):                                                              # case 4
+        for k in list(sd):
+            if k not in own:
+                log(f"Removing '{k}' from loaded state dict as the current model does not "
+                    "contain such key.")
+                sd.pop(k)
+
+    for k in list(sd):                                                                   # case 5
+        if _has(k, 'scene_decoder', 'head') and k in own and sd[k].shape[0] != own[k].shape[0]:
+            log(f"Skipping '{k}' as the number of scene classes differs "
+                f"{own[k].shape[0]} (current) vs. {sd[k].shape[0]} (pretraining).")
+            sd[k] = own[k]
+
+    if 'semantic' in tasks:                                                              # case 6
+        dataset = getattr(args, 'dataset', 'nyuv2')
+        sem = [k for k in sd if _has(k, 'semantic_decoder', 'head', 'conv') and k in own]
+        if dataset.startswith('nyuv2'):
+            for k in sem:
+                if sd[k].shape[0] == 37 and own[k].shape[0] == 40:
+                    log(f"Reusing 37/40 channels in '{k}'.")
+                    merged = own[k].clone()
+                    merged[:37] = sd[k]
+                    sd[k] = merged
+        if dataset.startswith('sunrgbd'):
+            for k in sem:
+                if sd[k].shape[0] == 40 and own[k].shape[0] == 37:
+                    log(f"Removing last 3 channels in '{k}'.")
+                    sd[k] = sd[k][:37]
+        elif (dataset.startswith('scannet')
+              and not getattr(args, 'validation_scannet_benchmark_mode', False)):
+            if any(sd[k].shape != own[k].shape for k in sem):
+                raise NotImplementedError(
+                    "ScanNet benchmark class remapping needs nicr_scene_analysis_datasets")
+        for k in sem:
+            if sd[k].shape != own[k].shape:
+                log(f"Removing '{k}' from loaded state dict as the shape does not match: "
+                    f"{tuple(sd[k].shape)} vs. {tuple(own[k].shape)}.")
+                sd[k] = own[k]
+
+    model.load_state_dict(sd, strict=True)
+    return model

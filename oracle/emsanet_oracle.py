@@ -252,22 +252,44 @@ class LearnedUpsampling(nn.Module):
         return self.conv(F.interpolate(x, scale_factor=2, mode='nearest'))
 
 
+class SemanticSideHead(nn.Module):
+    # key fragments ('semantic_decoder', 'head', 'conv') with shape[0] = n_classes: the only
+    # semantic keys the reference's checkpoint surgery resizes (weights.py:95-119,147-160)
+    def __init__(self, c, n_classes):
+        super().__init__()
+        self.conv = nn.Conv2d(c, n_classes, Spec.SIDE_OUTPUT_KERNEL)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class InstanceSideHead(nn.Module):
+    # per-task convs so that "remove orientation" = delete '...head...task_convs.2' keys
+    # (weights.py:28-52) without touching any other side-output shape
+    def __init__(self, c, with_orientation):
+        super().__init__()
+        outs = (1, 2, 2) if with_orientation else (1, 2)
+        self.task_convs = nn.ModuleList([nn.Conv2d(c, o, Spec.SIDE_OUTPUT_KERNEL) for o in outs])
+
+    def forward(self, x):
+        return torch.cat([conv(x) for conv in self.task_convs], dim=1)
+
+
 class DecoderModule(nn.Module):
-    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, n_side):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c):
         super().__init__()
         self.conv3x3 = ConvNormAct(cin, c, 3)
         self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
                                       for _ in range(n_blocks)])
-        self.side_output = nn.Conv2d(c, n_side, Spec.SIDE_OUTPUT_KERNEL)
         self.upsampling = LearnedUpsampling(c)
         if Spec.SKIP_FUSION_1X1 and skip_c != c:
             self.skip_fusion = ConvNormAct(skip_c, c, 1)
         else:
             self.skip_fusion = None
 
-    def forward(self, x, skip):
+    def forward(self, x, skip, side_head):
         x = self.blocks(self.conv3x3(x))
-        side = self.side_output(x) if self.training else None
+        side = side_head(x) if self.training else None
         x = self.upsampling(x)
         if self.skip_fusion is not None:
             skip = self.skip_fusion(skip)
@@ -276,19 +298,21 @@ class DecoderModule(nn.Module):
 
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
-                 fusion_downsamplings, n_side):
+                 fusion_downsamplings, side_head_factory):
         super().__init__()
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
-            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, n_side))
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc))
             cin = c
         self.decoder_modules = nn.ModuleList(mods)
+        self.side_output_heads = nn.ModuleList([side_head_factory(c) for c in n_channels])
         self.fusion_downsamplings = tuple(fusion_downsamplings)
 
     def forward(self, x, skips):
         sides = []
-        for m, ds in zip(self.decoder_modules, self.fusion_downsamplings):
-            x, s = m(x, skips[str(ds)]['rgb'])
+        for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
+                            self.fusion_downsamplings):
+            x, s = m(x, skips[str(ds)]['rgb'], h)
             sides.append(s)
         return x, tuple(sides)
 
@@ -305,7 +329,7 @@ class SemanticHead(nn.Module):
 
 class SemanticDecoder(DecoderBody):
     def __init__(self, n_classes, **kw):
-        super().__init__(n_side=n_classes, **kw)
+        super().__init__(side_head_factory=lambda c: SemanticSideHead(c, n_classes), **kw)
         self.head = SemanticHead(kw['n_channels'][-1], n_classes)
         self.side_output_downscales = (32, 16, 8)     # module order (taken before each x2)
 
@@ -344,7 +368,7 @@ class InstanceHead(nn.Module):
 class InstanceDecoder(DecoderBody):
     def __init__(self, with_orientation, sigmoid_for_center, tanh_for_offset, **kw):
         self.with_orientation = with_orientation
-        super().__init__(n_side=5 if with_orientation else 3, **kw)
+        super().__init__(side_head_factory=lambda c: InstanceSideHead(c, with_orientation), **kw)
         self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
         self.sigmoid_for_center = sigmoid_for_center
         self.tanh_for_offset = tanh_for_offset

@@ -170,7 +170,7 @@ def test_dry_run_orchestration(fake_lib, train, monkeypatch):
     flat = [sem[0], *inst[0], scene[0]] + list(sem[1]) + [t for s in inst[1] for t in s]
     torch.autograd.backward(flat, [torch.zeros_like(t) for t in flat])
     for k, p in model.named_parameters():
-        if not train and 'side_output' in k:
+        if not train and 'side_output_heads' in k:
             continue      # side heads are evaluated in training mode only
         assert p.grad is not None and p.grad.shape == p.shape, k
     c = fake_lib.calls

@@ -193,7 +193,7 @@ def test_full_model_small(mode):
     e_gpu_all, e_cpu_all, names = [], [], []
     gmax = max(p64[k].grad.abs().max().item() for k in p64 if p64[k].grad is not None)
     for k, p in model.named_parameters():
-        if not train and 'side_output' in k:
+        if not train and 'side_output_heads' in k:
             continue      # side heads are evaluated in training mode only
         assert p.grad is not None, f"no grad for {k}"
         assert torch.isfinite(p.grad).all(), f"non-finite grad for {k}"
