@@ -24,41 +24,52 @@
 
 #include <vector>
 
+#include "prof.h"
+
 namespace {
 
 // ---- optional per-launch timing (bench.py roofline): HIP events on the launch stream ---------
-struct ProfSlot {
+// (prof.h; shared with conv_wino.hip)
+struct ProfSlotImpl {
   hipEvent_t a, b;
   int cls;
   double flops;
 };
-std::vector<ProfSlot> g_prof_pool;
+std::vector<ProfSlotImpl> g_prof_pool;
 size_t g_prof_used = 0;
 int g_prof_every = 0;          // 0 = off, n = bracket every n-th launch of each kernel class
-int g_prof_seen[8] = {0};
-const char* const kProfNames[8] = {
+int g_prof_seen[kProfClasses] = {0};
+const char* const kProfNames[kProfClasses] = {
     "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,4,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
     "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1>",
-    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_kernel<64,64>"};
+    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_kernel<64,64>",
+    "conv1d_wino_kernel"};
+}  // namespace
 
-ProfSlot* prof_begin(int cls, double flops, hipStream_t st) {
-  if (g_prof_every <= 0) return nullptr;
-  if ((g_prof_seen[cls]++ % g_prof_every) != 0) return nullptr;
+int emsa_prof_begin(int cls, double flops, hipStream_t st) {
+  if (g_prof_every <= 0) return -1;
+  if ((g_prof_seen[cls]++ % g_prof_every) != 0) return -1;
   if (g_prof_used == g_prof_pool.size()) {
-    ProfSlot s;
-    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return nullptr;
+    ProfSlotImpl s;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
     g_prof_pool.push_back(s);
   }
-  ProfSlot* s = &g_prof_pool[g_prof_used++];
+  const int id = (int)g_prof_used++;
+  ProfSlotImpl* s = &g_prof_pool[id];
   s->cls = cls;
   s->flops = flops;
   (void)hipEventRecord(s->a, st);
-  return s;
+  return id;
 }
-void prof_end(ProfSlot* s, hipStream_t st) {
-  if (s) (void)hipEventRecord(s->b, st);
+void emsa_prof_end(int slot, hipStream_t st) {
+  if (slot >= 0) (void)hipEventRecord(g_prof_pool[slot].b, st);
 }
+
+namespace {
+using ProfSlot = int;
+inline int prof_begin(int cls, double flops, hipStream_t st) { return emsa_prof_begin(cls, flops, st); }
+inline void prof_end(int s, hipStream_t st) { emsa_prof_end(s, st); }
 
 // algorithmic (direct-convolution) FLOPs of one launch: 2 * pixels * k_ch * n_ch * taps, pixels
 // counted on the grid of the FORWARD conv's output (for a strided data gradient that is the
@@ -918,7 +929,7 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
   }
   const int grid = a.tiles_m * a.tiles_n;
   constexpr int cls = BN == 128 ? 0 : BN == 32 ? 3 : BM == 128 ? 1 : 2;
-  ProfSlot* ps = prof_begin(cls, algo_flops(a.g), st);
+  const int ps = prof_begin(cls, algo_flops(a.g), st);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st,
                      a);
   prof_end(ps, st);
@@ -947,7 +958,7 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   a.steps_per_split = (a.steps_total + ksplit - 1) / ksplit;
   ksplit = (a.steps_total + a.steps_per_split - 1) / a.steps_per_split;
   constexpr int cls = TT == 7 ? 4 : TT == 3 ? 7 : BCO == 128 ? 5 : 6;
-  ProfSlot* ps = prof_begin(cls, algo_flops(a.g), st);
+  const int ps = prof_begin(cls, algo_flops(a.g), st);
   hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>), dim3(a.n_tiles * ksplit),
                      dim3(256), lds, st, a);
   prof_end(ps, st);
@@ -1053,7 +1064,7 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     w.steps_per_split = (w.steps_total + ksplit - 1) / ksplit;
     ksplit = (w.steps_total + w.steps_per_split - 1) / w.steps_per_split;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
-    ProfSlot* ps = prof_begin(7, algo_flops(a.g), st);
+    const int ps = prof_begin(7, algo_flops(a.g), st);
     hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * ksplit), dim3(256), lds,
                        st, w);
     prof_end(ps, st);
@@ -1074,12 +1085,12 @@ extern "C" int emsa_prof_enable(int32_t every) {
 }
 extern "C" int emsa_prof_reset(void) {
   g_prof_used = 0;
-  for (int i = 0; i < 8; ++i) g_prof_seen[i] = 0;
+  for (int i = 0; i < kProfClasses; ++i) g_prof_seen[i] = 0;
   return EMSA_OK;
 }
-extern "C" int emsa_prof_seen(int32_t cls) { return (cls >= 0 && cls < 8) ? g_prof_seen[cls] : 0; }
+extern "C" int emsa_prof_seen(int32_t cls) { return (cls >= 0 && cls < kProfClasses) ? g_prof_seen[cls] : 0; }
 extern "C" const char* emsa_prof_name(int32_t cls) {
-  return (cls >= 0 && cls < 8) ? kProfNames[cls] : "";
+  return (cls >= 0 && cls < kProfClasses) ? kProfNames[cls] : "";
 }
 // call after the stream has been synchronised; sums over the launches recorded since reset
 extern "C" int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops,
@@ -1088,7 +1099,7 @@ extern "C" int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops
   double ms = 0.0, fl = 0.0;
   int n = 0;
   for (size_t i = 0; i < g_prof_used; ++i) {
-    const ProfSlot& s = g_prof_pool[i];
+    const ProfSlotImpl& s = g_prof_pool[i];
     if (s.cls != cls) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) return EMSA_E_LAUNCH;

@@ -1,0 +1,408 @@
+// 1-D Winograd F(2,3) convolution on fp32 MFMA for the stride-1, 3-tap, "same"-padded 3x1 / 1x3
+// convolutions of the NonBottleneck1D blocks (forward AND data gradient): 79 % of the model's
+// MACs.
+//
+//   y(2p)   = m0 + m1 + m2          m_j = sum_c U_j[n][c] * V_j[p][c]          (4 GEMMs, j=0..3)
+//   y(2p+1) = m1 - m2 - m3          V = (d0-d2, d1+d2, d2-d1, d1-d3),  d_r = x(2p-1+r)
+//                                   U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)   (emsa_pack_wino)
+// i.e. 4 MFMA GEMMs over HALF the pixels instead of 3 over all of them: 1.5x fewer matrix
+// instructions for the same direct-convolution result (coefficients 1, 1/2: exact in fp32, the
+// result differs from the direct kernel by ordinary fp32 roundoff).
+//
+// Workgroup = 32 output pairs (64 pixels along the convolution direction, pairs may sit on
+// different lines) x 64 output channels, 4 waves: wave j owns Winograd component j (2 MFMA
+// tiles of 32x32).  Per K step (16 channels) the RAW input rows d0..d3 of every pair are staged
+// once ([4][32][20] floats) and wave j forms its V_j operand on the fly as the sum/difference of
+// two conflict-free ds_read_b128; U_j is staged as [4][64][20].  Single LDS buffer + register
+// prefetch (30 KiB -> 5 workgroups per CU).  The epilogue transposes m_j through LDS, applies the
+// output transform and the same fused epilogue as conv_igemm (bias, BatchNorm statistics
+// partials, folded BatchNorm, residual, ReLU, ReLU-backward mask) with 16-B stores.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int kWK = 16;          // channels per K step
+constexpr int kWLD = kWK + 4;    // padded LDS row
+constexpr int kPairs = 32;       // output pairs per workgroup
+constexpr int kWN = 64;          // output channels per workgroup
+
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOOBw = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 wbuf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
+struct WinoArgs {
+  const float* in;
+  const float* u;
+  float* out;
+  const float* bias;
+  float* stats;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  const float* mask_src;
+  int ld_out, ld_res, ld_mask, act;
+  int L, PL, A, MP;                 // line length, pairs per line, lines per image, total pairs
+  int k_ch, n_ch;
+  int in_simg, in_sa, in_sb;        // input element strides (image, line, position on the line)
+  int px_simg, px_sa, px_sb;        // output PIXEL strides (x ld_out / ld_res / ld_mask)
+  int tiles_m, tiles_n, ksteps;
+  uint32_t in_bytes, u_bytes;
+  uint32_t mul_pl, sh_pl, mul_a, sh_a;     // magic division by PL and by A
+};
+
+__device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) {
+  return (__umulhi(n, mul) + n) >> sh;
+}
+
+__global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const As = smem;                          // [4 rows][32 pairs][kWLD]
+  float* const Bs = smem + 4 * kPairs * kWLD;      // [4 comps][64 n][kWLD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = component j
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
+  const int q0 = mt * kPairs, n0 = nt * kWN;
+  const __amdgpu_buffer_rsrc_t rs_in = wrsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_u = wrsrc(p.u, p.u_bytes);
+
+  // ---- loader state: a tile's pixels do not change over its K loop ----------------------
+  // A: 4 rows x 32 pairs x 4 float4 = 512 float4 -> 2 per thread; B: 4 x 64 x 4 = 1024 -> 4
+  const int c4 = (tid & 3) * 4;
+  uint32_t a_off[2], b_off[4];
+  auto setup_a = [&](int mtile) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rowid = (tid >> 2) + 64 * j;          // 0..127 = rr*32 + pair
+      const int rr = rowid >> 5, pr = rowid & 31;
+      const int q = mtile * kPairs + pr;
+      uint32_t off = kOOBw;
+      if (q < p.MP) {
+        const int line = (int)wdiv((uint32_t)q, p.mul_pl, p.sh_pl);
+        const int pp = q - line * p.PL;
+        const int img = (int)wdiv((uint32_t)line, p.mul_a, p.sh_a);
+        const int a = line - img * p.A;
+        const int b = 2 * pp - 1 + rr;
+        if (b >= 0 && b < p.L) off = (uint32_t)(img * p.in_simg + a * p.in_sa + b * p.in_sb) * 4u;
+      }
+      a_off[j] = off;
+    }
+  };
+  setup_a(mt);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rowid = (tid >> 2) + 64 * j;          // 0..255 = comp*64 + n
+    const int comp = rowid >> 6, n = n0 + (rowid & 63);
+    b_off[j] = n < p.n_ch ? (uint32_t)((comp * p.n_ch + n) * p.k_ch) * 4u : kOOBw;
+  }
+  float4 ra[2], rb[4];
+  auto load_regs = [&](int s) {
+    const int k = s * kWK + c4;
+    const uint32_t kb = k < p.k_ch ? (uint32_t)k * 4u : kOOBw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      ra[j] = wbuf_ld4(rs_in, ((a_off[j] | kb) & kOOBw) ? kOOBw : a_off[j] + kb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      rb[j] = wbuf_ld4(rs_u, ((b_off[j] | kb) & kOOBw) ? kOOBw : b_off[j] + kb);
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) emsa_st4(As + ((tid >> 2) + 64 * j) * kWLD + c4, ra[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) emsa_st4(Bs + ((tid >> 2) + 64 * j) * kWLD + c4, rb[j]);
+  };
+
+  // wave j: V_j = row[ra_] + sg * row[rb_]
+  const int ra_ = wave == 0 ? 0 : wave == 2 ? 2 : 1;
+  const int rb_ = wave == 2 ? 1 : wave == 3 ? 3 : 2;
+  const float sg = wave == 1 ? 1.f : -1.f;
+
+  load_regs(0);
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  store_lds();
+  __syncthreads();
+  for (int s = 0; s < p.ksteps; ++s) {
+    const bool has_next = s + 1 < p.ksteps;
+    if (has_next) load_regs(s + 1);
+    const float* a0 = As + (ra_ * kPairs + l31) * kWLD + lh * 4;
+    const float* a1 = As + (rb_ * kPairs + l31) * kWLD + lh * 4;
+    const float* b = Bs + (wave * kWN + l31) * kWLD + lh * 4;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < kWK / 8; ++t) {
+      const float4 x0 = emsa_ld4(a0 + t * 8), x1 = emsa_ld4(a1 + t * 8);
+      const float4 fb0 = emsa_ld4(b + t * 8), fb1 = emsa_ld4(b + 32 * kWLD + t * 8);
+      const float4 v = make_float4(x0.x + sg * x1.x, x0.y + sg * x1.y, x0.z + sg * x1.z,
+                                   x0.w + sg * x1.w);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, fb0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, fb1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, fb0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, fb1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, fb0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, fb1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb1.w, acc[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (has_next) store_lds();
+    __syncthreads();
+  }
+
+  // ---- epilogue: m_j -> LDS, output transform, fused epilogue ---------------------------------
+  // stage [4 comps][32 pairs][64 + 4]; thread (px = tid/16 + 16*k, col4 = tid%16) owns 4 of the
+  // 64 output pixels x one float4 of channels
+  constexpr int SLD = kWN + 4;
+  float* const stage = smem;                       // 4*32*68 floats = 34 KiB (dynamic LDS sized for it)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      stage[(wave * kPairs + row) * SLD + t * 32 + l31] = acc[t][r];
+    }
+  __syncthreads();
+  const int col4 = tid & 15, n = n0 + col4 * 4;
+  const bool nok = n < p.n_ch;
+  float4 y[4];
+  uint32_t opix[4];            // pixel index (< 2^29, checked by emsa_conv1d_wino_supported)
+  bool ok[4];
+  const float4 bv = (nok && p.bias) ? emsa_ld4(p.bias + n) : emsa_zero4();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = (tid >> 4) + 16 * k;            // 0..63 = pair*2 + e
+    const int pr = px >> 1, e = px & 1;
+    const float4 m1 = emsa_ld4(stage + (1 * kPairs + pr) * SLD + col4 * 4);
+    const float4 m2 = emsa_ld4(stage + (2 * kPairs + pr) * SLD + col4 * 4);
+    const float4 m03 = emsa_ld4(stage + ((e ? 3 : 0) * kPairs + pr) * SLD + col4 * 4);
+    float4 v;
+    if (e == 0) {
+      v = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z,
+                      m03.w + m1.w + m2.w);
+    } else {
+      v = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z,
+                      m1.w - m2.w - m03.w);
+    }
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    y[k] = v;
+    const int q = q0 + pr;
+    ok[k] = false;
+    opix[k] = 0;
+    if (q < p.MP) {
+      const int line = (int)wdiv((uint32_t)q, p.mul_pl, p.sh_pl);
+      const int pp = q - line * p.PL;
+      const int img = (int)wdiv((uint32_t)line, p.mul_a, p.sh_a);
+      const int a = line - img * p.A;
+      const int b = 2 * pp + e;
+      if (b < p.L) {
+        ok[k] = nok;
+        opix[k] = (uint32_t)(img * p.px_simg + a * p.px_sa + b * p.px_sb);
+      }
+    }
+  }
+
+  if (p.stats != nullptr) {
+    // per-tile (sum, M2 about the tile mean, count) over the tile's VALID output pixels
+    __syncthreads();                               // everyone has read `stage`
+    float* red = smem;                             // [16 row groups][64]
+    float* tmean = smem + 16 * kWN;                // [64]
+    int* scnt = reinterpret_cast<int*>(tmean + kWN);   // [16] valid pixels per row group
+    float4 s1 = emsa_zero4();
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ok[k]) {
+        s1.x += y[k].x; s1.y += y[k].y; s1.z += y[k].z; s1.w += y[k].w;
+        ++cnt;
+      }
+    emsa_st4(red + (tid >> 4) * kWN + col4 * 4, s1);
+    // the valid-pixel count is the same for every channel column: column 0 threads publish it
+    // (n0 < n_ch for every launched tile, so their `ok` flags are the pixel validity)
+    if (col4 == 0) scnt[tid >> 4] = cnt;
+    __syncthreads();
+    if (tid < kWN) {
+      float a1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a1 += red[g * kWN + tid];
+      int c = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) c += scnt[g];
+      tmean[tid] = c > 0 ? a1 / (float)c : 0.f;
+      if (n0 + tid < p.n_ch) {
+        p.stats[((size_t)0 * p.tiles_m + mt) * p.n_ch + n0 + tid] = a1;
+        p.stats[((size_t)2 * p.tiles_m + mt) * p.n_ch + n0 + tid] = (float)c;
+      }
+    }
+    __syncthreads();
+    const float4 mu = emsa_ld4(tmean + col4 * 4);
+    float4 s2 = emsa_zero4();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ok[k]) {
+        const float dx = y[k].x - mu.x, dy = y[k].y - mu.y, dz = y[k].z - mu.z, dw = y[k].w - mu.w;
+        s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+      }
+    __syncthreads();
+    emsa_st4(red + (tid >> 4) * kWN + col4 * 4, s2);
+    __syncthreads();
+    if (tid < kWN && n0 + tid < p.n_ch) {
+      float a2 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a2 += red[g * kWN + tid];
+      p.stats[((size_t)1 * p.tiles_m + mt) * p.n_ch + n0 + tid] = a2;
+    }
+  }
+
+  if (nok) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = emsa_zero4();
+    if (p.scale) {
+      sc = emsa_ld4(p.scale + n);
+      sh = emsa_ld4(p.shift + n);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+      float4 v = y[k];
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+      v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      if (p.residual) {
+        const float4 rr = emsa_ld4(p.residual + (size_t)opix[k] * p.ld_res + n);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      if (p.mask_src) {
+        const float4 mm = emsa_ld4(p.mask_src + (size_t)opix[k] * p.ld_mask + n);
+        v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
+        v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+      }
+      if (p.act == EMSA_ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      emsa_st4(p.out + (size_t)opix[k] * p.ld_out + n, v);
+    }
+  }
+}
+
+// U[4][n][k] from OIHW taps; dgrad: n = cin, k = cout, taps flipped
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout,
+                                 int cin, int dgrad) {
+  const int total = cout * cin;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ci = i % cin, co = i / cin;
+    const float* g = w + (size_t)i * 3;          // [co][ci][3] (3x1 or 1x3: taps contiguous)
+    const float g0 = dgrad ? g[2] : g[0], g1 = g[1], g2 = dgrad ? g[0] : g[2];
+    const size_t N = dgrad ? cin : cout, K = dgrad ? cout : cin;
+    const size_t o = dgrad ? (size_t)ci * K + co : (size_t)co * K + ci;
+    u[0 * N * K + o] = g0;
+    u[1 * N * K + o] = 0.5f * (g0 + g1 + g2);
+    u[2 * N * K + o] = 0.5f * (g0 - g1 + g2);
+    u[3 * N * K + o] = g2;
+  }
+}
+
+inline void magic(uint32_t d, uint32_t& mul, uint32_t& sh) {
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  sh = s;
+  mul = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+}
+
+}  // namespace
+
+extern "C" int emsa_pack_wino(const float* w_oihw, float* u, int32_t cout, int32_t cin,
+                              int32_t dgrad, void* stream) {
+  if (!w_oihw || !u) return EMSA_E_ARG;
+  const int total = cout * cin;
+  int grid = (total + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u,
+                     cout, cin, dgrad);
+  return emsa_launch_status();
+}
+
+// 1 if `g` (forward or data-gradient geometry of a conv) is a stride-1 3-tap 1-D "same" conv
+extern "C" int emsa_conv1d_wino_supported(const EmsaConvGeom* g) {
+  if (!g) return 0;
+  const bool aw = g->kh == 1 && g->kw == 3 && g->off_h == 0 && (g->off_w == -1 || g->off_w == 1);
+  const bool ah = g->kh == 3 && g->kw == 1 && g->off_w == 0 && (g->off_h == -1 || g->off_h == 1);
+  if (!(aw || ah)) return 0;
+  if (g->mul_h != 1 || g->mul_w != 1 || g->div_h != 1 || g->div_w != 1) return 0;
+  if (aw && g->step_w != -g->off_w) return 0;
+  if (ah && g->step_h != -g->off_h) return 0;
+  if (g->in_h != g->out_h || g->in_w != g->out_w) return 0;
+  if ((g->k_ch & 3) || (g->n_ch & 3) || (g->ld_out & 3) || (g->in_px_stride & 3)) return 0;
+  if ((long)g->n_img * g->in_img_stride >= (1L << 29)) return 0;
+  return 1;
+}
+
+extern "C" int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g) {
+  if (!emsa_conv1d_wino_supported(g)) return EMSA_E_SHAPE;
+  const bool aw = g->kw == 3;
+  const int L = aw ? g->out_w : g->out_h, A = aw ? g->out_h : g->out_w;
+  const long mp = (long)g->n_img * A * ((L + 1) / 2);
+  return (int)((mp + kPairs - 1) / kPairs);
+}
+
+extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, float* out,
+                                const float* bias, float* stats, const float* scale,
+                                const float* shift, const float* residual, int32_t ld_res,
+                                const float* mask_src, int32_t ld_mask, int32_t act,
+                                void* stream) {
+  if (!emsa_conv1d_wino_supported(g)) return EMSA_E_SHAPE;
+  if (!in || !u || !out) return EMSA_E_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!al16(out) || !al16(bias) || !al16(scale) || !al16(shift) ||
+      (residual && (!al16(residual) || (ld_res & 3))) ||
+      (mask_src && (!al16(mask_src) || (ld_mask & 3))))
+    return EMSA_E_SHAPE;
+  WinoArgs a;
+  a.in = in; a.u = u; a.out = out; a.bias = bias; a.stats = stats; a.scale = scale;
+  a.shift = shift; a.residual = residual; a.mask_src = mask_src;
+  a.ld_out = g->ld_out; a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
+  const bool aw = g->kw == 3;
+  const int H = g->out_h, W = g->out_w;
+  a.L = aw ? W : H;
+  a.A = aw ? H : W;
+  a.PL = (a.L + 1) / 2;
+  a.MP = g->n_img * a.A * a.PL;
+  a.k_ch = g->k_ch; a.n_ch = g->n_ch;
+  a.in_simg = (int)g->in_img_stride;
+  a.in_sa = aw ? (int)g->in_row_stride : g->in_px_stride;
+  a.in_sb = aw ? g->in_px_stride : (int)g->in_row_stride;
+  a.px_simg = H * W;
+  a.px_sa = aw ? W : 1;
+  a.px_sb = aw ? 1 : W;
+  a.tiles_m = (a.MP + kPairs - 1) / kPairs;
+  a.tiles_n = (g->n_ch + kWN - 1) / kWN;
+  a.ksteps = (g->k_ch + kWK - 1) / kWK;
+  a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
+  a.u_bytes = (uint32_t)((size_t)4 * g->n_ch * g->k_ch * sizeof(float));
+  magic((uint32_t)a.PL, a.mul_pl, a.sh_pl);
+  magic((uint32_t)a.A, a.mul_a, a.sh_a);
+  constexpr size_t lds_main = (size_t)(4 * kPairs + 4 * kWN) * kWLD * sizeof(float);
+  constexpr size_t lds_epi = (size_t)4 * kPairs * (kWN + 4) * sizeof(float);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  // algorithmic = direct-convolution FLOPs (3 taps); the kernel executes 4/6 of them on the MFMA
+  const double flops = 2.0 * g->n_img * H * W * (double)g->k_ch * g->n_ch * 3.0;
+  const int ps = emsa_prof_begin(kProfClassWino, flops, (hipStream_t)stream);
+  // one workgroup per tile: a persistent grid with cross-tile prefetch measured SLOWER on MI355X
+  // (static tile partition quantises to whole rounds: c256 /16 124 us vs 103 us)
+  hipLaunchKernelGGL(conv1d_wino_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
+                     (hipStream_t)stream, a);
+  emsa_prof_end(ps, (hipStream_t)stream);
+  return emsa_launch_status();
+}

@@ -1,0 +1,12 @@
+// Per-launch HIP-event timing of the convolution kernels (bench.py's roofline numbers).
+// Defined in conv_mfma.hip; events are recorded on the launch stream around every n-th launch of
+// a kernel class and read back through the emsa_prof_* C-ABI after the stream is synchronised.
+#pragma once
+#include <hip/hip_runtime.h>
+
+constexpr int kProfClasses = 9;
+constexpr int kProfClassWino = 8;
+
+// returns a slot id (or -1 when this launch is not sampled); `flops` = algorithmic FLOPs
+int emsa_prof_begin(int cls, double flops, hipStream_t st);
+void emsa_prof_end(int slot, hipStream_t st);

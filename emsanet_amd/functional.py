@@ -169,38 +169,61 @@ def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off
 # ---------------------------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------------------------
+def wino_eligible(spec):
+    """stride-1 3-tap 1-D "same" convolution (NBt1D 3x1 / 1x3) with channel counts the Winograd
+    kernel accepts"""
+    one_d = (spec.kh, spec.kw, spec.ph, spec.pw) in ((3, 1, 1, 0), (1, 3, 0, 1))
+    return one_d and spec.sh == 1 and spec.sw == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
+
+
+def pack_wino(w, dgrad):
+    """OIHW [cout][cin][3x1|1x3] -> Winograd F(2,3) weights U [4][n][k] (n,k = cout,cin or, for the
+    data gradient, cin,cout with flipped taps)"""
+    cout, cin = w.shape[:2]
+    u = _empty((4 * cout * cin,), w.device)
+    check(_lib.lib().emsa_pack_wino(_p(w.contiguous()), _p(u), cout, cin, 1 if dgrad else 0,
+                                    _stream()), 'emsa_pack_wino')
+    return u
+
+
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
-             act=ACT_NONE, out=None):
+             act=ACT_NONE, out=None, wino_u=None):
+    """wp = packed [tap][cout][cin] weights (MFMA implicit GEMM) -- or wino_u = Winograd weights
+    of an eligible 1-D conv (emsa_conv1d_wino)"""
     n, c, h, w = x.shape
     oh, ow = spec.out_hw(h, w)
     if out is None:
         out = act_empty(n, spec.cout, oh, ow, x.device)
     g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(out))
     L = _lib.lib()
+    fn, wt, name = (L.emsa_conv1d_wino, wino_u, 'emsa_conv1d_wino') if wino_u is not None \
+        else (L.emsa_conv_igemm, wp, 'emsa_conv_igemm')
     stats = None
     if want_stats:
-        rows = L.emsa_conv_stats_rows(g)
+        rows = (L.emsa_conv1d_wino_stats_rows if wino_u is not None else L.emsa_conv_stats_rows)(g)
         if rows <= 0:
             check(rows or -1, 'emsa_conv_stats_rows')
         stats = _empty((3, rows, spec.cout), x.device)
-    check(L.emsa_conv_igemm(g, _p(x), _p(wp), _p(out), _p(bias), _p(stats), _p(scale), _p(shift),
-                            _p(residual), ld_of(residual) if residual is not None else 0,
-                            None, 0, act, _stream()), 'emsa_conv_igemm')
+    check(fn(g, _p(x), _p(wt), _p(out), _p(bias), _p(stats), _p(scale), _p(shift),
+             _p(residual), ld_of(residual) if residual is not None else 0,
+             None, 0, act, _stream()), name)
     return (out, stats) if want_stats else out
 
 
-def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None):
+def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, wino_u=None):
     """dx = conv_transpose(dy); optional fused `* (mask_src > 0)` and `+ residual`."""
     n = dy.shape[0]
     h, w = in_hw
     if out is None:
         out = act_empty(n, spec.cin, h, w, dy.device)
     g = spec.geom_dgrad(n, h, w, ld_of(dy), ld_of(out))
-    check(_lib.lib().emsa_conv_igemm(
-        g, _p(dy), _p(wpd), _p(out), None, None, None, None,
-        _p(residual), ld_of(residual) if residual is not None else 0,
-        _p(mask_src), ld_of(mask_src) if mask_src is not None else 0, ACT_NONE, _stream()),
-        'emsa_conv_igemm(dgrad)')
+    L = _lib.lib()
+    fn, wt, name = (L.emsa_conv1d_wino, wino_u, 'emsa_conv1d_wino(dgrad)') if wino_u is not None \
+        else (L.emsa_conv_igemm, wpd, 'emsa_conv_igemm(dgrad)')
+    check(fn(g, _p(dy), _p(wt), _p(out), None, None, None, None,
+             _p(residual), ld_of(residual) if residual is not None else 0,
+             _p(mask_src), ld_of(mask_src) if mask_src is not None else 0, ACT_NONE, _stream()),
+          name)
     return out
 
 

@@ -8,6 +8,8 @@ backward with the ReLU masks and the residual add fused into the data-gradient e
 per conv+BN+act, per SE fusion, per learned upsampling ...  Every Function only sequences calls
 into libemsanet_hip.so (emsanet_amd/functional.py); autograd is used for graph bookkeeping only.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -52,6 +54,35 @@ class ConvRT:
         self._wp = None
         self._keyd = None
         self._wpd = None
+        # stride-1 3x1 / 1x3 convs run on the Winograd F(2,3) kernel (EMSA_WINO=0 disables it)
+        self.wino = Fn.wino_eligible(self.spec) and os.environ.get('EMSA_WINO', '1') != '0'
+        self._keyu = None
+        self._u = None
+        self._ud = None
+
+    def _wino_weights(self):
+        w = self.conv.weight
+        key = (w._version, w.data_ptr())
+        if key != self._keyu:
+            wd = w.detach()
+            self._u = Fn.pack_wino(wd, dgrad=False)
+            self._ud = Fn.pack_wino(wd, dgrad=True) if w.requires_grad else None
+            self._keyu = key
+        return self._u, self._ud
+
+    def forward(self, x, **kw):
+        """conv forward through the best kernel for this layer (fused-epilogue kwargs of conv_fwd)"""
+        if self.wino:
+            return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
+        return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
+
+    def dgrad(self, dy, in_hw, **kw):
+        if self.wino:
+            u, ud = self._wino_weights()
+            if ud is None:
+                ud = Fn.pack_wino(self.conv.weight.detach(), dgrad=True)
+            return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, **kw)
+        return Fn.conv_dgrad(dy, self.packed_dgrad(), self.spec, in_hw, **kw)
 
     def packed(self):
         w = self.conv.weight
@@ -114,10 +145,10 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
     returns out, y_raw, (mean, invstd)"""
     bias = crt.conv.bias.detach() if crt.conv.bias is not None else None
     if brt.batch_stats():
-        y, stats = Fn.conv_fwd(x, crt.packed(), crt.spec, bias=bias, want_stats=True)
+        y, stats = crt.forward(x, bias=bias, want_stats=True)
         count = y.shape[0] * y.shape[2] * y.shape[3]
     else:
-        y, stats, count = Fn.conv_fwd(x, crt.packed(), crt.spec, bias=bias), None, 0
+        y, stats, count = crt.forward(x, bias=bias), None, 0
     scale, shift, mean, invstd = brt.forward_stats(stats, count)
     out = Fn.bn_act(y, scale, shift, drop, residual, act)
     return out, y, mean, invstd
@@ -130,8 +161,7 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
     dw = Fn.unpack_wgrad(dwp, conv.weight)
     dx = None
     if need_dx:
-        dx = Fn.conv_dgrad(dy, crt.packed_dgrad(), crt.spec, x.shape[2:], mask_src=mask_src,
-                           residual=residual)
+        dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual)
     return dx, dw, db
 
 
@@ -169,9 +199,9 @@ class NBt1DFunction(Function):
     def forward(ctx, x, rt, drop, *params):
         x = Fn.as_act(x, dense=True)
         b = lambda c: c.conv.bias.detach()   # noqa: E731
-        y1 = Fn.conv_fwd(x, rt.c31_1.packed(), rt.c31_1.spec, bias=b(rt.c31_1), act=ACT_RELU)
+        y1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU)
         a2, y2, m1, is1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
-        y3 = Fn.conv_fwd(a2, rt.c31_2.packed(), rt.c31_2.spec, bias=b(rt.c31_2), act=ACT_RELU)
+        y3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU)
         if rt.cds is not None:
             idn, yd, md, isd = _conv_bn_forward(x, rt.cds, rt.bnds, ACT_NONE)
         else:
@@ -225,19 +255,17 @@ class NBt1DFunction(Function):
 def nbt1d_eval(x, rt):
     """no-grad / eval fast path: both BatchNorms folded into the conv epilogues (4 launches)."""
     b = lambda c: c.conv.bias.detach()   # noqa: E731
-    y1 = Fn.conv_fwd(x, rt.c31_1.packed(), rt.c31_1.spec, bias=b(rt.c31_1), act=ACT_RELU)
+    y1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU)
     s1, t1 = rt.bn1.folded()
-    a2 = Fn.conv_fwd(y1, rt.c13_1.packed(), rt.c13_1.spec, bias=b(rt.c13_1), scale=s1, shift=t1,
-                     act=ACT_RELU)
-    y3 = Fn.conv_fwd(a2, rt.c31_2.packed(), rt.c31_2.spec, bias=b(rt.c31_2), act=ACT_RELU)
+    a2 = rt.c13_1.forward(y1, bias=b(rt.c13_1), scale=s1, shift=t1, act=ACT_RELU)
+    y3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU)
     if rt.cds is not None:
         sd, td = rt.bnds.folded()
-        idn = Fn.conv_fwd(x, rt.cds.packed(), rt.cds.spec, scale=sd, shift=td)
+        idn = rt.cds.forward(x, scale=sd, shift=td)
     else:
         idn = x
     s2, t2 = rt.bn2.folded()
-    return Fn.conv_fwd(y3, rt.c13_2.packed(), rt.c13_2.spec, bias=b(rt.c13_2), scale=s2, shift=t2,
-                       residual=idn, act=ACT_RELU)
+    return rt.c13_2.forward(y3, bias=b(rt.c13_2), scale=s2, shift=t2, residual=idn, act=ACT_RELU)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -270,7 +298,7 @@ class ConvBNActFunction(Function):
 
 def conv_bn_act_eval(x, crt, brt, act):
     s, t = brt.folded()
-    return Fn.conv_fwd(x, crt.packed(), crt.spec, scale=s, shift=t, act=act)
+    return crt.forward(x, scale=s, shift=t, act=act)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -93,6 +93,21 @@ int emsa_conv_stats_rows(const EmsaConvGeom* g);
 int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout, float* dw,
                     float* dbias, void* stream);
 
+/* 1-D Winograd F(2,3) variant of emsa_conv_igemm for the stride-1 3-tap "same" 3x1 / 1x3
+ * convolutions of the NBt1D blocks (forward and data gradient): 4 MFMA GEMMs over half the pixels
+ * instead of 3 over all (1.5x fewer matrix instructions, fp32-exact coefficients 1 and 1/2).
+ * Same arguments and fused epilogue as emsa_conv_igemm, but `u` = transformed weights
+ * [4][n_ch][k_ch] from emsa_pack_wino (dgrad=1: data-gradient weights, taps flipped, channels
+ * transposed); stats partial rows = emsa_conv1d_wino_stats_rows(g).                          */
+int emsa_conv1d_wino_supported(const EmsaConvGeom* g);
+int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g);
+int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, float* out,
+                     const float* bias, float* stats, const float* scale, const float* shift,
+                     const float* residual, int32_t ld_res, const float* mask_src,
+                     int32_t ld_mask, int32_t act, void* stream);
+int emsa_pack_wino(const float* w_oihw, float* u, int32_t cout, int32_t cin, int32_t dgrad,
+                   void* stream);
+
 /* weight layout transforms between the reference's OIHW parameters and the packed layouts.
  * The packed buffer may be wider than the parameter (cout_total/cin_total >= cout/cin) and the
  * parameter is placed at (cout_off, cin_off): used to zero-pad channel counts to a multiple of 4

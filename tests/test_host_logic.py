@@ -19,7 +19,7 @@ class _FakeLib:
 
         def fn(*a):
             self.calls[name] += 1
-            if name in ('emsa_conv_stats_rows', 'emsa_bn_bwd_rows'):
+            if name in ('emsa_conv_stats_rows', 'emsa_conv1d_wino_stats_rows', 'emsa_bn_bwd_rows'):
                 return 3
             if name in ('emsa_channel_ws_floats', 'emsa_bn_finalize_ws_bytes'):
                 return 64
@@ -176,7 +176,9 @@ def test_dry_run_orchestration(fake_lib, train, monkeypatch):
     c = fake_lib.calls
     # 2 encoders x 16 + 2 decoders x 9 NBt1D blocks, 4 MFMA convs each (+3 downsample per encoder)
     assert c['emsa_conv_wgrad'] >= 50 * 4
-    assert c['emsa_conv_igemm'] > c['emsa_conv_wgrad']
+    assert c['emsa_conv_igemm'] + c['emsa_conv1d_wino'] > c['emsa_conv_wgrad']
+    # every stride-1 3x1/1x3 conv runs on the Winograd kernel, forward and data gradient
+    assert c['emsa_conv1d_wino'] >= 2 * (50 * 4 - 2 * 3 * 2) - 2
     assert c['emsa_se_mlp_fwd'] == 10 and c['emsa_maxpool3x3s2_fwd'] == 2
     assert c['emsa_up2x_dw3x3_fwd'] == 2 * 3 + 2 * 2
     # merged dict variant (do_postprocessing=True), /root/reference/emsanet/model.py:230-231

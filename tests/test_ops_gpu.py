@@ -89,6 +89,94 @@ def test_conv_dgrad(cfg, tile, monkeypatch):
     close(dx3, x.grad + res, what='dgrad residual')
 
 
+WINO = [
+    # cin, cout, kernel, n, h, w   (stride 1, "same" padding)
+    (64, 64, (3, 1), 2, 12, 20),
+    (64, 64, (1, 3), 2, 12, 20),
+    (128, 128, (1, 3), 3, 9, 13),        # odd line length: last pair of a line is half empty
+    (128, 128, (3, 1), 3, 9, 13),
+    (256, 128, (3, 1), 1, 15, 7),
+    (512, 512, (1, 3), 2, 3, 5),
+    (64, 40, (1, 3), 1, 30, 41),         # cout not a multiple of the 64-channel tile
+    (72, 64, (3, 1), 1, 5, 40),          # cin not a multiple of the K step
+    (64, 64, (1, 3), 1, 1, 1),           # single pixel
+]
+
+
+@pytest.mark.parametrize('cfg', WINO)
+def test_conv1d_winograd_fwd(cfg):
+    """F(2,3) Winograd kernel == direct convolution (fp64 reference) incl. the fused epilogues
+    and the BatchNorm statistics partials"""
+    Fn = _fn()
+    cin, cout, k, n, h, w = cfg
+    p = (k[0] // 2, k[1] // 2)
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    b = rnd(cout, seed=3)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=p)
+    spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
+    assert Fn.wino_eligible(spec)
+    u = Fn.pack_wino(wt.to(DEV), dgrad=False)
+    y, stats = Fn.conv_fwd(to_act(x), None, spec, bias=b.to(DEV), want_stats=True, wino_u=u)
+    torch.cuda.synchronize()
+    close(y, ref, what='wino conv')
+    cnt = ref.numel() / cout
+    assert float(stats[2][:, 0].sum()) == cnt
+    assert bool((stats[2] == stats[2][:, :1]).all())
+    mean = stats[0].sum(0) / cnt
+    close(mean, ref.mean((0, 2, 3)), what='stats mean')
+    tile_mean = stats[0] / stats[2].clamp(min=1)
+    m2 = stats[1].sum(0) + (stats[2] * (tile_mean - mean[None]) ** 2).sum(0)
+    close(m2 / cnt, ref.var((0, 2, 3), unbiased=False), tol=2e-4, what='stats var')
+    sc, sh = rnd(cout, seed=4), rnd(cout, seed=5)
+    res = rnd(*ref.shape, seed=6)
+    y2 = Fn.conv_fwd(to_act(x), None, spec, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV),
+                     residual=to_act(res), act=Fn.ACT_RELU, wino_u=u)
+    ref2 = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res)
+    close(y2, ref2, what='wino epilogue')
+    # same result as the implicit-GEMM kernel to fp32 rounding
+    y3 = Fn.conv_fwd(to_act(x), Fn.pack_weight(wt.to(DEV), 'fwd'), spec, bias=b.to(DEV))
+    close(y, y3.double(), tol=2e-5, what='wino vs igemm')
+
+
+@pytest.mark.parametrize('cfg', WINO)
+def test_conv1d_winograd_dgrad(cfg):
+    Fn = _fn()
+    cin, cout, k, n, h, w = cfg
+    p = (k[0] // 2, k[1] // 2)
+    x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    y = F.conv2d(x, wt.double(), None, padding=p)
+    dy = rnd(*y.shape, seed=7)
+    y.backward(dy.double())
+    spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
+    ud = Fn.pack_wino(wt.to(DEV), dgrad=True)
+    dx = Fn.conv_dgrad(to_act(dy), None, spec, (h, w), wino_u=ud)
+    torch.cuda.synchronize()
+    close(dx, x.grad, what='wino dgrad')
+    mask = rnd(n, cin, h, w, seed=8)
+    res = rnd(n, cin, h, w, seed=9)
+    dx2 = Fn.conv_dgrad(to_act(dy), None, spec, (h, w), mask_src=to_act(mask), wino_u=ud)
+    close(dx2, x.grad * (mask > 0), what='wino dgrad mask')
+    dx3 = Fn.conv_dgrad(to_act(dy), None, spec, (h, w), residual=to_act(res), wino_u=ud)
+    close(dx3, x.grad + res, what='wino dgrad residual')
+
+
+def test_conv1d_winograd_channel_slice_views():
+    """input and output that are channel slices of wider NHWC tensors (pixel stride > channels)"""
+    Fn = _fn()
+    n, h, w = 2, 7, 11
+    wide_in = to_act(rnd(n, 192, h, w, seed=1))
+    x = wide_in[:, 64:128]
+    wt = rnd(64, 64, 1, 3, seed=2, scale=0.1)
+    spec = Fn.ConvSpec(64, 64, (1, 3), (1, 1), (0, 1))
+    wide_out = Fn.act_empty(n, 128, h, w, DEV).zero_()
+    Fn.conv_fwd(x, None, spec, out=wide_out[:, 64:], wino_u=Fn.pack_wino(wt.to(DEV), False))
+    ref = F.conv2d(x.cpu().double(), wt.double(), padding=(0, 1))
+    close(wide_out[:, 64:], ref, what='wino slice')
+    assert float(wide_out[:, :64].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('cfg', CONVS)
 def test_conv_wgrad(cfg):
     Fn = _fn()

@@ -1,5 +1,5 @@
 """Micro-benchmark of the MFMA convolution kernels on the layer shapes of the bs=32 640x480
-workload (GPU box).  usage: python tools/conv_bench.py [fwd|dgrad|wgrad|all] [tile ...]
+workload (GPU box).  usage: python tools/conv_bench.py [fwd|dgrad|wgrad|wino|all] [tile ...]
 EMSA_LIB selects an alternative build (ablations)."""
 import os
 import sys
@@ -67,6 +67,16 @@ def main():
             if what in ('dgrad', 'all'):
                 us = timeit(lambda: Fn.conv_dgrad(dy, wpd, spec, (h, w), mask_src=x, out=dx))
                 row += f" dgrad[t{t}] {us:7.1f}us {flops / us / 1e6:6.1f}TF |"
+        if what in ('wino', 'all') and Fn.wino_eligible(spec):
+            u, ud = Fn.pack_wino(wt, False), Fn.pack_wino(wt, True)
+            us = timeit(lambda: Fn.conv_fwd(x, None, spec, bias=bias, act=1, out=y, wino_u=u))
+            row += f" WINO fwd {us:7.1f}us {flops / us / 1e6:6.1f}TF(eff) |"
+            us = timeit(lambda: Fn.conv_fwd(x, None, spec, bias=bias, want_stats=True, out=y,
+                                            wino_u=u))
+            row += f" +stats {flops / us / 1e6:6.1f} |"
+            us = timeit(lambda: Fn.conv_dgrad(dy, None, spec, (h, w), mask_src=x, out=dx,
+                                              wino_u=ud))
+            row += f" dgrad {us:7.1f}us {flops / us / 1e6:6.1f} |"
         if what in ('wgrad', 'all'):
             us = timeit(lambda: Fn.conv_wgrad(x, dy, spec, True))
             row += f" wgrad {us:7.1f}us {flops / us / 1e6:6.1f}TF |"
