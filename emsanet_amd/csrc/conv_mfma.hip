@@ -723,13 +723,24 @@ struct Wgrad1dArgs {
 // (tried: A operand by ds_read_b64 over even/odd channel tiles, waves splitting K -- halves the LDS
 //  read instructions but needs 96 accumulator registers -> 2 waves/SIMD -> 57 vs 77 TFLOP/s;
 //  occupancy beats instruction count with the 64-cycle fp32 MFMA.)
+#ifndef EMSA_W1DW_WPE
+#define EMSA_W1DW_WPE 3   // Winograd variant: 64 accumulator registers; 4 waves/SIMD would spill
+#endif
 #ifndef EMSA_W1D_WPE
 #define EMSA_W1D_WPE 4
 #endif
-template <int BCO, int BCI>
-__global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(const Wgrad1dArgs p) {
+// WINO = Winograd F(3,2) over pixel PAIRS along the line (needs an even line length):
+//   dW_t = sum_pairs sum_i e_i d_(i+t),  e_i = dy(2p+i), d_r = x(2p-1+r)   ->   4 products per pair
+//   E = (e0, e0+e1, e0-e1, -e1)   D = (d0-d2, d1+d2, d2-d1, d1-d3)   M_k = sum_pairs E_k (x) D_k
+//   dW_0 = M0 + (M1+M2)/2    dW_1 = (M1-M2)/2    dW_2 = (M1+M2)/2 + M3
+// i.e. 4 MFMAs per pixel pair instead of 6 (the transposed form of the forward F(2,3) kernel in
+// conv_wino.hip); operands are formed on the fly from the same raw LDS rows, the output
+// transform is applied to the accumulators in registers before the atomics.
+template <int BCO, int BCI, bool WINO>
+__global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv_wgrad1d_kernel(
+    const Wgrad1dArgs p) {
   static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
-  constexpr int PK = 32, XROWS = PK + 2;
+  constexpr int PK = 32, XROWS = PK + 2;   // pixels per K step (64 spills: measured slower)
   constexpr int DTPR = BCO / 4, XTPR = BCI / 4;
   constexpr int DR = PK * DTPR / 256;
   constexpr int XR = (XROWS * XTPR + 255) / 256;
@@ -797,11 +808,12 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(const W
     }
   };
 
-  f32x16 acc[NQ][3];
+  constexpr int NACC = WINO ? 4 : 3;
+  f32x16 acc[NQ][NACC];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
 
@@ -822,6 +834,25 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(const W
     const uint32_t mleft = (uint32_t)__ballot(lane < 32 && pos == 0);
     const uint32_t mright = (uint32_t)__ballot(lane < 32 && pos == p.L - 1);
 
+    if constexpr (WINO) {
+      // K index of the MFMA = pixel pair: lane half lh takes pair 2*kk + lh of the step's 16
+      const float* d = dS + wco * 32 + l31;
+      const float* x = xS + wci * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < PK / 4; ++kk) {
+        const int row = 2 * (2 * kk + lh);           // first pixel of the pair within the step
+        const float e0 = d[row * BCO], e1 = d[(row + 1) * BCO];
+        float d0 = x[row * BCI];                     // xS row 0 = pixel k0 - 1
+        const float d1 = x[(row + 1) * BCI], d2 = x[(row + 2) * BCI];
+        float d3 = x[(row + 3) * BCI];
+        d0 = ((mleft >> row) & 1u) ? 0.f : d0;
+        d3 = ((mright >> (row + 1)) & 1u) ? 0.f : d3;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, d0 - d2, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, d1 + d2, acc[0][1], 0, 0, 0);
+        acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, d2 - d1, acc[0][2], 0, 0, 0);
+        acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-e1, d1 - d3, acc[0][3], 0, 0, 0);
+      }
+    } else {
     const float* d = dS + lh * BCO + wco * 32 + l31;
     const float* x = xS + lh * BCI + wci * 32 + l31;
 #pragma unroll
@@ -837,9 +868,22 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(const W
         acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0][t], 0, 0, 0);
       }
     }
+    }
     __syncthreads();
     if (has_next) store_lds();
     __syncthreads();
+  }
+
+  if constexpr (WINO) {
+    // output transform G^T on the accumulators: acc[0][0..2] <- dW_0, dW_1, dW_2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][0][r], m1 = acc[0][1][r], m2 = acc[0][2][r], m3 = acc[0][3][r];
+      const float hs = 0.5f * (m1 + m2);
+      acc[0][0][r] = m0 + hs;
+      acc[0][1][r] = 0.5f * (m1 - m2);
+      acc[0][2][r] = hs + m3;
+    }
   }
 
 #pragma unroll
@@ -1057,7 +1101,20 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     w.n_ci_tiles = (g->k_ch + BCI - 1) / BCI;
     w.n_tiles = w.n_co_tiles * w.n_ci_tiles;
     w.steps_total = (w.M + 31) / 32;
-    int ksplit = 1536 / w.n_tiles;
+    // even line length -> Winograd F(3,2) over pixel pairs (EMSA_WGRAD_WINO=0: direct form)
+    static const bool wino_on = [] {
+      const char* e = getenv("EMSA_WGRAD_WINO");
+      return !(e && e[0] == '0');
+    }();
+    const bool wino = wino_on && (w.L & 1) == 0;
+    // split-K: one round of resident workgroups for the Winograd variant (3 per CU), two rounds
+    // of 3 for the direct one (4 per CU) -- measured optima (EMSA_W1D_BLOCKS: tuning only)
+    static const int forced_blocks = [] {
+      const char* e = getenv("EMSA_W1D_BLOCKS");
+      return e ? atoi(e) : 0;
+    }();
+    const int target_blocks = forced_blocks > 0 ? forced_blocks : (wino ? 768 : 1536);
+    int ksplit = target_blocks / w.n_tiles;
     const int max_split = (w.steps_total + 7) / 8;
     if (ksplit > max_split) ksplit = max_split;
     if (ksplit < 1) ksplit = 1;
@@ -1065,8 +1122,12 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     ksplit = (w.steps_total + w.steps_per_split - 1) / w.steps_per_split;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     const int ps = prof_begin(7, algo_flops(a.g), st);
-    hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * ksplit), dim3(256), lds,
-                       st, w);
+    if (wino)
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, true>), dim3(w.n_tiles * ksplit),
+                         dim3(256), lds, st, w);
+    else
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, false>), dim3(w.n_tiles * ksplit),
+                         dim3(256), lds, st, w);
     prof_end(ps, st);
     return emsa_launch_status();
   }
