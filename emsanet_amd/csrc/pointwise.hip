@@ -94,35 +94,6 @@ __global__ void stem_pack_weight_kernel(const float* __restrict__ w, float* __re
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm
-// ------------------------------------------------------------------------------------------
-// reduce partial[2][rows][c] over rows in fp64: block = 32 channels x 8 row groups
-__device__ __forceinline__ void reduce_rows(const float* __restrict__ partial, int rows, int c,
-                                            double& o1, double& o2, int& ch_out, bool& leader) {
-  __shared__ double red[2][8][32];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + cl;
-  double a1 = 0.0, a2 = 0.0;
-  if (ch < c) {
-    for (int r = rg; r < rows; r += 8) {
-      a1 += (double)partial[((long)0 * rows + r) * c + ch];
-      a2 += (double)partial[((long)1 * rows + r) * c + ch];
-    }
-  }
-  red[0][rg][cl] = a1;
-  red[1][rg][cl] = a2;
-  __syncthreads();
-  leader = rg == 0 && ch < c;
-  ch_out = ch;
-  o1 = o2 = 0.0;
-  if (leader) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      o1 += red[0][k][cl];
-      o2 += red[1][k][cl];
-    }
-  }
-}
-
 // stats = float[3][rows][c]: per-tile sum, M2 (about the tile mean), count.
 // Two-level merge in fp64.  Level 1 (grid = channel groups x row slices): per slice
 //   S0 = sum n_t, S1 = sum sum_t, Q = sum (M2_t + sum_t^2 / n_t)        [= sum of squares]
@@ -268,7 +239,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
                                      const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ invstd,
                                      const float* __restrict__ drop, long pixels, long hw, int c4n,
-                                     int act, int rows, float* __restrict__ partial) {
+                                     int act, int rows_alloc, float* __restrict__ partial) {
+  const int rows = gridDim.x;            // partial = [2][rows_alloc][c], rows [0, rows) written here
   const long chunk = (pixels + rows - 1) / rows;
   const long p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
   float4 o1, o2;
@@ -297,20 +269,40 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
       o1, o2, leader, c4);
   if (leader) {
     const int c = c4n * 4;
-    emsa_st4(partial + ((long)0 * rows + blockIdx.x) * c + c4 * 4, o1);
-    emsa_st4(partial + ((long)1 * rows + blockIdx.x) * c + c4 * 4, o2);
+    emsa_st4(partial + ((long)0 * rows_alloc + blockIdx.x) * c + c4 * 4, o1);
+    emsa_st4(partial + ((long)1 * rows_alloc + blockIdx.x) * c + c4 * 4, o2);
   }
 }
 
-__global__ void bn_bwd_sum_kernel(const float* __restrict__ partial, int rows, int c,
-                                  float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  double s1, s2;
-  int ch;
-  bool leader;
-  reduce_rows(partial, rows, c, s1, s2, ch, leader);
-  if (leader) {
-    dbeta[ch] = (float)s1;
-    dgamma[ch] = (float)s2;
+// partial = float[2][rows_alloc][c], rows_alloc = rows + kBwdSlices.  Level 1 (grid = channel
+// groups x kBwdSlices): slice sums of rows [0, rows) in fp64 -> rows [rows, rows_alloc).  Level 2
+// (merging the kBwdSlices slice sums) is the prologue of bn_bwd_apply_kernel.  A single-level
+// version (c/32 workgroups looping over up to 1024 rows) was latency bound at 35 us per layer.
+constexpr int kBwdSlices = 16;
+__global__ void bn_bwd_sum_kernel(float* __restrict__ partial, int rows, int rows_alloc, int c) {
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl, sl = blockIdx.y;
+  const int per = (rows + kBwdSlices - 1) / kBwdSlices;
+  const int r0 = sl * per, r1 = min(rows, r0 + per);
+  double a1 = 0.0, a2 = 0.0;
+  if (ch < c) {
+    for (int r = r0 + rg; r < r1; r += 8) {
+      a1 += (double)partial[((long)0 * rows_alloc + r) * c + ch];
+      a2 += (double)partial[((long)1 * rows_alloc + r) * c + ch];
+    }
+  }
+  red[0][rg][cl] = a1;
+  red[1][rg][cl] = a2;
+  __syncthreads();
+  if (rg == 0 && ch < c) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      a1 += red[0][k][cl];
+      a2 += red[1][k][cl];
+    }
+    partial[((long)0 * rows_alloc + rows + sl) * c + ch] = (float)a1;
+    partial[((long)1 * rows_alloc + rows + sl) * c + ch] = (float)a2;
   }
 }
 
@@ -319,10 +311,30 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean,
                                     const float* __restrict__ invstd,
                                     const float* __restrict__ drop,
-                                    const float* __restrict__ dbeta,
-                                    const float* __restrict__ dgamma, long hw, int c4n,
+                                    const float* __restrict__ partial, int rows,
+                                    int rows_alloc, float* __restrict__ dbeta_out,
+                                    float* __restrict__ dgamma_out, long hw, int c4n,
                                     long total4, float inv_count, int act, int train,
                                     float* __restrict__ dx, float* __restrict__ dres) {
+  // level 2 of the (sum dy, sum dy*xhat) reduction: merge the slice sums of bn_bwd_sum_kernel
+  extern __shared__ __attribute__((aligned(16))) float sums[];   // [2][c]
+  float* const dbeta = sums;
+  float* const dgamma = sums + c4n * 4;
+  for (int ch = threadIdx.x; ch < c4n * 4; ch += blockDim.x) {
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBwdSlices; ++sl) {
+      a1 += (double)partial[((long)0 * rows_alloc + rows + sl) * (c4n * 4) + ch];
+      a2 += (double)partial[((long)1 * rows_alloc + rows + sl) * (c4n * 4) + ch];
+    }
+    dbeta[ch] = (float)a1;
+    dgamma[ch] = (float)a2;
+    if (blockIdx.x == 0) {
+      dbeta_out[ch] = (float)a1;
+      dgamma_out[ch] = (float)a2;
+    }
+  }
+  __syncthreads();
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
        i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
@@ -1065,8 +1077,9 @@ static int bn_bwd_rows_for(long pixels, int c) {
   if (r > 1024) r = 1024;
   return (int)r;
 }
+// rows to ALLOCATE: the per-workgroup partial rows plus kBwdSlices rows of level-1 slice sums
 extern "C" int emsa_bn_bwd_rows(int64_t pixels, int32_t c) {
-  return bn_bwd_rows_for((long)pixels, c);
+  return bn_bwd_rows_for((long)pixels, c) + kBwdSlices;
 }
 
 extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x,
@@ -1081,15 +1094,15 @@ extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* 
   const int c4n = c / 4, lanes = kThreads / c4n;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
-                     dy, y, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act, rows,
-                     partial);
+                     dy, y, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act,
+                     rows + kBwdSlices, partial);
   return emsa_launch_status();
 }
 
 extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x,
                                  const float* gamma, const float* save_mean,
                                  const float* save_invstd, const float* drop,
-                                 const float* partial, int32_t rows, int32_t n_img, int64_t hw,
+                                 float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw,
                                  int32_t c, int32_t act, int32_t train, float* dx, float* dres,
                                  float* dgamma, float* dbeta, void* stream) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
@@ -1097,12 +1110,15 @@ extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x
   if (act == EMSA_ACT_RELU && !y) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32), dim3(256), 0, st, partial, rows, c,
-                     dbeta, dgamma);
   const long pixels = (long)n_img * hw;
+  const int rows = bn_bwd_rows_for(pixels, c);
+  if (rows_alloc != rows + kBwdSlices) return EMSA_E_ARG;
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32, kBwdSlices), dim3(256), 0, st, partial,
+                     rows, rows_alloc, c);
   const long total4 = pixels * (c / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads), 0, st, dy, y, x,
-                     gamma, save_mean, save_invstd, drop, dbeta, dgamma, (long)hw, c / 4, total4,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads),
+                     (size_t)2 * c * sizeof(float), st, dy, y, x, gamma, save_mean, save_invstd,
+                     drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / 4, total4,
                      1.0f / (float)pixels, act, train, dx, dres);
   return emsa_launch_status();
 }

@@ -1,0 +1,52 @@
+"""gpurun_out/pmc_traffic/raw.json (tools/pmc_traffic.sh) -> profiles/<name>.json: HBM bytes per
+launch of every conv kernel class.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
+128-B requests as 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section) -- checked against
+the 1 GiB calibration copies of the same pass.   usage: python tools/pmc_traffic_json.py raw.json out.json"""
+import json
+import sys
+
+
+def main():
+    raw = json.load(open(sys.argv[1]))
+    fetch, write = raw['FETCH_SIZE'], raw['WRITE_SIZE']
+    # calibration: the elementwise copies of exactly 1 GiB
+    calib = {}
+    for name, d in (('FETCH', fetch), ('WRITE', write)):
+        best = None
+        for k, v in d.items():
+            if 'copy' not in k.lower():
+                continue
+            avg = v['sum'] / v['launches']
+            if best is None or avg > best[1]:
+                best = (k, avg, v['launches'])
+        calib[name] = best
+    out = {'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- '
+                      'python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing '
+                      '(after 4 calibration copies of 1 GiB)',
+           'calibration': {
+               'copy_bytes': 1 << 30,
+               'copy_kernel': calib['FETCH'][0][:80],
+               'FETCH_SIZE_KiB_avg_over_copy_launches': round(calib['FETCH'][1], 1),
+               'WRITE_SIZE_KiB_avg_over_copy_launches': round(calib['WRITE'][1], 1),
+               'note': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled '
+                       '(MI355X_MICROARCH.md HBM section); WRITE_SIZE exact; the copy class also '
+                       'contains smaller copies of the bench, so its average is below 1 GiB'},
+           'kernels': {}}
+    for k in sorted(fetch):
+        if not (k.startswith('conv') or 'wino' in k):
+            continue
+        n = fetch[k]['launches']
+        rd = fetch[k]['sum'] / n * 1024 * 2
+        wr = write.get(k, {'sum': 0, 'launches': 1})
+        wr = wr['sum'] / max(wr['launches'], 1) * 1024
+        out['kernels'][k.replace(' ', '')] = {
+            'launches_profiled': n, 'hbm_read_bytes_per_launch': int(rd),
+            'hbm_write_bytes_per_launch': int(wr), 'hbm_bytes_per_launch': int(rd + wr)}
+    json.dump(out, open(sys.argv[2], 'w'), indent=1)
+    for k, v in out['kernels'].items():
+        print(f"{k:50s} {v['launches_profiled']:6d} launches  rd {v['hbm_read_bytes_per_launch'] / 1e6:8.1f} MB"
+              f"  wr {v['hbm_write_bytes_per_launch'] / 1e6:8.1f} MB")
+
+
+if __name__ == '__main__':
+    main()
