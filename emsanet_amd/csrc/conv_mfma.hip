@@ -716,6 +716,9 @@ struct Wgrad1dArgs {
   int in_sa, in_sb, in_simg;         // element strides of x for (a, b, img)
   int dy_sa, dy_sb, dy_simg;         // element strides of dy
   int steps_total, steps_per_split, n_co_tiles, n_ci_tiles, n_tiles;
+  float* ws;                         // NULL: atomics into dw; else split-K partial tiles (see
+                                     // wgrad1d_reduce_kernel), ws_bias behind them
+  float* ws_bias;
   uint32_t in_bytes, dout_bytes;
   FastDiv div_al, div_l;
 };
@@ -886,6 +889,18 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
     }
   }
 
+  if (p.ws != nullptr) {
+    // deterministic split-K: this workgroup's partial tile [3][BCO][BCI] goes to the workspace
+    // with plain (coalesced along ci) stores; wgrad1d_reduce_kernel sums the splits
+    float* wt = p.ws + ((size_t)ks * p.n_tiles + tile) * (3 * BCO * BCI);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        wt[(t * BCO + wco * 32 + row) * BCI + wci * 32 + l31] = acc[0][t][r];
+      }
+  } else {
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -903,18 +918,75 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
           unsafeAtomicAdd(p.dw + ((size_t)t * p.n_ch + co) * p.k_ch + ci, acc[q][t][r]);
       }
     }
+  }
   if (do_bias) {
     float* red = smem;   // [256/DTPR][BCO]
+    __syncthreads();     // (the K loop's LDS reads are done; red overlays dS)
     red[d_r * BCO + d_c4 + 0] = bsum.x;
     red[d_r * BCO + d_c4 + 1] = bsum.y;
     red[d_r * BCO + d_c4 + 2] = bsum.z;
     red[d_r * BCO + d_c4 + 3] = bsum.w;
     __syncthreads();
-    if (tid < BCO && co0 + tid < p.n_ch) {
+    if (tid < BCO) {
       float a = 0.f;
       for (int r = 0; r < 256 / DTPR; ++r) a += red[r * BCO + tid];
-      unsafeAtomicAdd(p.dbias + co0 + tid, a);
+      if (p.ws_bias != nullptr)
+        p.ws_bias[((size_t)ks * p.n_co_tiles + co_t) * BCO + tid] = a;
+      else if (co0 + tid < p.n_ch)
+        unsafeAtomicAdd(p.dbias + co0 + tid, a);
     }
+  }
+}
+
+// second pass of the deterministic split-K: dw[co][ci][t] (OIHW of a 3-tap 1-D conv) =
+// sum over splits of ws[split][tile][t][co_l][ci_l]; dbias[co] = sum of ws_bias[split][co].
+// workgroup = one (tile, t, co_l) row of 64 ci (16 float4 columns) x 16 split groups; the
+// workgroups behind the weight rows reduce the bias.  (A finer 8 x 32 split with 4 loads in
+// flight was slower on every layer shape: most split groups idle when there are few splits.)
+__global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
+    const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
+    int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, float* __restrict__ dw,
+    float* __restrict__ dbias) {
+  __shared__ float4 red[16][16];
+  const int tid = threadIdx.x;
+  const int weight_blocks = n_tiles * 192;
+  if ((int)blockIdx.x < weight_blocks) {
+    const int tile = blockIdx.x / 192, row = blockIdx.x % 192;      // row = t*64 + co_l
+    const int col = tid & 15, sg = tid >> 4;
+    const float* src = ws + (size_t)tile * 12288 + row * 64 + col * 4;
+    float4 a = emsa_zero4();
+    for (int sp = sg; sp < splits; sp += 16) {
+      const float4 v = emsa_ld4(src + (size_t)sp * n_tiles * 12288);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    red[sg][col] = a;
+    __syncthreads();
+    if (sg == 0) {
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = red[k][col];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      const int t = row >> 6, co = (tile / n_ci_tiles) * 64 + (row & 63);
+      const int ci = (tile % n_ci_tiles) * 64 + col * 4;
+      if (co < n_ch) {
+        float* o = dw + ((size_t)co * k_ch + ci) * 3 + t;
+        if (ci + 0 < k_ch) o[0] = a.x;
+        if (ci + 1 < k_ch) o[3] = a.y;
+        if (ci + 2 < k_ch) o[6] = a.z;
+        if (ci + 3 < k_ch) o[9] = a.w;
+      }
+    }
+  } else if (dbias != nullptr) {
+    __shared__ float redb[4][64];
+    const int co_t = blockIdx.x - weight_blocks;
+    const int cl = tid & 63, sg = tid >> 6;
+    float a = 0.f;
+    for (int sp = sg; sp < splits; sp += 4) a += ws_bias[((size_t)sp * n_co_tiles + co_t) * 64 + cl];
+    redb[sg][cl] = a;
+    __syncthreads();
+    if (sg == 0 && co_t * 64 + cl < n_ch)
+      dbias[co_t * 64 + cl] = redb[0][cl] + redb[1][cl] + redb[2][cl] + redb[3][cl];
   }
 }
 
@@ -1055,8 +1127,83 @@ extern "C" int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const flo
   }
 }
 
+namespace {
+// stride-1 3-tap 1-D convolution with "same" padding -> halo kernel conv_wgrad1d_kernel.
+// Fills the geometry part of `w` and the split-K plan; false if `g` is not such a convolution.
+struct Wgrad1dPlan {
+  Wgrad1dArgs w;
+  int ksplit;
+  bool wino;
+};
+bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
+  const bool along_w = g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0;
+  const bool along_h = g->kh == 3 && g->kw == 1 && g->off_h == -1 && g->off_w == 0;
+  if (!((along_w || along_h) && g->mul_h == 1 && g->mul_w == 1 && g->step_h == 1 &&
+        g->step_w == 1 && g->div_h == 1 && g->div_w == 1 && g->in_h == g->out_h &&
+        g->in_w == g->out_w && dout_aligned) ||
+      getenv("EMSA_WGRAD_GENERIC"))
+    return false;
+  Wgrad1dArgs& w = pl.w;
+  w.M = g->n_img * g->out_h * g->out_w; w.n_ch = g->n_ch; w.k_ch = g->k_ch;
+  const int H = g->out_h, W = g->out_w;
+  w.L = along_w ? W : H;
+  const int A = along_w ? H : W;
+  w.in_simg = (int)g->in_img_stride;
+  w.dy_simg = H * W * g->ld_out;
+  if (along_w) {
+    w.in_sa = (int)g->in_row_stride; w.in_sb = g->in_px_stride;
+    w.dy_sa = W * g->ld_out; w.dy_sb = g->ld_out;
+  } else {
+    w.in_sa = g->in_px_stride; w.in_sb = (int)g->in_row_stride;
+    w.dy_sa = g->ld_out; w.dy_sb = W * g->ld_out;
+  }
+  w.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
+  w.dout_bytes = (uint32_t)((size_t)w.M * g->ld_out * sizeof(float));
+  w.div_al = make_fastdiv((uint32_t)(A * w.L));
+  w.div_l = make_fastdiv((uint32_t)w.L);
+  w.n_co_tiles = (g->n_ch + 63) / 64;
+  w.n_ci_tiles = (g->k_ch + 63) / 64;
+  w.n_tiles = w.n_co_tiles * w.n_ci_tiles;
+  w.steps_total = (w.M + 31) / 32;
+  // even line length -> Winograd F(3,2) over pixel pairs (EMSA_WGRAD_WINO=0: direct form)
+  static const bool wino_on = [] {
+    const char* e = getenv("EMSA_WGRAD_WINO");
+    return !(e && e[0] == '0');
+  }();
+  pl.wino = wino_on && (w.L & 1) == 0;
+  // split-K: one round of resident workgroups for the Winograd variant (3 per CU), two rounds
+  // of 3 for the direct one (4 per CU) -- measured optima (EMSA_W1D_BLOCKS: tuning only)
+  static const int forced_blocks = [] {
+    const char* e = getenv("EMSA_W1D_BLOCKS");
+    return e ? atoi(e) : 0;
+  }();
+  const int target_blocks = forced_blocks > 0 ? forced_blocks : (pl.wino ? 768 : 1536);
+  int ksplit = target_blocks / w.n_tiles;
+  const int max_split = (w.steps_total + 7) / 8;
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  w.steps_per_split = (w.steps_total + ksplit - 1) / ksplit;
+  pl.ksplit = (w.steps_total + w.steps_per_split - 1) / w.steps_per_split;
+  return true;
+}
+bool dout_is_aligned(const EmsaConvGeom* g, const float* dout) {
+  return ((g->ld_out & 3) == 0) && ((g->n_ch & 3) == 0) && ((((uintptr_t)dout) & 15) == 0);
+}
+
+}  // namespace
+
+// bytes of workspace for the deterministic two-pass weight gradient of `g` (0: not available for
+// this geometry -> emsa_conv_wgrad accumulates with atomics into the packed layout)
+extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
+  if (!geom_ok(g)) return 0;
+  Wgrad1dPlan pl;
+  if (!plan_wgrad1d(g, dout_is_aligned(g, nullptr), pl)) return 0;
+  return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * 12288 + (int64_t)pl.w.n_co_tiles * 64) *
+         (int64_t)sizeof(float);
+}
+
 extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout,
-                               float* dw, float* dbias, void* stream) {
+                               float* dw, float* dbias, float* ws, void* stream) {
   if (!geom_ok(g)) return EMSA_E_SHAPE;
   if (!in || !dout || !dw) return EMSA_E_ARG;
   if (g->div_h != 1 || g->div_w != 1) return EMSA_E_SHAPE;
@@ -1064,70 +1211,34 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   a.g = *g;
   a.in = in; a.dout = dout; a.dw = dw; a.dbias = dbias;
   a.M = g->n_img * g->out_h * g->out_w;
-  a.dout_aligned = ((g->ld_out & 3) == 0) && ((g->n_ch & 3) == 0) &&
-                   ((((uintptr_t)dout) & 15) == 0);
+  a.dout_aligned = dout_is_aligned(g, dout);
   a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
   a.dout_bytes = (uint32_t)((size_t)a.M * g->ld_out * sizeof(float));
   a.div_ohw = make_fastdiv((uint32_t)(g->out_h * g->out_w));
   a.div_ow = make_fastdiv((uint32_t)g->out_w);
   hipStream_t st = (hipStream_t)stream;
   const int taps = g->kh * g->kw;
-  // stride-1 3-tap 1-D convolution with "same" padding -> halo kernel
-  const bool along_w = g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0;
-  const bool along_h = g->kh == 3 && g->kw == 1 && g->off_h == -1 && g->off_w == 0;
-  if ((along_w || along_h) && g->mul_h == 1 && g->mul_w == 1 && g->step_h == 1 &&
-      g->step_w == 1 && g->in_h == g->out_h && g->in_w == g->out_w && a.dout_aligned &&
-      !getenv("EMSA_WGRAD_GENERIC")) {
-    Wgrad1dArgs w;
+  Wgrad1dPlan pl;
+  const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl);
+  if (ws != nullptr && !one_d) return EMSA_E_SHAPE;      // emsa_conv_wgrad_ws_bytes(g) was 0
+  if (one_d) {
+    Wgrad1dArgs& w = pl.w;
     w.in = in; w.dout = dout; w.dw = dw; w.dbias = dbias;
-    w.M = a.M; w.n_ch = g->n_ch; w.k_ch = g->k_ch;
-    const int H = g->out_h, W = g->out_w;
-    w.L = along_w ? W : H;
-    const int A = along_w ? H : W;
-    w.in_simg = (int)g->in_img_stride;
-    w.dy_simg = H * W * g->ld_out;
-    if (along_w) {
-      w.in_sa = (int)g->in_row_stride; w.in_sb = g->in_px_stride;
-      w.dy_sa = W * g->ld_out; w.dy_sb = g->ld_out;
-    } else {
-      w.in_sa = g->in_px_stride; w.in_sb = (int)g->in_row_stride;
-      w.dy_sa = g->ld_out; w.dy_sb = W * g->ld_out;
-    }
-    w.in_bytes = a.in_bytes; w.dout_bytes = a.dout_bytes;
-    w.div_al = make_fastdiv((uint32_t)(A * w.L));
-    w.div_l = make_fastdiv((uint32_t)w.L);
+    w.ws = ws;
+    w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * 12288 : nullptr;
     constexpr int BCO = 64, BCI = 64;
-    w.n_co_tiles = (g->n_ch + BCO - 1) / BCO;
-    w.n_ci_tiles = (g->k_ch + BCI - 1) / BCI;
-    w.n_tiles = w.n_co_tiles * w.n_ci_tiles;
-    w.steps_total = (w.M + 31) / 32;
-    // even line length -> Winograd F(3,2) over pixel pairs (EMSA_WGRAD_WINO=0: direct form)
-    static const bool wino_on = [] {
-      const char* e = getenv("EMSA_WGRAD_WINO");
-      return !(e && e[0] == '0');
-    }();
-    const bool wino = wino_on && (w.L & 1) == 0;
-    // split-K: one round of resident workgroups for the Winograd variant (3 per CU), two rounds
-    // of 3 for the direct one (4 per CU) -- measured optima (EMSA_W1D_BLOCKS: tuning only)
-    static const int forced_blocks = [] {
-      const char* e = getenv("EMSA_W1D_BLOCKS");
-      return e ? atoi(e) : 0;
-    }();
-    const int target_blocks = forced_blocks > 0 ? forced_blocks : (wino ? 768 : 1536);
-    int ksplit = target_blocks / w.n_tiles;
-    const int max_split = (w.steps_total + 7) / 8;
-    if (ksplit > max_split) ksplit = max_split;
-    if (ksplit < 1) ksplit = 1;
-    w.steps_per_split = (w.steps_total + ksplit - 1) / ksplit;
-    ksplit = (w.steps_total + w.steps_per_split - 1) / w.steps_per_split;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     const int ps = prof_begin(7, algo_flops(a.g), st);
-    if (wino)
-      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, true>), dim3(w.n_tiles * ksplit),
+    if (pl.wino)
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, true>), dim3(w.n_tiles * pl.ksplit),
                          dim3(256), lds, st, w);
     else
-      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, false>), dim3(w.n_tiles * ksplit),
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, false>), dim3(w.n_tiles * pl.ksplit),
                          dim3(256), lds, st, w);
+    if (ws != nullptr)
+      hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * 192 + w.n_co_tiles), dim3(256),
+                         0, st, ws, w.ws_bias, pl.ksplit, w.n_tiles, w.n_ci_tiles, w.n_co_tiles,
+                         w.n_ch, w.k_ch, dw, dbias);
     prof_end(ps, st);
     return emsa_launch_status();
   }

@@ -296,20 +296,30 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   }
 }
 
-// U[4][n][k] from OIHW taps; dgrad: n = cin, k = cout, taps flipped
-__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout,
-                                 int cin, int dgrad) {
+// U[4][n][k] from OIHW taps: forward (n = cout, k = cin) and/or data gradient (n = cin, k = cout,
+// taps flipped)
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u,
+                                 float* __restrict__ ud, int cout, int cin) {
   const int total = cout * cin;
+  const size_t NK = (size_t)total;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int ci = i % cin, co = i / cin;
     const float* g = w + (size_t)i * 3;          // [co][ci][3] (3x1 or 1x3: taps contiguous)
-    const float g0 = dgrad ? g[2] : g[0], g1 = g[1], g2 = dgrad ? g[0] : g[2];
-    const size_t N = dgrad ? cin : cout, K = dgrad ? cout : cin;
-    const size_t o = dgrad ? (size_t)ci * K + co : (size_t)co * K + ci;
-    u[0 * N * K + o] = g0;
-    u[1 * N * K + o] = 0.5f * (g0 + g1 + g2);
-    u[2 * N * K + o] = 0.5f * (g0 - g1 + g2);
-    u[3 * N * K + o] = g2;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const float s = 0.5f * (g0 + g2), h = 0.5f * g1;
+    if (u) {
+      u[0 * NK + i] = g0;
+      u[1 * NK + i] = s + h;
+      u[2 * NK + i] = s - h;
+      u[3 * NK + i] = g2;
+    }
+    if (ud) {
+      const size_t o = (size_t)ci * cout + co;
+      ud[0 * NK + o] = g2;
+      ud[1 * NK + o] = s + h;
+      ud[2 * NK + o] = s - h;
+      ud[3 * NK + o] = g0;
+    }
   }
 }
 
@@ -322,14 +332,14 @@ inline void magic(uint32_t d, uint32_t& mul, uint32_t& sh) {
 
 }  // namespace
 
-extern "C" int emsa_pack_wino(const float* w_oihw, float* u, int32_t cout, int32_t cin,
-                              int32_t dgrad, void* stream) {
-  if (!w_oihw || !u) return EMSA_E_ARG;
+extern "C" int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout,
+                              int32_t cin, void* stream) {
+  if (!w_oihw || (!u && !u_dgrad)) return EMSA_E_ARG;
   const int total = cout * cin;
   int grid = (total + 255) / 256;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u,
-                     cout, cin, dgrad);
+                     u_dgrad, cout, cin);
   return emsa_launch_status();
 }
 

@@ -176,14 +176,16 @@ def wino_eligible(spec):
     return one_d and spec.sh == 1 and spec.sw == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
 
 
-def pack_wino(w, dgrad):
-    """OIHW [cout][cin][3x1|1x3] -> Winograd F(2,3) weights U [4][n][k] (n,k = cout,cin or, for the
-    data gradient, cin,cout with flipped taps)"""
+def pack_wino(w, fwd=True, dgrad=False):
+    """OIHW [cout][cin][3x1|1x3] -> Winograd F(2,3) weights U [4][n][k]: forward (n,k = cout,cin)
+    and/or data gradient (n,k = cin,cout, flipped taps), one launch.  -> (u or None, ud or None)"""
     cout, cin = w.shape[:2]
-    u = _empty((4 * cout * cin,), w.device)
-    check(_lib.lib().emsa_pack_wino(_p(w.contiguous()), _p(u), cout, cin, 1 if dgrad else 0,
-                                    _stream()), 'emsa_pack_wino')
-    return u
+    buf = _empty((int(fwd) + int(dgrad), 4 * cout * cin), w.device)
+    u = buf[0] if fwd else None
+    ud = buf[-1] if dgrad else None
+    check(_lib.lib().emsa_pack_wino(_p(w.contiguous()), _p(u), _p(ud), cout, cin, _stream()),
+          'emsa_pack_wino')
+    return u, ud
 
 
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
@@ -227,18 +229,40 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
     return out
 
 
-def conv_wgrad(x, dy, spec, want_bias):
-    """returns (dw packed [tap][cout][cin], dbias or None)"""
+def deterministic_wgrad():
+    """EMSA_DETERMINISTIC=1: every 1-D conv weight gradient through the atomics-free two-pass
+    kernel (bit-reproducible); default: only where it is at least as fast as the fp32-atomics
+    form (>= 256 channels: 124/122 us vs 127/129 us per launch, but 181 vs 155 us at 64)"""
+    return os.environ.get('EMSA_DETERMINISTIC', '0') == '1'
+
+
+def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None):
+    """weight (+bias) gradient.  returns (dw, dbias or None, packed):
+    packed=False: dw is already in the parameter layout [cout][cin][kh][kw] (deterministic
+    two-pass kernel of the 1-D convs, needs `like` = the weight for the shape);
+    packed=True: dw is the flat packed [tap][cout][cin] accumulator (-> unpack_wgrad)."""
+    if two_pass is None:
+        two_pass = deterministic_wgrad() or min(spec.cin, spec.cout) >= 256
     n, c, h, w = x.shape
     g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(dy))
+    L = _lib.lib()
     taps = spec.kh * spec.kw
     nw = taps * spec.cout * spec.cin
-    buf = torch.zeros(nw + (spec.cout if want_bias else 0), device=x.device, dtype=torch.float32)
-    dwp = buf[:nw]
+    nb = spec.cout if want_bias else 0
+    ws_bytes = L.emsa_conv_wgrad_ws_bytes(g) if (like is not None and two_pass) else 0
+    if ws_bytes > 0:
+        buf = _empty((nw + nb,), x.device)
+        ws = _empty((ws_bytes // 4,), x.device)
+    else:
+        buf = torch.zeros(nw + nb, device=x.device, dtype=torch.float32)
+        ws = None
+    dw = buf[:nw]
     db = buf[nw:] if want_bias else None
-    check(_lib.lib().emsa_conv_wgrad(g, _p(x), _p(dy), _p(dwp), _p(db), _stream()),
+    check(L.emsa_conv_wgrad(g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _stream()),
           'emsa_conv_wgrad')
-    return dwp, db
+    if ws is not None:
+        return dw.view(like.shape), db, False
+    return dw, db, True
 
 
 # ---------------------------------------------------------------------------------------------
@@ -311,7 +335,7 @@ def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift):
 def stem_wgrad(xp, dy, spec, n, h, w, like):
     g = spec.geom(n, h, w, ld_of(dy))
     dwp = torch.zeros(7 * spec.cout * 32, device=dy.device, dtype=torch.float32)
-    check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), None, _stream()),
+    check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), None, None, _stream()),
           'emsa_conv_wgrad(stem)')
     dw = _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),

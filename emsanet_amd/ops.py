@@ -64,9 +64,7 @@ class ConvRT:
         w = self.conv.weight
         key = (w._version, w.data_ptr())
         if key != self._keyu:
-            wd = w.detach()
-            self._u = Fn.pack_wino(wd, dgrad=False)
-            self._ud = Fn.pack_wino(wd, dgrad=True) if w.requires_grad else None
+            self._u, self._ud = Fn.pack_wino(w.detach(), fwd=True, dgrad=w.requires_grad)
             self._keyu = key
         return self._u, self._ud
 
@@ -80,7 +78,7 @@ class ConvRT:
         if self.wino:
             u, ud = self._wino_weights()
             if ud is None:
-                ud = Fn.pack_wino(self.conv.weight.detach(), dgrad=True)
+                ud = Fn.pack_wino(self.conv.weight.detach(), fwd=False, dgrad=True)[1]
             return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, **kw)
         return Fn.conv_dgrad(dy, self.packed_dgrad(), self.spec, in_hw, **kw)
 
@@ -157,8 +155,9 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
 def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
     """-> dx (or None), dw (OIHW), dbias (or None)"""
     conv = crt.conv
-    dwp, db = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None)
-    dw = Fn.unpack_wgrad(dwp, conv.weight)
+    dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight)
+    if packed:
+        dw = Fn.unpack_wgrad(dw, conv.weight)
     dx = None
     if need_dx:
         dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual)
@@ -370,7 +369,7 @@ class MultiConvFunction(Function):
         (x,) = ctx.saved_tensors
         dy = Fn.as_act(dy)
         s = rt.spec
-        dwp, db = Fn.conv_wgrad(x, dy, s, rt.has_bias)
+        dwp, db, _ = Fn.conv_wgrad(x, dy, s, rt.has_bias)
         grads = []
         for m, co, ci in rt.placements:
             w4 = rt._w4(m)

@@ -87,17 +87,25 @@ int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const float* w, floa
 /* number of M tiles (rows of the stats partial buffer) emsa_conv_igemm will use for `g` */
 int emsa_conv_stats_rows(const EmsaConvGeom* g);
 
-/* dw[tap][n][c] += sum_m dout[m][n] * in[gather(m,tap)][c]     (dw must be zeroed by the caller)
- *   dout     gradient of the produced tensor, pixel stride g->ld_out
- *   dbias    NULL or [n_ch], += sum_m dout[m][n]               (must be zeroed by the caller) */
+/* weight gradient  dw[tap][n][c] = sum_m dout[m][n] * in[gather(m,tap)][c],  dbias[n] = sum_m dout
+ *   dout   gradient of the produced tensor, pixel stride g->ld_out
+ *   dbias  NULL or [n_ch]
+ *   ws     NULL: split-K partial sums are accumulated with fp32 atomics into dw in the packed
+ *          layout [tap][n][c] (emsa_unpack_wgrad converts) and into dbias; BOTH MUST BE ZEROED by
+ *          the caller.
+ *          non-NULL (only when emsa_conv_wgrad_ws_bytes(g) > 0: the stride-1 3-tap 1-D convs;
+ *          at least that many bytes): deterministic two-pass form -- the partial tiles are stored
+ *          to ws and a reduce kernel writes dw directly in the reference's OIHW parameter layout
+ *          [n][c][tap] and dbias; no zeroing, no unpack pass, bit-reproducible.                */
+int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g);
 int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout, float* dw,
-                    float* dbias, void* stream);
+                    float* dbias, float* ws, void* stream);
 
 /* 1-D Winograd F(2,3) variant of emsa_conv_igemm for the stride-1 3-tap "same" 3x1 / 1x3
  * convolutions of the NBt1D blocks (forward and data gradient): 4 MFMA GEMMs over half the pixels
  * instead of 3 over all (1.5x fewer matrix instructions, fp32-exact coefficients 1 and 1/2).
  * Same arguments and fused epilogue as emsa_conv_igemm, but `u` = transformed weights
- * [4][n_ch][k_ch] from emsa_pack_wino (dgrad=1: data-gradient weights, taps flipped, channels
+ * [4][n_ch][k_ch] from emsa_pack_wino (u_dgrad: data-gradient weights, taps flipped, channels
  * transposed); stats partial rows = emsa_conv1d_wino_stats_rows(g).                          */
 int emsa_conv1d_wino_supported(const EmsaConvGeom* g);
 int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g);
@@ -105,7 +113,9 @@ int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, flo
                      const float* bias, float* stats, const float* scale, const float* shift,
                      const float* residual, int32_t ld_res, const float* mask_src,
                      int32_t ld_mask, int32_t act, void* stream);
-int emsa_pack_wino(const float* w_oihw, float* u, int32_t cout, int32_t cin, int32_t dgrad,
+/* u (forward weights [4][cout][cin]) and/or u_dgrad (data-gradient weights [4][cin][cout]) from
+ * the OIHW taps in one launch; either output may be NULL                                       */
+int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout, int32_t cin,
                    void* stream);
 
 /* weight layout transforms between the reference's OIHW parameters and the packed layouts.

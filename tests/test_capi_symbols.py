@@ -11,7 +11,7 @@ def _declared():
     src = open(os.path.join(ROOT, 'include', 'emsanet_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     decls = {}
-    for m in re.finditer(r'\b(?:int|const char\*)\s+(emsa_\w+)\s*\(([^;]*?)\)\s*;', src, re.S):
+    for m in re.finditer(r'\b(?:int|int64_t|const char\*)\s+(emsa_\w+)\s*\(([^;]*?)\)\s*;', src, re.S):
         args = m.group(2).strip()
         n = 0 if args in ('', 'void') else len([a for a in args.split(',') if a.strip()])
         decls[m.group(1)] = n

@@ -116,7 +116,7 @@ def test_conv1d_winograd_fwd(cfg):
     ref = F.conv2d(x.double(), wt.double(), b.double(), padding=p)
     spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
     assert Fn.wino_eligible(spec)
-    u = Fn.pack_wino(wt.to(DEV), dgrad=False)
+    u = Fn.pack_wino(wt.to(DEV))[0]
     y, stats = Fn.conv_fwd(to_act(x), None, spec, bias=b.to(DEV), want_stats=True, wino_u=u)
     torch.cuda.synchronize()
     close(y, ref, what='wino conv')
@@ -150,7 +150,7 @@ def test_conv1d_winograd_dgrad(cfg):
     dy = rnd(*y.shape, seed=7)
     y.backward(dy.double())
     spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
-    ud = Fn.pack_wino(wt.to(DEV), dgrad=True)
+    ud = Fn.pack_wino(wt.to(DEV), fwd=False, dgrad=True)[1]
     dx = Fn.conv_dgrad(to_act(dy), None, spec, (h, w), wino_u=ud)
     torch.cuda.synchronize()
     close(dx, x.grad, what='wino dgrad')
@@ -171,7 +171,7 @@ def test_conv1d_winograd_channel_slice_views():
     wt = rnd(64, 64, 1, 3, seed=2, scale=0.1)
     spec = Fn.ConvSpec(64, 64, (1, 3), (1, 1), (0, 1))
     wide_out = Fn.act_empty(n, 128, h, w, DEV).zero_()
-    Fn.conv_fwd(x, None, spec, out=wide_out[:, 64:], wino_u=Fn.pack_wino(wt.to(DEV), False))
+    Fn.conv_fwd(x, None, spec, out=wide_out[:, 64:], wino_u=Fn.pack_wino(wt.to(DEV))[0])
     ref = F.conv2d(x.cpu().double(), wt.double(), padding=(0, 1))
     close(wide_out[:, 64:], ref, what='wino slice')
     assert float(wide_out[:, :64].abs().max()) == 0.0
@@ -188,11 +188,23 @@ def test_conv_wgrad(cfg):
     dy = rnd(*y.shape, seed=7)
     y.backward(dy.double())
     spec = Fn.ConvSpec(cin, cout, k, s, p)
-    dwp, db = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True)
+    dwp, db, packed = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True)
+    assert packed
     dw = Fn.unpack_wgrad(dwp, wt.detach().float().to(DEV))
     torch.cuda.synchronize()
     close(dw, wt.grad, what='wgrad')
     close(db, b.grad, what='bgrad')
+    # deterministic two-pass form (1-D stride-1 convs): OIHW directly, bit-reproducible
+    like = wt.detach().float().to(DEV)
+    dw2, db2, packed2 = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True)
+    if not packed2:
+        assert k in ((3, 1), (1, 3)) and s == (1, 1)
+        close(dw2, wt.grad, what='wgrad two-pass')
+        close(db2, b.grad, what='bgrad two-pass')
+        dw3, db3, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True)
+        assert torch.equal(dw2, dw3) and torch.equal(db2, db3)
+    else:
+        assert not (k in ((3, 1), (1, 3)) and s == (1, 1))
 
 
 def test_conv_wgrad_split_k_large():
@@ -206,9 +218,15 @@ def test_conv_wgrad_split_k_large():
     dy = rnd(*y.shape, seed=7, scale=0.1)
     y.backward(dy.double())
     spec = Fn.ConvSpec(cin, cout, (1, 3), 1, (0, 1))
-    dwp, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, False)
+    dwp, _, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, False)
     dw = Fn.unpack_wgrad(dwp, wt.detach().float().to(DEV))
     close(dw, wt.grad, tol=2e-4, what='wgrad split-k')
+    like = wt.detach().float().to(DEV)
+    dw2, _, packed = Fn.conv_wgrad(to_act(x), to_act(dy), spec, False, like=like, two_pass=True)
+    assert not packed
+    close(dw2, wt.grad, tol=2e-4, what='wgrad split-k two-pass')
+    dw3, _, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, False, like=like, two_pass=True)
+    assert torch.equal(dw2, dw3), 'two-pass weight gradient is not bit-reproducible'
 
 
 @pytest.mark.parametrize('cin', [3, 1])

@@ -75,7 +75,7 @@ def main():
                                                     mask_src=X[i % nb], out=DX[i % nb]))
                 row += f" dgrad[t{t}] {us:7.1f}us {flops / us / 1e6:6.1f}TF |"
         if what in ('wino', 'all') and Fn.wino_eligible(spec):
-            u, ud = Fn.pack_wino(wt, False), Fn.pack_wino(wt, True)
+            u, ud = Fn.pack_wino(wt, fwd=True, dgrad=True)
             us = timeit(lambda i: Fn.conv_fwd(X[i % nb], None, spec, bias=bias, act=1,
                                               out=Y[i % nb], wino_u=u))
             row += f" WINO fwd {us:7.1f}us {flops / us / 1e6:6.1f}TF(eff) |"
@@ -88,6 +88,9 @@ def main():
         if what in ('wgrad', 'all'):
             us = timeit(lambda i: Fn.conv_wgrad(X[i % nb], DY[i % nb], spec, True))
             row += f" wgrad {us:7.1f}us {flops / us / 1e6:6.1f}TF |"
+            us = timeit(lambda i: Fn.conv_wgrad(X[i % nb], DY[i % nb], spec, True, like=wt,
+                                                two_pass=True))
+            row += f" two-pass {us:7.1f}us |"
         print(row, flush=True)
 
 
