@@ -54,6 +54,10 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
     ap.add_argument('--force-dist', action='store_true',
                     help='validation: RCCL process group + bucketed all-reduce path with ONE rank')
+    ap.add_argument('--losses', action='store_true',
+                    help='complete training step: all task losses on device (semantic / scene CE, '
+                         'instance MSE / L1 / von Mises, multi-scale, reference weights) and '
+                         'loss.backward() instead of fixed output cotangents')
     ap.add_argument('--graph', action='store_true',
                     help='with --eval: replay the whole-model hipGraph (BASELINE config 5 shape)')
     return ap.parse_args()
@@ -79,6 +83,29 @@ def deterministic_init_(model, seed=0):
         for name, p in model.named_parameters():
             if name.endswith('bn2.weight'):
                 p.copy_(torch.empty(p.shape).uniform_(0.2, 0.4, generator=g))
+
+
+def training_losses_and_targets(a, bs, h, w, dev):
+    """--losses: TrainingLosses with the reference's published task weighting (README.md:621-622)
+    and synthetic targets of every supervised scale (full resolution, /32, /16, /8)"""
+    from emsanet_amd.loss import TrainingLosses
+    a.tasks_weighting = (1.0, 0.25, 3.0, 0.5)
+    g = torch.Generator(device='cpu').manual_seed(99)
+    class_weights = torch.rand(40, generator=g) * 2 + 0.3
+    crit = TrainingLosses(a, class_weights, 10).to(dev)
+    sizes = [(h, w)] + [(h // s, w // s) for s in (32, 16, 8)]
+    sem, inst = [], []
+    for hh, ww in sizes:
+        sem.append(torch.randint(0, 41, (bs, hh, ww), generator=g).to(dev))
+        fg = torch.rand(bs, hh, ww, generator=g) > 0.5
+        inst.append({'center': (torch.rand(bs, 1, hh, ww, generator=g) ** 4).to(dev),
+                     'offset': (torch.rand(bs, 2, hh, ww, generator=g) * 2 - 1).to(dev),
+                     'foreground': fg.to(dev),
+                     'orientation': ((torch.rand(bs, hh, ww, generator=g) * 2 - 1) * 3.1415).to(dev),
+                     'orientation_foreground': (fg & (torch.rand(bs, hh, ww, generator=g) > 0.5)).to(dev)})
+    targets = {'semantic': sem, 'instance': inst,
+               'scene': torch.randint(0, 11, (bs,), generator=g).to(dev)}
+    return crit, targets
 
 
 def flatten_outputs(outs):
@@ -178,6 +205,9 @@ def run(args):
     # net stays finite over the benchmark steps
     opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
     cots = None
+    crit, targets = None, None
+    if args.losses and not args.eval:
+        crit, targets = training_losses_and_targets(a, bs, args.height, args.width, dev)
 
     graphed = None
     if args.eval and args.graph:
@@ -194,6 +224,14 @@ def run(args):
                 model(batch)
             return
         buckets.reset()
+        if crit is not None:
+            # --losses: the complete training step (all task losses on device, weighted like the
+            # reference's training command) instead of fixed output cotangents
+            total, _ = crit(model(batch), targets)
+            total.backward()
+            buckets.finish()
+            opt.step()
+            return
         flat = flatten_outputs(model(batch))
         if cots is None:
             g = torch.Generator(device='cpu').manual_seed(4321)
@@ -302,7 +340,8 @@ def run(args):
                                'cotangents) + grad all-reduce + SGD-nesterov update',
                    'global_batch': bs * world, 'parallelism': f'dp{world}',
                    'weights': 'random init (deterministic)',
-                   'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval else 'train'},
+                   'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval
+                   else ('train+losses' if args.losses else 'train')},
         'roofline': roofline,
         'conv_kernels': kernels,
         'conv_mfma_time_share': round(conv_ms / (dt * 1e3), 4) if kernels else None,

@@ -83,8 +83,16 @@ SIGNATURES = {
     'emsa_copy_channels': (c_int, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_axpy': (c_int, [_P, _P, c_int64, c_float, _P]),
     'emsa_ce_semantic_blocks': (c_int, [c_int64]),
-    'emsa_ce_semantic_fwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, _P, _P, _P]),
-    'emsa_ce_semantic_bwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, _P, _P, _P, c_int32, _P]),
+    'emsa_ce_semantic_fwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P,
+                                     _P]),
+    'emsa_ce_semantic_bwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P,
+                                     _P, c_int32, _P]),
+    'emsa_instance_loss_blocks': (c_int, [c_int64]),
+    'emsa_instance_loss_fwd': (c_int, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P,
+                                       c_int64, c_float, _P, _P, _P]),
+    'emsa_instance_loss_bwd': (c_int, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P,
+                                       c_int64, c_float, _P, _P, _P, c_int32, _P, c_int32, _P,
+                                       c_int32, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
     'emsa_prof_reset': (c_int, []),
     'emsa_prof_seen': (c_int, [c_int32]),

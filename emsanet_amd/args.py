@@ -62,6 +62,15 @@ _DEFAULTS = {
     'instance_center_encoding': ('sigmoid', 506),
     'instance_offset_distance_threshold': (None, 528),
     'dropout_p': (0.1, 619),
+    # training losses; tasks_weighting None -> (1,)*len(tasks), args.py:1346-1348
+    'tasks_weighting': (None, 696),
+    'semantic_loss_label_smoothing': (0.0, 724),
+    'semantic_no_multiscale_supervision': (False, 731),
+    'instance_weighting': ((2, 1), 740),
+    'instance_center_loss': ('mse', 750),
+    'instance_no_multiscale_supervision': (False, 757),
+    'orientation_kappa': (1.0, 766),
+    'scene_loss_label_smoothing': (0.1, 791),
     'he_init': (('encoder-fusion',), 626),
     'no_zero_init_decoder_residuals': (False, 640),
     'debug': (False, 1116),
@@ -80,6 +89,12 @@ def default_args(**overrides) -> Namespace:
     # post-parse fix-up the reference applies (args.py:1317-1321)
     if len(ns.input_modalities) == 1:
         ns.encoder_fusion = 'none'
+    # default task weighting (args.py:1346-1353)
+    if ns.tasks_weighting is None:
+        ns.tasks_weighting = (1,) * len(ns.tasks)
+    if len(ns.tasks_weighting) != len(ns.tasks):
+        raise ValueError("Length for given task weighting does not match number of tasks: "
+                         f"{len(ns.tasks_weighting)} vs. {len(ns.tasks)}.")
     return ns
 
 

@@ -261,23 +261,57 @@ int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y, int
 int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Class-weighted semantic cross-entropy (`task_helper.training_step`,
- * main.py:131-141; numerics pinned by emsanet/tests/test_semantic_loss.py:15-48):
- *   loss = sum_p w[t_p-1] * -log softmax(x_p)[t_p-1] / sum_p w[t_p-1],   target 0 = void.
+ * Class-weighted cross-entropy with optional label smoothing (SURVEY.md 8f-1;
+ * `task_helper.training_step`, main.py:131-141): the semantic head and its side outputs
+ * (numerics pinned by emsanet/tests/test_semantic_loss.py:15-48) and -- with 1x1 "images" --
+ * the scene head (label smoothing 0.1, args.py:790-796).  target 0 = void (ignored):
+ *   l_p  = (1-eps) * w[t] * -log p_p[t]  +  eps/C * sum_c w[c] * -log p_p[c]      (t = t_p - 1)
+ *   loss = sum_p l_p / sum_p w[t_p-1]         (torch.nn.CrossEntropyLoss semantics for eps, w)
  * logits NHWC with pixel stride ld (>= n_classes rounded up to 4), target int64 [pixels].
+ *   weights_sum  sum_c w[c] (only read when label_smoothing != 0)
  *   partial  float[2 * emsa_ce_semantic_blocks(pixels)] scratch
  *   out      float[2]: out[0] = loss, out[1] = divisor (kept for backward)
- *   backward: dlogits = grad_out[0] * w[t] / divisor * (softmax - onehot), 0 for void pixels and
- *             for padding channels; grad_out is a DEVICE scalar (no host sync)
+ *   backward: dlogits = grad_out[0]/divisor * d l_p / d x, 0 for void pixels and for padding
+ *             channels; grad_out is a DEVICE scalar (no host sync)
  * ------------------------------------------------------------------------------------------ */
 int emsa_ce_semantic_blocks(int64_t pixels);
 int emsa_ce_semantic_fwd(const float* logits, int32_t ld, const int64_t* target,
-                         const float* weights, int32_t n_classes, int64_t pixels, float* partial,
-                         float* out, void* stream);
+                         const float* weights, int32_t n_classes, int64_t pixels,
+                         float label_smoothing, float weights_sum, float* partial, float* out,
+                         void* stream);
 int emsa_ce_semantic_bwd(const float* logits, int32_t ld, const int64_t* target,
                          const float* weights, int32_t n_classes, int64_t pixels,
-                         const float* sums, const float* grad_out, float* dlogits, int32_t ld_d,
-                         void* stream);
+                         float label_smoothing, float weights_sum, const float* sums,
+                         const float* grad_out, float* dlogits, int32_t ld_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Instance-decoder losses in one fused pass (defaults args.py:739-770): MSE on
+ * the centre heatmap, L1 on the offsets inside the instance foreground, von-Mises loss
+ * 1 - exp(kappa (cos(dtheta) - 1)) on the (sin, cos) orientation pair inside the foreground with
+ * an orientation label.  The loss classes are in the un-vendored nicr_mt_scene_analysis library:
+ * restated from the published definitions (oracle/instance_loss_oracle.py, parity unpinned).
+ *   center/offset/orient  predictions, pixel strides ld_* (orient may be NULL)
+ *   center_gt [pixels], offset_gt [pixels][2], orient_gt [pixels] (angle, rad)
+ *   center_mask (NULL = all pixels), fg, fg_orient: uint8 [pixels]
+ *   partial  float[6 * emsa_instance_loss_blocks(pixels)] scratch
+ *   out      float[6]: losses (centre, offset, orientation), then their divisors
+ *   backward: grad_out = DEVICE float[3]; d_* written with pixel strides ldd_*
+ * ------------------------------------------------------------------------------------------ */
+int emsa_instance_loss_blocks(int64_t pixels);
+int emsa_instance_loss_fwd(const float* center, int32_t ld_c, const float* offset, int32_t ld_o,
+                           const float* orient, int32_t ld_r, const float* center_gt,
+                           const float* offset_gt, const float* orient_gt,
+                           const uint8_t* center_mask, const uint8_t* fg,
+                           const uint8_t* fg_orient, int64_t pixels, float kappa, float* partial,
+                           float* out, void* stream);
+int emsa_instance_loss_bwd(const float* center, int32_t ld_c, const float* offset, int32_t ld_o,
+                           const float* orient, int32_t ld_r, const float* center_gt,
+                           const float* offset_gt, const float* orient_gt,
+                           const uint8_t* center_mask, const uint8_t* fg,
+                           const uint8_t* fg_orient, int64_t pixels, float kappa,
+                           const float* sums, const float* grad_out, float* d_center,
+                           int32_t ldd_c, float* d_offset, int32_t ldd_o, float* d_orient,
+                           int32_t ldd_r, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every n-th

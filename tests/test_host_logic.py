@@ -21,7 +21,8 @@ class _FakeLib:
             self.calls[name] += 1
             if name in ('emsa_conv_stats_rows', 'emsa_conv1d_wino_stats_rows', 'emsa_bn_bwd_rows'):
                 return 3
-            if name in ('emsa_channel_ws_floats', 'emsa_bn_finalize_ws_bytes'):
+            if name in ('emsa_channel_ws_floats', 'emsa_bn_finalize_ws_bytes',
+                        'emsa_ce_semantic_blocks', 'emsa_instance_loss_blocks'):
                 return 64
             return 0
         return fn
@@ -198,3 +199,34 @@ def test_dry_run_fast_eval_uses_folded_kernels(fake_lib, monkeypatch):
     assert c['emsa_bn_finalize'] == 0 and c['emsa_bn_fold'] > 0
     # NBt1D blocks: exactly 4 conv launches each, BatchNorm folded, no separate bn_act pass
     assert c['emsa_bn_act_fwd'] == 0
+
+
+def test_dry_run_training_losses(fake_lib, monkeypatch):
+    """TrainingLosses on the engine's raw training outputs: every supervised scale reaches its
+    loss kernel, the weighted total back-propagates into every parameter (stubbed C-ABI)"""
+    import emsanet_amd.model as M
+    from emsanet_amd import full_args
+    from emsanet_amd.loss import TrainingLosses
+    from oracle.emsanet_oracle import synthetic_batch
+    args = full_args(input_height=64, input_width=96, tasks_weighting=(1.0, 0.25, 3.0, 0.5))
+    model = _model(args).train()
+    monkeypatch.setattr(M.EMSANet, 'forward', _bypass_device_check(model))
+    outs = model(synthetic_batch(2, 64, 96))
+    sizes = [(64, 96), (2, 3), (4, 6), (8, 12)]
+    targets = {'semantic': [torch.ones(2, h, w, dtype=torch.long) for h, w in sizes],
+               'instance': [dict(center=torch.zeros(2, 1, h, w), offset=torch.zeros(2, 2, h, w),
+                                 foreground=torch.ones(2, h, w, dtype=torch.bool),
+                                 orientation=torch.zeros(2, h, w),
+                                 orientation_foreground=torch.ones(2, h, w, dtype=torch.bool))
+                            for h, w in sizes],
+               'scene': torch.ones(2, dtype=torch.long)}
+    crit = TrainingLosses(args, torch.ones(40), 10)
+    total, losses = crit(outs, targets)
+    assert set(losses) == {'semantic', 'scene', 'instance_center', 'instance_offset',
+                           'instance_orientation'}
+    c = fake_lib.calls
+    assert c['emsa_ce_semantic_fwd'] == 4 + 1 and c['emsa_instance_loss_fwd'] == 4
+    total.backward()
+    assert c['emsa_ce_semantic_bwd'] == 5 and c['emsa_instance_loss_bwd'] == 4
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
