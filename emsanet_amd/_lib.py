@@ -41,7 +41,8 @@ SIGNATURES = {
     'emsa_conv1d_wino_supported': (c_int, [_GP]),
     'emsa_conv1d_wino_stats_rows': (c_int, [_GP]),
     'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P]),
-    'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, _P]),
+    'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    'emsa_pack_wino_packed': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_conv_wgrad_ws_bytes': (c_int64, [_GP]),
     'emsa_conv_wgrad': (c_int, [_GP, _P, _P, _P, _P, _P, _P]),
     'emsa_pack_weight_fwd': (c_int, [_P, _P] + [c_int32] * 8 + [_P]),

@@ -17,6 +17,8 @@
 // prefetch (30 KiB -> 5 workgroups per CU).  The epilogue transposes m_j through LDS, applies the
 // output transform and the same fused epilogue as conv_igemm (bias, BatchNorm statistics
 // partials, folded BatchNorm, residual, ReLU, ReLU-backward mask) with 16-B stores.
+#include <cstdlib>
+
 #include "common.h"
 #include "prof.h"
 
@@ -25,7 +27,6 @@ namespace {
 constexpr int kWK = 16;          // channels per K step
 constexpr int kWLD = kWK + 4;    // padded LDS row
 constexpr int kPairs = 32;       // output pairs per workgroup
-constexpr int kWN = 64;          // output channels per workgroup
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 constexpr uint32_t kOOBw = 0x80000000u;
@@ -48,7 +49,8 @@ struct WinoArgs {
   const float* mask_src;
   int ld_out, ld_res, ld_mask, act;
   int L, PL, A, MP;                 // line length, pairs per line, lines per image, total pairs
-  int k_ch, n_ch;
+  int k_ch, n_ch;                   // k_ch = R * c_in (GEMM K), n_ch output channels
+  int R, c_in, ksteps_c;            // perpendicular taps (1: 1-D conv, 3: 3x3), channels and K steps per tap
   int in_simg, in_sa, in_sb;        // input element strides (image, line, position on the line)
   int px_simg, px_sa, px_sb;        // output PIXEL strides (x ld_out / ld_res / ld_mask)
   int tiles_m, tiles_n, ksteps;
@@ -60,10 +62,16 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
   return (__umulhi(n, mul) + n) >> sh;
 }
 
+template <int kWN>      // output channels per workgroup: 64 (2 MFMA tiles per wave) or 32 (1)
 __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
+  constexpr int NT = kWN / 32;                    // accumulator tiles per wave
+  constexpr int NC4 = kWN / 4;                    // float4 columns of a tile row
+  constexpr int RG = 256 / NC4;                   // pixel rows covered by one pass of the block
+  constexpr int PXI = 64 / RG;                    // output pixels per thread in the epilogue
+  constexpr int BLD = 4 * kWN * 4 / 256;          // B float4 loads per thread and K step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;                          // [4 rows][32 pairs][kWLD]
-  float* const Bs = smem + 4 * kPairs * kWLD;      // [4 comps][64 n][kWLD]
+  float* const Bs = smem + 4 * kPairs * kWLD;      // [4 comps][kWN n][kWLD]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = component j
   const int l31 = lane & 31, lh = lane >> 5;
@@ -76,7 +84,8 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   // ---- loader state: a tile's pixels do not change over its K loop ----------------------
   // A: 4 rows x 32 pairs x 4 float4 = 512 float4 -> 2 per thread; B: 4 x 64 x 4 = 1024 -> 4
   const int c4 = (tid & 3) * 4;
-  uint32_t a_off[2], b_off[4];
+  uint32_t a_off[2], b_off[BLD];
+  int a_line[2];                                    // line index within the image (3x3: row taps)
   auto setup_a = [&](int mtile) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -84,6 +93,7 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
       const int rr = rowid >> 5, pr = rowid & 31;
       const int q = mtile * kPairs + pr;
       uint32_t off = kOOBw;
+      int al = 0;
       if (q < p.MP) {
         const int line = (int)wdiv((uint32_t)q, p.mul_pl, p.sh_pl);
         const int pp = q - line * p.PL;
@@ -91,33 +101,44 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
         const int a = line - img * p.A;
         const int b = 2 * pp - 1 + rr;
         if (b >= 0 && b < p.L) off = (uint32_t)(img * p.in_simg + a * p.in_sa + b * p.in_sb) * 4u;
+        al = a;
       }
       a_off[j] = off;
+      a_line[j] = al;
     }
   };
   setup_a(mt);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rowid = (tid >> 2) + 64 * j;          // 0..255 = comp*64 + n
-    const int comp = rowid >> 6, n = n0 + (rowid & 63);
+  for (int j = 0; j < BLD; ++j) {
+    const int rowid = (tid >> 2) + 64 * j;          // 0..4*kWN-1 = comp*kWN + n
+    const int comp = rowid / kWN, n = n0 + (rowid % kWN);
     b_off[j] = n < p.n_ch ? (uint32_t)((comp * p.n_ch + n) * p.k_ch) * 4u : kOOBw;
   }
-  float4 ra[2], rb[4];
+  float4 ra[2], rb[BLD];
   auto load_regs = [&](int s) {
-    const int k = s * kWK + c4;
-    const uint32_t kb = k < p.k_ch ? (uint32_t)k * 4u : kOOBw;
+    // K step s = (perpendicular tap r, channel chunk): r = 0 for the 1-D convs
+    const int r = s >= 2 * p.ksteps_c ? 2 : (s >= p.ksteps_c ? 1 : 0);
+    const int c = (s - r * p.ksteps_c) * kWK + c4;                 // input channel
+    const bool cok = c < p.c_in;
+    const uint32_t ka = cok ? (uint32_t)c * 4u : kOOBw;
+    const uint32_t kb = cok ? (uint32_t)(r * p.c_in + c) * 4u : kOOBw;
+    const int dr = p.R == 3 ? r - 1 : 0;                           // line shift of this tap
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      ra[j] = wbuf_ld4(rs_in, ((a_off[j] | kb) & kOOBw) ? kOOBw : a_off[j] + kb);
+    for (int j = 0; j < 2; ++j) {
+      const int al = a_line[j] + dr;
+      const bool lok = al >= 0 && al < p.A;
+      const uint32_t off = a_off[j] + (uint32_t)(dr * p.in_sa * 4);
+      ra[j] = wbuf_ld4(rs_in, (((a_off[j] | ka) & kOOBw) || !lok) ? kOOBw : off + ka);
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < BLD; ++j)
       rb[j] = wbuf_ld4(rs_u, ((b_off[j] | kb) & kOOBw) ? kOOBw : b_off[j] + kb);
   };
   auto store_lds = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) emsa_st4(As + ((tid >> 2) + 64 * j) * kWLD + c4, ra[j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) emsa_st4(Bs + ((tid >> 2) + 64 * j) * kWLD + c4, rb[j]);
+    for (int j = 0; j < BLD; ++j) emsa_st4(Bs + ((tid >> 2) + 64 * j) * kWLD + c4, rb[j]);
   };
 
   // wave j: V_j = row[ra_] + sg * row[rb_]
@@ -126,9 +147,9 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   const float sg = wave == 1 ? 1.f : -1.f;
 
   load_regs(0);
-  f32x16 acc[2];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -144,17 +165,23 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
 #pragma unroll
     for (int t = 0; t < kWK / 8; ++t) {
       const float4 x0 = emsa_ld4(a0 + t * 8), x1 = emsa_ld4(a1 + t * 8);
-      const float4 fb0 = emsa_ld4(b + t * 8), fb1 = emsa_ld4(b + 32 * kWLD + t * 8);
       const float4 v = make_float4(x0.x + sg * x1.x, x0.y + sg * x1.y, x0.z + sg * x1.z,
                                    x0.w + sg * x1.w);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, fb0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, fb1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, fb0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, fb1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, fb0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, fb1.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb0.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb1.w, acc[1], 0, 0, 0);
+      float4 fb[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) fb[u] = emsa_ld4(b + u * 32 * kWLD + t * 8);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, fb[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, fb[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, fb[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb[u].w, acc[u], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
@@ -163,27 +190,28 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   }
 
   // ---- epilogue: m_j -> LDS, output transform, fused epilogue ---------------------------------
-  // stage [4 comps][32 pairs][64 + 4]; thread (px = tid/16 + 16*k, col4 = tid%16) owns 4 of the
-  // 64 output pixels x one float4 of channels
+  // stage [4 comps][32 pairs][kWN + 4]; thread (px = tid/NC4 + RG*k, col4 = tid%NC4) owns PXI of
+  // the 64 output pixels x one float4 of channels
   constexpr int SLD = kWN + 4;
-  float* const stage = smem;                       // 4*32*68 floats = 34 KiB (dynamic LDS sized for it)
+  float* const stage = smem;                       // 4*32*(kWN+4) floats (dynamic LDS sized for it)
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
       stage[(wave * kPairs + row) * SLD + t * 32 + l31] = acc[t][r];
     }
   __syncthreads();
-  const int col4 = tid & 15, n = n0 + col4 * 4;
+  const int col4 = tid % NC4, n = n0 + col4 * 4;
+  const int rgi = tid / NC4;                       // row group of this thread
   const bool nok = n < p.n_ch;
-  float4 y[4];
-  uint32_t opix[4];            // pixel index (< 2^29, checked by emsa_conv1d_wino_supported)
-  bool ok[4];
+  float4 y[PXI];
+  uint32_t opix[PXI];          // pixel index (< 2^29, checked by emsa_conv1d_wino_supported)
+  bool ok[PXI];
   const float4 bv = (nok && p.bias) ? emsa_ld4(p.bias + n) : emsa_zero4();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int px = (tid >> 4) + 16 * k;            // 0..63 = pair*2 + e
+  for (int k = 0; k < PXI; ++k) {
+    const int px = rgi + RG * k;                   // 0..63 = pair*2 + e
     const int pr = px >> 1, e = px & 1;
     const float4 m1 = emsa_ld4(stage + (1 * kPairs + pr) * SLD + col4 * 4);
     const float4 m2 = emsa_ld4(stage + (2 * kPairs + pr) * SLD + col4 * 4);
@@ -217,29 +245,29 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   if (p.stats != nullptr) {
     // per-tile (sum, M2 about the tile mean, count) over the tile's VALID output pixels
     __syncthreads();                               // everyone has read `stage`
-    float* red = smem;                             // [16 row groups][64]
-    float* tmean = smem + 16 * kWN;                // [64]
-    int* scnt = reinterpret_cast<int*>(tmean + kWN);   // [16] valid pixels per row group
+    float* red = smem;                             // [RG row groups][kWN]
+    float* tmean = smem + RG * kWN;                // [kWN]
+    int* scnt = reinterpret_cast<int*>(tmean + kWN);   // [RG] valid pixels per row group
     float4 s1 = emsa_zero4();
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < PXI; ++k)
       if (ok[k]) {
         s1.x += y[k].x; s1.y += y[k].y; s1.z += y[k].z; s1.w += y[k].w;
         ++cnt;
       }
-    emsa_st4(red + (tid >> 4) * kWN + col4 * 4, s1);
+    emsa_st4(red + rgi * kWN + col4 * 4, s1);
     // the valid-pixel count is the same for every channel column: column 0 threads publish it
     // (n0 < n_ch for every launched tile, so their `ok` flags are the pixel validity)
-    if (col4 == 0) scnt[tid >> 4] = cnt;
+    if (col4 == 0) scnt[rgi] = cnt;
     __syncthreads();
     if (tid < kWN) {
       float a1 = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) a1 += red[g * kWN + tid];
+      for (int g = 0; g < RG; ++g) a1 += red[g * kWN + tid];
       int c = 0;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) c += scnt[g];
+      for (int g = 0; g < RG; ++g) c += scnt[g];
       tmean[tid] = c > 0 ? a1 / (float)c : 0.f;
       if (n0 + tid < p.n_ch) {
         p.stats[((size_t)0 * p.tiles_m + mt) * p.n_ch + n0 + tid] = a1;
@@ -250,18 +278,18 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
     const float4 mu = emsa_ld4(tmean + col4 * 4);
     float4 s2 = emsa_zero4();
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < PXI; ++k)
       if (ok[k]) {
         const float dx = y[k].x - mu.x, dy = y[k].y - mu.y, dz = y[k].z - mu.z, dw = y[k].w - mu.w;
         s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
       }
     __syncthreads();
-    emsa_st4(red + (tid >> 4) * kWN + col4 * 4, s2);
+    emsa_st4(red + rgi * kWN + col4 * 4, s2);
     __syncthreads();
     if (tid < kWN && n0 + tid < p.n_ch) {
       float a2 = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) a2 += red[g * kWN + tid];
+      for (int g = 0; g < RG; ++g) a2 += red[g * kWN + tid];
       p.stats[((size_t)1 * p.tiles_m + mt) * p.n_ch + n0 + tid] = a2;
     }
   }
@@ -273,7 +301,7 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
       sh = emsa_ld4(p.shift + n);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PXI; ++k) {
       if (!ok[k]) continue;
       float4 v = y[k];
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
@@ -296,30 +324,53 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   }
 }
 
-// U[4][n][k] from OIHW taps: forward (n = cout, k = cin) and/or data gradient (n = cin, k = cout,
-// taps flipped)
+// U[4][n][R*K] from OIHW weights [co][ci][R][3] (R = 1: 3x1 / 1x3 taps contiguous; R = 3: 3x3,
+// Winograd along kw): forward (n = cout, K = cin) and/or data gradient (n = cin, K = cout, taps
+// flipped in both directions)
 __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ u,
-                                 float* __restrict__ ud, int cout, int cin) {
-  const int total = cout * cin;
-  const size_t NK = (size_t)total;
+                                 float* __restrict__ ud, int cout, int cin, int R) {
+  const int total = cout * cin * R;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int ci = i % cin, co = i / cin;
-    const float* g = w + (size_t)i * 3;          // [co][ci][3] (3x1 or 1x3: taps contiguous)
+    const int r = i % R, ci = (i / R) % cin, co = i / (R * cin);
+    const float* g = w + (size_t)i * 3;          // [co][ci][r][3]
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     const float s = 0.5f * (g0 + g2), h = 0.5f * g1;
     if (u) {
-      u[0 * NK + i] = g0;
-      u[1 * NK + i] = s + h;
-      u[2 * NK + i] = s - h;
-      u[3 * NK + i] = g2;
+      const size_t NK = (size_t)cout * R * cin, o = ((size_t)co * R + r) * cin + ci;
+      u[0 * NK + o] = g0;
+      u[1 * NK + o] = s + h;
+      u[2 * NK + o] = s - h;
+      u[3 * NK + o] = g2;
     }
     if (ud) {
-      const size_t o = (size_t)ci * cout + co;
+      const size_t NK = (size_t)cin * R * cout, o = ((size_t)ci * R + (R - 1 - r)) * cout + co;
       ud[0 * NK + o] = g2;
       ud[1 * NK + o] = s + h;
       ud[2 * NK + o] = s - h;
       ud[3 * NK + o] = g0;
     }
+  }
+}
+
+// same transform from the PACKED implicit-GEMM layout wp[tap = r*3 + t][n][k] (what the merged /
+// channel-padded head convs are assembled in): U_j[n][r*k_ch + k]; flip = 1 for the data-gradient
+// pack ([tap][cin][cout], taps not flipped there) -> taps flipped here
+__global__ void pack_wino_packed_kernel(const float* __restrict__ wp, float* __restrict__ u, int n,
+                                        int k, int R, int flip) {
+  const int total = n * k * R;
+  const size_t NK = (size_t)total, plane = (size_t)n * k;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int kk = i % k, r = (i / k) % R, nn = i / (k * R);
+    const int rs = flip ? R - 1 - r : r;
+    const float* g = wp + (size_t)rs * 3 * plane + (size_t)nn * k + kk;
+    float g0 = g[0], g1 = g[plane], g2 = g[2 * plane];
+    if (flip) { const float t = g0; g0 = g2; g2 = t; }
+    const float s = 0.5f * (g0 + g2), h = 0.5f * g1;
+    const size_t o = ((size_t)nn * R + r) * k + kk;
+    u[0 * NK + o] = g0;
+    u[1 * NK + o] = s + h;
+    u[2 * NK + o] = s - h;
+    u[3 * NK + o] = g2;
   }
 }
 
@@ -333,25 +384,40 @@ inline void magic(uint32_t d, uint32_t& mul, uint32_t& sh) {
 }  // namespace
 
 extern "C" int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout,
-                              int32_t cin, void* stream) {
+                              int32_t cin, int32_t rows, void* stream) {
   if (!w_oihw || (!u && !u_dgrad)) return EMSA_E_ARG;
-  const int total = cout * cin;
+  if (rows != 1 && rows != 3) return EMSA_E_SHAPE;
+  const int total = cout * cin * rows;
   int grid = (total + 255) / 256;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u,
-                     u_dgrad, cout, cin);
+                     u_dgrad, cout, cin, rows);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_pack_wino_packed(const float* w_packed, float* u, int32_t n_ch, int32_t k_ch,
+                                     int32_t rows, int32_t flip, void* stream) {
+  if (!w_packed || !u) return EMSA_E_ARG;
+  if (rows != 1 && rows != 3) return EMSA_E_SHAPE;
+  const int total = n_ch * k_ch * rows;
+  int grid = (total + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_wino_packed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     w_packed, u, n_ch, k_ch, rows, flip ? 1 : 0);
   return emsa_launch_status();
 }
 
 // 1 if `g` (forward or data-gradient geometry of a conv) is a stride-1 3-tap 1-D "same" conv
 extern "C" int emsa_conv1d_wino_supported(const EmsaConvGeom* g) {
   if (!g) return 0;
-  const bool aw = g->kh == 1 && g->kw == 3 && g->off_h == 0 && (g->off_w == -1 || g->off_w == 1);
-  const bool ah = g->kh == 3 && g->kw == 1 && g->off_w == 0 && (g->off_h == -1 || g->off_h == 1);
-  if (!(aw || ah)) return 0;
+  // forward geometry: off = -1, step = +1; data gradient: off = +1, step = -1
+  auto tap3 = [](int off, int step) { return (off == -1 || off == 1) && step == -off; };
+  const bool aw = g->kh == 1 && g->kw == 3 && g->off_h == 0 && tap3(g->off_w, g->step_w);
+  const bool ah = g->kh == 3 && g->kw == 1 && g->off_w == 0 && tap3(g->off_h, g->step_h);
+  const bool sq = g->kh == 3 && g->kw == 3 && tap3(g->off_w, g->step_w) &&
+                  tap3(g->off_h, g->step_h) && g->off_h == g->off_w;
+  if (!(aw || ah || sq)) return 0;
   if (g->mul_h != 1 || g->mul_w != 1 || g->div_h != 1 || g->div_w != 1) return 0;
-  if (aw && g->step_w != -g->off_w) return 0;
-  if (ah && g->step_h != -g->off_h) return 0;
   if (g->in_h != g->out_h || g->in_w != g->out_w) return 0;
   if ((g->k_ch & 3) || (g->n_ch & 3) || (g->ld_out & 3) || (g->in_px_stride & 3)) return 0;
   if ((long)g->n_img * g->in_img_stride >= (1L << 29)) return 0;
@@ -389,30 +455,43 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   a.A = aw ? H : W;
   a.PL = (a.L + 1) / 2;
   a.MP = g->n_img * a.A * a.PL;
-  a.k_ch = g->k_ch; a.n_ch = g->n_ch;
+  a.R = g->kh == 3 && g->kw == 3 ? 3 : 1;
+  a.c_in = g->k_ch;
+  a.k_ch = a.R * g->k_ch; a.n_ch = g->n_ch;
   a.in_simg = (int)g->in_img_stride;
   a.in_sa = aw ? (int)g->in_row_stride : g->in_px_stride;
   a.in_sb = aw ? g->in_px_stride : (int)g->in_row_stride;
   a.px_simg = H * W;
   a.px_sa = aw ? W : 1;
   a.px_sb = aw ? 1 : W;
+  // channel-tile width: EMSA_WINO_WN=32|64 forces it (tuning)
+  static const int forced_wn = [] {
+    const char* e = getenv("EMSA_WINO_WN");
+    return e ? atoi(e) : 0;
+  }();
+  const int wn = forced_wn == 32 || forced_wn == 64 ? forced_wn : 64;
   a.tiles_m = (a.MP + kPairs - 1) / kPairs;
-  a.tiles_n = (g->n_ch + kWN - 1) / kWN;
-  a.ksteps = (g->k_ch + kWK - 1) / kWK;
+  a.tiles_n = (g->n_ch + wn - 1) / wn;
+  a.ksteps_c = (g->k_ch + kWK - 1) / kWK;
+  a.ksteps = a.R * a.ksteps_c;
   a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
-  a.u_bytes = (uint32_t)((size_t)4 * g->n_ch * g->k_ch * sizeof(float));
+  a.u_bytes = (uint32_t)((size_t)4 * g->n_ch * a.k_ch * sizeof(float));
   magic((uint32_t)a.PL, a.mul_pl, a.sh_pl);
   magic((uint32_t)a.A, a.mul_a, a.sh_a);
-  constexpr size_t lds_main = (size_t)(4 * kPairs + 4 * kWN) * kWLD * sizeof(float);
-  constexpr size_t lds_epi = (size_t)4 * kPairs * (kWN + 4) * sizeof(float);
-  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  const size_t lds_main = (size_t)(4 * kPairs + 4 * wn) * kWLD * sizeof(float);
+  const size_t lds_epi = (size_t)4 * kPairs * (wn + 4) * sizeof(float);
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   // algorithmic = direct-convolution FLOPs (3 taps); the kernel executes 4/6 of them on the MFMA
-  const double flops = 2.0 * g->n_img * H * W * (double)g->k_ch * g->n_ch * 3.0;
+  const double flops = 2.0 * g->n_img * H * W * (double)g->k_ch * g->n_ch * 3.0 * a.R;
   const int ps = emsa_prof_begin(kProfClassWino, flops, (hipStream_t)stream);
   // one workgroup per tile: a persistent grid with cross-tile prefetch measured SLOWER on MI355X
   // (static tile partition quantises to whole rounds: c256 /16 124 us vs 103 us)
-  hipLaunchKernelGGL(conv1d_wino_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
-                     (hipStream_t)stream, a);
+  if (wn == 64)
+    hipLaunchKernelGGL(conv1d_wino_kernel<64>, dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv1d_wino_kernel<32>, dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
+                       (hipStream_t)stream, a);
   emsa_prof_end(ps, (hipStream_t)stream);
   return emsa_launch_status();
 }

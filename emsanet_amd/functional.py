@@ -170,22 +170,36 @@ def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off
 # convolution
 # ---------------------------------------------------------------------------------------------
 def wino_eligible(spec):
-    """stride-1 3-tap 1-D "same" convolution (NBt1D 3x1 / 1x3) with channel counts the Winograd
-    kernel accepts"""
-    one_d = (spec.kh, spec.kw, spec.ph, spec.pw) in ((3, 1, 1, 0), (1, 3, 0, 1))
-    return one_d and spec.sh == 1 and spec.sw == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
+    """stride-1 "same" convolution with a 3-tap row (NBt1D 3x1 / 1x3, decoder / head 3x3) and
+    channel counts the Winograd kernel accepts"""
+    shape = (spec.kh, spec.kw, spec.ph, spec.pw) in ((3, 1, 1, 0), (1, 3, 0, 1), (3, 3, 1, 1))
+    return shape and spec.sh == 1 and spec.sw == 1 and spec.cin % 4 == 0 and spec.cout % 4 == 0
+
+
+def wino_rows(spec):
+    return 3 if (spec.kh, spec.kw) == (3, 3) else 1
 
 
 def pack_wino(w, fwd=True, dgrad=False):
     """OIHW [cout][cin][3x1|1x3] -> Winograd F(2,3) weights U [4][n][k]: forward (n,k = cout,cin)
     and/or data gradient (n,k = cin,cout, flipped taps), one launch.  -> (u or None, ud or None)"""
-    cout, cin = w.shape[:2]
-    buf = _empty((int(fwd) + int(dgrad), 4 * cout * cin), w.device)
+    cout, cin, kh, kw = w.shape
+    rows = 3 if (kh, kw) == (3, 3) else 1
+    buf = _empty((int(fwd) + int(dgrad), 4 * rows * cout * cin), w.device)
     u = buf[0] if fwd else None
     ud = buf[-1] if dgrad else None
-    check(_lib.lib().emsa_pack_wino(_p(w.contiguous()), _p(u), _p(ud), cout, cin, _stream()),
-          'emsa_pack_wino')
+    check(_lib.lib().emsa_pack_wino(_p(w.contiguous()), _p(u), _p(ud), cout, cin, rows,
+                                    _stream()), 'emsa_pack_wino')
     return u, ud
+
+
+def pack_wino_packed(wp, n_ch, k_ch, rows, flip):
+    """Winograd weights from a PACKED [tap][n_ch][k_ch] weight (merged / channel-padded convs);
+    flip=True for a data-gradient pack [tap][cin][cout]"""
+    u = _empty((4 * rows * n_ch * k_ch,), wp.device)
+    check(_lib.lib().emsa_pack_wino_packed(_p(wp), _p(u), n_ch, k_ch, rows, 1 if flip else 0,
+                                           _stream()), 'emsa_pack_wino_packed')
+    return u
 
 
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,

@@ -313,7 +313,10 @@ class MultiConvRT:
         self._key = None
         self._wp = None
         self._bias = None
+        self._u = None
         self.has_bias = any(m.bias is not None for m, _, _ in placements)
+        # 3x3 stride-1 merged convs (the task heads) run on the Winograd kernel as well
+        self.wino = Fn.wino_eligible(self.spec) and os.environ.get('EMSA_WINO', '1') != '0'
 
     def _w4(self, m):
         w = m.weight
@@ -332,7 +335,23 @@ class MultiConvRT:
                 if m.bias is not None:
                     bias[co:co + m.bias.shape[0]].copy_(m.bias.detach())
             self._wp, self._bias, self._key = wp, bias, key
+            self._u = Fn.pack_wino_packed(wp, s.cout, s.cin, Fn.wino_rows(s), flip=False) \
+                if self.wino else None
         return self._wp, self._bias
+
+    def forward(self, x):
+        wp, bias = self.packed()
+        if self.wino:
+            return Fn.conv_fwd(x, None, self.spec, bias=bias, wino_u=self._u)
+        return Fn.conv_fwd(x, wp, self.spec, bias=bias)
+
+    def dgrad(self, dy, in_hw):
+        wpd = self.packed_dgrad()
+        if self.wino:
+            s = self.spec
+            ud = Fn.pack_wino_packed(wpd, s.cin, s.cout, Fn.wino_rows(s), flip=True)
+            return Fn.conv_dgrad(dy, None, s, in_hw, wino_u=ud)
+        return Fn.conv_dgrad(dy, wpd, self.spec, in_hw)
 
     def packed_dgrad(self):
         s = self.spec
@@ -355,8 +374,7 @@ class MultiConvFunction(Function):
     @staticmethod
     def forward(ctx, x, rt, *params):
         x = Fn.as_act(x)
-        wp, bias = rt.packed()
-        y = Fn.conv_fwd(x, wp, rt.spec, bias=bias)
+        y = rt.forward(x)
         ctx.rt = rt
         ctx.save_for_backward(x)
         return y
@@ -379,7 +397,7 @@ class MultiConvFunction(Function):
                 grads.append(db[co:co + m.bias.shape[0]].clone())
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = Fn.conv_dgrad(dy, rt.packed_dgrad(), s, x.shape[2:])
+            dx = rt.dgrad(dy, x.shape[2:])
         return (dx, None) + tuple(grads)
 
 

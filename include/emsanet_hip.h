@@ -101,22 +101,29 @@ int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g);
 int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout, float* dw,
                     float* dbias, float* ws, void* stream);
 
-/* 1-D Winograd F(2,3) variant of emsa_conv_igemm for the stride-1 3-tap "same" 3x1 / 1x3
- * convolutions of the NBt1D blocks (forward and data gradient): 4 MFMA GEMMs over half the pixels
- * instead of 3 over all (1.5x fewer matrix instructions, fp32-exact coefficients 1 and 1/2).
+/* Winograd F(2,3) variant of emsa_conv_igemm for the stride-1 "same" convolutions with a 3-tap
+ * row: the 3x1 / 1x3 convs of the NBt1D blocks and the 3x3 convs of the decoders / heads (forward
+ * and data gradient).  Along the 3-tap direction two outputs cost 4 products instead of 6: 4 MFMA
+ * GEMMs over half the pixels instead of 3 over all (1.5x fewer matrix instructions, fp32-exact
+ * coefficients 1 and 1/2); a 3x3 conv is transformed along W and its three kernel rows are part of
+ * the GEMM K dimension (K = 3 * k_ch).
  * Same arguments and fused epilogue as emsa_conv_igemm, but `u` = transformed weights
- * [4][n_ch][k_ch] from emsa_pack_wino (u_dgrad: data-gradient weights, taps flipped, channels
- * transposed); stats partial rows = emsa_conv1d_wino_stats_rows(g).                          */
+ * [4][n_ch][rows * k_ch] (rows = 1 or 3 kernel rows) from emsa_pack_wino (from the OIHW parameter;
+ * u_dgrad: data-gradient weights, taps flipped, channels transposed) or emsa_pack_wino_packed
+ * (from the packed [tap][n][k] layout, flip = 1 for a data-gradient pack);
+ * stats partial rows = emsa_conv1d_wino_stats_rows(g).                                          */
 int emsa_conv1d_wino_supported(const EmsaConvGeom* g);
 int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g);
 int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, float* out,
                      const float* bias, float* stats, const float* scale, const float* shift,
                      const float* residual, int32_t ld_res, const float* mask_src,
                      int32_t ld_mask, int32_t act, void* stream);
-/* u (forward weights [4][cout][cin]) and/or u_dgrad (data-gradient weights [4][cin][cout]) from
- * the OIHW taps in one launch; either output may be NULL                                       */
+/* u (forward weights [4][cout][rows*cin]) and/or u_dgrad (data-gradient weights
+ * [4][cin][rows*cout]) from the OIHW taps in one launch; either output may be NULL              */
 int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout, int32_t cin,
-                   void* stream);
+                   int32_t rows, void* stream);
+int emsa_pack_wino_packed(const float* w_packed, float* u, int32_t n_ch, int32_t k_ch,
+                          int32_t rows, int32_t flip, void* stream);
 
 /* weight layout transforms between the reference's OIHW parameters and the packed layouts.
  * The packed buffer may be wider than the parameter (cout_total/cin_total >= cout/cin) and the

@@ -91,6 +91,11 @@ def test_conv_dgrad(cfg, tile, monkeypatch):
 
 WINO = [
     # cin, cout, kernel, n, h, w   (stride 1, "same" padding)
+    (64, 64, (3, 3), 2, 12, 20),         # 3x3: Winograd along W, kernel rows in the GEMM K
+    (128, 40, (3, 3), 1, 9, 13),
+    (96, 8, (3, 3), 2, 5, 7),
+    (8, 96, (3, 3), 1, 6, 6),
+    (72, 64, (3, 3), 1, 3, 40),
     (64, 64, (3, 1), 2, 12, 20),
     (64, 64, (1, 3), 2, 12, 20),
     (128, 128, (1, 3), 3, 9, 13),        # odd line length: last pair of a line is half empty
@@ -135,8 +140,12 @@ def test_conv1d_winograd_fwd(cfg):
     ref2 = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res)
     close(y2, ref2, what='wino epilogue')
     # same result as the implicit-GEMM kernel to fp32 rounding
-    y3 = Fn.conv_fwd(to_act(x), Fn.pack_weight(wt.to(DEV), 'fwd'), spec, bias=b.to(DEV))
+    wp = Fn.pack_weight(wt.to(DEV), 'fwd')
+    y3 = Fn.conv_fwd(to_act(x), wp, spec, bias=b.to(DEV))
     close(y, y3.double(), tol=2e-5, what='wino vs igemm')
+    # Winograd weights from the packed layout (merged head convs) == from the OIHW parameter
+    u2 = Fn.pack_wino_packed(wp, cout, cin, Fn.wino_rows(spec), flip=False)
+    assert torch.equal(u, u2)
 
 
 @pytest.mark.parametrize('cfg', WINO)
@@ -160,6 +169,9 @@ def test_conv1d_winograd_dgrad(cfg):
     close(dx2, x.grad * (mask > 0), what='wino dgrad mask')
     dx3 = Fn.conv_dgrad(to_act(dy), None, spec, (h, w), residual=to_act(res), wino_u=ud)
     close(dx3, x.grad + res, what='wino dgrad residual')
+    ud2 = Fn.pack_wino_packed(Fn.pack_weight(wt.to(DEV), 'dgrad'), cin, cout, Fn.wino_rows(spec),
+                              flip=True)
+    assert torch.equal(ud, ud2)
 
 
 def test_conv1d_winograd_channel_slice_views():
