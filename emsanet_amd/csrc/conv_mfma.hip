@@ -716,6 +716,7 @@ struct Wgrad1dArgs {
   int in_sa, in_sb, in_simg;         // element strides of x for (a, b, img)
   int dy_sa, dy_sb, dy_simg;         // element strides of dy
   int steps_total, steps_per_split, n_co_tiles, n_ci_tiles, n_tiles;
+  int R, A;                          // kernel rows (1, or 3 for a 3x3 conv: one per workgroup), lines per image
   float* ws;                         // NULL: atomics into dw; else split-K partial tiles (see
                                      // wgrad1d_reduce_kernel), ws_bias behind them
   float* ws_bias;
@@ -755,7 +756,10 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
   const int l31 = lane & 31, lh = lane >> 5;
   const int wco = wave & 1, wci = wave >> 1;
   constexpr int NQ = 1;
-  const int tile = blockIdx.x % p.n_tiles, ks = blockIdx.x / p.n_tiles;
+  // blockIdx = (split * R + kernel row) * n_tiles + tile
+  const int tile = blockIdx.x % p.n_tiles, kr = (blockIdx.x / p.n_tiles) % p.R;
+  const int ks = blockIdx.x / (p.n_tiles * p.R);
+  const int dline = p.R == 3 ? kr - 1 : 0;         // x is read `dline` lines away (3x3 row tap)
   const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int s_begin = ks * p.steps_per_split;
@@ -764,14 +768,17 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
   const int d_c4 = (tid % DTPR) * 4, d_r = tid / DTPR;
   const int x_c4 = (tid % XTPR) * 4, x_r = tid / XTPR;
-  const bool do_bias = p.dbias != nullptr && ci_t == 0;
+  const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
 
-  auto pixel_off = [&](int k, int sa, int sb, int simg) -> uint32_t {
+  // dl = line shift (x of a 3x3 row tap; a shifted line outside the image is zero padding)
+  auto pixel_off = [&](int k, int sa, int sb, int simg, int dl) -> uint32_t {
     if (k < 0 || k >= p.M) return kOOB;
     const int img = (int)fast_div((uint32_t)k, p.div_al);
     const int rem = k - img * (int)p.div_al.d;
     const int a = (int)fast_div((uint32_t)rem, p.div_l), b = rem - a * p.L;
-    return (uint32_t)(img * simg + a * sa + b * sb) * 4u;
+    const int a2 = a + dl;
+    if (a2 < 0 || a2 >= p.A) return kOOB;
+    return (uint32_t)(img * simg + a2 * sa + b * sb) * 4u;
   };
 
   float4 rd[DR], rx[XR];
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
     const uint32_t cib = (ci0 + x_c4) < p.k_ch ? (uint32_t)(ci0 + x_c4) * 4u : kOOB;
 #pragma unroll
     for (int j = 0; j < DR; ++j) {
-      const uint32_t o = pixel_off(k0 + d_r + j * (256 / DTPR), p.dy_sa, p.dy_sb, p.dy_simg);
+      const uint32_t o = pixel_off(k0 + d_r + j * (256 / DTPR), p.dy_sa, p.dy_sb, p.dy_simg, 0);
 #if EMSA_ABL & 1
       rd[j] = make_float4(o, cob, 1.f, 2.f);
 #else
@@ -793,7 +800,8 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int r = x_r + j * (256 / XTPR);
-      const uint32_t o = r < XROWS ? pixel_off(k0 - 1 + r, p.in_sa, p.in_sb, p.in_simg) : kOOB;
+      const uint32_t o = r < XROWS ? pixel_off(k0 - 1 + r, p.in_sa, p.in_sb, p.in_simg, dline)
+                                   : kOOB;
 #if EMSA_ABL & 1
       rx[j] = make_float4(o, cib, 1.f, 2.f);
 #else
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
 #else
         if (co < p.n_ch && ci < p.k_ch)
 #endif
-          unsafeAtomicAdd(p.dw + ((size_t)t * p.n_ch + co) * p.k_ch + ci, acc[q][t][r]);
+          unsafeAtomicAdd(p.dw + ((size_t)(kr * 3 + t) * p.n_ch + co) * p.k_ch + ci, acc[q][t][r]);
       }
     }
   }
@@ -1136,7 +1144,9 @@ struct Wgrad1dPlan {
   bool wino;
 };
 bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
-  const bool along_w = g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0;
+  // a 3x3 conv = three row taps, each a 3-tap 1-D weight gradient along W on x shifted by a line
+  const bool sq = g->kh == 3 && g->kw == 3 && g->off_w == -1 && g->off_h == -1;
+  const bool along_w = (g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0) || sq;
   const bool along_h = g->kh == 3 && g->kw == 1 && g->off_h == -1 && g->off_w == 0;
   if (!((along_w || along_h) && g->mul_h == 1 && g->mul_w == 1 && g->step_h == 1 &&
         g->step_w == 1 && g->div_h == 1 && g->div_w == 1 && g->in_h == g->out_h &&
@@ -1148,6 +1158,8 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
   const int H = g->out_h, W = g->out_w;
   w.L = along_w ? W : H;
   const int A = along_w ? H : W;
+  w.A = A;
+  w.R = sq ? 3 : 1;
   w.in_simg = (int)g->in_img_stride;
   w.dy_simg = H * W * g->ld_out;
   if (along_w) {
@@ -1178,7 +1190,7 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
     return e ? atoi(e) : 0;
   }();
   const int target_blocks = forced_blocks > 0 ? forced_blocks : (pl.wino ? 768 : 1536);
-  int ksplit = target_blocks / w.n_tiles;
+  int ksplit = target_blocks / (w.n_tiles * w.R);
   const int max_split = (w.steps_total + 7) / 8;
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
@@ -1198,6 +1210,7 @@ extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
   if (!geom_ok(g)) return 0;
   Wgrad1dPlan pl;
   if (!plan_wgrad1d(g, dout_is_aligned(g, nullptr), pl)) return 0;
+  if (pl.w.R != 1) return 0;            // 3x3: atomics into the packed layout
   return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * 12288 + (int64_t)pl.w.n_co_tiles * 64) *
          (int64_t)sizeof(float);
 }
@@ -1220,7 +1233,7 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   const int taps = g->kh * g->kw;
   Wgrad1dPlan pl;
   const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl);
-  if (ws != nullptr && !one_d) return EMSA_E_SHAPE;      // emsa_conv_wgrad_ws_bytes(g) was 0
+  if (ws != nullptr && (!one_d || pl.w.R != 1)) return EMSA_E_SHAPE;   // ws_bytes(g) was 0
   if (one_d) {
     Wgrad1dArgs& w = pl.w;
     w.in = in; w.dout = dout; w.dw = dw; w.dbias = dbias;
@@ -1230,10 +1243,10 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     const int ps = prof_begin(7, algo_flops(a.g), st);
     if (pl.wino)
-      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, true>), dim3(w.n_tiles * pl.ksplit),
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, true>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), lds, st, w);
     else
-      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, false>), dim3(w.n_tiles * pl.ksplit),
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, false>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), lds, st, w);
     if (ws != nullptr)
       hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * 192 + w.n_co_tiles), dim3(256),
