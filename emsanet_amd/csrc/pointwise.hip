@@ -624,6 +624,12 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 __global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const float* __restrict__ skip,
                                    float* __restrict__ y, int n, int h, int w, int c4n) {
+  // the depth-wise weights [c][9], transposed to [9][c] in LDS once per workgroup: 9 ds_read_b128
+  // per thread instead of 36 strided scalar global loads (the kernel was load-instruction bound)
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int C = c4n * 4;
+  for (int j = threadIdx.x; j < 9 * C; j += blockDim.x) wl[(j % 9) * C + j / 9] = wdw[j];
+  __syncthreads();
   const long total = (long)n * h * w * c4n;
   const int ow_n = 2 * w;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -645,7 +651,7 @@ __global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __r
       }
     float4 k[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) k[t] = dw_weight4(wdw, c4 * 4, t);
+    for (int t = 0; t < 9; ++t) k[t] = emsa_ld4(wl + t * C + c4 * 4);
     const float4 bv = bias ? emsa_ld4(bias + c4 * 4) : emsa_zero4();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -678,6 +684,23 @@ __global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __r
 __global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
                                         const float* __restrict__ wdw, float* __restrict__ dx,
                                         int n, int h, int w, int c4n) {
+  // collapsed taps per (p, q) of the 4x4 output neighbourhood, [16][c] in LDS once per workgroup:
+  // taps kh with oh+kh-1 in {2ih, 2ih+1}  <=>  kh in {2-p, 3-p} intersect [0,2] (same for kw, q)
+  extern __shared__ __attribute__((aligned(16))) float wc[];
+  const int C = c4n * 4;
+  for (int j = threadIdx.x; j < 16 * C; j += blockDim.x) {
+    const int c = j % C, pq = j / C, pp = pq >> 2, qq = pq & 3;
+    float a = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      if (kh != 2 - pp && kh != 3 - pp) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kw != 2 - qq && kw != 3 - qq) continue;
+        a += wdw[c * 9 + kh * 3 + kw];
+      }
+    }
+    wc[pq * C + c] = a;
+  }
+  __syncthreads();
   const int oh_n = 2 * h, ow_n = 2 * w;
   const long total = (long)n * h * w * c4n;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -687,9 +710,6 @@ __global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
     const int iw = (int)(r % w); r /= w;
     const int ih = (int)(r % h);
     const int img = (int)(r / h);
-    float4 k[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) k[t] = dw_weight4(wdw, c4 * 4, t);
     float4 a = emsa_zero4();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -700,18 +720,7 @@ __global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
         const int ow = 2 * iw - 1 + q;
         if (ow < 0 || ow >= ow_n) continue;
         const float4 g = emsa_ld4(dy + ((((long)img * oh_n + oh) * ow_n + ow) * c4n + c4) * 4);
-        // taps kh with oh+kh-1 in {2ih, 2ih+1}  <=>  kh in {2-p, 3-p} intersect [0,2]
-        float4 ws = emsa_zero4();
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          if (kh != 2 - p && kh != 3 - p) continue;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            if (kw != 2 - q && kw != 3 - q) continue;
-            const float4 kk = k[kh * 3 + kw];
-            ws.x += kk.x; ws.y += kk.y; ws.z += kk.z; ws.w += kk.w;
-          }
-        }
+        const float4 ws = emsa_ld4(wc + (p * 4 + q) * C + c4 * 4);
         a.x += g.x * ws.x; a.y += g.y * ws.y; a.z += g.z * ws.z; a.w += g.w * ws.w;
       }
     }
@@ -1233,8 +1242,9 @@ extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float
   if (!x || !wdw || !y) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * 4 * h * w * (c / 4);
-  hipLaunchKernelGGL(up2x_dw_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, wdw, bias, skip, y, n, h, w, c / 4);
+  hipLaunchKernelGGL(up2x_dw_fwd_kernel, dim3(grid_for(total)), dim3(kThreads),
+                     (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
+                     h, w, c / 4);
   return emsa_launch_status();
 }
 extern "C" int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float* dx, int32_t n,
@@ -1242,8 +1252,9 @@ extern "C" int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float
   if (!dy || !wdw || !dx) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * h * w * (c / 4);
-  hipLaunchKernelGGL(up2x_dw_bwd_data_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dy, wdw, dx, n, h, w, c / 4);
+  hipLaunchKernelGGL(up2x_dw_bwd_data_kernel, dim3(grid_for(total)), dim3(kThreads),
+                     (size_t)16 * c * sizeof(float), (hipStream_t)stream, dy, wdw, dx, n, h, w,
+                     c / 4);
   return emsa_launch_status();
 }
 extern "C" int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db,
