@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
     ap.add_argument('--force-dist', action='store_true',
                     help='validation: RCCL process group + bucketed all-reduce path with ONE rank')
+    ap.add_argument('--torch-optimizer', action='store_true',
+                    help='A/B: torch.optim.SGD (foreach) instead of the fused bucket-wise SGD kernel')
     ap.add_argument('--losses', action='store_true',
                     help='complete training step: all task losses on device (semantic / scene CE, '
                          'instance MSE / L1 / von Mises, multi-scale, reference weights) and '
@@ -203,7 +205,12 @@ def run(args):
     buckets = GradientBuckets(params, force_collectives=args.force_dist)
     # LR rule of the reference: 0.01 * batch/8 (args.py:1338-1344); tiny here so that the random
     # net stays finite over the benchmark steps
-    opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    if args.torch_optimizer:
+        opt = torch.optim.SGD(params, lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    else:
+        # one fused kernel per flat bucket (emsa_sgd_nesterov), same update rule
+        from emsanet_amd.optim import FusedSGD
+        opt = FusedSGD(buckets, lr=1e-5, momentum=0.9, weight_decay=1e-4)
     cots = None
     crit, targets = None, None
     if args.losses and not args.eval:

@@ -88,6 +88,8 @@ SIGNATURES = {
                                      _P]),
     'emsa_ce_semantic_bwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P,
                                      _P, c_int32, _P]),
+    'emsa_sgd_nesterov': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
+                                  _P]),
     'emsa_instance_loss_blocks': (c_int, [c_int64]),
     'emsa_instance_loss_fwd': (c_int, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P,
                                        c_int64, c_float, _P, _P, _P]),

@@ -1,0 +1,98 @@
+# -*- coding: utf-8 -*-
+"""
+Optimizer step and learning-rate schedule of the reference's training loop on device
+(SURVEY.md §8f-3).
+
+* `FusedSGD`: torch.optim.SGD(lr, momentum, weight_decay, nesterov=True) exactly as
+  /root/reference/emsanet/optimizer.py:29-36 configures it, but executed as ONE kernel per flat
+  bucket (`emsa_sgd_nesterov`, csrc/pointwise.hip) on the flat gradient buffers of
+  `GradientBuckets`: parameters and momentum live in flat buffers with the same layout (the
+  nn.Parameters become views, so `state_dict()` / `load_state_dict()` are unchanged), the
+  1/world_size averaging of the all-reduced gradients is folded into the update.
+* `one_cycle(step, ...)`: the schedule of /root/reference/emsanet/lr_scheduler.py:23-31 --
+  torch's OneCycleLR(max_lr, total_steps=n_epochs, div_factor=25, pct_start=0.1,
+  anneal_strategy='cos', final_div_factor=1e4), stepped once per EPOCH, INCLUDING the momentum
+  cycling between 0.95 and 0.85 that OneCycleLR applies by default (the reference does not switch
+  `cycle_momentum` off).  Tested against torch's scheduler.
+"""
+import math
+
+import torch
+
+from . import _lib
+from . import functional as Fn
+from ._lib import check
+
+
+def _cos_anneal(start, end, pct):
+    return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+
+def one_cycle(step, total_steps, max_lr, div_factor=25.0, pct_start=0.1, final_div_factor=1e4,
+              base_momentum=0.85, max_momentum=0.95):
+    """-> (lr, momentum) after `step` scheduler steps (step 0 = the values at construction)"""
+    if not 0 <= step < total_steps:
+        raise ValueError(f"Tried to step {step} times. The specified number of total steps is "
+                         f"{total_steps}")
+    initial_lr = max_lr / div_factor
+    min_lr = initial_lr / final_div_factor
+    end1 = float(pct_start * total_steps) - 1.0
+    end2 = float(total_steps - 1)
+    if step <= end1:
+        pct = step / end1
+        return _cos_anneal(initial_lr, max_lr, pct), _cos_anneal(max_momentum, base_momentum, pct)
+    pct = (step - end1) / (end2 - end1)
+    return _cos_anneal(max_lr, min_lr, pct), _cos_anneal(base_momentum, max_momentum, pct)
+
+
+class FusedSGD:
+    """usage per step:  buckets.reset(); loss.backward(); buckets.finish(); opt.step()"""
+
+    def __init__(self, buckets, lr=0.01, momentum=0.9, weight_decay=1e-4):
+        self.buckets = buckets
+        self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
+        self._first = True
+        self.flat_params, self.flat_momentum = [], []
+        with torch.no_grad():
+            for flat_g, ps, views in buckets.buckets:
+                fp = torch.empty_like(flat_g)
+                off = 0
+                for p in ps:
+                    n = p.numel()
+                    fp[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = fp[off:off + n].view(p.shape)     # the Parameter becomes a view
+                    off += n
+                self.flat_params.append(fp)
+                self.flat_momentum.append(torch.zeros_like(fp))
+
+    def set_schedule(self, lr, momentum):
+        self.lr, self.momentum = float(lr), float(momentum)
+
+    @torch.no_grad()
+    def step(self):
+        b = self.buckets
+        # the collectives leave the SUM in the flat buffers when GradientBuckets does not average
+        scale = 1.0
+        L = _lib.lib()
+        for (flat_g, ps, views), fp, fm in zip(b.buckets, self.flat_params, self.flat_momentum):
+            stray = [(v, p.grad) for v, p in zip(views, ps)
+                     if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            missing = any(p.grad is None for p in ps)
+            if missing:
+                flat_g.zero_()
+            if stray:       # single-process mode: gradients were not gathered by the hooks
+                torch._foreach_copy_([v for v, _ in stray], [g for _, g in stray])
+            check(L.emsa_sgd_nesterov(Fn._p(fp), Fn._p(flat_g), Fn._p(fm), fp.numel(), self.lr,
+                                      self.momentum, self.weight_decay, scale,
+                                      1 if self._first else 0, Fn._stream()), 'emsa_sgd_nesterov')
+        self._first = False
+
+    def state_dict(self):
+        return {'lr': self.lr, 'momentum': self.momentum, 'weight_decay': self.weight_decay,
+                'first': self._first, 'momentum_buffers': [m.clone() for m in self.flat_momentum]}
+
+    def load_state_dict(self, sd):
+        self.lr, self.momentum, self.weight_decay = sd['lr'], sd['momentum'], sd['weight_decay']
+        self._first = sd['first']
+        for m, src in zip(self.flat_momentum, sd['momentum_buffers']):
+            m.copy_(src)

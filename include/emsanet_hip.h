@@ -321,6 +321,17 @@ int emsa_instance_loss_bwd(const float* center, int32_t ld_c, const float* offse
                            int32_t ldd_r, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optimizer step over one flat bucket: torch.optim.SGD(momentum, weight_decay,
+ * nesterov=True) as the reference configures it (emsanet/optimizer.py:29-36), one pass:
+ *   d = grad * grad_scale + weight_decay * p;  buf = first_step ? d : momentum * buf + d;
+ *   p -= lr * (d + momentum * buf)
+ * grad_scale folds the 1/world_size averaging of the all-reduced bucket into the update.
+ * ------------------------------------------------------------------------------------------ */
+int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
+                      float momentum, float weight_decay, float grad_scale, int32_t first_step,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every n-th
  * emsa_conv_igemm / emsa_conv_wgrad launch of each class is bracketed by HIP events on its own
  * stream (bracketing EVERY launch costs ~3 % of a training step, every 4th < 1 %).
