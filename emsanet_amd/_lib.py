@@ -88,6 +88,14 @@ SIGNATURES = {
                                      _P]),
     'emsa_ce_semantic_bwd': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, c_float, c_float, _P, _P,
                                      _P, c_int32, _P]),
+    'emsa_softmax_argmax': (c_int, [_P, c_int32, c_int32, c_int64, _P, _P, _P]),
+    'emsa_center_candidates_max': (c_int, []),
+    'emsa_instance_centers': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                                      c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'emsa_instance_assign': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P,
+                                     _P, c_int32, _P, c_float, _P, _P]),
+    'emsa_normalize_rgb': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
+    'emsa_normalize_depth': (c_int, [_P, _P, c_int64, c_float, c_float, c_int32, _P]),
     'emsa_sgd_nesterov': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
                                   _P]),
     'emsa_instance_loss_blocks': (c_int, [c_int64]),

@@ -1,0 +1,277 @@
+// Eval-time post-processing and input normalisation on device:
+//  * semantic / scene: per-pixel softmax score + arg-max in one pass over the NHWC logits
+//    (`semantic_segmentation_idx|score`, `scene_class_idx|score`, Appendix C of SURVEY.md)
+//  * instance centres: threshold 0.1 -> 17x17 max-pool NMS -> top-k 64
+//    (/root/reference/emsanet/args.py:468-504, decoder.py:95-104), then every pixel is assigned to
+//    the centre nearest to (pixel + predicted offset)  (Panoptic-DeepLab grouping, which the
+//    un-vendored nicr_mt_scene_analysis post-processing follows; restated in
+//    oracle/postprocessing_oracle.py, parity unpinned)
+//  * NormalizeRGB / NormalizeDepth + HWC->CHW of the uint8 / uint16 camera frames
+//    (/root/reference/emsanet/preprocessing.py:216-226) so that the H2D copy moves 1-2 bytes per
+//    value instead of 4.
+// All HBM-bound single-pass kernels.
+#include "common.h"
+
+namespace {
+
+constexpr int kPix = 256;
+
+template <int C4>
+__global__ __launch_bounds__(kPix) void softmax_argmax_kernel(const float* __restrict__ logits,
+                                                              int ld, int n_classes, long pixels,
+                                                              float* __restrict__ score,
+                                                              int64_t* __restrict__ idx) {
+  constexpr int LD = C4 * 4 + 4;           // conflict-free ds_read_b128 rows
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const long p0 = (long)blockIdx.x * kPix;
+#pragma unroll
+  for (int j = 0; j < C4; ++j) {
+    const int i = threadIdx.x + kPix * j;
+    const int px = i / C4, c4 = i % C4;
+    float4 v = emsa_zero4();
+    if (p0 + px < pixels && c4 * 4 < ld) v = emsa_ld4(logits + (p0 + px) * (long)ld + c4 * 4);
+    emsa_st4(tile + px * LD + c4 * 4, v);
+  }
+  __syncthreads();
+  const long p = p0 + threadIdx.x;
+  if (p >= pixels) return;
+  float v[C4 * 4];
+#pragma unroll
+  for (int j = 0; j < C4; ++j)
+    *reinterpret_cast<float4*>(v + 4 * j) = emsa_ld4(tile + threadIdx.x * LD + 4 * j);
+  float m = -INFINITY;
+  int am = 0;
+#pragma unroll
+  for (int c = 0; c < C4 * 4; ++c)
+    if (c < n_classes && v[c] > m) { m = v[c]; am = c; }       // first maximum wins (torch.max)
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C4 * 4; ++c)
+    if (c < n_classes) s += expf(v[c] - m);
+  score[p] = 1.f / s;                                           // softmax value of the arg-max
+  idx[p] = am;
+}
+
+// ---- instance centres -----------------------------------------------------------------------
+constexpr int kMaxCand = 1024;     // candidates kept per image before the top-k selection
+
+// a pixel is a centre candidate iff heat >= threshold and heat == max over its k x k window
+// (max-pool NMS with "same" padding; equal neighbours are all kept, like pooled == heat)
+__global__ void center_nms_kernel(const float* __restrict__ heat, int ld, int n, int h, int w,
+                                  int ksize, float threshold, const uint8_t* __restrict__ fg,
+                                  int* __restrict__ count, float* __restrict__ cand_score,
+                                  int* __restrict__ cand_pos) {
+  const long total = (long)n * h * w;
+  const int r = ksize / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    float v = heat[i * ld];
+    if (fg && !fg[i]) v = 0.f;
+    if (!(v >= threshold)) continue;
+    const int x = (int)(i % w), y = (int)((i / w) % h), img = (int)(i / ((long)w * h));
+    bool is_max = true;
+    for (int dy = -r; dy <= r && is_max; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= h) continue;
+      for (int dx = -r; dx <= r; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= w) continue;
+        const long j = ((long)img * h + yy) * w + xx;
+        float u = heat[j * ld];
+        if (fg && !fg[j]) u = 0.f;
+        if (u > v) { is_max = false; break; }
+      }
+    }
+    if (!is_max) continue;
+    const int slot = atomicAdd(count + img, 1);
+    if (slot < kMaxCand) {
+      cand_score[(long)img * kMaxCand + slot] = v;
+      cand_pos[(long)img * kMaxCand + slot] = y * w + x;
+    }
+  }
+}
+
+// one workgroup per image: bitonic sort of the candidates by (score desc, position asc) -- the
+// result does not depend on the order the atomics appended them -- and write the top k
+__global__ __launch_bounds__(kMaxCand) void center_topk_kernel(
+    const int* __restrict__ count, const float* __restrict__ cand_score,
+    const int* __restrict__ cand_pos, int w, int top_k, float* __restrict__ centers,
+    float* __restrict__ scores, int* __restrict__ n_centers) {
+  __shared__ float ss[kMaxCand];
+  __shared__ int sp[kMaxCand];
+  const int img = blockIdx.x, t = threadIdx.x;
+  const int cnt = min(count[img], kMaxCand);
+  ss[t] = t < cnt ? cand_score[(long)img * kMaxCand + t] : -1.f;
+  sp[t] = t < cnt ? cand_pos[(long)img * kMaxCand + t] : 0x7fffffff;
+  __syncthreads();
+  for (int k = 2; k <= kMaxCand; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int o = t ^ j;
+      if (o > t) {
+        const bool desc = (t & k) == 0;
+        const bool t_first = ss[t] > ss[o] || (ss[t] == ss[o] && sp[t] < sp[o]);
+        if (desc != t_first) {
+          const float fs = ss[t]; ss[t] = ss[o]; ss[o] = fs;
+          const int fp = sp[t]; sp[t] = sp[o]; sp[o] = fp;
+        }
+      }
+      __syncthreads();
+    }
+  const int keep = min(cnt, top_k);
+  if (t < top_k) {
+    const bool ok = t < keep;
+    centers[((long)img * top_k + t) * 2 + 0] = ok ? (float)(sp[t] / w) : -1.f;   // y
+    centers[((long)img * top_k + t) * 2 + 1] = ok ? (float)(sp[t] % w) : -1.f;   // x
+    scores[(long)img * top_k + t] = ok ? ss[t] : 0.f;
+  }
+  if (t == 0) n_centers[img] = keep;
+}
+
+// id(p) = 1 + argmin_k |(y + off_y*sy, x + off_x*sx) - centre_k|^2, 0 outside the foreground or
+// without centres (first minimum wins)
+__global__ void instance_assign_kernel(const float* __restrict__ offset, int ld, int n, int h,
+                                       int w, float sy, float sx,
+                                       const float* __restrict__ centers,
+                                       const int* __restrict__ n_centers, int top_k,
+                                       const uint8_t* __restrict__ fg, float max_dist2,
+                                       int32_t* __restrict__ ids) {
+  extern __shared__ float cs[];                   // [top_k][2] of this image
+  const int img = blockIdx.y;
+  const int nc = n_centers[img];
+  for (int j = threadIdx.x; j < top_k * 2; j += blockDim.x) cs[j] = centers[(long)img * top_k * 2 + j];
+  __syncthreads();
+  const long hw = (long)h * w;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < hw;
+       q += (long)gridDim.x * blockDim.x) {
+    const long i = img * hw + q;
+    int id = 0;
+    if (nc > 0 && (!fg || fg[i])) {
+      const float cy = (float)(q / w) + offset[i * ld] * sy;
+      const float cx = (float)(q % w) + offset[i * ld + 1] * sx;
+      float best = INFINITY;
+      for (int k = 0; k < nc; ++k) {
+        const float dy = cy - cs[2 * k], dx = cx - cs[2 * k + 1];
+        const float d = dy * dy + dx * dx;
+        if (d < best) { best = d; id = k + 1; }
+      }
+      if (max_dist2 > 0.f && best > max_dist2) id = 0;
+    }
+    ids[i] = id;
+  }
+}
+
+// ---- input normalisation ---------------------------------------------------------------------
+// rgb uint8 [n][h][w][3] -> float [n][3][h][w]: (v * scale - mean[c]) / std[c]
+__global__ void normalize_rgb_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                     long hw, long total, float scale, float m0, float m1,
+                                     float m2, float i0, float i1, float i2) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long img = i / hw, q = i - img * hw;
+    const uint8_t* s = src + i * 3;
+    float* d = dst + img * 3 * hw + q;
+    d[0] = ((float)s[0] * scale - m0) * i0;
+    d[hw] = ((float)s[1] * scale - m1) * i1;
+    d[2 * hw] = ((float)s[2] * scale - m2) * i2;
+  }
+}
+
+// depth uint16 [n][h][w] -> float [n][1][h][w]: (v - mean) / std, invalid (0) stays 0
+__global__ void normalize_depth_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                       long total, float mean, float inv_std, int keep_zero) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const float v = (float)src[i];
+    dst[i] = (keep_zero && src[i] == 0) ? 0.f : (v - mean) * inv_std;
+  }
+}
+
+inline int grid1d(long items) {
+  long b = (items + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+template <int C4>
+int launch_argmax(const float* x, int ld, int nc, long pixels, float* score, int64_t* idx,
+                  hipStream_t st) {
+  const int grid = (int)((pixels + kPix - 1) / kPix);
+  const size_t lds = (size_t)kPix * (C4 * 4 + 4) * sizeof(float);
+  hipLaunchKernelGGL(softmax_argmax_kernel<C4>, dim3(grid), dim3(kPix), lds, st, x, ld, nc, pixels,
+                     score, idx);
+  return emsa_launch_status();
+}
+
+}  // namespace
+
+extern "C" int emsa_softmax_argmax(const float* logits, int32_t ld, int32_t n_classes,
+                                   int64_t pixels, float* score, int64_t* idx, void* stream) {
+  if (!logits || !score || !idx) return EMSA_E_ARG;
+  if (n_classes < 1 || n_classes > 64 || (ld & 3) || ld < ((n_classes + 3) & ~3) ||
+      (((uintptr_t)logits) & 15) || pixels < 1)
+    return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int c4 = (n_classes + 3) / 4;
+  if (c4 <= 4) return launch_argmax<4>(logits, ld, n_classes, pixels, score, idx, st);
+  if (c4 <= 10) return launch_argmax<10>(logits, ld, n_classes, pixels, score, idx, st);
+  return launch_argmax<16>(logits, ld, n_classes, pixels, score, idx, st);
+}
+
+extern "C" int emsa_center_candidates_max(void) { return kMaxCand; }
+
+extern "C" int emsa_instance_centers(const float* heat, int32_t ld, int32_t n, int32_t h,
+                                     int32_t w, int32_t nms_kernel, float threshold,
+                                     int32_t top_k, const uint8_t* fg, int32_t* ws_count,
+                                     float* ws_score, int32_t* ws_pos, float* centers,
+                                     float* scores, int32_t* n_centers, void* stream) {
+  if (!heat || !ws_count || !ws_score || !ws_pos || !centers || !scores || !n_centers)
+    return EMSA_E_ARG;
+  if (n < 1 || h < 1 || w < 1 || ld < 1 || nms_kernel < 1 || !(nms_kernel & 1) || top_k < 1 ||
+      top_k > kMaxCand)
+    return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws_count, 0, (size_t)n * sizeof(int), st) != hipSuccess) return EMSA_E_LAUNCH;
+  hipLaunchKernelGGL(center_nms_kernel, dim3(grid1d((long)n * h * w)), dim3(256), 0, st, heat, ld,
+                     n, h, w, nms_kernel, threshold, fg, ws_count, ws_score, ws_pos);
+  hipLaunchKernelGGL(center_topk_kernel, dim3(n), dim3(kMaxCand), 0, st, ws_count, ws_score, ws_pos,
+                     w, top_k, centers, scores, n_centers);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_instance_assign(const float* offset, int32_t ld, int32_t n, int32_t h,
+                                    int32_t w, float scale_y, float scale_x, const float* centers,
+                                    const int32_t* n_centers, int32_t top_k, const uint8_t* fg,
+                                    float max_distance, int32_t* ids, void* stream) {
+  if (!offset || !centers || !n_centers || !ids) return EMSA_E_ARG;
+  if (n < 1 || h < 1 || w < 1 || ld < 2 || top_k < 1 || top_k > kMaxCand) return EMSA_E_SHAPE;
+  const long hw = (long)h * w;
+  int gx = (int)((hw + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(instance_assign_kernel, dim3(gx, n), dim3(256),
+                     (size_t)top_k * 2 * sizeof(float), (hipStream_t)stream, offset, ld, n, h, w,
+                     scale_y, scale_x, centers, n_centers, top_k, fg,
+                     max_distance > 0.f ? max_distance * max_distance : 0.f, ids);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_normalize_rgb(const uint8_t* rgb_hwc, float* out_chw, int32_t n, int32_t h,
+                                  int32_t w, float scale, const float* mean3, const float* std3,
+                                  void* stream) {
+  if (!rgb_hwc || !out_chw || !mean3 || !std3) return EMSA_E_ARG;
+  if (n < 1 || h < 1 || w < 1 || std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f)
+    return EMSA_E_SHAPE;
+  const long hw = (long)h * w, total = hw * n;
+  hipLaunchKernelGGL(normalize_rgb_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+                     rgb_hwc, out_chw, hw, total, scale, mean3[0], mean3[1], mean3[2],
+                     1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t total, float mean,
+                                    float std, int32_t keep_zero, void* stream) {
+  if (!depth || !out) return EMSA_E_ARG;
+  if (total < 1 || std == 0.f) return EMSA_E_SHAPE;
+  hipLaunchKernelGGL(normalize_depth_kernel, dim3(grid1d((long)total)), dim3(256), 0,
+                     (hipStream_t)stream, depth, out, (long)total, mean, 1.f / std,
+                     keep_zero ? 1 : 0);
+  return emsa_launch_status();
+}

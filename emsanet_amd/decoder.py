@@ -19,6 +19,7 @@ import torch.nn as nn
 from . import functional as Fn
 from . import ops
 from .nn import ConvNormAct, LearnedUpsampling, NonBottleneck1D, make_plain_conv_rt, plain_conv
+from .postprocessing import InstancePostprocessing, softmax_argmax
 
 KNOWN_DECODERS = (
     'emsanet',         # decoder used in EMSANet publication
@@ -131,7 +132,7 @@ class SemanticDecoder(DecoderBody):
             return out, sides
         r = {'semantic_output': out, 'semantic_side_outputs': sides}
         if not self.training:
-            score, idx = torch.softmax(out, dim=1).max(dim=1)
+            score, idx = softmax_argmax(out)             # one fused pass over the logits
             r['semantic_segmentation_score'], r['semantic_segmentation_idx'] = score, idx
         return r
 
@@ -195,6 +196,11 @@ class InstanceDecoder(DecoderBody):
              'instance_centers': out[0], 'instance_offsets': out[1]}
         if self.with_orientation:
             r['instance_orientation'] = out[2]
+        if not self.training and self.postprocessing is not None:
+            # centre NMS / top-k and pixel grouping; the foreground comes from the batch when the
+            # reference's ground-truth-foreground key is present
+            fg = None if batch is None else batch.get('instance_segmentation_gt_foreground')
+            r.update(self.postprocessing(out[0], out[1], fg))
         return r
 
 
@@ -217,7 +223,7 @@ class SceneClassificationDecoder(nn.Module):
             return out, ()
         r = {'scene_output': out}
         if not self.training:
-            score, idx = torch.softmax(out, dim=1).max(dim=1)
+            score, idx = softmax_argmax(out)
             r['scene_class_score'], r['scene_class_idx'] = score, idx
         return r
 
@@ -276,6 +282,14 @@ def get_decoders(
             dropout_p=args.instance_decoder_block_dropout_p,
             fusion_n_channels=tuple(fusion_n_channels),
             fusion_downsamplings=fusion_downsamplings)
+        # post-processing parameters as in /root/reference/emsanet/decoder.py:95-104
+        decoders['instance_decoder'].postprocessing = InstancePostprocessing(
+            heatmap_threshold=args.instance_center_heatmap_threshold,
+            heatmap_nms_kernel_size=args.instance_center_heatmap_nms_kernel_size,
+            heatmap_apply_foreground_mask=args.instance_center_heatmap_apply_foreground_mask,
+            top_k_instances=args.instance_center_heatmap_top_k,
+            normalized_offset=instance_normalized_offset,
+            offset_distance_threshold=instance_offset_distance_threshold)
     if getattr(args, 'enable_panoptic', False):
         raise NotImplementedError("PanopticHelper (eval-time merge) is a 'next' row, SURVEY §8f")
     if 'normal' in args.tasks:

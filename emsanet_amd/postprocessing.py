@@ -1,0 +1,138 @@
+# -*- coding: utf-8 -*-
+"""
+Eval-time post-processing and input normalisation on device.
+
+The reference wires its post-processing classes into the decoders
+(/root/reference/emsanet/decoder.py:61-69,95-104 with the parameters of args.py:468-504); the
+classes themselves are part of the un-vendored `nicr_mt_scene_analysis` library, so the instance
+grouping below follows the published Panoptic-DeepLab procedure the library implements
+(threshold -> max-pool NMS -> top-k centres; every pixel votes for the centre nearest to
+pixel + offset) -- restated in oracle/postprocessing_oracle.py, PARITY UNPINNED -- while
+arg-max / softmax score are unambiguous.  Arithmetic: csrc/postproc.hip.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import functional as Fn
+from ._lib import check
+
+
+def softmax_argmax(logits):
+    """logits (N,C,H,W) or (N,C) -> (score, idx): idx = argmax over C (int64), score = its
+    softmax probability (== torch.softmax(logits, 1).max(1))"""
+    if logits.dim() == 2:
+        n, c = logits.shape
+        cp = Fn.pad4(c)
+        x = torch.cat([logits, logits.new_zeros(n, cp - c)], 1) if cp != c else logits.contiguous()
+        x4 = x.view(n, 1, 1, cp).permute(0, 3, 1, 2)[:, :c]
+        s, i = softmax_argmax(x4)
+        return s.view(n), i.view(n)
+    x = Fn.as_act(logits)
+    n, c, h, w = x.shape
+    if Fn.ld_of(x) % 4:          # rows must be 16-byte aligned: re-lay out with a padded stride
+        xp = Fn.act_empty(n, Fn.pad4(c), h, w, x.device)
+        xp[:, :c].copy_(x)
+        x = xp[:, :c]
+    score = Fn._empty((n, h, w), x.device)
+    idx = torch.empty((n, h, w), device=x.device, dtype=torch.int64)
+    check(_lib.lib().emsa_softmax_argmax(Fn._p(x), Fn.ld_of(x), c, n * h * w, Fn._p(score),
+                                         idx.data_ptr(), Fn._stream()), 'emsa_softmax_argmax')
+    return score, idx
+
+
+def _u8(m):
+    return None if m is None else m.reshape(-1).to(torch.uint8).contiguous()
+
+
+def instance_centers(heatmap, threshold=0.1, nms_kernel_size=17, top_k=64, foreground=None):
+    """heatmap (N,1,H,W) -> centers (N,top_k,2) float (y, x; -1 padded), scores (N,top_k),
+    n_centers (N,) int32 (defaults: /root/reference/emsanet/args.py:469-504)"""
+    x = Fn.as_act(heatmap)
+    n, _, h, w = x.shape
+    L = _lib.lib()
+    cmax = L.emsa_center_candidates_max()
+    dev = x.device
+    ws_count = torch.empty(n, device=dev, dtype=torch.int32)
+    ws_score = Fn._empty((n * cmax,), dev)
+    ws_pos = torch.empty(n * cmax, device=dev, dtype=torch.int32)
+    centers = Fn._empty((n, top_k, 2), dev)
+    scores = Fn._empty((n, top_k), dev)
+    n_centers = torch.empty(n, device=dev, dtype=torch.int32)
+    fg = _u8(foreground)
+    check(L.emsa_instance_centers(Fn._p(x), Fn.ld_of(x), n, h, w, nms_kernel_size, threshold,
+                                  top_k, Fn._p(fg), ws_count.data_ptr(), Fn._p(ws_score),
+                                  ws_pos.data_ptr(), Fn._p(centers), Fn._p(scores),
+                                  n_centers.data_ptr(), Fn._stream()), 'emsa_instance_centers')
+    return centers, scores, n_centers
+
+
+def instance_assign(offsets, centers, n_centers, foreground=None, normalized_offset=True,
+                    offset_distance_threshold=None):
+    """offsets (N,2,H,W) (dy, dx; in units of the image height / width when normalized) ->
+    instance ids (N,H,W) int32: 1 + index of the nearest centre, 0 = no instance"""
+    o = Fn.as_act(offsets)
+    n, _, h, w = o.shape
+    ids = torch.empty((n, h, w), device=o.device, dtype=torch.int32)
+    sy, sx = (float(h), float(w)) if normalized_offset else (1.0, 1.0)
+    fg = _u8(foreground)
+    check(_lib.lib().emsa_instance_assign(Fn._p(o), Fn.ld_of(o), n, h, w, sy, sx, Fn._p(centers),
+                                          n_centers.data_ptr(), centers.shape[1], Fn._p(fg),
+                                          float(offset_distance_threshold or 0.0),
+                                          ids.data_ptr(), Fn._stream()), 'emsa_instance_assign')
+    return ids
+
+
+class InstancePostprocessing:
+    """parameters as `get_postprocessing_class('instance', ...)` receives them
+    (/root/reference/emsanet/decoder.py:95-104)"""
+
+    def __init__(self, heatmap_threshold=0.1, heatmap_nms_kernel_size=17,
+                 heatmap_apply_foreground_mask=False, top_k_instances=64, normalized_offset=True,
+                 offset_distance_threshold=None):
+        self.threshold = heatmap_threshold
+        self.kernel = heatmap_nms_kernel_size
+        self.apply_fg = heatmap_apply_foreground_mask
+        self.top_k = top_k_instances
+        self.normalized = normalized_offset
+        self.dist = offset_distance_threshold
+
+    def __call__(self, center, offset, foreground=None):
+        c, s, nc = instance_centers(center, self.threshold, self.kernel, self.top_k,
+                                    foreground if self.apply_fg else None)
+        ids = instance_assign(offset, c, nc, foreground, self.normalized, self.dist)
+        return {'instance_predicted_centers': c, 'instance_predicted_centers_scores': s,
+                'instance_predicted_centers_count': nc, 'instance_segmentation_idx': ids}
+
+
+# ImageNet statistics on [0, 1]-scaled RGB: [U] (the library's NormalizeRGB is not vendored)
+RGB_MEAN, RGB_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def normalize_rgb(rgb_u8_hwc, mean=RGB_MEAN, std=RGB_STD, scale=1.0 / 255.0):
+    """uint8 (N,H,W,3) on the GPU -> float (N,3,H,W)  (`NormalizeRGB` + `ToTorchTensors`,
+    /root/reference/emsanet/preprocessing.py:216-226): the H2D copy moves 1 byte per value"""
+    x = rgb_u8_hwc.contiguous()
+    if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[-1] != 3 or not x.is_cuda:
+        raise _lib.EmsaError("normalize_rgb expects a uint8 (N,H,W,3) tensor on the GPU")
+    n, h, w, _ = x.shape
+    out = Fn._empty((n, 3, h, w), x.device)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    check(_lib.lib().emsa_normalize_rgb(x.data_ptr(), Fn._p(out), n, h, w, scale, m, s,
+                                        Fn._stream()), 'emsa_normalize_rgb')
+    return out
+
+
+def normalize_depth(depth_u16, mean, std, keep_invalid_zero=True):
+    """uint16 (N,H,W) depth in mm on the GPU -> float (N,1,H,W): (d - mean)/std, invalid pixels
+    (0) stay 0  (`NormalizeDepth(depth_mean, depth_std, raw_depth)`, preprocessing.py:218-224)"""
+    x = depth_u16.contiguous()
+    if x.dtype not in (torch.uint16, torch.int16) or not x.is_cuda:
+        raise _lib.EmsaError("normalize_depth expects a uint16 tensor on the GPU")
+    out = Fn._empty((x.shape[0], 1) + tuple(x.shape[-2:]), x.device)
+    check(_lib.lib().emsa_normalize_depth(x.data_ptr(), Fn._p(out), x.numel(), float(mean),
+                                          float(std), 1 if keep_invalid_zero else 0,
+                                          Fn._stream()), 'emsa_normalize_depth')
+    return out

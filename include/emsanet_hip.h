@@ -321,6 +321,36 @@ int emsa_instance_loss_bwd(const float* center, int32_t ld_c, const float* offse
                            int32_t ldd_r, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Eval post-processing and input normalisation (csrc/postproc.hip).
+ *   emsa_softmax_argmax     per pixel: idx = argmax_c logits, score = softmax(logits)[idx]
+ *                           (`semantic_segmentation_idx|score`, `scene_class_idx|score`)
+ *   emsa_instance_centers   heat >= threshold  ->  k x k max-pool NMS  ->  top_k by score
+ *                           (args.py:468-504); centers float[n][top_k][2] = (y, x) or -1,
+ *                           scores float[n][top_k], n_centers int[n]; ws_* = scratch: count
+ *                           int[n], score float[n * emsa_center_candidates_max()], pos alike;
+ *                           fg (may be NULL): uint8 foreground applied to the heatmap first
+ *   emsa_instance_assign    ids[p] = 1 + argmin_k |(y + off_y*scale_y, x + off_x*scale_x) - c_k|,
+ *                           0 outside fg / without centres / beyond max_distance (<= 0: off)
+ *   emsa_normalize_rgb      uint8 [n][h][w][3] -> float [n][3][h][w]: (v*scale - mean)/std
+ *   emsa_normalize_depth    uint16 -> float: (v - mean)/std, 0 kept 0 when keep_zero
+ * ------------------------------------------------------------------------------------------ */
+int emsa_softmax_argmax(const float* logits, int32_t ld, int32_t n_classes, int64_t pixels,
+                        float* score, int64_t* idx, void* stream);
+int emsa_center_candidates_max(void);
+int emsa_instance_centers(const float* heat, int32_t ld, int32_t n, int32_t h, int32_t w,
+                          int32_t nms_kernel, float threshold, int32_t top_k, const uint8_t* fg,
+                          int32_t* ws_count, float* ws_score, int32_t* ws_pos, float* centers,
+                          float* scores, int32_t* n_centers, void* stream);
+int emsa_instance_assign(const float* offset, int32_t ld, int32_t n, int32_t h, int32_t w,
+                         float scale_y, float scale_x, const float* centers,
+                         const int32_t* n_centers, int32_t top_k, const uint8_t* fg,
+                         float max_distance, int32_t* ids, void* stream);
+int emsa_normalize_rgb(const uint8_t* rgb_hwc, float* out_chw, int32_t n, int32_t h, int32_t w,
+                       float scale, const float* mean3, const float* std3, void* stream);
+int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t total, float mean, float std,
+                         int32_t keep_zero, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer step over one flat bucket: torch.optim.SGD(momentum, weight_decay,
  * nesterov=True) as the reference configures it (emsanet/optimizer.py:29-36), one pass:
  *   d = grad * grad_scale + weight_decay * p;  buf = first_step ? d : momentum * buf + d;

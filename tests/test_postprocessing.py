@@ -1,0 +1,111 @@
+"""Eval post-processing and input normalisation on device against the
+plain-PyTorch restatement in oracle/postprocessing_oracle.py (instance grouping: parity unpinned;
+arg-max / softmax score / normalisation: defined by torch arithmetic)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('c,shape', [(40, (2, 30, 41)), (10, (3, 1, 1)), (8, (1, 7, 5))])
+def test_softmax_argmax(c, shape):
+    from emsanet_amd.postprocessing import softmax_argmax
+    from oracle.postprocessing_oracle import softmax_argmax as ref_fn
+    g = torch.Generator().manual_seed(0)
+    n, h, w = shape
+    x = torch.randn(n, c, h, w, generator=g) * 4
+    x[0, 3, 0, 0] = x[0, 5, 0, 0] = 9.0           # a tie: first maximum wins
+    score, idx = softmax_argmax(x.to(DEV))
+    rs, ri = ref_fn(x)
+    assert torch.equal(idx.cpu(), ri)
+    assert (score.cpu().double() - rs).abs().max() <= 1e-6
+    # (N, C) logits of the scene head
+    s2, i2 = softmax_argmax(x[:, :, 0, 0].contiguous().to(DEV))
+    assert torch.equal(i2.cpu(), ri[:, 0, 0]) and (s2.cpu().double() - rs[:, 0, 0]).abs().max() <= 1e-6
+
+
+def _heatmap(n, h, w, seed, n_blobs=12):
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')
+    heat = torch.zeros(n, 1, h, w)
+    for i in range(n):
+        for _ in range(n_blobs):
+            cy, cx = float(torch.rand(1, generator=g) * h), float(torch.rand(1, generator=g) * w)
+            a = float(torch.rand(1, generator=g)) * 0.9 + 0.05
+            heat[i, 0] = torch.maximum(heat[i, 0], a * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 32.0))
+    return heat + torch.rand(n, 1, h, w, generator=g) * 0.02
+
+
+@pytest.mark.parametrize('top_k,with_fg', [(64, False), (5, False), (64, True)])
+def test_instance_centers_and_assignment(top_k, with_fg):
+    from emsanet_amd.postprocessing import instance_assign, instance_centers
+    from oracle import postprocessing_oracle as O
+    n, h, w = 2, 60, 80
+    heat = _heatmap(n, h, w, seed=1)
+    g = torch.Generator().manual_seed(2)
+    fg = (torch.rand(n, h, w, generator=g) > 0.3) if with_fg else None
+    off = (torch.rand(n, 2, h, w, generator=g) * 2 - 1) * 0.2
+    centers, scores, nc = instance_centers(heat.to(DEV), 0.1, 17, top_k,
+                                           fg.to(DEV) if with_fg else None)
+    ref = O.instance_centers(heat, 0.1, 17, top_k, fg)
+    for i in range(n):
+        k = int(nc[i])
+        assert k == len(ref[i][0]) and k > 0
+        assert torch.equal(centers[i, :k].cpu(), ref[i][0])
+        assert torch.equal(scores[i, :k].cpu(), ref[i][1])
+        assert bool((centers[i, k:] == -1).all())
+    ids = instance_assign(off.to(DEV), centers, nc, fg.to(DEV) if with_fg else None, True)
+    rid = O.instance_assign(off, ref, fg, True)
+    mism = (ids.cpu() != rid).float().mean().item()
+    assert mism <= 1e-4, mism                      # exact up to fp ties between two centres
+    # distance threshold and the no-centre image
+    ids2 = instance_assign(off.to(DEV), centers, nc, None, True, offset_distance_threshold=6)
+    rid2 = O.instance_assign(off, ref, None, True, max_distance=6)
+    assert (ids2.cpu() != rid2).float().mean().item() <= 1e-3
+    c0, s0, n0 = instance_centers(torch.zeros(1, 1, 20, 20, device=DEV))
+    assert int(n0[0]) == 0
+    assert int(instance_assign(off[:1, :, :20, :20].contiguous().to(DEV), c0, n0).abs().max()) == 0
+
+
+def test_input_normalisation():
+    from emsanet_amd.postprocessing import RGB_MEAN, RGB_STD, normalize_depth, normalize_rgb
+    g = torch.Generator().manual_seed(3)
+    rgb = torch.randint(0, 256, (2, 37, 53, 3), generator=g, dtype=torch.uint8)
+    depth = torch.randint(0, 9000, (2, 37, 53), generator=g, dtype=torch.int32)
+    depth[0, :5] = 0
+    out = normalize_rgb(rgb.to(DEV))
+    ref = ((rgb.float() / 255.0 - torch.tensor(RGB_MEAN)) / torch.tensor(RGB_STD)).permute(0, 3, 1, 2)
+    assert out.shape == (2, 3, 37, 53) and (out.cpu() - ref).abs().max() <= 2e-6
+    d16 = torch.from_numpy(depth.numpy().astype(np.uint16).view(np.int16)).to(DEV)
+    od = normalize_depth(d16, 2841.9, 1417.3)
+    rd = torch.where(depth == 0, torch.zeros(()), (depth.float() - 2841.9) / 1417.3)[:, None]
+    assert od.shape == (2, 1, 37, 53) and (od.cpu() - rd).abs().max() <= 2e-6
+
+
+def test_model_postprocessing_keys():
+    """eval forward with do_postprocessing=True: the reference's post-processed keys
+     are produced on device"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    args = full_args(input_height=64, input_width=96)
+    model = EMSANet(args, nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    with torch.no_grad():
+        r = model(batch, do_postprocessing=True)
+    for k in ('semantic_segmentation_idx', 'semantic_segmentation_score', 'scene_class_idx',
+              'scene_class_score', 'instance_centers', 'instance_offsets',
+              'instance_predicted_centers', 'instance_segmentation_idx'):
+        assert k in r, k
+    sc, ix = torch.softmax(r['semantic_output'].float(), 1).max(1)
+    assert torch.equal(ix, r['semantic_segmentation_idx'])
+    assert (sc - r['semantic_segmentation_score']).abs().max() <= 1e-6
+    assert r['instance_segmentation_idx'].shape == (2, 64, 96)
