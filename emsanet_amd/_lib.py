@@ -56,11 +56,13 @@ SIGNATURES = {
                                  _P, _P, _P, _P, _P, _P, _P, _P]),
     'emsa_bn_finalize_ws_bytes': (c_int, [c_int32]),
     'emsa_bn_fold': (c_int, [_P, _P, _P, _P, c_float, c_int32, _P, _P, _P, _P]),
-    'emsa_bn_act_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P]),
-    'emsa_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32,
+    'emsa_relu_mask_words': (c_int64, [c_int64]),
+    'emsa_bn_act_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P,
+                                _P]),
+    'emsa_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32,
                                    _P, _P]),
     'emsa_bn_bwd_rows': (c_int, [c_int64, c_int32]),
-    'emsa_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64,
+    'emsa_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64,
                                   c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'emsa_dropout2d_mask': (c_int, [_P, c_int32, c_int32, c_float, c_uint32, c_uint32, _P]),
     'emsa_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),

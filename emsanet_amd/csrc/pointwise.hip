@@ -178,7 +178,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ drop,
                                   const float* __restrict__ residual, long hw, int c4n, long total4,
-                                  int act) {
+                                  int act, uint64_t* __restrict__ mask_bits) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
        i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
@@ -199,7 +199,26 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     emsa_st4(y + i * 4, v);
+    if (mask_bits) {
+      // (y > 0) as 1 bit per element for the backward pass (which otherwise re-reads y only for
+      // this): the wave's 64 float4 indices [i & ~63, +64) -> 4 words, one per component; lanes
+      // past the end are inactive here and contribute 0 bits
+      const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f);
+      const uint64_t b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+      if ((i & 63) == 0) {
+        uint64_t* m = mask_bits + (i >> 6) * 4;
+        m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+      }
+    }
   }
+}
+
+// (y > 0) of float4 index i from the bit mask written by bn_act_fwd_kernel
+__device__ __forceinline__ void relu_mask4(const uint64_t* __restrict__ bits, long i, bool (&m)[4]) {
+  const uint64_t* w = bits + (i >> 6) * 4;
+  const int sh = (int)(i & 63);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = (w[k] >> sh) & 1ull;
 }
 
 // generic "per-channel reduction of up to two float4 quantities over a pixel range":
@@ -236,6 +255,7 @@ __device__ __forceinline__ void column_reduce(long p0, long p1, int c4n, F f, fl
 }
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                     const uint64_t* __restrict__ mask_bits,
                                      const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ invstd,
                                      const float* __restrict__ drop, long pixels, long hw, int c4n,
@@ -252,9 +272,16 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         const long i = (p * c4n + cc) * 4;
         float4 g = emsa_ld4(dy + i);
         if (act == EMSA_ACT_RELU) {
-          const float4 yy = emsa_ld4(y + i);
-          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+          if (mask_bits) {
+            bool m[4];
+            relu_mask4(mask_bits, p * c4n + cc, m);
+            g.x = m[0] ? g.x : 0.f; g.y = m[1] ? g.y : 0.f;
+            g.z = m[2] ? g.z : 0.f; g.w = m[3] ? g.w : 0.f;
+          } else {
+            const float4 yy = emsa_ld4(y + i);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+          }
         }
         if (drop) {
           const float4 d = emsa_ld4(drop + ((p / hw) * c4n + cc) * 4);
@@ -307,6 +334,7 @@ __global__ void bn_bwd_sum_kernel(float* __restrict__ partial, int rows, int row
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    const uint64_t* __restrict__ mask_bits,
                                     const float* __restrict__ x, const float* __restrict__ gamma,
                                     const float* __restrict__ mean,
                                     const float* __restrict__ invstd,
@@ -341,9 +369,16 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     const long pix = i / c4n;
     float4 g = emsa_ld4(dy + i * 4);
     if (act == EMSA_ACT_RELU) {
-      const float4 yy = emsa_ld4(y + i * 4);
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+      if (mask_bits) {
+        bool m[4];
+        relu_mask4(mask_bits, i, m);
+        g.x = m[0] ? g.x : 0.f; g.y = m[1] ? g.y : 0.f;
+        g.z = m[2] ? g.z : 0.f; g.w = m[3] ? g.w : 0.f;
+      } else {
+        const float4 yy = emsa_ld4(y + i * 4);
+        g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+        g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+      }
     }
     if (dres) emsa_st4(dres + i * 4, g);
     if (drop) {
@@ -1099,15 +1134,20 @@ extern "C" int emsa_bn_fold(const float* gamma, const float* beta, const float* 
   return emsa_launch_status();
 }
 
+extern "C" int64_t emsa_relu_mask_words(int64_t elements) {
+  return ((elements / 4 + 63) / 64) * 4;
+}
+
 extern "C" int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift,
                                const float* drop, const float* residual, int32_t n_img,
-                               int64_t hw, int32_t c, int32_t act, void* stream) {
+                               int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits,
+                               void* stream) {
   if (!x || !y || !scale || !shift) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total4 = (long)n_img * hw * (c / 4);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, scale, shift, drop, residual, (long)hw, c / 4,
-                     total4, act);
+                     total4, act, mask_bits);
   return emsa_launch_status();
 }
 
@@ -1126,32 +1166,33 @@ extern "C" int emsa_bn_bwd_rows(int64_t pixels, int32_t c) {
   return bn_bwd_rows_for((long)pixels, c) + kBwdSlices;
 }
 
-extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x,
-                                  const float* save_mean, const float* save_invstd,
-                                  const float* drop, int32_t n_img, int64_t hw, int32_t c,
-                                  int32_t act, float* partial, void* stream) {
+extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const uint64_t* mask_bits,
+                                  const float* x, const float* save_mean,
+                                  const float* save_invstd, const float* drop, int32_t n_img,
+                                  int64_t hw, int32_t c, int32_t act, float* partial,
+                                  void* stream) {
   if (!dy || !x || !save_mean || !save_invstd || !partial) return EMSA_E_ARG;
-  if (act == EMSA_ACT_RELU && !y) return EMSA_E_ARG;
+  if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long pixels = (long)n_img * hw;
   const int rows = bn_bwd_rows_for(pixels, c);
   const int c4n = c / 4, lanes = kThreads / c4n;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
-                     dy, y, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act,
+                     dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act,
                      rows + kBwdSlices, partial);
   return emsa_launch_status();
 }
 
-extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x,
-                                 const float* gamma, const float* save_mean,
+extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t* mask_bits,
+                                 const float* x, const float* gamma, const float* save_mean,
                                  const float* save_invstd, const float* drop,
                                  float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw,
                                  int32_t c, int32_t act, int32_t train, float* dx, float* dres,
                                  float* dgamma, float* dbeta, void* stream) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
     return EMSA_E_ARG;
-  if (act == EMSA_ACT_RELU && !y) return EMSA_E_ARG;
+  if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const long pixels = (long)n_img * hw;
@@ -1161,8 +1202,8 @@ extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x
                      rows, rows_alloc, c);
   const long total4 = pixels * (c / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads),
-                     (size_t)2 * c * sizeof(float), st, dy, y, x, gamma, save_mean, save_invstd,
-                     drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / 4, total4,
+                     (size_t)2 * c * sizeof(float), st, dy, y, mask_bits, x, gamma, save_mean,
+                     save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / 4, total4,
                      1.0f / (float)pixels, act, train, dx, dres);
   return emsa_launch_status();
 }

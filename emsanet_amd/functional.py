@@ -379,28 +379,40 @@ def bn_fold(gamma, beta, running_mean, running_var, eps):
     return buf[0], buf[1], buf[2]               # scale, shift, invstd
 
 
-def bn_act(x, scale, shift, drop=None, residual=None, act=ACT_NONE):
+def bn_act(x, scale, shift, drop=None, residual=None, act=ACT_NONE, want_mask=False):
+    """y = act((x*scale + shift)*drop + residual); want_mask: also (y > 0) as a bit mask
+    (int64 words) that `bn_bwd` reads instead of y  -> y or (y, mask)"""
     n, c, h, w = x.shape
     assert ld_of(x) == c and (residual is None or ld_of(residual) == c)
     y = act_empty(n, c, h, w, x.device)
-    check(_lib.lib().emsa_bn_act_fwd(_p(x), _p(y), _p(scale), _p(shift), _p(drop), _p(residual),
-                                     n, h * w, c, act, _stream()), 'emsa_bn_act_fwd')
-    return y
+    L = _lib.lib()
+    bits = None
+    if want_mask and act == ACT_RELU:
+        bits = torch.empty(L.emsa_relu_mask_words(n * c * h * w), device=x.device,
+                           dtype=torch.int64)
+    check(L.emsa_bn_act_fwd(_p(x), _p(y), _p(scale), _p(shift), _p(drop), _p(residual),
+                            n, h * w, c, act, _p(bits), _stream()), 'emsa_bn_act_fwd')
+    return (y, bits) if want_mask else y
 
 
 def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
-    """returns dx, dres (or None), dgamma, dbeta"""
+    """returns dx, dres (or None), dgamma, dbeta.  `y` = the activation output (ReLU mask y > 0)
+    or the int64 bit mask `bn_act(..., want_mask=True)` produced"""
     n, c, h, w = x.shape
     assert ld_of(x) == c and ld_of(dy) == c
     L = _lib.lib()
+    bits = None
+    if y is not None and y.dtype == torch.int64:
+        y, bits = None, y
     rows = L.emsa_bn_bwd_rows(n * h * w, c)
     partial = _empty((2, rows, c), x.device)
-    check(L.emsa_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(drop), n, h * w, c,
-                               act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
+    check(L.emsa_bn_bwd_reduce(_p(dy), _p(y), _p(bits), _p(x), _p(mean), _p(invstd), _p(drop), n,
+                               h * w, c, act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
     dx = act_empty(n, c, h, w, x.device)
     dres = act_empty(n, c, h, w, x.device) if want_dres else None
     dgb = _empty((2, c), x.device)
-    check(L.emsa_bn_bwd_apply(_p(dy), _p(y), _p(x), _p(gamma), _p(mean), _p(invstd), _p(drop),
+    check(L.emsa_bn_bwd_apply(_p(dy), _p(y), _p(bits), _p(x), _p(gamma), _p(mean), _p(invstd),
+                              _p(drop),
                               _p(partial), rows, n, h * w, c, act, 1 if train else 0, _p(dx),
                               _p(dres), _p(dgb[0]), _p(dgb[1]), _stream()), 'emsa_bn_bwd_apply')
     return dx, dres, dgb[0], dgb[1]

@@ -140,7 +140,8 @@ class BNRT:
 
 def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
     """conv (+bias) -> BN (batch or frozen statistics) -> *drop -> +residual -> act.
-    returns out, y_raw, (mean, invstd)"""
+    returns out, y_raw, mean, invstd, relu_mask (bit mask of out > 0 for the backward pass, or
+    None without ReLU)"""
     bias = crt.conv.bias.detach() if crt.conv.bias is not None else None
     if brt.batch_stats():
         y, stats = crt.forward(x, bias=bias, want_stats=True)
@@ -148,8 +149,8 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
     else:
         y, stats, count = crt.forward(x, bias=bias), None, 0
     scale, shift, mean, invstd = brt.forward_stats(stats, count)
-    out = Fn.bn_act(y, scale, shift, drop, residual, act)
-    return out, y, mean, invstd
+    out, mask = Fn.bn_act(y, scale, shift, drop, residual, act, want_mask=True)
+    return out, y, mean, invstd, mask
 
 
 def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
@@ -199,17 +200,19 @@ class NBt1DFunction(Function):
         x = Fn.as_act(x, dense=True)
         b = lambda c: c.conv.bias.detach()   # noqa: E731
         y1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU)
-        a2, y2, m1, is1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
+        a2, y2, m1, is1, k1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
         y3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU)
         if rt.cds is not None:
-            idn, yd, md, isd = _conv_bn_forward(x, rt.cds, rt.bnds, ACT_NONE)
+            idn, yd, md, isd, _ = _conv_bn_forward(x, rt.cds, rt.bnds, ACT_NONE)
         else:
             idn, yd, md, isd = x, None, None, None
-        out, y4, m2, is2 = _conv_bn_forward(y3, rt.c13_2, rt.bn2, ACT_RELU, drop=drop,
-                                            residual=idn)
+        out, y4, m2, is2, k2 = _conv_bn_forward(y3, rt.c13_2, rt.bn2, ACT_RELU, drop=drop,
+                                                residual=idn)
         ctx.rt, ctx.drop = rt, drop
-        ctx.save_for_backward(x, out)
-        ctx.saved = (y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd)
+        ctx.save_for_backward(x)
+        # the ReLU masks of the two BatchNorm outputs travel as bit masks (k1, k2): the block
+        # output itself is not kept for the backward pass
+        ctx.saved = (y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd, k1, k2)
         ctx.bn_train = (rt.bn1.batch_stats(), rt.bn2.batch_stats(),
                         rt.bnds.batch_stats() if rt.bnds is not None else False)
         return out
@@ -219,21 +222,21 @@ class NBt1DFunction(Function):
     @_traced
     def backward(ctx, dout):
         rt, drop = ctx.rt, ctx.drop
-        x, out = ctx.saved_tensors
-        y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd = ctx.saved
+        (x,) = ctx.saved_tensors
+        y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd, k1, k2 = ctx.saved
         ctx.saved = None
         dout = Fn.as_act(dout, dense=True)
         t1, t2, tds = ctx.bn_train
         need_dx = ctx.needs_input_grad[0]
 
         # out = relu(bn2(y4)*drop + idn)
-        dy4, dres, dg2, db2 = Fn.bn_bwd(dout, out, y4, rt.bn2.bn.weight.detach(), m2, is2, drop,
+        dy4, dres, dg2, db2 = Fn.bn_bwd(dout, k2, y4, rt.bn2.bn.weight.detach(), m2, is2, drop,
                                         ACT_RELU, t2, want_dres=True)
         # conv1x3_2 (input y3 = relu(.)): ReLU mask fused into the dgrad epilogue
         dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3)
         # conv3x1_2 (input a2 = relu(bn1(y2)))
         da2, dw3, dbias3 = _conv_backward(a2, dz3, rt.c31_2, True)
-        dy2, _, dg1, db1 = Fn.bn_bwd(da2, a2, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
+        dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
                                      ACT_RELU, t1, want_dres=False)
         dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1)
         grads = []
@@ -274,10 +277,10 @@ class ConvBNActFunction(Function):
     @staticmethod
     def forward(ctx, x, crt, brt, act, weight, gamma, beta):
         x = Fn.as_act(x)
-        out, y, mean, invstd = _conv_bn_forward(x, crt, brt, act)
+        out, y, mean, invstd, mask = _conv_bn_forward(x, crt, brt, act)
         ctx.crt, ctx.brt, ctx.act = crt, brt, act
-        ctx.save_for_backward(x, out)
-        ctx.saved = (y, mean, invstd)
+        ctx.save_for_backward(x)
+        ctx.saved = (y, mean, invstd, mask)
         ctx.bn_train = brt.batch_stats()
         return out
 
@@ -285,11 +288,11 @@ class ConvBNActFunction(Function):
     @once_differentiable
     @_traced
     def backward(ctx, dout):
-        x, out = ctx.saved_tensors
-        y, mean, invstd = ctx.saved
+        (x,) = ctx.saved_tensors
+        y, mean, invstd, mask = ctx.saved
         ctx.saved = None
         dout = Fn.as_act(dout, dense=True)
-        dy, _, dg, db = Fn.bn_bwd(dout, out, y, ctx.brt.bn.weight.detach(), mean, invstd, None,
+        dy, _, dg, db = Fn.bn_bwd(dout, mask, y, ctx.brt.bn.weight.detach(), mean, invstd, None,
                                   ctx.act, ctx.bn_train, want_dres=False)
         dx, dw, _ = _conv_backward(x, dy, ctx.crt, ctx.needs_input_grad[0])
         return dx, None, None, None, dw, dg, db
@@ -433,11 +436,10 @@ class StemFunction(Function):
             y, _ = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=False)
             stats, count = None, 0
         scale, shift, mean, invstd = brt.forward_stats(stats, count)
-        out = Fn.bn_act(y, scale, shift, None, None, ACT_RELU)
+        out, mask = Fn.bn_act(y, scale, shift, None, None, ACT_RELU, want_mask=True)
         ctx.rt = rt
         ctx.hw = (n, h, w)
-        ctx.save_for_backward(out)
-        ctx.saved = (xp, y, mean, invstd)
+        ctx.saved = (xp, y, mean, invstd, mask)
         ctx.bn_train = brt.batch_stats()
         return out
 
@@ -446,12 +448,11 @@ class StemFunction(Function):
     @_traced
     def backward(ctx, dout):
         rt = ctx.rt
-        (out,) = ctx.saved_tensors
-        xp, y, mean, invstd = ctx.saved
+        xp, y, mean, invstd, mask = ctx.saved
         ctx.saved = None
         n, h, w = ctx.hw
         dout = Fn.as_act(dout, dense=True)
-        dy, _, dg, db = Fn.bn_bwd(dout, out, y, rt.brt.bn.weight.detach(), mean, invstd, None,
+        dy, _, dg, db = Fn.bn_bwd(dout, mask, y, rt.brt.bn.weight.detach(), mean, invstd, None,
                                   ACT_RELU, ctx.bn_train, want_dres=False)
         dw = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight)
         # gradient w.r.t. the network input is not produced (the reference never needs it:

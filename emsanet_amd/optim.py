@@ -55,13 +55,13 @@ class FusedSGD:
         self.flat_params, self.flat_momentum = [], []
         with torch.no_grad():
             for flat_g, ps, views in buckets.buckets:
-                fp = torch.empty_like(flat_g)
-                off = 0
-                for p in ps:
+                fp = torch.zeros_like(flat_g)
+                for p, v in zip(ps, views):
+                    # same (16-byte aligned) offsets as the gradient views of the bucket
+                    off = v.storage_offset() - flat_g.storage_offset()
                     n = p.numel()
                     fp[off:off + n].copy_(p.detach().reshape(-1))
                     p.data = fp[off:off + n].view(p.shape)     # the Parameter becomes a view
-                    off += n
                 self.flat_params.append(fp)
                 self.flat_momentum.append(torch.zeros_like(fp))
 

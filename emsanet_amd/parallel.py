@@ -54,13 +54,17 @@ class GradientBuckets:
                     p.register_post_accumulate_grad_hook(self._hook)
         self.reset()
 
+    ALIGN = 4        # elements: every tensor starts on a 16-byte boundary (float4 kernels read
+    #                  parameters that FusedSGD re-homes into buffers of this layout)
+
     def _close(self, ps):
-        n = sum(p.numel() for p in ps)
+        pad = lambda k: (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN      # noqa: E731
+        n = sum(pad(p.numel()) for p in ps)
         flat = torch.zeros(n, device=ps[0].device, dtype=ps[0].dtype)
         views, off = [], 0
         for p in ps:
             views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += pad(p.numel())
         self.buckets.append((flat, ps, views))
 
     def reset(self):

@@ -174,23 +174,29 @@ int emsa_bn_finalize_ws_bytes(int32_t c);
 int emsa_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, int32_t c, float* scale, float* shift,
                  float* save_invstd, void* stream);
-/* y = act( (x*scale[c] + shift[c]) * drop[n][c] + residual ), drop/residual may be NULL */
+/* y = act( (x*scale[c] + shift[c]) * drop[n][c] + residual ), drop/residual may be NULL.
+ * mask_bits (may be NULL): uint64[emsa_relu_mask_words(n_img*hw*c)], receives (y > 0) as 1 bit per
+ * element -- the backward passes below read it INSTEAD of y (1/32 of the traffic)               */
+int64_t emsa_relu_mask_words(int64_t elements);
 int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift,
                     const float* drop, const float* residual, int32_t n_img, int64_t hw,
-                    int32_t c, int32_t act, void* stream);
-/* backward, pass 1: g = dy * (y>0 if act) ; partial[2][rows][c] of  sum g*drop  and
+                    int32_t c, int32_t act, uint64_t* mask_bits, void* stream);
+/* backward, pass 1: g = dy * (y>0 if act; from mask_bits when given, then y may be NULL);
+ * partial[2][rows][c] of  sum g*drop  and
  * sum g*drop*xhat  with xhat = (x-mean)*invstd.  rows = emsa_bn_bwd_rows(n_img*hw, c) is the row
  * count to ALLOCATE (per-workgroup partial rows + the slice-sum rows pass 2 uses as scratch)   */
-int emsa_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* save_mean,
-                       const float* save_invstd, const float* drop, int32_t n_img, int64_t hw,
-                       int32_t c, int32_t act, float* partial, void* stream);
+int emsa_bn_bwd_reduce(const float* dy, const float* y, const uint64_t* mask_bits, const float* x,
+                       const float* save_mean, const float* save_invstd, const float* drop,
+                       int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial,
+                       void* stream);
 int emsa_bn_bwd_rows(int64_t pixels, int32_t c);
 /* backward, pass 2: reduces `partial` in two levels (its trailing rows are scratch, so it is
  * not const; rows = the emsa_bn_bwd_rows value it was allocated with; dgamma, dbeta written), then
  *   train: dx = gamma*invstd*(g*drop - dbeta/M - xhat*dgamma/M);  eval (train=0): dx = g*drop*scale
  *   dres (may be NULL) = g                                                                  */
-int emsa_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* gamma,
-                      const float* save_mean, const float* save_invstd, const float* drop,
+int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t* mask_bits, const float* x,
+                      const float* gamma, const float* save_mean, const float* save_invstd,
+                      const float* drop,
                       float* partial, int32_t rows, int32_t n_img, int64_t hw, int32_t c,
                       int32_t act, int32_t train, float* dx, float* dres, float* dgamma,
                       float* dbeta, void* stream);

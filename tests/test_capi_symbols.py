@@ -53,7 +53,7 @@ def test_geometry_rejected_cleanly():
     assert L.emsa_conv_stats_rows(ctypes.byref(g)) == -1
     assert L.emsa_conv_igemm(ctypes.byref(g), None, None, None, None, None, None, None, None, 0,
                              None, 0, 0, None) == -1
-    assert L.emsa_bn_act_fwd(None, None, None, None, None, None, 1, 1, 64, 0, None) == -2
+    assert L.emsa_bn_act_fwd(None, None, None, None, None, None, 1, 1, 64, 0, None, None) == -2
 
 
 def test_gfx950_code_object_present():

@@ -319,6 +319,18 @@ def test_bn_fwd_bwd(c, act, train):
     close(dres, res.grad, what='bn dres')
     close(dg, gamma.grad, what='bn dgamma')
     close(db, beta.grad, what='bn dbeta')
+    # ReLU mask as 1 bit per element instead of re-reading y: bit-identical results
+    y2, bits = Fn.bn_act(xa, scale, shift, drop.float().to(DEV), to_act(res.detach().float()), act,
+                         want_mask=True)
+    assert torch.equal(y2, y)
+    if act == Fn.ACT_RELU:
+        assert bits.dtype == torch.int64 and bits.numel() * 64 >= y.numel()
+        r2 = Fn.bn_bwd(to_act(dy), bits, xa, g, mean, invstd, drop.float().to(DEV), act, train,
+                       want_dres=True)
+        for a, b_, name in zip(r2, (dx, dres, dg, db), ('dx', 'dres', 'dgamma', 'dbeta')):
+            assert torch.equal(a, b_), f'bit-mask path differs: {name}'
+    else:
+        assert bits is None
 
 
 def test_dropout_mask_matches_oracle():

@@ -39,6 +39,7 @@ def test_fused_sgd_matches_torch_sgd():
     opt = FusedSGD(buckets, lr=0.01, momentum=0.9, weight_decay=1e-4)
     for p, q in zip(mine, ref):                                  # parameters are views now
         assert torch.equal(p.detach().cpu(), q.detach())
+        assert p.data_ptr() % 16 == 0                            # float4 kernels read them
     for step in range(4):
         lr, mom = one_cycle(step, 20, 0.05)
         for grp in topt.param_groups:
