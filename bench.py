@@ -312,7 +312,9 @@ def run(args):
     if kernels:
         k = kernels[0]
         if pmc and (args.height, args.width, bs) == (480, 640, 32) and not args.eval:
-            ent = pmc['kernels'].get(k['kernel'].replace(' ', ''))
+            name = k['kernel'].replace(' ', '')
+            ent = pmc['kernels'].get(name) or next(
+                (v for kk, v in pmc['kernels'].items() if kk.startswith(name + '<')), None)
             if ent:
                 traffic = ent['hbm_bytes_per_launch']
                 traffic_src = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / ' \
