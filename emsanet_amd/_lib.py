@@ -40,7 +40,9 @@ SIGNATURES = {
     'emsa_conv_stats_rows': (c_int, [_GP]),
     'emsa_conv1d_wino_supported': (c_int, [_GP]),
     'emsa_conv1d_wino_stats_rows': (c_int, [_GP]),
-    'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P]),
+    'emsa_conv_relu_bits_words': (c_int64, [c_int64, c_int32]),
+    'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P,
+                                 _P, _P]),
     'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
     'emsa_pack_wino_packed': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_conv_wgrad_ws_bytes': (c_int64, [_GP]),

@@ -47,6 +47,9 @@ struct WinoArgs {
   const float* shift;
   const float* residual;
   const float* mask_src;
+  const uint64_t* mask_bits;        // alternative to mask_src: 1 bit per element, see relu_bits
+  uint64_t* relu_bits;              // out: (result > 0), one word per (pixel, 64-channel tile):
+                                    // bit = component*16 + float4 column
   int ld_out, ld_res, ld_mask, act;
   int L, PL, A, MP;                 // line length, pairs per line, lines per image, total pairs
   int k_ch, n_ch;                   // k_ch = R * c_in (GEMM K), n_ch output channels
@@ -294,32 +297,53 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
     }
   }
 
-  if (nok) {
+  {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = emsa_zero4();
-    if (p.scale) {
+    if (nok && p.scale) {
       sc = emsa_ld4(p.scale + n);
       sh = emsa_ld4(p.shift + n);
     }
 #pragma unroll
     for (int k = 0; k < PXI; ++k) {
-      if (!ok[k]) continue;
+      const bool live = nok && ok[k];
       float4 v = y[k];
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
       v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-      if (p.residual) {
+      if (live && p.residual) {
         const float4 rr = emsa_ld4(p.residual + (size_t)opix[k] * p.ld_res + n);
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
-      if (p.mask_src) {
+      if (live && p.mask_src) {
         const float4 mm = emsa_ld4(p.mask_src + (size_t)opix[k] * p.ld_mask + n);
         v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
         v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
+      }
+      if constexpr (kWN == 64) {
+        // ReLU masks as bits: the 16 lanes that share a pixel share one 64-bit word
+        if (live && p.mask_bits) {
+          const uint64_t mw = p.mask_bits[(size_t)opix[k] * p.tiles_n + nt];
+          v.x = ((mw >> col4) & 1ull) ? v.x : 0.f;
+          v.y = ((mw >> (16 + col4)) & 1ull) ? v.y : 0.f;
+          v.z = ((mw >> (32 + col4)) & 1ull) ? v.z : 0.f;
+          v.w = ((mw >> (48 + col4)) & 1ull) ? v.w : 0.f;
+        }
       }
       if (p.act == EMSA_ACT_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      emsa_st4(p.out + (size_t)opix[k] * p.ld_out + n, v);
+      if (live) emsa_st4(p.out + (size_t)opix[k] * p.ld_out + n, v);
+      if constexpr (kWN == 64) {
+        if (p.relu_bits) {                           // uniform branch: ballots see every lane
+          const uint64_t b0 = __ballot(live && v.x > 0.f), b1 = __ballot(live && v.y > 0.f);
+          const uint64_t b2 = __ballot(live && v.z > 0.f), b3 = __ballot(live && v.w > 0.f);
+          const int sh16 = (lane >> 4) * 16;         // this pixel's 16 lanes within the wave
+          if (col4 == 0 && ok[k])
+            p.relu_bits[(size_t)opix[k] * p.tiles_n + nt] =
+                ((b0 >> sh16) & 0xFFFFull) | (((b1 >> sh16) & 0xFFFFull) << 16) |
+                (((b2 >> sh16) & 0xFFFFull) << 32) | (((b3 >> sh16) & 0xFFFFull) << 48);
+        }
+      }
     }
   }
 }
@@ -424,6 +448,10 @@ extern "C" int emsa_conv1d_wino_supported(const EmsaConvGeom* g) {
   return 1;
 }
 
+extern "C" int64_t emsa_conv_relu_bits_words(int64_t pixels, int32_t n_ch) {
+  return pixels * ((n_ch + 63) / 64);
+}
+
 extern "C" int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g) {
   if (!emsa_conv1d_wino_supported(g)) return EMSA_E_SHAPE;
   const bool aw = g->kw == 3;
@@ -436,7 +464,7 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
                                 const float* bias, float* stats, const float* scale,
                                 const float* shift, const float* residual, int32_t ld_res,
                                 const float* mask_src, int32_t ld_mask, int32_t act,
-                                void* stream) {
+                                const uint64_t* mask_bits, uint64_t* relu_bits, void* stream) {
   if (!emsa_conv1d_wino_supported(g)) return EMSA_E_SHAPE;
   if (!in || !u || !out) return EMSA_E_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
@@ -448,6 +476,7 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   WinoArgs a;
   a.in = in; a.u = u; a.out = out; a.bias = bias; a.stats = stats; a.scale = scale;
   a.shift = shift; a.residual = residual; a.mask_src = mask_src;
+  a.mask_bits = mask_bits; a.relu_bits = relu_bits;
   a.ld_out = g->ld_out; a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
   const bool aw = g->kw == 3;
   const int H = g->out_h, W = g->out_w;
@@ -470,6 +499,8 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
     return e ? atoi(e) : 0;
   }();
   const int wn = forced_wn == 32 || forced_wn == 64 ? forced_wn : 64;
+  if ((mask_bits || relu_bits) && wn != 64) return EMSA_E_SHAPE;
+  if (mask_bits && mask_src) return EMSA_E_ARG;
   a.tiles_m = (a.MP + kPairs - 1) / kPairs;
   a.tiles_n = (g->n_ch + wn - 1) / wn;
   a.ksteps_c = (g->k_ch + kWK - 1) / kWK;

@@ -203,43 +203,62 @@ def pack_wino_packed(wp, n_ch, k_ch, rows, flip):
 
 
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
-             act=ACT_NONE, out=None, wino_u=None):
+             act=ACT_NONE, out=None, wino_u=None, want_relu_bits=False):
     """wp = packed [tap][cout][cin] weights (MFMA implicit GEMM) -- or wino_u = Winograd weights
-    of an eligible 1-D conv (emsa_conv1d_wino)"""
+    of an eligible conv (emsa_conv1d_wino).  want_relu_bits (Winograd kernel with act = ReLU):
+    additionally returns (out > 0) as a bit mask for `conv_dgrad(mask_bits=...)`, else None."""
     n, c, h, w = x.shape
     oh, ow = spec.out_hw(h, w)
     if out is None:
         out = act_empty(n, spec.cout, oh, ow, x.device)
     g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(out))
     L = _lib.lib()
-    fn, wt, name = (L.emsa_conv1d_wino, wino_u, 'emsa_conv1d_wino') if wino_u is not None \
-        else (L.emsa_conv_igemm, wp, 'emsa_conv_igemm')
     stats = None
     if want_stats:
         rows = (L.emsa_conv1d_wino_stats_rows if wino_u is not None else L.emsa_conv_stats_rows)(g)
         if rows <= 0:
             check(rows or -1, 'emsa_conv_stats_rows')
         stats = _empty((3, rows, spec.cout), x.device)
-    check(fn(g, _p(x), _p(wt), _p(out), _p(bias), _p(stats), _p(scale), _p(shift),
-             _p(residual), ld_of(residual) if residual is not None else 0,
-             None, 0, act, _stream()), name)
-    return (out, stats) if want_stats else out
+    lr = ld_of(residual) if residual is not None else 0
+    bits = None
+    if wino_u is not None:
+        if want_relu_bits and act == ACT_RELU:
+            bits = torch.empty(L.emsa_conv_relu_bits_words(n * oh * ow, spec.cout),
+                               device=x.device, dtype=torch.int64)
+        check(L.emsa_conv1d_wino(g, _p(x), _p(wino_u), _p(out), _p(bias), _p(stats), _p(scale),
+                                 _p(shift), _p(residual), lr, None, 0, act, None, _p(bits),
+                                 _stream()), 'emsa_conv1d_wino')
+    else:
+        check(L.emsa_conv_igemm(g, _p(x), _p(wp), _p(out), _p(bias), _p(stats), _p(scale),
+                                _p(shift), _p(residual), lr, None, 0, act, _stream()),
+              'emsa_conv_igemm')
+    res = (out, stats) if want_stats else out
+    return (res, bits) if want_relu_bits else res
 
 
-def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, wino_u=None):
-    """dx = conv_transpose(dy); optional fused `* (mask_src > 0)` and `+ residual`."""
+def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, wino_u=None,
+               mask_bits=None):
+    """dx = conv_transpose(dy); optional fused `* (mask_src > 0)` -- or the same mask as bits
+    (`mask_bits`, Winograd kernel only) -- and `+ residual`."""
     n = dy.shape[0]
     h, w = in_hw
     if out is None:
         out = act_empty(n, spec.cin, h, w, dy.device)
     g = spec.geom_dgrad(n, h, w, ld_of(dy), ld_of(out))
     L = _lib.lib()
-    fn, wt, name = (L.emsa_conv1d_wino, wino_u, 'emsa_conv1d_wino(dgrad)') if wino_u is not None \
-        else (L.emsa_conv_igemm, wpd, 'emsa_conv_igemm(dgrad)')
-    check(fn(g, _p(dy), _p(wt), _p(out), None, None, None, None,
-             _p(residual), ld_of(residual) if residual is not None else 0,
-             _p(mask_src), ld_of(mask_src) if mask_src is not None else 0, ACT_NONE, _stream()),
-          name)
+    lr = ld_of(residual) if residual is not None else 0
+    if wino_u is not None:
+        if mask_bits is not None:
+            mask_src = None
+        lm = ld_of(mask_src) if mask_src is not None else 0
+        check(L.emsa_conv1d_wino(g, _p(dy), _p(wino_u), _p(out), None, None, None, None,
+                                 _p(residual), lr, _p(mask_src), lm, ACT_NONE, _p(mask_bits), None,
+                                 _stream()), 'emsa_conv1d_wino(dgrad)')
+    else:
+        lm = ld_of(mask_src) if mask_src is not None else 0
+        check(L.emsa_conv_igemm(g, _p(dy), _p(wpd), _p(out), None, None, None, None,
+                                _p(residual), lr, _p(mask_src), lm, ACT_NONE, _stream()),
+              'emsa_conv_igemm(dgrad)')
     return out
 
 

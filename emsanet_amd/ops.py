@@ -74,12 +74,14 @@ class ConvRT:
             return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
         return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
 
-    def dgrad(self, dy, in_hw, **kw):
+    def dgrad(self, dy, in_hw, mask_bits=None, **kw):
+        """mask_bits: the ReLU mask of the producing layer as bits (conv_fwd(want_relu_bits));
+        used by the Winograd kernel, otherwise the float `mask_src` applies"""
         if self.wino:
             u, ud = self._wino_weights()
             if ud is None:
                 ud = Fn.pack_wino(self.conv.weight.detach(), fwd=False, dgrad=True)[1]
-            return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, **kw)
+            return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, mask_bits=mask_bits, **kw)
         return Fn.conv_dgrad(dy, self.packed_dgrad(), self.spec, in_hw, **kw)
 
     def packed(self):
@@ -153,7 +155,7 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
     return out, y, mean, invstd, mask
 
 
-def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
+def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None):
     """-> dx (or None), dw (OIHW), dbias (or None)"""
     conv = crt.conv
     dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight)
@@ -161,7 +163,8 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None):
         dw = Fn.unpack_wgrad(dw, conv.weight)
     dx = None
     if need_dx:
-        dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual)
+        dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual,
+                       mask_bits=mask_bits)
     return dx, dw, db
 
 
@@ -199,9 +202,11 @@ class NBt1DFunction(Function):
     def forward(ctx, x, rt, drop, *params):
         x = Fn.as_act(x, dense=True)
         b = lambda c: c.conv.bias.detach()   # noqa: E731
-        y1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU)
+        # y1, y3 = relu(conv): their ReLU masks go to the backward pass as bits (q1, q3; None when
+        # the layer does not run on the Winograd kernel)
+        y1, q1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU, want_relu_bits=True)
         a2, y2, m1, is1, k1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
-        y3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU)
+        y3, q3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU, want_relu_bits=True)
         if rt.cds is not None:
             idn, yd, md, isd, _ = _conv_bn_forward(x, rt.cds, rt.bnds, ACT_NONE)
         else:
@@ -212,7 +217,7 @@ class NBt1DFunction(Function):
         ctx.save_for_backward(x)
         # the ReLU masks of the two BatchNorm outputs travel as bit masks (k1, k2): the block
         # output itself is not kept for the backward pass
-        ctx.saved = (y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd, k1, k2)
+        ctx.saved = (y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd, k1, k2, q1, q3)
         ctx.bn_train = (rt.bn1.batch_stats(), rt.bn2.batch_stats(),
                         rt.bnds.batch_stats() if rt.bnds is not None else False)
         return out
@@ -223,7 +228,7 @@ class NBt1DFunction(Function):
     def backward(ctx, dout):
         rt, drop = ctx.rt, ctx.drop
         (x,) = ctx.saved_tensors
-        y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd, k1, k2 = ctx.saved
+        y1, y2, a2, y3, y4, yd, m1, is1, m2, is2, md, isd, k1, k2, q1, q3 = ctx.saved
         ctx.saved = None
         dout = Fn.as_act(dout, dense=True)
         t1, t2, tds = ctx.bn_train
@@ -233,12 +238,12 @@ class NBt1DFunction(Function):
         dy4, dres, dg2, db2 = Fn.bn_bwd(dout, k2, y4, rt.bn2.bn.weight.detach(), m2, is2, drop,
                                         ACT_RELU, t2, want_dres=True)
         # conv1x3_2 (input y3 = relu(.)): ReLU mask fused into the dgrad epilogue
-        dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3)
+        dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3, mask_bits=q3)
         # conv3x1_2 (input a2 = relu(bn1(y2)))
         da2, dw3, dbias3 = _conv_backward(a2, dz3, rt.c31_2, True)
         dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
                                      ACT_RELU, t1, want_dres=False)
-        dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1)
+        dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1, mask_bits=q1)
         grads = []
         if rt.cds is None:
             # identity skip: dx = dgrad(conv3x1_1) + dres, add fused into the epilogue

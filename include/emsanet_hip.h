@@ -114,10 +114,17 @@ int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout, f
  * stats partial rows = emsa_conv1d_wino_stats_rows(g).                                          */
 int emsa_conv1d_wino_supported(const EmsaConvGeom* g);
 int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g);
+/* ReLU masks as bits (1/32 of the traffic of a float mask tensor): relu_bits (out, may be NULL)
+ * receives (result > 0) as uint64[pixels][ceil(n_ch/64)] -- one word per pixel and 64-channel
+ * tile, bit = (channel % 4) * 16 + (channel % 64) / 4; mask_bits (in, may be NULL; excludes
+ * mask_src) applies such a mask of the producing layer like mask_src does.
+ * emsa_conv_relu_bits_words(pixels, n_ch) = number of words of such a mask.                     */
+int64_t emsa_conv_relu_bits_words(int64_t pixels, int32_t n_ch);
 int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, float* out,
                      const float* bias, float* stats, const float* scale, const float* shift,
                      const float* residual, int32_t ld_res, const float* mask_src,
-                     int32_t ld_mask, int32_t act, void* stream);
+                     int32_t ld_mask, int32_t act, const uint64_t* mask_bits,
+                     uint64_t* relu_bits, void* stream);
 /* u (forward weights [4][cout][rows*cin]) and/or u_dgrad (data-gradient weights
  * [4][cin][rows*cout]) from the OIHW taps in one launch; either output may be NULL              */
 int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout, int32_t cin,

@@ -174,6 +174,39 @@ def test_conv1d_winograd_dgrad(cfg):
     assert torch.equal(ud, ud2)
 
 
+@pytest.mark.parametrize('cfg', [(64, 64, (3, 1), 2, 12, 20), (128, 128, (1, 3), 3, 9, 13),
+                                 (64, 40, (1, 3), 1, 7, 41), (64, 64, (3, 3), 1, 6, 10)])
+def test_conv1d_winograd_relu_bit_masks(cfg):
+    """forward with fused ReLU emits (out > 0) as bits; the data gradient of the NEXT conv masked
+    by those bits == masked by the float tensor (bit-identical)"""
+    Fn = _fn()
+    cin, cout, k, n, h, w = cfg
+    p = (k[0] // 2, k[1] // 2)
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
+    u = Fn.pack_wino(wt.to(DEV))[0]
+    y, bits = Fn.conv_fwd(to_act(x), None, spec, act=Fn.ACT_RELU, wino_u=u, want_relu_bits=True)
+    assert bits is not None and bits.numel() == n * h * w * ((cout + 63) // 64)
+    # decode on the host: word per (pixel, 64-channel tile), bit = (c % 4) * 16 + (c % 64) // 4
+    yb = y.permute(0, 2, 3, 1).reshape(-1, cout).cpu() > 0
+    words = bits.cpu().numpy().view('uint64').reshape(n * h * w, -1)
+    import numpy as np
+    for c in (0, 1, 5, cout - 1, cout // 2):
+        got = (words[:, c // 64] >> np.uint64((c % 4) * 16 + (c % 64) // 4)) & np.uint64(1)
+        assert np.array_equal(got.astype(bool), yb[:, c].numpy()), c
+    # consumer: a conv whose INPUT has `cout` channels; its data gradient is masked by y > 0
+    k2 = (k[1], k[0])
+    spec2 = Fn.ConvSpec(cout, 64, k2, (1, 1), (k2[0] // 2, k2[1] // 2))
+    w2 = rnd(64, cout, *k2, seed=4, scale=0.1)
+    ud2 = Fn.pack_wino(w2.to(DEV), fwd=False, dgrad=True)[1]
+    dy = to_act(rnd(n, 64, h, w, seed=5))
+    a = Fn.conv_dgrad(dy, None, spec2, (h, w), mask_src=y, wino_u=ud2)
+    b = Fn.conv_dgrad(dy, None, spec2, (h, w), wino_u=ud2, mask_bits=bits)
+    assert torch.equal(a, b)
+    assert float(a.abs().max()) > 0
+
+
 def test_conv1d_winograd_channel_slice_views():
     """input and output that are channel slices of wider NHWC tensors (pixel stride > channels)"""
     Fn = _fn()
