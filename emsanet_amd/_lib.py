@@ -130,6 +130,11 @@ def _load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C emsanet_amd/csrc). "
             "There is no CPU / torch fallback for the EMSANet engine.")
+    # torch first: it ships its own libamdhip64 (same SONAME as /opt/rocm's, which this library
+    # is linked against).  Whichever is loaded first serves the whole process, and device memory,
+    # streams and kernels must all come from ONE HIP runtime -- torch's, since the tensors are
+    # torch's.  (Loading this library before torch made every launch fail with EMSA_E_LAUNCH.)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

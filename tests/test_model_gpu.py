@@ -319,3 +319,26 @@ def test_missing_gpu_input_fails_loudly():
     model = EMSANet(full_args(input_height=64, input_width=64), nyuv2_config()).to(DEV)
     with pytest.raises(_lib.EmsaError):
         model(synthetic_batch(1, 64, 64))      # CPU tensors: no CPU fallback
+
+
+def test_library_loaded_before_torch_use_subprocess():
+    """`__graft_entry__.build()` resolves the C-ABI before anything touched the GPU and `smoke()`
+    may follow in the same process: the HIP runtime serving the library must still be torch's
+    (the library is linked against /opt/rocm's libamdhip64, torch ships its own)"""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import __graft_entry__ as g\n"
+            "from emsanet_amd import _lib\n"
+            "L = _lib.lib()\n"
+            "import torch\n"
+            "from emsanet_amd import functional as Fn\n"
+            "x = torch.randn(2, 64, 8, 8, device='cuda')\n"
+            "y, _ = Fn.maxpool_fwd(Fn.as_act(x))\n"
+            "torch.cuda.synchronize()\n"
+            "assert torch.equal(y, torch.nn.functional.max_pool2d(x, 3, 2, 1))\n"
+            "print('ORDER_OK')\n")
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
+                       timeout=300)
+    assert 'ORDER_OK' in r.stdout, r.stderr[-2000:]
