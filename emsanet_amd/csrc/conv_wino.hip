@@ -25,7 +25,9 @@
 namespace {
 
 constexpr int kWK = 16;          // channels per K step
-constexpr int kWLD = kWK + 4;    // padded LDS row
+constexpr int kWLD = kWK;        // LDS row = 16 floats (64 B), unpadded: 16-B chunks XOR-swizzled by the
+                                 // row (wswz) -> conflict-free ds_write_b128 (8 lanes = 2 whole rows = 32
+                                 // banks) AND ds_read_b128 (the 16 rows of a lane group hit 16 slots)
 constexpr int kPairs = 32;       // output pairs per workgroup
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
@@ -60,6 +62,11 @@ struct WinoArgs {
   uint32_t in_bytes, u_bytes;
   uint32_t mul_pl, sh_pl, mul_a, sh_a;     // magic division by PL and by A
 };
+
+// float offset of logical 16-B chunk `c4/4` of LDS row `row`: physical chunk = chunk ^ ((row>>2)&3)
+__device__ __forceinline__ int wswz(int row, int c4) {
+  return row * kWLD + (c4 ^ (((row >> 2) & 3) << 2));
+}
 
 __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) {
   return (__umulhi(n, mul) + n) >> sh;
@@ -139,9 +146,9 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   };
   auto store_lds = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) emsa_st4(As + ((tid >> 2) + 64 * j) * kWLD + c4, ra[j]);
+    for (int j = 0; j < 2; ++j) emsa_st4(As + wswz((tid >> 2) + 64 * j, c4), ra[j]);
 #pragma unroll
-    for (int j = 0; j < BLD; ++j) emsa_st4(Bs + ((tid >> 2) + 64 * j) * kWLD + c4, rb[j]);
+    for (int j = 0; j < BLD; ++j) emsa_st4(Bs + wswz((tid >> 2) + 64 * j, c4), rb[j]);
   };
 
   // wave j: V_j = row[ra_] + sg * row[rb_]
@@ -161,18 +168,22 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   for (int s = 0; s < p.ksteps; ++s) {
     const bool has_next = s + 1 < p.ksteps;
     if (has_next) load_regs(s + 1);
-    const float* a0 = As + (ra_ * kPairs + l31) * kWLD + lh * 4;
-    const float* a1 = As + (rb_ * kPairs + l31) * kWLD + lh * 4;
-    const float* b = Bs + (wave * kWN + l31) * kWLD + lh * 4;
+    // rows ra_*32 + l31 etc.: the swizzle term depends on (l31 >> 2) & 3 only (row bases are
+    // multiples of 32); logical chunk of step t = lh + 2*t
+    const int sw = ((l31 >> 2) & 3) << 2;
+    const float* a0 = As + (ra_ * kPairs + l31) * kWLD;
+    const float* a1 = As + (rb_ * kPairs + l31) * kWLD;
+    const float* b = Bs + (wave * kWN + l31) * kWLD;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < kWK / 8; ++t) {
-      const float4 x0 = emsa_ld4(a0 + t * 8), x1 = emsa_ld4(a1 + t * 8);
+      const int co = ((lh + 2 * t) << 2) ^ sw;     // swizzled chunk offset (floats)
+      const float4 x0 = emsa_ld4(a0 + co), x1 = emsa_ld4(a1 + co);
       const float4 v = make_float4(x0.x + sg * x1.x, x0.y + sg * x1.y, x0.z + sg * x1.z,
                                    x0.w + sg * x1.w);
       float4 fb[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) fb[u] = emsa_ld4(b + u * 32 * kWLD + t * 8);
+      for (int u = 0; u < NT; ++u) fb[u] = emsa_ld4(b + u * 32 * kWLD + co);
 #pragma unroll
       for (int u = 0; u < NT; ++u)
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, fb[u].x, acc[u], 0, 0, 0);
