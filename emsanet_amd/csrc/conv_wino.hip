@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
 }
 
 template <int kWN>      // output channels per workgroup: 64 (2 MFMA tiles per wave) or 32 (1)
-__global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
+__global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(const WinoArgs p) {
   constexpr int NT = kWN / 32;                    // accumulator tiles per wave
   constexpr int NC4 = kWN / 4;                    // float4 columns of a tile row
   constexpr int RG = 256 / NC4;                   // pixel rows covered by one pass of the block
@@ -204,18 +204,12 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   }
 
   // ---- epilogue: m_j -> LDS, output transform, fused epilogue ---------------------------------
-  // stage [4 comps][32 pairs][kWN + 4]; thread (px = tid/NC4 + RG*k, col4 = tid%NC4) owns PXI of
-  // the 64 output pixels x one float4 of channels
+  // in two halves of 16 pairs (stage [4 comps][16 pairs][kWN + 4] = 17 KiB: with the 24 KiB of the
+  // main loop the workgroup stays under 32 KiB -> 5 workgroups per CU); thread
+  // (px = tid/NC4 + RG*k, col4 = tid%NC4) owns PXI of the 64 output pixels x one float4 of channels
   constexpr int SLD = kWN + 4;
-  float* const stage = smem;                       // 4*32*(kWN+4) floats (dynamic LDS sized for it)
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      stage[(wave * kPairs + row) * SLD + t * 32 + l31] = acc[t][r];
-    }
-  __syncthreads();
+  constexpr int HP = kPairs / 2;
+  float* const stage = smem;
   const int col4 = tid % NC4, n = n0 + col4 * 4;
   const int rgi = tid / NC4;                       // row group of this thread
   const bool nok = n < p.n_ch;
@@ -224,12 +218,23 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
   bool ok[PXI];
   const float4 bv = (nok && p.bias) ? emsa_ld4(p.bias + n) : emsa_zero4();
 #pragma unroll
-  for (int k = 0; k < PXI; ++k) {
-    const int px = rgi + RG * k;                   // 0..63 = pair*2 + e
-    const int pr = px >> 1, e = px & 1;
-    const float4 m1 = emsa_ld4(stage + (1 * kPairs + pr) * SLD + col4 * 4);
-    const float4 m2 = emsa_ld4(stage + (2 * kPairs + pr) * SLD + col4 * 4);
-    const float4 m03 = emsa_ld4(stage + ((e ? 3 : 0) * kPairs + pr) * SLD + col4 * 4);
+  for (int h = 0; h < 2; ++h) {
+  if (h) __syncthreads();                          // half 0 of the stage has been consumed
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 8 * h; r < 8 * h + 8; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // in [16h, 16h + 16)
+      stage[(wave * HP + row - HP * h) * SLD + t * 32 + l31] = acc[t][r];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int k = h * (PXI / 2); k < (h + 1) * (PXI / 2); ++k) {
+    const int px = rgi + RG * k;                   // 0..63 = pair*2 + e, in [32h, 32h + 32)
+    const int pr = px >> 1, e = px & 1, prl = pr - HP * h;
+    const float4 m1 = emsa_ld4(stage + (1 * HP + prl) * SLD + col4 * 4);
+    const float4 m2 = emsa_ld4(stage + (2 * HP + prl) * SLD + col4 * 4);
+    const float4 m03 = emsa_ld4(stage + ((e ? 3 : 0) * HP + prl) * SLD + col4 * 4);
     float4 v;
     if (e == 0) {
       v = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z,
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256) void conv1d_wino_kernel(const WinoArgs p) {
       }
     }
   }
+  }   // halves
 
   if (p.stats != nullptr) {
     // per-tile (sum, M2 about the tile mean, count) over the tile's VALID output pixels
@@ -521,7 +527,7 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   magic((uint32_t)a.PL, a.mul_pl, a.sh_pl);
   magic((uint32_t)a.A, a.mul_a, a.sh_a);
   const size_t lds_main = (size_t)(4 * kPairs + 4 * wn) * kWLD * sizeof(float);
-  const size_t lds_epi = (size_t)4 * kPairs * (wn + 4) * sizeof(float);
+  const size_t lds_epi = (size_t)4 * (kPairs / 2) * (wn + 4) * sizeof(float);
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   // algorithmic = direct-convolution FLOPs (3 taps); the kernel executes 4/6 of them on the MFMA
   const double flops = 2.0 * g->n_img * H * W * (double)g->k_ch * g->n_ch * 3.0 * a.R;
