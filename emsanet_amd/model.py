@@ -125,6 +125,11 @@ class EMSANet(nn.Module):
         if 'depth' in self.args.input_modalities:
             enc_inputs['depth'] = batch['depth']
         for k, v in enc_inputs.items():
+            if v.dim() != 4 or v.shape[-2] % 32 or v.shape[-1] % 32:
+                # five stride-2 encoder stages and x2 decoder upsampling with skip additions
+                raise _lib.EmsaError(
+                    f"batch['{k}'] has shape {tuple(v.shape)}: height and width must be multiples "
+                    "of 32 (encoder downsampling 32, decoder skip connections)")
             if not v.is_cuda:
                 raise _lib.EmsaError(
                     f"batch['{k}'] lives on {v.device}: the EMSANet engine only runs on an AMD "

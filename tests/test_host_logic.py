@@ -230,3 +230,10 @@ def test_dry_run_training_losses(fake_lib, monkeypatch):
     assert c['emsa_ce_semantic_bwd'] == 5 and c['emsa_instance_loss_bwd'] == 4
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape, k
+
+
+def test_input_size_must_be_multiple_of_32():
+    from emsanet_amd import _lib, full_args
+    model = _model(full_args(input_height=64, input_width=96))
+    with pytest.raises(_lib.EmsaError, match='multiples of 32'):
+        model({'rgb': torch.zeros(1, 3, 72, 104), 'depth': torch.zeros(1, 1, 72, 104)})
