@@ -67,6 +67,9 @@ class _Cuda:
         self.shape = t.shape
         self.device = t.device
 
+    def dim(self):
+        return self.t.dim()
+
     def detach(self):
         return self.t.detach()
 
