@@ -15,6 +15,12 @@ LIB_PATH = os.environ.get('EMSA_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'lib', 'libemsanet_hip.so')   # EMSA_LIB: tuning builds
 
 
+class EmsaPackJob(Structure):
+    _fields_ = [('src', c_void_p), ('dst0', c_void_p), ('dst1', c_void_p), ('cout', c_int32),
+                ('cin', c_int32), ('kh', c_int32), ('kw', c_int32), ('kind', c_int32),
+                ('first_block', c_int32)]
+
+
 class EmsaConvGeom(Structure):
     _fields_ = [
         ('n_img', c_int32),
@@ -44,6 +50,7 @@ SIGNATURES = {
     'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P,
                                  _P, _P]),
     'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    'emsa_pack_batch': (c_int, [_P, c_int32, c_int32, _P]),
     'emsa_pack_wino_packed': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_conv_wgrad_ws_bytes': (c_int64, [_GP]),
     'emsa_conv_wgrad': (c_int, [_GP, _P, _P, _P, _P, _P, _P]),

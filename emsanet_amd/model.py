@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import ops
 from .decoder import get_decoders
 from .nn import (Dropout2dHash, FusedEncoder, NonBottleneck1D, PyramidPoolingModule, ResNetNBt1D)
 
@@ -114,6 +115,17 @@ class EMSANet(nn.Module):
                 m.seed_fn = self._dropout_seed
                 lid += 1
 
+        # every convolution's weight transforms (packed / Winograd layouts) in one launch per step
+        rts = []
+        for m in self.modules():
+            rt = getattr(m, '_rt', None)
+            if isinstance(rt, ops.NBt1DRT):
+                rts += [rt.c31_1, rt.c13_1, rt.c31_2, rt.c13_2] + ([rt.cds] if rt.cds else [])
+            crt = getattr(m, '_crt', None)
+            if isinstance(crt, ops.ConvRT):
+                rts.append(crt)
+        self._pack_plan = ops.PackPlan(rts)
+
     def _dropout_seed(self):
         return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF
 
@@ -134,6 +146,8 @@ class EMSANet(nn.Module):
                 raise _lib.EmsaError(
                     f"batch['{k}'] lives on {v.device}: the EMSANet engine only runs on an AMD "
                     "GPU (no CPU fallback)")
+
+        self._pack_plan.refresh()
 
         # forward (fused) encoder(s) (model.py:206)
         enc_outputs, enc_dec_skips = self.encoder(enc_inputs)

@@ -131,6 +131,21 @@ int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout, 
                    int32_t rows, void* stream);
 int emsa_pack_wino_packed(const float* w_packed, float* u, int32_t n_ch, int32_t k_ch,
                           int32_t rows, int32_t flip, void* stream);
+/* All weight transforms of a model in ONE launch: a table of jobs in DEVICE memory, job j owns the
+ * workgroups [first_block_j, first_block_(j+1)) of a grid of total_blocks (first_block ascending
+ * from 0).  kind 0: OIHW -> the packed layouts of emsa_pack_weight_pair (dst0 forward, dst1 data
+ * gradient); kind 1: OIHW -> the Winograd weights of emsa_pack_wino (dst0 = u, dst1 = u_dgrad).
+ * NULL destinations are skipped.                                                                */
+typedef struct EmsaPackJob {
+  const float* src;
+  float* dst0;
+  float* dst1;
+  int32_t cout, cin, kh, kw;
+  int32_t kind;
+  int32_t first_block;
+} EmsaPackJob;
+int emsa_pack_batch(const EmsaPackJob* jobs_device, int32_t n_jobs, int32_t total_blocks,
+                    void* stream);
 
 /* weight layout transforms between the reference's OIHW parameters and the packed layouts.
  * The packed buffer may be wider than the parameter (cout_total/cin_total >= cout/cin) and the

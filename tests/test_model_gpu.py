@@ -342,3 +342,40 @@ def test_library_loaded_before_torch_use_subprocess():
     r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
                        timeout=300)
     assert 'ORDER_OK' in r.stdout, r.stderr[-2000:]
+
+
+def test_pack_plan_matches_per_layer_transforms():
+    """the one-launch weight transform of the whole model == the per-layer kernels, bit for bit;
+    it re-runs when a weight changes and when requires_grad flips"""
+    from emsanet_amd import functional as Fn
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from util import deterministic_state_dict
+    model = EMSANet(full_args(input_height=64, input_width=96), nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to('cuda:0').train()
+    plan = model._pack_plan
+    assert len(plan.rts) > 200
+    plan.refresh()
+    n_wino = 0
+    for rt in plan.rts:
+        w = rt.conv.weight.detach()
+        if rt.wino:
+            u, ud = Fn.pack_wino(w, fwd=True, dgrad=True)
+            assert torch.equal(rt._u, u) and torch.equal(rt._ud, ud)
+            n_wino += 1
+        else:
+            wp, wpd = Fn.pack_weight_pair(w)
+            assert torch.equal(rt._wp, wp) and torch.equal(rt._wpd, wpd)
+    assert n_wino > 150
+    rt = plan.rts[5]
+    before = rt._u.clone() if rt.wino else rt._wp.clone()
+    with torch.no_grad():
+        rt.conv.weight.mul_(2.0)
+    plan.refresh()
+    after = rt._u if rt.wino else rt._wp
+    assert torch.equal(after, before * 2.0)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    plan.refresh()
+    assert all((r._ud if r.wino else None) is None for r in plan.rts if r.wino)
