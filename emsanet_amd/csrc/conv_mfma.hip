@@ -770,26 +770,47 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
   const int x_c4 = (tid % XTPR) * 4, x_r = tid / XTPR;
   const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
 
+  // Address of pixel k0 + c (c = this thread's row within the step, -1..33).  The step base k0 is
+  // uniform: it is decomposed into (image, line, position) ONCE per step on the scalar unit
+  // (`base`), each thread then walks its few pixels of carry and multiplies with 24-bit
+  // full-rate multiplies -- the per-load address arithmetic was ~45 VALU instructions with seven
+  // quarter-rate 32-bit multiplies, i.e. as much VALU time as the step's MFMA time.
   // dl = line shift (x of a 3x3 row tap; a shifted line outside the image is zero padding)
-  auto pixel_off = [&](int k, int sa, int sb, int simg, int dl) -> uint32_t {
+  struct StepBase { int k0, img, a, b; };
+  auto step_base = [&](int k0) -> StepBase {
+    const int img = (int)fast_div((uint32_t)k0, p.div_al);
+    const int rem = k0 - img * (int)p.div_al.d;
+    const int a = (int)fast_div((uint32_t)rem, p.div_l);
+    return StepBase{k0, img, a, rem - a * p.L};
+  };
+  auto pixel_off = [&](const StepBase& sbs, int c, int sa, int sb, int simg, int dl) -> uint32_t {
+    const int k = sbs.k0 + c;
     if (k < 0 || k >= p.M) return kOOB;
-    const int img = (int)fast_div((uint32_t)k, p.div_al);
-    const int rem = k - img * (int)p.div_al.d;
-    const int a = (int)fast_div((uint32_t)rem, p.div_l), b = rem - a * p.L;
+    int img = sbs.img, a = sbs.a, b = sbs.b + c;
+    if (b < 0) {                                   // c = -1 at the start of a line
+      b += p.L;
+      if (--a < 0) { a += p.A; --img; }
+    }
+    while (b >= p.L) {                             // at most ceil(34 / L) iterations
+      b -= p.L;
+      if (++a >= p.A) { a -= p.A; ++img; }
+    }
     const int a2 = a + dl;
     if (a2 < 0 || a2 >= p.A) return kOOB;
-    return (uint32_t)(img * simg + a2 * sa + b * sb) * 4u;
+    return (__umul24((uint32_t)img, (uint32_t)simg) + __umul24((uint32_t)a2, (uint32_t)sa) +
+            __umul24((uint32_t)b, (uint32_t)sb)) * 4u;
   };
 
   float4 rd[DR], rx[XR];
   float4 bsum = emsa_zero4();
   auto load_regs = [&](int s) {
     const int k0 = s * PK;
+    const StepBase sbs = step_base(k0);
     const uint32_t cob = (co0 + d_c4) < p.n_ch ? (uint32_t)(co0 + d_c4) * 4u : kOOB;
     const uint32_t cib = (ci0 + x_c4) < p.k_ch ? (uint32_t)(ci0 + x_c4) * 4u : kOOB;
 #pragma unroll
     for (int j = 0; j < DR; ++j) {
-      const uint32_t o = pixel_off(k0 + d_r + j * (256 / DTPR), p.dy_sa, p.dy_sb, p.dy_simg, 0);
+      const uint32_t o = pixel_off(sbs, d_r + j * (256 / DTPR), p.dy_sa, p.dy_sb, p.dy_simg, 0);
 #if EMSA_ABL & 1
       rd[j] = make_float4(o, cob, 1.f, 2.f);
 #else
@@ -800,7 +821,7 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int r = x_r + j * (256 / XTPR);
-      const uint32_t o = r < XROWS ? pixel_off(k0 - 1 + r, p.in_sa, p.in_sb, p.in_simg, dline)
+      const uint32_t o = r < XROWS ? pixel_off(sbs, r - 1, p.in_sa, p.in_sb, p.in_simg, dline)
                                    : kOOB;
 #if EMSA_ABL & 1
       rx[j] = make_float4(o, cib, 1.f, 2.f);
@@ -1169,6 +1190,10 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
     w.in_sa = g->in_px_stride; w.in_sb = (int)g->in_row_stride;
     w.dy_sa = g->ld_out; w.dy_sb = W * g->ld_out;
   }
+  // the loader multiplies (image, line, position) by the strides with 24-bit multiplies
+  if (w.in_simg >= (1 << 24) || w.dy_simg >= (1 << 24) || w.in_sa >= (1 << 24) ||
+      w.dy_sa >= (1 << 24) || g->n_img >= (1 << 24))
+    return false;
   w.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
   w.dout_bytes = (uint32_t)((size_t)w.M * g->ld_out * sizeof(float));
   w.div_al = make_fastdiv((uint32_t)(A * w.L));
