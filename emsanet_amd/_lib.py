@@ -105,6 +105,8 @@ SIGNATURES = {
                                       c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'emsa_instance_assign': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P,
                                      _P, c_int32, _P, c_float, _P, _P]),
+    'emsa_panoptic_merge': (c_int, [_P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_int32, _P, _P,
+                                    _P, _P, _P, _P]),
     'emsa_normalize_rgb': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
     'emsa_normalize_depth': (c_int, [_P, _P, c_int64, c_float, c_float, c_int32, _P]),
     'emsa_sgd_nesterov': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,

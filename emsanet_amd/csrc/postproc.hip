@@ -186,6 +186,63 @@ __global__ void normalize_depth_kernel(const uint16_t* __restrict__ src, float* 
   }
 }
 
+
+// ---- panoptic merge (Panoptic-DeepLab, Cheng et al. CVPR 2020, Sec. 3.3) ---------------------
+// votes[n][top_k + 1][n_classes] += 1 for every thing pixel with an instance id: the semantic
+// class histogram of each instance (int32 atomics: deterministic)
+__global__ void panoptic_votes_kernel(const int64_t* __restrict__ sem, const int32_t* __restrict__ ids,
+                                      const uint8_t* __restrict__ is_thing, long hw, long total,
+                                      int n_classes, int slots, int32_t* __restrict__ votes) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int id = ids[i];
+    const int c = (int)sem[i];
+    if (id > 0 && id < slots && c >= 0 && c < n_classes && is_thing[c])
+      atomicAdd(votes + ((i / hw) * slots + id) * n_classes + c, 1);
+  }
+}
+
+// class of every instance = arg-max of its votes (first maximum wins; -1 without votes)
+__global__ void panoptic_class_kernel(const int32_t* __restrict__ votes, int n_classes, int total,
+                                      int32_t* __restrict__ cls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int best = 0, arg = -1;
+  for (int c = 0; c < n_classes; ++c) {
+    const int v = votes[(long)i * n_classes + c];
+    if (v > best) { best = v; arg = c; }
+  }
+  cls[i] = arg;
+}
+
+// per pixel: thing pixel with an instance -> (instance class, id); stuff pixel -> (class, 0);
+// thing pixel without an instance -> void.  panoptic id = (class + 1) * label_divisor + id, 0 = void
+__global__ void panoptic_merge_kernel(const int64_t* __restrict__ sem, const int32_t* __restrict__ ids,
+                                      const uint8_t* __restrict__ is_thing,
+                                      const int32_t* __restrict__ cls, long hw, long total,
+                                      int n_classes, int slots, int label_divisor,
+                                      int64_t* __restrict__ pan_sem, int32_t* __restrict__ pan_inst,
+                                      int64_t* __restrict__ pan_id) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)sem[i];
+    const bool thing = c >= 0 && c < n_classes && is_thing[c];
+    int oc = -1, oi = 0;
+    if (!thing) {
+      oc = (c >= 0 && c < n_classes) ? c : -1;
+    } else {
+      const int id = ids[i];
+      if (id > 0 && id < slots) {
+        const int k = cls[(i / hw) * slots + id];
+        if (k >= 0) { oc = k; oi = id; }
+      }
+    }
+    pan_sem[i] = oc;
+    pan_inst[i] = oi;
+    pan_id[i] = oc < 0 ? 0 : (int64_t)(oc + 1) * label_divisor + oi;
+  }
+}
+
 inline int grid1d(long items) {
   long b = (items + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -273,5 +330,29 @@ extern "C" int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t t
   hipLaunchKernelGGL(normalize_depth_kernel, dim3(grid1d((long)total)), dim3(256), 0,
                      (hipStream_t)stream, depth, out, (long)total, mean, 1.f / std,
                      keep_zero ? 1 : 0);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_panoptic_merge(const int64_t* semantic_idx, const int32_t* instance_ids,
+                                   const uint8_t* class_is_thing, int32_t n, int64_t hw,
+                                   int32_t n_classes, int32_t top_k, int32_t label_divisor,
+                                   int32_t* ws_votes, int32_t* ws_class, int64_t* pan_semantic,
+                                   int32_t* pan_instance, int64_t* pan_id, void* stream) {
+  if (!semantic_idx || !instance_ids || !class_is_thing || !ws_votes || !ws_class ||
+      !pan_semantic || !pan_instance || !pan_id)
+    return EMSA_E_ARG;
+  if (n < 1 || hw < 1 || n_classes < 1 || top_k < 1 || label_divisor <= top_k) return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int slots = top_k + 1;
+  const long total = (long)n * hw;
+  if (hipMemsetAsync(ws_votes, 0, (size_t)n * slots * n_classes * sizeof(int32_t), st) != hipSuccess)
+    return EMSA_E_LAUNCH;
+  hipLaunchKernelGGL(panoptic_votes_kernel, dim3(grid1d(total)), dim3(256), 0, st, semantic_idx,
+                     instance_ids, class_is_thing, (long)hw, total, n_classes, slots, ws_votes);
+  hipLaunchKernelGGL(panoptic_class_kernel, dim3((n * slots + 255) / 256), dim3(256), 0, st, ws_votes,
+                     n_classes, n * slots, ws_class);
+  hipLaunchKernelGGL(panoptic_merge_kernel, dim3(grid1d(total)), dim3(256), 0, st, semantic_idx,
+                     instance_ids, class_is_thing, ws_class, (long)hw, total, n_classes, slots,
+                     label_divisor, pan_semantic, pan_instance, pan_id);
   return emsa_launch_status();
 }

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import functional as Fn
 from . import ops
 from .nn import ConvNormAct, LearnedUpsampling, NonBottleneck1D, make_plain_conv_rt, plain_conv
-from .postprocessing import InstancePostprocessing, softmax_argmax
+from .postprocessing import InstancePostprocessing, PanopticPostprocessing, softmax_argmax
 
 KNOWN_DECODERS = (
     'emsanet',         # decoder used in EMSANet publication
@@ -204,6 +204,36 @@ class InstanceDecoder(DecoderBody):
         return r
 
 
+class PanopticHelper(nn.Module):
+    """`PanopticHelper(semantic_decoder, instance_decoder, postprocessing)` of
+    /root/reference/emsanet/decoder.py:141-158: same two decoders (state-dict keys
+    `decoders.panoptic_helper.{semantic,instance}_decoder.*`, weights.py:58-66), raw output
+    ((semantic logits, instance outputs), (semantic side outputs, instance side outputs))
+    (inference_time_whole_model.py:324-333), eval post-processing = Panoptic-DeepLab merge."""
+
+    def __init__(self, semantic_decoder, instance_decoder, classes_is_thing):
+        super().__init__()
+        self.semantic_decoder = semantic_decoder
+        self.instance_decoder = instance_decoder
+        self.side_output_downscales = semantic_decoder.side_output_downscales
+        self.postprocessing = PanopticPostprocessing(instance_decoder.postprocessing,
+                                                     classes_is_thing)
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        sem, sem_side = self.semantic_decoder(x, skips, batch, do_postprocessing=False)
+        inst, inst_side = self.instance_decoder(x, skips, batch, do_postprocessing=False)
+        if not do_postprocessing:
+            return (sem, inst), (sem_side, inst_side)
+        r = {'semantic_output': sem, 'semantic_side_outputs': sem_side, 'instance_output': inst,
+             'instance_side_outputs': inst_side, 'instance_centers': inst[0],
+             'instance_offsets': inst[1]}
+        if len(inst) > 2:
+            r['instance_orientation'] = inst[2]
+        if not self.training:
+            r.update(self.postprocessing(sem, inst[0], inst[1]))
+        return r
+
+
 class SceneClassificationDecoder(nn.Module):
     """`SceneClassificationDecoder(...)` of /root/reference/emsanet/decoder.py:191-199."""
 
@@ -291,7 +321,12 @@ def get_decoders(
             normalized_offset=instance_normalized_offset,
             offset_distance_threshold=instance_offset_distance_threshold)
     if getattr(args, 'enable_panoptic', False):
-        raise NotImplementedError("PanopticHelper (eval-time merge) is a 'next' row, SURVEY §8f")
+        # /root/reference/emsanet/decoder.py:141-158: both decoders move under one helper
+        if 'semantic_decoder' not in decoders or 'instance_decoder' not in decoders:
+            raise ValueError("enable_panoptic needs the semantic and the instance task")
+        helper = PanopticHelper(decoders.pop('semantic_decoder'), decoders.pop('instance_decoder'),
+                                panoptic_semantic_classes_is_thing)
+        decoders = OrderedDict([('panoptic_helper', helper)] + list(decoders.items()))
     if 'normal' in args.tasks:
         raise NotImplementedError("normal decoder is not part of the BASELINE.json configs")
     if 'scene' in args.tasks:

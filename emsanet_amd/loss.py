@@ -239,6 +239,7 @@ class TrainingLosses(torch.nn.Module):
     def __init__(self, args, semantic_class_weights, n_scene_classes):
         super().__init__()
         self.tasks = tuple(args.tasks)
+        self.panoptic = bool(getattr(args, 'enable_panoptic', False))
         self.weights = loss_weights(args)
         self.sem_multiscale = not args.semantic_no_multiscale_supervision
         self.inst_multiscale = not args.instance_no_multiscale_supervision
@@ -251,6 +252,11 @@ class TrainingLosses(torch.nn.Module):
     def forward(self, outputs, targets):
         """-> (total, dict of unweighted per-task losses summed over the scales)"""
         losses = {}
+        outputs = list(outputs)
+        if self.panoptic:
+            # PanopticHelper: ((semantic, instance), (semantic sides, instance sides)) first
+            (sem, inst), (sem_side, inst_side) = outputs[0]
+            outputs = [(sem, sem_side), (inst, inst_side)] + outputs[1:]
         it = iter(outputs)
         if 'semantic' in self.tasks:
             full, side = next(it)

@@ -136,3 +136,51 @@ def normalize_depth(depth_u16, mean, std, keep_invalid_zero=True):
                                           float(std), 1 if keep_invalid_zero else 0,
                                           Fn._stream()), 'emsa_normalize_depth')
     return out
+
+
+def panoptic_merge(semantic_idx, instance_ids, classes_is_thing, top_k=64, label_divisor=1000):
+    """Panoptic-DeepLab merge on device.  semantic_idx (N,H,W) int64 in [0, C); instance_ids
+    (N,H,W) int32 from `instance_assign` on the thing pixels -> dict(semantic (-1 = void),
+    instance, panoptic id = (class + 1) * label_divisor + instance, 0 = void)"""
+    n, h, w = semantic_idx.shape
+    dev = semantic_idx.device
+    nc = len(classes_is_thing)
+    thing = torch.tensor([1 if t else 0 for t in classes_is_thing], dtype=torch.uint8, device=dev)
+    sem = semantic_idx.contiguous()
+    ids = instance_ids.contiguous()
+    ws_votes = torch.empty(n * (top_k + 1) * nc, device=dev, dtype=torch.int32)
+    ws_class = torch.empty(n * (top_k + 1), device=dev, dtype=torch.int32)
+    pan_sem = torch.empty((n, h, w), device=dev, dtype=torch.int64)
+    pan_inst = torch.empty((n, h, w), device=dev, dtype=torch.int32)
+    pan_id = torch.empty((n, h, w), device=dev, dtype=torch.int64)
+    check(_lib.lib().emsa_panoptic_merge(sem.data_ptr(), ids.data_ptr(), thing.data_ptr(), n, h * w,
+                                         nc, top_k, label_divisor, ws_votes.data_ptr(),
+                                         ws_class.data_ptr(), pan_sem.data_ptr(),
+                                         pan_inst.data_ptr(), pan_id.data_ptr(), Fn._stream()),
+          'emsa_panoptic_merge')
+    return {'semantic': pan_sem, 'instance': pan_inst, 'panoptic': pan_id}
+
+
+class PanopticPostprocessing:
+    """`get_postprocessing_class('panoptic', ...)` of /root/reference/emsanet/decoder.py:141-155:
+    semantic arg-max -> thing mask as instance foreground -> centres / grouping -> merge."""
+
+    def __init__(self, instance_postprocessing, semantic_classes_is_thing, label_divisor=1000):
+        self.inst = instance_postprocessing
+        self.is_thing = tuple(bool(t) for t in semantic_classes_is_thing)
+        self.label_divisor = label_divisor
+
+    def __call__(self, semantic_logits, center, offset):
+        score, idx = softmax_argmax(semantic_logits)
+        thing = torch.tensor(self.is_thing, device=idx.device)[idx]          # (N,H,W) bool
+        r = {'semantic_segmentation_score': score, 'semantic_segmentation_idx': idx,
+             'panoptic_foreground_mask': thing}
+        inst = InstancePostprocessing(self.inst.threshold, self.inst.kernel, True, self.inst.top_k,
+                                      self.inst.normalized, self.inst.dist)(center, offset, thing)
+        r.update(inst)
+        m = panoptic_merge(idx, inst['instance_segmentation_idx'], self.is_thing, self.inst.top_k,
+                           self.label_divisor)
+        r['panoptic_segmentation_deeplab'] = m['panoptic']
+        r['panoptic_segmentation_deeplab_semantic_idx'] = m['semantic']
+        r['panoptic_segmentation_deeplab_instance_idx'] = m['instance']
+        return r

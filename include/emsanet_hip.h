@@ -373,6 +373,16 @@ int emsa_instance_assign(const float* offset, int32_t ld, int32_t n, int32_t h, 
                          float scale_y, float scale_x, const float* centers,
                          const int32_t* n_centers, int32_t top_k, const uint8_t* fg,
                          float max_distance, int32_t* ids, void* stream);
+/* panoptic merge: every instance (ids from emsa_instance_assign on the thing pixels) takes the
+ * majority semantic class of its pixels; stuff pixels keep their class; thing pixels without an
+ * instance become void.  pan_semantic (-1 = void), pan_instance, pan_id = (class+1)*label_divisor
+ * + instance (0 = void).  class_is_thing uint8[n_classes] (DEVICE); ws_votes int32[n*(top_k+1)*
+ * n_classes], ws_class int32[n*(top_k+1)] scratch.                                              */
+int emsa_panoptic_merge(const int64_t* semantic_idx, const int32_t* instance_ids,
+                        const uint8_t* class_is_thing, int32_t n, int64_t hw, int32_t n_classes,
+                        int32_t top_k, int32_t label_divisor, int32_t* ws_votes,
+                        int32_t* ws_class, int64_t* pan_semantic, int32_t* pan_instance,
+                        int64_t* pan_id, void* stream);
 int emsa_normalize_rgb(const uint8_t* rgb_hwc, float* out_chw, int32_t n, int32_t h, int32_t w,
                        float scale, const float* mean3, const float* std3, void* stream);
 int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t total, float mean, float std,

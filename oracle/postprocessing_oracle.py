@@ -63,3 +63,29 @@ def instance_assign(offsets, centers_per_image, foreground=None, normalized_offs
             lab[~foreground[i].bool()] = 0
         ids[i] = lab
     return ids
+
+
+def panoptic_merge(semantic_idx, instance_ids, classes_is_thing, label_divisor=1000):
+    """every instance takes the majority class (first maximum) of its thing pixels, stuff pixels
+    keep their class, thing pixels without an instance become void (-1 / panoptic id 0)"""
+    n = semantic_idx.shape[0]
+    thing_c = torch.tensor(classes_is_thing, dtype=torch.bool)
+    sem_o = torch.full_like(semantic_idx, -1)
+    inst_o = torch.zeros_like(instance_ids)
+    nc = len(classes_is_thing)
+    for i in range(n):
+        sem, ids = semantic_idx[i], instance_ids[i]
+        thing = thing_c[sem]
+        sem_o[i][~thing] = sem[~thing]
+        for k in ids.unique().tolist():
+            if k <= 0:
+                continue
+            m = (ids == k) & thing
+            if not m.any():
+                continue
+            votes = torch.bincount(sem[m], minlength=nc)
+            cls = int(votes.argmax())            # torch.argmax: first maximum
+            sem_o[i][m] = cls
+            inst_o[i][m] = k
+    pan = torch.where(sem_o < 0, torch.zeros_like(sem_o), (sem_o + 1) * label_divisor + inst_o.long())
+    return {'semantic': sem_o, 'instance': inst_o, 'panoptic': pan}

@@ -240,3 +240,37 @@ def test_input_size_must_be_multiple_of_32():
     model = _model(full_args(input_height=64, input_width=96))
     with pytest.raises(_lib.EmsaError, match='multiples of 32'):
         model({'rgb': torch.zeros(1, 3, 72, 104), 'depth': torch.zeros(1, 1, 72, 104)})
+
+
+def test_dry_run_panoptic_helper(fake_lib, monkeypatch):
+    """--enable-panoptic (/root/reference/emsanet/decoder.py:141-158): both decoders under
+    `decoders.panoptic_helper`, nested raw outputs, losses still reach every parameter"""
+    import emsanet_amd.model as M
+    from emsanet_amd import full_args
+    from emsanet_amd.loss import TrainingLosses
+    from oracle.emsanet_oracle import synthetic_batch
+    args = full_args(input_height=64, input_width=96, enable_panoptic=True)
+    model = _model(args).train()
+    keys = list(model.state_dict())
+    assert any(k.startswith('decoders.panoptic_helper.semantic_decoder.') for k in keys)
+    assert any(k.startswith('decoders.panoptic_helper.instance_decoder.') for k in keys)
+    assert not any(k.startswith('decoders.semantic_decoder.') for k in keys)
+    assert list(model.decoders.keys()) == ['panoptic_helper', 'scene_decoder']
+    monkeypatch.setattr(M.EMSANet, 'forward', _bypass_device_check(model))
+    outs = model(synthetic_batch(2, 64, 96))
+    (sem, inst), (sem_side, inst_side) = outs[0]
+    assert sem.shape == (2, 40, 64, 96) and len(inst) == 3 and len(sem_side) == 3
+    sizes = [(64, 96), (2, 3), (4, 6), (8, 12)]
+    targets = {'semantic': [torch.ones(2, h, w, dtype=torch.long) for h, w in sizes],
+               'instance': [dict(center=torch.zeros(2, 1, h, w), offset=torch.zeros(2, 2, h, w),
+                                 foreground=torch.ones(2, h, w, dtype=torch.bool),
+                                 orientation=torch.zeros(2, h, w),
+                                 orientation_foreground=torch.ones(2, h, w, dtype=torch.bool))
+                            for h, w in sizes],
+               'scene': torch.ones(2, dtype=torch.long)}
+    total, losses = TrainingLosses(args, torch.ones(40), 10)(outs, targets)
+    total.backward()
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+    # the surgery case "semantic-only model fed a panoptic checkpoint" still applies to these keys
+    from emsanet_amd.weights import load_weights        # noqa: F401

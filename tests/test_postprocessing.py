@@ -109,3 +109,48 @@ def test_model_postprocessing_keys():
     assert torch.equal(ix, r['semantic_segmentation_idx'])
     assert (sc - r['semantic_segmentation_score']).abs().max() <= 1e-6
     assert r['instance_segmentation_idx'].shape == (2, 64, 96)
+
+
+def test_panoptic_merge_vs_oracle():
+    from emsanet_amd.postprocessing import panoptic_merge
+    from oracle import postprocessing_oracle as O
+    g = torch.Generator().manual_seed(11)
+    n, h, w, nc, k = 2, 40, 56, 40, 64
+    is_thing = [bool(i % 3) for i in range(nc)]
+    # blocky semantic / instance maps so that instances have real majorities
+    sem = torch.randint(0, nc, (n, h // 4, w // 4), generator=g).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    ids = torch.randint(0, 9, (n, h // 8, w // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    ids = ids.to(torch.int32)
+    got = panoptic_merge(sem.to(DEV), ids.to(DEV), is_thing, top_k=k)
+    ref = O.panoptic_merge(sem, ids, is_thing)
+    for key in ('semantic', 'instance', 'panoptic'):
+        assert torch.equal(got[key].cpu(), ref[key].to(got[key].dtype)), key
+    assert (got['semantic'] == -1).any() and (got['instance'] > 0).any()
+
+
+def test_model_panoptic_postprocessing():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    args = full_args(input_height=64, input_width=96, enable_panoptic=True)
+    model = EMSANet(args, nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    with torch.no_grad():
+        raw = model(batch)
+        r = model(batch, do_postprocessing=True)
+    (sem, inst), (s1, s2) = raw[0]
+    assert sem.shape == (2, 40, 64, 96) and s1 == () and s2 == ()
+    for k in ('panoptic_segmentation_deeplab', 'panoptic_segmentation_deeplab_semantic_idx',
+              'panoptic_segmentation_deeplab_instance_idx', 'panoptic_foreground_mask',
+              'semantic_segmentation_idx', 'scene_class_idx'):
+        assert k in r, k
+    pan, ps, pi = (r['panoptic_segmentation_deeplab'], r['panoptic_segmentation_deeplab_semantic_idx'],
+                   r['panoptic_segmentation_deeplab_instance_idx'])
+    assert torch.equal(pan, torch.where(ps < 0, torch.zeros_like(pan), (ps + 1) * 1000 + pi.long()))
