@@ -357,6 +357,7 @@ def run(args):
         'conv_mfma_tflops_overall': round(conv_fl / conv_ms, 2) if conv_ms else None,
         'model_tflops_effective': round(step_gflop * world * args.steps / dt / 1e3, 2)
         if step_gflop else None,
+        'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args)
