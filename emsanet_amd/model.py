@@ -6,7 +6,6 @@
 tuples, or one merged dict), same attributes callers touch (`encoder`, `context_module`,
 `decoders`, `state_dict()`), see SURVEY.md §8(b).  All arithmetic runs in libemsanet_hip.so.
 """
-from collections import ChainMap
 from typing import Any, Dict
 
 import torch
@@ -23,75 +22,52 @@ class EMSANet(nn.Module):
         super().__init__()
         _lib.lib()     # fail loudly at construction if the HIP extension is missing
 
-        # store args and dataset parameters (model.py:34-36)
-        self.args = args
-        self.dataset_config = dataset_config
+        self.args, self.dataset_config = args, dataset_config          # (model.py:34-36)
+        labels = dataset_config.semantic_label_list_without_void       # (model.py:39-43)
+        n_sem, n_scene = len(labels), len(dataset_config.scene_label_list_without_void)
 
-        # dataset properties (model.py:39-43)
-        semantic_labels = dataset_config.semantic_label_list_without_void
-        semantic_n_classes = len(semantic_labels)
-        scene_n_classes = len(dataset_config.scene_label_list_without_void)
-        panoptic_semantic_classes_is_thing = semantic_labels.classes_is_thing
-        panoptic_use_orientation = tuple(semantic_labels.classes_use_orientations)
-
-        # encoders (model.py:46-92)
-        def backbone(name, block, n_in):
-            if block != 'nonbottleneck1d':
-                raise NotImplementedError(f"resnet block '{block}' (hot path is NBt1D)")
-            return ResNetNBt1D(name, n_in, args.dropout_p)
-
+        # --- encoders (model.py:46-106): one NBt1D ResNet per modality, SE-add fusion ----------
         if 'rgbd' in args.input_modalities:
             raise NotImplementedError("single rgbd encoder is not part of the hot path")
-        backbone_rgb = backbone(args.rgb_encoder_backbone,
-                                args.rgb_encoder_backbone_resnet_block, 3) \
-            if 'rgb' in args.input_modalities else None
-        backbone_depth = backbone(args.depth_encoder_backbone,
-                                  args.depth_encoder_backbone_resnet_block, 1) \
-            if 'depth' in args.input_modalities else None
         if getattr(args, 'activation', 'relu') != 'relu':
             raise NotImplementedError("only the default 'relu' activation has kernels")
-
-        # fused encoder (model.py:95-106)
-        self.encoder = FusedEncoder(backbone_rgb, backbone_depth, args.encoder_fusion,
+        nets = {}
+        for modality, n_in in (('rgb', 3), ('depth', 1)):
+            if modality not in args.input_modalities:
+                nets[modality] = None
+                continue
+            block = getattr(args, f'{modality}_encoder_backbone_resnet_block')
+            if block != 'nonbottleneck1d':
+                raise NotImplementedError(f"resnet block '{block}' (hot path is NBt1D)")
+            nets[modality] = ResNetNBt1D(getattr(args, f'{modality}_encoder_backbone'), n_in,
+                                         args.dropout_p)
+        self.encoder = FusedEncoder(nets['rgb'], nets['depth'], args.encoder_fusion,
                                     args.encoder_decoder_skip_downsamplings)
-        enc_downsampling = self.encoder.downsampling
-        enc_n_channels_out = self.encoder.n_channels_out
-        enc_skips_n_channels = self.encoder.skips_n_channels
+        c_enc, ds_enc = self.encoder.n_channels_out, self.encoder.downsampling
 
-        # context module (model.py:109-119)
+        # --- context module (model.py:109-119) --------------------------------------------------
         if args.context_module != 'ppm':
             raise NotImplementedError(f"context module '{args.context_module}'")
         self.context_module = PyramidPoolingModule(
-            enc_n_channels_out, enc_n_channels_out,
-            (args.input_height // enc_downsampling, args.input_width // enc_downsampling))
+            c_enc, c_enc, (args.input_height // ds_enc, args.input_width // ds_enc))
 
-        # decoders (model.py:122-160)
-        if args.instance_offset_encoding == 'tanh':
-            instance_normalized_offset, instance_tanh_for_offset = True, True
-        elif args.instance_offset_encoding == 'relative':
-            instance_normalized_offset, instance_tanh_for_offset = True, False
-        elif args.instance_offset_encoding == 'deeplab':
-            instance_normalized_offset, instance_tanh_for_offset = False, False
-        else:
-            raise NotImplementedError
-        instance_sigmoid_for_center = args.instance_center_encoding == 'sigmoid'
-
-        self.decoders = get_decoders(
-            args,
-            n_channels_in=enc_n_channels_out,
-            downsampling_in=enc_downsampling,
-            semantic_n_classes=semantic_n_classes,
-            instance_normalized_offset=instance_normalized_offset,
-            instance_offset_distance_threshold=args.instance_offset_distance_threshold,
-            instance_sigmoid_for_center=instance_sigmoid_for_center,
-            instance_tanh_for_offset=instance_tanh_for_offset,
-            normal_n_channels_out=3,
+        # --- decoders (model.py:122-160) ----------------------------------------------------------
+        # offset encoding -> (normalised by the image size?, tanh on the head?)
+        encodings = {'tanh': (True, True), 'relative': (True, False), 'deeplab': (False, False)}
+        if args.instance_offset_encoding not in encodings:
+            raise NotImplementedError(args.instance_offset_encoding)
+        offsets_normalised, offsets_tanh = encodings[args.instance_offset_encoding]
+        head_options = dict(
+            semantic_n_classes=n_sem, scene_n_classes=n_scene, normal_n_channels_out=3,
             scene_n_channels_in=self.context_module.n_channels_reduction,
-            scene_n_classes=scene_n_classes,
-            panoptic_semantic_classes_is_thing=panoptic_semantic_classes_is_thing,
-            panoptic_has_orientation=panoptic_use_orientation,
-            fusion_n_channels=enc_skips_n_channels[::-1],
-        )
+            instance_normalized_offset=offsets_normalised, instance_tanh_for_offset=offsets_tanh,
+            instance_sigmoid_for_center=args.instance_center_encoding == 'sigmoid',
+            instance_offset_distance_threshold=args.instance_offset_distance_threshold,
+            panoptic_semantic_classes_is_thing=labels.classes_is_thing,
+            panoptic_has_orientation=tuple(labels.classes_use_orientations),
+            fusion_n_channels=tuple(reversed(self.encoder.skips_n_channels)))
+        self.decoders = get_decoders(args, n_channels_in=c_enc, downsampling_in=ds_enc,
+                                     **head_options)
 
         # initialisation (model.py:162-190)
         if 'encoder-fusion' in args.he_init and self.encoder.two:
@@ -130,45 +106,33 @@ class EMSANet(nn.Module):
         return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF
 
     def forward(self, batch, do_postprocessing=False) -> Dict[str, Any]:
-        # determine input (model.py:194-204)
-        enc_inputs = {}
-        if 'rgb' in self.args.input_modalities:
-            enc_inputs['rgb'] = batch['rgb']
-        if 'depth' in self.args.input_modalities:
-            enc_inputs['depth'] = batch['depth']
-        for k, v in enc_inputs.items():
-            if v.dim() != 4 or v.shape[-2] % 32 or v.shape[-1] % 32:
+        """contract of /root/reference/emsanet/model.py:192-233: list of per-decoder
+        (outputs, side outputs) in `self.decoders` order, or one merged dict when post-processing"""
+        feeds = {m: batch[m] for m in ('rgb', 'depth') if m in self.args.input_modalities}
+        for name, t in feeds.items():
+            if t.dim() != 4 or t.shape[-2] % 32 or t.shape[-1] % 32:
                 # five stride-2 encoder stages and x2 decoder upsampling with skip additions
                 raise _lib.EmsaError(
-                    f"batch['{k}'] has shape {tuple(v.shape)}: height and width must be multiples "
-                    "of 32 (encoder downsampling 32, decoder skip connections)")
-            if not v.is_cuda:
+                    f"batch['{name}'] has shape {tuple(t.shape)}: height and width must be "
+                    "multiples of 32 (encoder downsampling 32, decoder skip connections)")
+            if not t.is_cuda:
                 raise _lib.EmsaError(
-                    f"batch['{k}'] lives on {v.device}: the EMSANet engine only runs on an AMD "
-                    "GPU (no CPU fallback)")
-
+                    f"batch['{name}'] lives on {t.device}: the EMSANet engine only runs on an "
+                    "AMD GPU (no CPU fallback)")
         self._pack_plan.refresh()
 
-        # forward (fused) encoder(s) (model.py:206)
-        enc_outputs, enc_dec_skips = self.encoder(enc_inputs)
+        deep, skips = self.encoder(feeds)
+        # the context module sees the fused rgb stream, or the only stream there is
+        ctx_in = deep['rgb'] if len(feeds) == 2 else next(iter(deep.values()))
+        ctx, ctx_branches = self.context_module(ctx_in)
 
-        # context module input (model.py:209-217)
-        if len(self.args.input_modalities) == 2:
-            con_input = enc_outputs['rgb']
-        else:
-            assert len(enc_inputs) == 1
-            con_input = enc_outputs[list(enc_inputs.keys())[0]]
-        con_outputs, con_context_outputs = self.context_module(con_input)
-
-        # decoders (model.py:220-227)
-        outputs = []
-        for decoder in self.decoders.values():
-            outputs.append(decoder((con_outputs, con_context_outputs), enc_dec_skips, batch,
-                                   do_postprocessing=do_postprocessing))
+        results = [dec((ctx, ctx_branches), skips, batch, do_postprocessing=do_postprocessing)
+                   for dec in self.decoders.values()]
         if self.training:
             self.dropout_step += 1
-
-        # simplify output if postprocessing was applied (model.py:230-231)
-        if do_postprocessing:
-            outputs = dict(ChainMap(*outputs))
-        return outputs
+        if not do_postprocessing:
+            return results
+        merged = {}
+        for r in reversed(results):          # earlier decoders win on duplicate keys
+            merged.update(r)
+        return merged
