@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   float* const As = smem;                          // [4 rows][32 pairs][kWLD]
   float* const Bs = smem + 4 * kPairs * kWLD;      // [4 comps][kWN n][kWLD]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave = component j
+  // wave = component j; uniform -> kept in an SGPR (so are the row choice and sign below)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
   const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
