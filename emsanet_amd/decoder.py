@@ -180,7 +180,10 @@ class InstanceDecoder(DecoderBody):
         if n_sig or n_tanh:
             if n_tanh and not n_sig:
                 raise NotImplementedError("tanh offsets without sigmoid centres")
-            y = ops.HeadActFunction.apply(y, n_sig, n_tanh)
+            # activation + split in one autograd node (its backward assembles the task gradients
+            # with strided channel copies instead of autograd's zero-filled slice gradients)
+            sizes = (1, 2, 2) if self.with_orientation else (1, 2)
+            return ops.HeadActFunction.apply(y, n_sig, n_tanh, sizes)
         center, offset = y[:, 0:1], y[:, 1:3]
         if not self.with_orientation:
             return center, offset

@@ -689,16 +689,35 @@ class PPMConcatFunction(Function):
 # head activations
 # ---------------------------------------------------------------------------------------------
 class HeadActFunction(Function):
+    """sigmoid / tanh on the leading channels of the (channel-padded) instance head output and the
+    split into the task tensors.  The outputs are channel-slice VIEWS of one activated tensor;
+    backward gathers their gradients into one padded tensor with strided channel copies -- slicing
+    outside (autograd's SliceBackward) materialised a zero-filled full-size tensor per task and
+    added them up: three fills, three copies and two adds of the 315 MB full-resolution tensor."""
+
     @staticmethod
-    def forward(ctx, x, n_sig, n_tanh):
+    def forward(ctx, x, n_sig, n_tanh, sizes):
         y = Fn.head_act_fwd(Fn.as_act(x, dense=True), n_sig, n_tanh)
         ctx.save_for_backward(y)
         ctx.cfg = (n_sig, n_tanh)
-        return y
+        ctx.sizes = tuple(sizes)
+        outs, o = [], 0
+        for sz in sizes:
+            outs.append(y[:, o:o + sz])
+            o += sz
+        return tuple(outs)
 
     @staticmethod
     @once_differentiable
     @_traced
-    def backward(ctx, dy):
+    def backward(ctx, *dys):
         (y,) = ctx.saved_tensors
-        return Fn.head_act_bwd(Fn.as_act(dy, dense=True), y, *ctx.cfg), None, None
+        n, c, h, w = y.shape
+        dy = Fn.act_empty(n, c, h, w, y.device)
+        o = 0
+        for sz, g in zip(ctx.sizes, dys):
+            Fn.copy_channels(Fn.as_act(g), dy[:, o:o + sz])
+            o += sz
+        if o < c:
+            dy[:, o:].zero_()                      # padding channels carry no gradient
+        return Fn.head_act_bwd(dy, y, *ctx.cfg), None, None, None

@@ -492,10 +492,16 @@ def test_head_act():
     dy = rnd(*y.shape, seed=2)
     y.backward(dy.double())
     xg = to_act(x.detach().float()).requires_grad_(True)
-    yg = ops.HeadActFunction.apply(xg, 1, 2)
-    close(yg, y, what='head act')
-    yg.backward(to_act(dy))
-    close(xg.grad, x.grad, what='head act bwd')
+    c, o, r = ops.HeadActFunction.apply(xg, 1, 2, (1, 2, 2))      # task slices of one tensor
+    assert c.shape[1] == 1 and o.shape[1] == 2 and r.shape[1] == 2
+    close(torch.cat([c, o, r], 1), y[:, :5], what='head act')
+    # gradients arrive per task (contiguous NCHW like a loss would produce them); the padding
+    # channels 5..7 receive none
+    torch.autograd.backward([c, o, r], [dy[:, :1].contiguous().to(DEV), dy[:, 1:3].contiguous().to(DEV),
+                                        dy[:, 3:5].contiguous().to(DEV)])
+    ref = x.grad.clone()       # activation-wise gradient; no cotangent reached channels 5..7
+    ref[:, 5:] = 0
+    close(xg.grad, ref, what='head act bwd')
 
 
 def test_copy_axpy():
