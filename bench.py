@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
     ap.add_argument('--force-dist', action='store_true',
                     help='validation: RCCL process group + bucketed all-reduce path with ONE rank')
+    ap.add_argument('--backbone', default='resnet34', choices=('resnet18', 'resnet34', 'resnet101'),
+                    help='NBt1D ResNet of both encoders (BASELINE config 4: resnet101 at 960x736)')
     ap.add_argument('--torch-optimizer', action='store_true',
                     help='A/B: torch.optim.SGD (foreach) instead of the fused bucket-wise SGD kernel')
     ap.add_argument('--losses', action='store_true',
@@ -124,7 +126,8 @@ def cpu_baseline(args):
     from emsanet_amd import full_args, nyuv2_config
     from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
     cores = torch.get_num_threads()
-    a = full_args(input_height=args.height, input_width=args.width)
+    a = full_args(input_height=args.height, input_width=args.width,
+                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone)
     o = EMSANetOracle(a, nyuv2_config())
     o.load_state_dict(deterministic_state_dict(o, 0))
     o.train()
@@ -188,7 +191,8 @@ def run(args):
     from emsanet_amd.parallel import GradientBuckets, broadcast_parameters
 
     L = _lib.lib()
-    a = full_args(input_height=args.height, input_width=args.width)
+    a = full_args(input_height=args.height, input_width=args.width,
+                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone)
     torch.manual_seed(0)
     model = EMSANet(a, nyuv2_config())
     deterministic_init_(model)
@@ -342,7 +346,7 @@ def run(args):
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'BASELINE.json configs[1]: full EMSANet RGB-D (ResNet-34-NBt1D x2, '
+        'config': {'workload': f'BASELINE.json configs[1]: full EMSANet RGB-D ({args.backbone}-NBt1D x2, '
                                'SE-add fusion, PPM, semantic+instance+orientation+scene heads), '
                                f'{args.width}x{args.height}, bs={bs}/GPU, fp32, train mode '
                                '(BN batch stats, Dropout2d), step = fwd + bwd (fixed output '
