@@ -85,6 +85,9 @@ class FusedSGD:
             check(L.emsa_sgd_nesterov(Fn._p(fp), Fn._p(flat_g), Fn._p(fm), fp.numel(), self.lr,
                                       self.momentum, self.weight_decay, scale,
                                       1 if self._first else 0, Fn._stream()), 'emsa_sgd_nesterov')
+            # the kernel wrote the parameters through raw pointers: tell autograd (and with it the
+            # engine's packed-weight caches, which key on `_version`) that they changed in place
+            torch.autograd.graph.increment_version(ps)
         self._first = False
 
     def state_dict(self):

@@ -62,3 +62,65 @@ def test_fused_sgd_matches_torch_sgd():
     sd = opt.state_dict()
     opt.load_state_dict(sd)
     assert len(sd['momentum_buffers']) == len(buckets.buckets)
+
+
+@pytest.mark.gpu
+def test_fused_sgd_invalidates_packed_weight_caches():
+    """FusedSGD writes the parameters through raw pointers; the engine's packed / Winograd weight
+    caches (keyed on the parameters' version counters) must be refreshed afterwards: after one
+    step the forward output equals that of an identical model stepped with torch.optim.SGD."""
+    import copy
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.optim import FusedSGD
+    from emsanet_amd.parallel import GradientBuckets
+    dev = 'cuda:0'
+    args = full_args(input_height=64, input_width=96)
+    m1 = EMSANet(args, nyuv2_config())
+    m1.load_state_dict(deterministic_state_dict(m1))
+    m1.to(dev).train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(0)
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(dev),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(dev)}
+
+    def fwd_bwd(m):
+        m.dropout_step = 0
+        outs = m(batch)
+        flat = [outs[0][0], *outs[1][0], outs[2][0]]
+        torch.autograd.backward(flat, [torch.ones_like(t) * 1e-4 for t in flat])
+        return [t.detach().clone() for t in flat]
+
+    b1 = GradientBuckets(list(m1.parameters()))
+    o1 = FusedSGD(b1, lr=1e-5, momentum=0.9, weight_decay=1e-4)
+    o2 = torch.optim.SGD(m2.parameters(), lr=1e-5, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    b1.reset()
+    before = fwd_bwd(m1)
+    fwd_bwd(m2)
+    v0 = next(m1.parameters())._version
+    b1.finish()
+    o1.step()
+    o2.step()
+    assert next(m1.parameters())._version > v0
+    with torch.no_grad():
+        m1.eval(); m2.eval()
+        a = m1(batch)[0][0]
+        b = m2(batch)[0][0]
+    assert torch.isfinite(b).all() and (a - b).abs().max() <= 1e-4 * b.abs().max()
+    # the cached Winograd / packed weights are those of the UPDATED parameters, bit for bit
+    from emsanet_amd import functional as Fn
+    changed = 0
+    for rt in m1._pack_plan.rts[:40]:
+        w = rt.conv.weight.detach()
+        if rt.wino:
+            assert torch.equal(rt._u, Fn.pack_wino(w)[0])
+        else:
+            assert torch.equal(rt._wp, Fn.pack_weight(w, 'fwd'))
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        assert (p1 - p2).abs().max() <= 2e-6 * max(1.0, float(p2.abs().max()))
+        changed += int(p1.grad is not None)
+    assert changed > 700 and before[0].isfinite().all()
