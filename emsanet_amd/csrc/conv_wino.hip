@@ -422,7 +422,12 @@ __global__ void pack_wino_packed_kernel(const float* __restrict__ wp, float* __r
 // job j owns workgroups [first_block[j], first_block[j+1]); kind 0: OIHW -> packed implicit-GEMM
 // layouts (dst0 = [tap][cout][cin], dst1 = [tap][cin][cout]); kind 1: OIHW -> Winograd U
 // (dst0 forward, dst1 data gradient; rows = 3 for a 3x3 kernel); NULL outputs are skipped
-__global__ void pack_batch_kernel(const EmsaPackJob* __restrict__ jobs, int n_jobs) {
+__global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __restrict__ jobs,
+                                                         int n_jobs) {
+  // 32 (co) x 32 (ci) tiles: reads and forward-layout writes run along ci, the transposed
+  // (data-gradient) layouts are written along co through an LDS transpose -- the element-wise
+  // version scattered 4-byte stores with stride cout and took 1.2 ms for the 63 M weights
+  __shared__ float tr[4][32][33];
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {                       // last job with first_block <= blockIdx.x
     const int mid = (lo + hi + 1) >> 1;
@@ -431,33 +436,60 @@ __global__ void pack_batch_kernel(const EmsaPackJob* __restrict__ jobs, int n_jo
   const EmsaPackJob jb = jobs[lo];
   const int nblk = (lo + 1 < n_jobs ? jobs[lo + 1].first_block : (int)gridDim.x) - jb.first_block;
   const int cout = jb.cout, cin = jb.cin;
-  const int start = (blockIdx.x - jb.first_block) * blockDim.x + threadIdx.x;
-  const int stride = nblk * blockDim.x;
-  if (jb.kind == 0) {
-    const int taps = jb.kh * jb.kw, total = cout * cin * taps;
-    for (int i = start; i < total; i += stride) {
-      const int tap = i % taps, r = i / taps, ci = r % cin, co = r / cin;
-      const float v = jb.src[i];
-      if (jb.dst0) jb.dst0[((size_t)tap * cout + co) * cin + ci] = v;
-      if (jb.dst1) jb.dst1[((size_t)tap * cin + ci) * cout + co] = v;
-    }
-  } else {
-    const int R = (jb.kh == 3 && jb.kw == 3) ? 3 : 1, total = cout * cin * R;
-    for (int i = start; i < total; i += stride) {
-      const int r = i % R, ci = (i / R) % cin, co = i / (R * cin);
-      const float* g = jb.src + (size_t)i * 3;
-      const float g0 = g[0], g1 = g[1], g2 = g[2];
-      const float sm = 0.5f * (g0 + g2), h = 0.5f * g1;
-      const size_t NK = (size_t)cout * R * cin;
-      if (jb.dst0) {
-        const size_t o = ((size_t)co * R + r) * cin + ci;
-        jb.dst0[0 * NK + o] = g0; jb.dst0[1 * NK + o] = sm + h;
-        jb.dst0[2 * NK + o] = sm - h; jb.dst0[3 * NK + o] = g2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+  const int tco = (cout + 31) / 32, tci = (cin + 31) / 32;
+  const bool wino = jb.kind == 1;
+  const int taps = jb.kh * jb.kw;
+  const int R = wino ? ((jb.kh == 3 && jb.kw == 3) ? 3 : 1) : taps;   // slices per (co, ci)
+  const int n_tiles = tco * tci * R;
+  for (int tile = blockIdx.x - jb.first_block; tile < n_tiles; tile += nblk) {
+    const int r = tile % R, t2 = tile / R, ci0 = (t2 % tci) * 32, co0 = (t2 / tci) * 32;
+    float vals[4][4];                      // [row group k][component]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+      const bool ok = co < cout && ci < cin;
+      if (wino) {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (ok) {
+          const float* g = jb.src + (((size_t)co * cin + ci) * R + r) * 3;
+          g0 = g[0]; g1 = g[1]; g2 = g[2];
+        }
+        const float sm = 0.5f * (g0 + g2), h = 0.5f * g1;
+        vals[k][0] = g0; vals[k][1] = sm + h; vals[k][2] = sm - h; vals[k][3] = g2;
+        if (ok && jb.dst0) {
+          const size_t NK = (size_t)cout * R * cin, o = ((size_t)co * R + r) * cin + ci;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) jb.dst0[j * NK + o] = vals[k][j];
+        }
+      } else {
+        const float v = ok ? jb.src[((size_t)co * cin + ci) * taps + r] : 0.f;
+        vals[k][0] = v;
+        if (ok && jb.dst0) jb.dst0[((size_t)r * cout + co) * cin + ci] = v;
       }
-      if (jb.dst1) {
-        const size_t o = ((size_t)ci * R + (R - 1 - r)) * cout + co;
-        jb.dst1[0 * NK + o] = g2; jb.dst1[1 * NK + o] = sm + h;
-        jb.dst1[2 * NK + o] = sm - h; jb.dst1[3 * NK + o] = g0;
+    }
+    if (jb.dst1) {
+      const int ncomp = wino ? 4 : 1;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < ncomp; ++j) tr[j][ty + 8 * k][tx] = vals[k][j];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ci = ci0 + ty + 8 * k, co = co0 + tx;          // transposed roles
+        if (ci < cin && co < cout) {
+          if (wino) {
+            // data gradient: taps flipped (components 0 <-> 3) and kernel rows reversed
+            const size_t NK = (size_t)cin * R * cout, o = ((size_t)ci * R + (R - 1 - r)) * cout + co;
+            jb.dst1[0 * NK + o] = tr[3][tx][ty + 8 * k];
+            jb.dst1[1 * NK + o] = tr[1][tx][ty + 8 * k];
+            jb.dst1[2 * NK + o] = tr[2][tx][ty + 8 * k];
+            jb.dst1[3 * NK + o] = tr[0][tx][ty + 8 * k];
+          } else {
+            jb.dst1[((size_t)r * cin + ci) * cout + co] = tr[0][tx][ty + 8 * k];
+          }
+        }
       }
     }
   }
