@@ -713,6 +713,9 @@ struct Wgrad1dArgs {
   float* dw;
   float* dbias;
   int M, L, n_ch, k_ch;              // M = n_img*A*L pixels, L = line length along the conv
+  int Lr;                            // real line length: L = Lr, or Lr + 1 (an odd line gets one
+                                     // virtual zero pixel so that the Winograd pairs never
+                                     // straddle lines; positions >= Lr read as zero)
   int in_sa, in_sb, in_simg;         // element strides of x for (a, b, img)
   int dy_sa, dy_sb, dy_simg;         // element strides of dy
   int steps_total, steps_per_split, n_co_tiles, n_ci_tiles, n_tiles;
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
       if (++a >= p.A) { a -= p.A; ++img; }
     }
     const int a2 = a + dl;
-    if (a2 < 0 || a2 >= p.A) return kOOB;
+    if (a2 < 0 || a2 >= p.A || b >= p.Lr) return kOOB;
     return (__umul24((uint32_t)img, (uint32_t)simg) + __umul24((uint32_t)a2, (uint32_t)sa) +
             __umul24((uint32_t)b, (uint32_t)sb)) * 4u;
   };
@@ -1175,9 +1178,9 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
       getenv("EMSA_WGRAD_GENERIC"))
     return false;
   Wgrad1dArgs& w = pl.w;
-  w.M = g->n_img * g->out_h * g->out_w; w.n_ch = g->n_ch; w.k_ch = g->k_ch;
+  w.n_ch = g->n_ch; w.k_ch = g->k_ch;
   const int H = g->out_h, W = g->out_w;
-  w.L = along_w ? W : H;
+  w.Lr = along_w ? W : H;
   const int A = along_w ? H : W;
   w.A = A;
   w.R = sq ? 3 : 1;
@@ -1194,20 +1197,23 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
   if (w.in_simg >= (1 << 24) || w.dy_simg >= (1 << 24) || w.in_sa >= (1 << 24) ||
       w.dy_sa >= (1 << 24) || g->n_img >= (1 << 24))
     return false;
+  // even line length -> Winograd F(3,2) over pixel pairs (EMSA_WGRAD_WINO=0: direct form); an odd
+  // line is enumerated with one virtual zero pixel appended (e.g. the 15-pixel lines at /32)
+  static const bool wino_on = [] {
+    const char* e = getenv("EMSA_WGRAD_WINO");
+    return !(e && e[0] == '0');
+  }();
+  pl.wino = wino_on;
+  w.L = (pl.wino && (w.Lr & 1)) ? w.Lr + 1 : w.Lr;
+  w.M = g->n_img * A * w.L;
   w.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
-  w.dout_bytes = (uint32_t)((size_t)w.M * g->ld_out * sizeof(float));
+  w.dout_bytes = (uint32_t)((size_t)g->n_img * H * W * g->ld_out * sizeof(float));
   w.div_al = make_fastdiv((uint32_t)(A * w.L));
   w.div_l = make_fastdiv((uint32_t)w.L);
   w.n_co_tiles = (g->n_ch + 63) / 64;
   w.n_ci_tiles = (g->k_ch + 63) / 64;
   w.n_tiles = w.n_co_tiles * w.n_ci_tiles;
   w.steps_total = (w.M + 31) / 32;
-  // even line length -> Winograd F(3,2) over pixel pairs (EMSA_WGRAD_WINO=0: direct form)
-  static const bool wino_on = [] {
-    const char* e = getenv("EMSA_WGRAD_WINO");
-    return !(e && e[0] == '0');
-  }();
-  pl.wino = wino_on && (w.L & 1) == 0;
   // split-K: one round of resident workgroups for the Winograd variant (3 per CU), two rounds
   // of 3 for the direct one (4 per CU) -- measured optima (EMSA_W1D_BLOCKS: tuning only)
   static const int forced_blocks = [] {
