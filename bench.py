@@ -344,7 +344,10 @@ def run(args):
         'metric': 'images/sec (640x480 RGB-D, bs=32/GPU) fwd+bwd',
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 2),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        # EMSA_BF16_MFMA=1 is an opt-in mixed-precision mode (BASELINE config 3), never the headline
+        'dtype': 'bf16-mfma/f32-accumulate+storage' if os.environ.get('EMSA_BF16_MFMA') == '1'
+        else 'f32',
         'data': 'synthetic',
         'config': {'workload': f'BASELINE.json configs[1]: full EMSANet RGB-D ({args.backbone}-NBt1D x2, '
                                'SE-add fusion, PPM, semantic+instance+orientation+scene heads), '

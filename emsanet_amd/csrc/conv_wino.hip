@@ -31,6 +31,7 @@ constexpr int kWLD = kWK;        // LDS row = 16 floats (64 B), unpadded: 16-B c
 constexpr int kPairs = 32;       // output pairs per workgroup
 
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 constexpr uint32_t kOOBw = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -72,7 +73,11 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
   return (__umulhi(n, mul) + n) >> sh;
 }
 
-template <int kWN>      // output channels per workgroup: 64 (2 MFMA tiles per wave) or 32 (1)
+// BF16 (EMSA_BF16_MFMA=1, NOT the default and not the headline metric: BASELINE config 3's mixed
+// precision): the operands are rounded to bf16 when they leave LDS and one
+// v_mfma_f32_32x32x16_bf16 replaces eight fp32 MFMAs; accumulation, the Winograd transforms and
+// everything in HBM stay fp32.
+template <int kWN, bool BF16 = false>   // kWN: output channels per workgroup, 64 (2 MFMA tiles per wave) or 32
 __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(const WinoArgs p) {
   constexpr int NT = kWN / 32;                    // accumulator tiles per wave
   constexpr int NC4 = kWN / 4;                    // float4 columns of a tile row
@@ -176,6 +181,25 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     const float* a1 = As + (rb_ * kPairs + l31) * kWLD;
     const float* b = Bs + (wave * kWN + l31) * kWLD;
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (BF16) {
+      // this lane's 8 k values of the step: chunks lh and lh + 2 (the same permutation for A and B)
+      const int c0 = (lh << 2) ^ sw, c1 = ((lh + 2) << 2) ^ sw;
+      const float4 p0 = emsa_ld4(a0 + c0), q0 = emsa_ld4(a1 + c0);
+      const float4 p1 = emsa_ld4(a0 + c1), q1 = emsa_ld4(a1 + c1);
+      wbf16x8 va;
+      va[0] = (__bf16)(p0.x + sg * q0.x); va[1] = (__bf16)(p0.y + sg * q0.y);
+      va[2] = (__bf16)(p0.z + sg * q0.z); va[3] = (__bf16)(p0.w + sg * q0.w);
+      va[4] = (__bf16)(p1.x + sg * q1.x); va[5] = (__bf16)(p1.y + sg * q1.y);
+      va[6] = (__bf16)(p1.z + sg * q1.z); va[7] = (__bf16)(p1.w + sg * q1.w);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const float4 w0 = emsa_ld4(b + u * 32 * kWLD + c0), w1 = emsa_ld4(b + u * 32 * kWLD + c1);
+        wbf16x8 vb;
+        vb[0] = (__bf16)w0.x; vb[1] = (__bf16)w0.y; vb[2] = (__bf16)w0.z; vb[3] = (__bf16)w0.w;
+        vb[4] = (__bf16)w1.x; vb[5] = (__bf16)w1.y; vb[6] = (__bf16)w1.z; vb[7] = (__bf16)w1.w;
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc[u], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < kWK / 8; ++t) {
       const int co = ((lh + 2 * t) << 2) ^ sw;     // swizzled chunk offset (floats)
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
 #pragma unroll
       for (int u = 0; u < NT; ++u)
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb[u].w, acc[u], 0, 0, 0);
+    }
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
@@ -623,12 +648,19 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   const int ps = emsa_prof_begin(kProfClassWino, flops, (hipStream_t)stream);
   // one workgroup per tile: a persistent grid with cross-tile prefetch measured SLOWER on MI355X
   // (static tile partition quantises to whole rounds: c256 /16 124 us vs 103 us)
-  if (wn == 64)
-    hipLaunchKernelGGL(conv1d_wino_kernel<64>, dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
+  static const bool bf16 = [] {
+    const char* e = getenv("EMSA_BF16_MFMA");
+    return e && e[0] == '1';
+  }();
+  if (wn == 64 && bf16)
+    hipLaunchKernelGGL((conv1d_wino_kernel<64, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
                        (hipStream_t)stream, a);
+  else if (wn == 64)
+    hipLaunchKernelGGL((conv1d_wino_kernel<64, false>), dim3(a.tiles_m * a.tiles_n), dim3(256),
+                       lds, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(conv1d_wino_kernel<32>, dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv1d_wino_kernel<32, false>), dim3(a.tiles_m * a.tiles_n), dim3(256),
+                       lds, (hipStream_t)stream, a);
   emsa_prof_end(ps, (hipStream_t)stream);
   return emsa_launch_status();
 }

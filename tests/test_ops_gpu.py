@@ -518,3 +518,34 @@ def test_copy_axpy():
     b0 = b.clone()
     Fn.axpy_(b, a, 0.5)
     close(b, b0.cpu() + 0.5 * a.cpu(), tol=1e-6, what='axpy')
+
+
+def test_conv1d_winograd_bf16_mfma_subprocess():
+    """EMSA_BF16_MFMA=1 (opt-in mixed precision, BASELINE config 3): operands rounded to bf16 for
+    the matrix instruction, fp32 accumulate / storage.  Checked in a subprocess (the mode is a
+    process-wide switch) against the fp64 convolution with a bf16-sized tolerance."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, torch
+sys.path.insert(0, "tests")
+import torch.nn.functional as F
+from util import DEV, rnd, to_act
+from emsanet_amd import functional as Fn
+worst = 0.0
+for cin, cout, k in ((64, 64, (1, 3)), (256, 128, (3, 1)), (128, 40, (3, 3))):
+    x = rnd(2, cin, 12, 20, seed=1); wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    ref = F.conv2d(x.double(), wt.double(), padding=(k[0] // 2, k[1] // 2))
+    spec = Fn.ConvSpec(cin, cout, k, (1, 1), (k[0] // 2, k[1] // 2))
+    y = Fn.conv_fwd(to_act(x), None, spec, wino_u=Fn.pack_wino(wt.to(DEV))[0])
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    worst = max(worst, err)
+    assert 1e-5 < err < 2e-2, err      # really bf16 (not the fp32 path), and bf16-accurate
+print("BF16_OK %.2e" % worst)
+'''
+    env = dict(os.environ, EMSA_BF16_MFMA='1')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert 'BF16_OK' in r.stdout, r.stderr[-2000:]
