@@ -178,13 +178,17 @@ def run(args):
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # RCCL over xGMI
+        # RCCL over xGMI; EMSA_DIST_BACKEND=gloo only exists to rehearse the multi-rank flow on a
+        # one-GPU box (RCCL refuses two ranks on one device)
+        dist.init_process_group(os.environ.get('EMSA_DIST_BACKEND', 'nccl'), rank=rank,
+                                world_size=world)
 
     from emsanet_amd import _lib, full_args, nyuv2_config
     from emsanet_amd.model import EMSANet

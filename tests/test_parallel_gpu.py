@@ -1,0 +1,147 @@
+"""Two ranks, real kernels: the data-parallel step of SURVEY.md §8(e) rehearsed on ONE GPU.
+
+RCCL refuses two ranks on one device, so the ranks exchange through gloo (which accepts device
+tensors) while every kernel of the engine runs on cuda:0 -- the flow is exactly the one
+`bench.py --gpus N` runs under torch.distributed.run: broadcast of the start parameters, one
+bs/GPU shard per rank, bucketed asynchronous all-reduce fired from the autograd hooks while the
+backward pass is still running, fused SGD on the flat buckets."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W, BS = 64, 96, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flatten(outs):
+    flat = []
+    for o, sides in outs:
+        flat += list(o) if isinstance(o, tuple) else [o]
+        for s in sides:
+            flat += list(s) if isinstance(s, tuple) else [s]
+    return flat
+
+
+def _batch(rank, dev):
+    rng = np.random.default_rng(1234 + rank)
+    rgb = rng.integers(0, 255, (BS, H, W, 3), dtype=np.uint8).astype(np.float32) / 255
+    depth = rng.integers(0, 40000, (BS, H, W), dtype=np.uint16).astype(np.float32) / 20000
+    return {'rgb': torch.from_numpy(rgb.transpose(0, 3, 1, 2).copy()).to(dev),
+            'depth': torch.from_numpy(depth[:, None].copy()).to(dev)}
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['EMSA_DETERMINISTIC'] = '1'       # two-pass weight gradients: run-to-run identical
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.optim import FusedSGD
+    from emsanet_amd.parallel import GradientBuckets, broadcast_parameters
+
+    torch.manual_seed(rank)                      # replicas start DIFFERENT; broadcast must fix it
+    model = EMSANet(full_args(input_height=H, input_width=W), nyuv2_config()).to(dev)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('bn2.weight'):
+                p.fill_(0.3)
+    broadcast_parameters(model)
+    model.train()
+    batch = _batch(rank, dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def backward():
+        model.dropout_step = 0
+        flat = _flatten(model(batch))
+        g = torch.Generator().manual_seed(4321)
+        cots = [(torch.randn(t.shape, generator=g) * 1e-2).to(dev).contiguous(
+            memory_format=torch.channels_last if t.dim() == 4 else torch.contiguous_format)
+            for t in flat]
+        torch.autograd.backward(flat, cots)
+
+    # (1) this rank's own gradients, no exchange; the expected result is their mean over ranks.
+    # Taken twice: what differs between the two is the run-to-run rounding noise of the kernels
+    # that accumulate with atomics, the yardstick for (2)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    backward()
+    local = [p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    backward()
+    again = [p.grad.detach().clone() for p in params]
+
+    def mean_over_ranks(ts):
+        out = []
+        for g in ts:
+            t = g.clone()
+            dist.all_reduce(t)
+            out.append(t / world)
+        return out
+
+    expect, expect2 = mean_over_ranks(local), mean_over_ranks(again)
+    gmax = max(e.abs().max().item() for e in expect)
+
+    def rel(a, b):
+        # (biases in front of a train-mode BatchNorm have a mathematically zero gradient: only
+        # rounding noise, so the yardstick has a floor relative to the largest gradient)
+        return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-2 * gmax)
+
+    noise = max(rel(a, b) for a, b in zip(expect2, expect))
+
+    # (2) the product flow: hooks -> bucket gather -> async all-reduce -> average
+    buckets = GradientBuckets(params, bucket_bytes=8 << 20)
+    opt = FusedSGD(buckets, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    buckets.reset()
+    backward()
+    buckets.finish()
+    errs = [rel(p.grad, e) for p, e in zip(params, expect)]
+    worst = max(errs)
+    worst_name = names[errs.index(worst)]
+    in_bucket = all(p.grad.data_ptr() == v.data_ptr()
+                    for _, ps, views in buckets.buckets for p, v in zip(ps, views))
+    opt.step()
+    # (3) replicas stay bit-identical after the update
+    digest = torch.stack([p.detach().double().sum() for p in params])
+    both = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(both, digest)
+    same = bool((both[0] == both[1]).all().item())
+    differs = any((a - b).abs().max().item() > 0 for a, b in zip(local, expect))
+    if rank == 0:
+        ret.update(worst=worst, noise=noise, worst_name=worst_name, in_bucket=in_bucket, same=same, differs=differs,
+                   n_buckets=len(buckets.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_training_step_on_one_gpu():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret['n_buckets'] > 1
+    assert ret['differs'], "ranks saw the same data: the test would not notice a missing exchange"
+    assert ret['in_bucket'], "gradients must live in the reduced flat buffers after finish()"
+    # all-reduced bucket == mean of the ranks' own gradients, up to the run-to-run rounding noise
+    print(f"bucket vs mean-of-ranks: worst {ret['worst']:.2e} ({ret['worst_name']}), "
+          f"run-to-run noise {ret['noise']:.2e}")
+    assert ret['worst'] <= max(1e-5, 4 * ret['noise']), (ret['worst'], ret['noise'],
+                                                          ret['worst_name'])
+    assert ret['same'], "replicas diverged after the fused SGD step"
