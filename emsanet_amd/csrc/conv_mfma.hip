@@ -564,7 +564,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       }
 #endif
       rd[j] = v;
-      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
     }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
@@ -598,7 +597,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     float* d = smem + buf * BUF;
     float* x = d + PK * BCO;
 #pragma unroll
-    for (int j = 0; j < DR; ++j) emsa_st4(d + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+    for (int j = 0; j < DR; ++j) {
+      // (the bias gradient = column sums of dy is accumulated HERE, where the prefetched
+      //  registers are consumed anyway: summing right behind the load puts the wave to sleep
+      //  on s_waitcnt until the next step's data has arrived, before this step's MFMAs)
+      bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;
+      emsa_st4(d + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+    }
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
@@ -736,6 +741,9 @@ struct Wgrad1dArgs {
 #ifndef EMSA_W1D_WPE
 #define EMSA_W1D_WPE 4
 #endif
+#ifndef EMSA_W1D_PIPE
+#define EMSA_W1D_PIPE 0   // pin the LDS reads of the next pixel pair ahead of the MFMA group
+#endif
 // WINO = Winograd F(3,2) over pixel PAIRS along the line (needs an even line length):
 //   dW_t = sum_pairs sum_i e_i d_(i+t),  e_i = dy(2p+i), d_r = x(2p-1+r)   ->   4 products per pair
 //   E = (e0, e0+e1, e0-e1, -e1)   D = (d0-d2, d1+d2, d2-d1, d1-d3)   M_k = sum_pairs E_k (x) D_k
@@ -773,59 +781,54 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
   const int x_c4 = (tid % XTPR) * 4, x_r = tid / XTPR;
   const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
 
-  // Address of pixel k0 + c (c = this thread's row within the step, -1..33).  The step base k0 is
-  // uniform: it is decomposed into (image, line, position) ONCE per step on the scalar unit
-  // (`base`), each thread then walks its few pixels of carry and multiplies with 24-bit
-  // full-rate multiplies -- the per-load address arithmetic was ~45 VALU instructions with seven
-  // quarter-rate 32-bit multiplies, i.e. as much VALU time as the step's MFMA time.
-  // dl = line shift (x of a 3x3 row tap; a shifted line outside the image is zero padding)
-  struct StepBase { int k0, img, a, b; };
-  auto step_base = [&](int k0) -> StepBase {
-    const int img = (int)fast_div((uint32_t)k0, p.div_al);
-    const int rem = k0 - img * (int)p.div_al.d;
-    const int a = (int)fast_div((uint32_t)rem, p.div_l);
-    return StepBase{k0, img, a, rem - a * p.L};
-  };
-  auto pixel_off = [&](const StepBase& sbs, int c, int sa, int sb, int simg, int dl) -> uint32_t {
-    const int k = sbs.k0 + c;
-    if (k < 0 || k >= p.M) return kOOB;
-    int img = sbs.img, a = sbs.a, b = sbs.b + c;
-    if (b < 0) {                                   // c = -1 at the start of a line
-      b += p.L;
-      if (--a < 0) { a += p.A; --img; }
-    }
-    while (b >= p.L) {                             // at most ceil(34 / L) iterations
-      b -= p.L;
-      if (++a >= p.A) { a -= p.A; ++img; }
-    }
-    const int a2 = a + dl;
-    if (a2 < 0 || a2 >= p.A || b >= p.Lr) return kOOB;
-    return (__umul24((uint32_t)img, (uint32_t)simg) + __umul24((uint32_t)a2, (uint32_t)sa) +
-            __umul24((uint32_t)b, (uint32_t)sb)) * 4u;
-  };
-
+  // Addresses of the step's pixels k0 - 1 .. k0 + 32: every row of the two tiles is one pixel,
+  // shared by the 16 lanes that load its channels, so lane l of each wave decomposes pixel
+  // k0 + l - 1 ONCE (image, line, position -> byte offsets into x and dy, or kOOB) and the
+  // loading threads fetch their rows' offsets with wave shuffles (ds_bpermute).  ~45 VALU
+  // instructions per step; per-thread decomposition of each of the five loads was ~350, as much
+  // issue time as the step's 32 MFMAs.
+  // x is read `dline` lines away (3x3 row tap; a shifted line outside the image is zero padding)
+  uint32_t mleft = 0, mright = 0, mleft_n = 0, mright_n = 0;
   float4 rd[DR], rx[XR];
   float4 bsum = emsa_zero4();
   auto load_regs = [&](int s) {
-    const int k0 = s * PK;
-    const StepBase sbs = step_base(k0);
+    const int k = s * PK + lane - 1;
+    const bool valid = lane < XROWS && k >= 0 && k < p.M;
+    const uint32_t ku = valid ? (uint32_t)k : 0u;
+    const uint32_t img = fast_div(ku, p.div_al);
+    const uint32_t line = fast_div(ku, p.div_l);                 // = img * A + a
+    const int b_ = (int)(ku - __umul24(line, (uint32_t)p.L));
+    const int a_ = (int)(line - __umul24(img, (uint32_t)p.A));
+    const int a2 = a_ + dline;
+    const bool in_line = valid && b_ < p.Lr;
+    const uint32_t off_d = in_line
+        ? (__umul24(img, (uint32_t)p.dy_simg) + __umul24((uint32_t)a_, (uint32_t)p.dy_sa) +
+           __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * 4u : kOOB;
+    const uint32_t off_x = (in_line && a2 >= 0 && a2 < p.A)
+        ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa) +
+           __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * 4u : kOOB;
+    // line-end masks of the step's 32 pixels (lanes 1..32): bit r set = tap 0 (left) / tap 2
+    // (right) of pixel k0 + r crosses a line end
+    const bool px = lane >= 1 && lane <= PK;
+    mleft_n = (uint32_t)(__ballot(px && b_ == 0) >> 1);
+    mright_n = (uint32_t)(__ballot(px && b_ == p.L - 1) >> 1);
     const uint32_t cob = (co0 + d_c4) < p.n_ch ? (uint32_t)(co0 + d_c4) * 4u : kOOB;
     const uint32_t cib = (ci0 + x_c4) < p.k_ch ? (uint32_t)(ci0 + x_c4) * 4u : kOOB;
 #pragma unroll
     for (int j = 0; j < DR; ++j) {
-      const uint32_t o = pixel_off(sbs, d_r + j * (256 / DTPR), p.dy_sa, p.dy_sb, p.dy_simg, 0);
+      const int r = d_r + j * (256 / DTPR);                      // dy row r = pixel k0 + r
+      const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((r + 1) * 4, (int)off_d);
 #if EMSA_ABL & 1
       rd[j] = make_float4(o, cob, 1.f, 2.f);
 #else
       rd[j] = buf_ld4(rs_dy, ((o | cob) & kOOB) ? kOOB : o + cob);
 #endif
-      bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;
     }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
-      const int r = x_r + j * (256 / XTPR);
-      const uint32_t o = r < XROWS ? pixel_off(sbs, r - 1, p.in_sa, p.in_sb, p.in_simg, dline)
-                                   : kOOB;
+      const int r = x_r + j * (256 / XTPR);                      // x row r = pixel k0 + r - 1
+      uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((r & 63) * 4, (int)off_x);
+      o = r < XROWS ? o : kOOB;
 #if EMSA_ABL & 1
       rx[j] = make_float4(o, cib, 1.f, 2.f);
 #else
@@ -835,7 +838,12 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
   };
   auto store_lds = [&]() {
 #pragma unroll
-    for (int j = 0; j < DR; ++j) emsa_st4(dS + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+    for (int j = 0; j < DR; ++j) {
+      // (bias gradient: summed where the prefetched registers are consumed, never right behind
+      //  the load -- that would stall this step's MFMAs on the NEXT step's data)
+      bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;
+      emsa_st4(dS + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+    }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int r = x_r + j * (256 / XTPR);
@@ -860,32 +868,39 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
 
   for (int s = s_begin; s < s_end; ++s) {
     const bool has_next = s + 1 < s_end;
+    mleft = mleft_n;                         // masks of THIS step (set when it was loaded)
+    mright = mright_n;
     if (has_next) load_regs(s + 1);
-    // line-end masks of this step's 32 pixels: bit r set = tap 0 (left) / tap 2 (right) invalid
-    const int k0 = s * PK;
-    const int kk0 = k0 + (lane & 31);
-    const int a_ = (int)fast_div((uint32_t)kk0, p.div_l);
-    const int pos = kk0 - a_ * p.L;          // (img*A + a)*L + b  ->  b (L divides A*L)
-    const uint32_t mleft = (uint32_t)__ballot(lane < 32 && pos == 0);
-    const uint32_t mright = (uint32_t)__ballot(lane < 32 && pos == p.L - 1);
-
     if constexpr (WINO) {
       // K index of the MFMA = pixel pair: lane half lh takes pair 2*kk + lh of the step's 16
       const float* d = dS + wco * 32 + l31;
       const float* x = xS + wci * 32 + l31;
+      // operands of pair kk + 1 are read from LDS BEFORE the four MFMAs of pair kk are issued,
+      // so the LDS latency hides behind 256 matrix-pipe cycles instead of the last 64
+      float e0, e1, d0, d1, d2, d3;
+      auto lds_pair = [&](int kk, float& f0, float& f1, float& g0, float& g1, float& g2,
+                          float& g3) {
+        const int row = 2 * (2 * kk + lh);           // first pixel of the pair within the step
+        f0 = d[row * BCO]; f1 = d[(row + 1) * BCO];
+        g0 = x[row * BCI];                           // xS row 0 = pixel k0 - 1
+        g1 = x[(row + 1) * BCI]; g2 = x[(row + 2) * BCI]; g3 = x[(row + 3) * BCI];
+      };
+      lds_pair(0, e0, e1, d0, d1, d2, d3);
 #pragma unroll
       for (int kk = 0; kk < PK / 4; ++kk) {
-        const int row = 2 * (2 * kk + lh);           // first pixel of the pair within the step
-        const float e0 = d[row * BCO], e1 = d[(row + 1) * BCO];
-        float d0 = x[row * BCI];                     // xS row 0 = pixel k0 - 1
-        const float d1 = x[(row + 1) * BCI], d2 = x[(row + 2) * BCI];
-        float d3 = x[(row + 3) * BCI];
+        const int row = 2 * (2 * kk + lh);
+        float n0 = 0.f, n1 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+        if (kk + 1 < PK / 4) lds_pair(kk + 1, n0, n1, m0, m1, m2, m3);
+#if EMSA_W1D_PIPE
+        __builtin_amdgcn_sched_barrier(0);           // keep the reads AHEAD of the MFMA group
+#endif
         d0 = ((mleft >> row) & 1u) ? 0.f : d0;
         d3 = ((mright >> (row + 1)) & 1u) ? 0.f : d3;
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, d0 - d2, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, d1 + d2, acc[0][1], 0, 0, 0);
         acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, d2 - d1, acc[0][2], 0, 0, 0);
         acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-e1, d1 - d3, acc[0][3], 0, 0, 0);
+        e0 = n0; e1 = n1; d0 = m0; d1 = m1; d2 = m2; d3 = m3;
       }
     } else {
     const float* d = dS + lh * BCO + wco * 32 + l31;
