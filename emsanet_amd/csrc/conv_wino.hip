@@ -39,6 +39,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* p, uint32_t 
 __device__ __forceinline__ float4 wbuf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) {
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
+// per-thread offset in a VGPR + wave-uniform offset in an SGPR (the K-loop advance costs no VALU
+// instruction: on gfx950 every VALU instruction takes its four cycles away from the fp32 MFMA
+// pipe -- same ALUs, tools/mfma_peak.hip).  kOOBw in `voff` still reads as zero.
+__device__ __forceinline__ float4 wbuf_ld4s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float4,
+                            __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoArgs {
   const float* in;
@@ -98,9 +106,11 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   const __amdgpu_buffer_rsrc_t rs_u = wrsrc(p.u, p.u_bytes);
 
   // ---- loader state: a tile's pixels do not change over its K loop ----------------------
-  // A: 4 rows x 32 pairs x 4 float4 = 512 float4 -> 2 per thread; B: 4 x 64 x 4 = 1024 -> 4
+  // A: 4 rows x 32 pairs x 4 float4 = 512 float4 -> 2 per thread; B: 4 x 64 x 4 = 1024 -> 4.
+  // Every load address = per-thread byte offset (fixed for the tile, or per kernel row of a 3x3)
+  // + a wave-uniform K offset that travels in the instruction's scalar-offset operand.
   const int c4 = (tid & 3) * 4;
-  uint32_t a_off[2], b_off[BLD];
+  uint32_t a_base[2], a_voff[2], b_voff[BLD];
   int a_line[2];                                    // line index within the image (3x3: row taps)
   auto setup_a = [&](int mtile) {
 #pragma unroll
@@ -116,10 +126,11 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
         const int img = (int)wdiv((uint32_t)line, p.mul_a, p.sh_a);
         const int a = line - img * p.A;
         const int b = 2 * pp - 1 + rr;
-        if (b >= 0 && b < p.L) off = (uint32_t)(img * p.in_simg + a * p.in_sa + b * p.in_sb) * 4u;
+        if (b >= 0 && b < p.L)
+          off = (uint32_t)(img * p.in_simg + a * p.in_sa + b * p.in_sb + c4) * 4u;
         al = a;
       }
-      a_off[j] = off;
+      a_base[j] = off;
       a_line[j] = al;
     }
   };
@@ -128,27 +139,38 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   for (int j = 0; j < BLD; ++j) {
     const int rowid = (tid >> 2) + 64 * j;          // 0..4*kWN-1 = comp*kWN + n
     const int comp = rowid / kWN, n = n0 + (rowid % kWN);
-    b_off[j] = n < p.n_ch ? (uint32_t)((comp * p.n_ch + n) * p.k_ch) * 4u : kOOBw;
+    b_voff[j] = n < p.n_ch ? (uint32_t)((comp * p.n_ch + n) * p.k_ch + c4) * 4u : kOOBw;
   }
-  float4 ra[2], rb[BLD];
-  auto load_regs = [&](int s) {
-    // K step s = (perpendicular tap r, channel chunk): r = 0 for the 1-D convs
-    const int r = s >= 2 * p.ksteps_c ? 2 : (s >= p.ksteps_c ? 1 : 0);
-    const int c = (s - r * p.ksteps_c) * kWK + c4;                 // input channel
-    const bool cok = c < p.c_in;
-    const uint32_t ka = cok ? (uint32_t)c * 4u : kOOBw;
-    const uint32_t kb = cok ? (uint32_t)(r * p.c_in + c) * 4u : kOOBw;
-    const int dr = p.R == 3 ? r - 1 : 0;                           // line shift of this tap
+  // offsets of the tile's pixels on kernel row r (r = 0 only for the 1-D convs): the line shifts
+  // by r - 1 and may leave the image (zero padding)
+  auto set_row = [&](int r) {
+    const int dr = p.R == 3 ? r - 1 : 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int al = a_line[j] + dr;
-      const bool lok = al >= 0 && al < p.A;
-      const uint32_t off = a_off[j] + (uint32_t)(dr * p.in_sa * 4);
-      ra[j] = wbuf_ld4(rs_in, (((a_off[j] | ka) & kOOBw) || !lok) ? kOOBw : off + ka);
+      const bool ok = !(a_base[j] & kOOBw) && al >= 0 && al < p.A;
+      a_voff[j] = ok ? a_base[j] + (uint32_t)(dr * p.in_sa * 4) : kOOBw;
     }
+  };
+  float4 ra[2], rb[BLD];
+  auto load_regs = [&](int s) {
+    // K step s = (perpendicular tap r, channel chunk), all wave-uniform
+    const int r = s >= 2 * p.ksteps_c ? 2 : (s >= p.ksteps_c ? 1 : 0);
+    const int ch = (s - r * p.ksteps_c) * kWK;                     // first input channel
+    if (ch == 0) set_row(r);
+    const uint32_t sa = (uint32_t)ch * 4u, sb = (uint32_t)(r * p.c_in + ch) * 4u;
+    if (ch + kWK <= p.c_in) {
 #pragma unroll
-    for (int j = 0; j < BLD; ++j)
-      rb[j] = wbuf_ld4(rs_u, ((b_off[j] | kb) & kOOBw) ? kOOBw : b_off[j] + kb);
+      for (int j = 0; j < 2; ++j) ra[j] = wbuf_ld4s(rs_in, a_voff[j], sa);
+#pragma unroll
+      for (int j = 0; j < BLD; ++j) rb[j] = wbuf_ld4s(rs_u, b_voff[j], sb);
+    } else {                      // last, partial channel chunk (c_in not a multiple of 16)
+      const bool cok = ch + c4 < p.c_in;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ra[j] = wbuf_ld4s(rs_in, cok ? a_voff[j] : kOOBw, sa);
+#pragma unroll
+      for (int j = 0; j < BLD; ++j) rb[j] = wbuf_ld4s(rs_u, cok ? b_voff[j] : kOOBw, sb);
+    }
   };
   auto store_lds = [&]() {
 #pragma unroll
@@ -204,8 +226,11 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     for (int t = 0; t < kWK / 8; ++t) {
       const int co = ((lh + 2 * t) << 2) ^ sw;     // swizzled chunk offset (floats)
       const float4 x0 = emsa_ld4(a0 + co), x1 = emsa_ld4(a1 + co);
-      const float4 v = make_float4(x0.x + sg * x1.x, x0.y + sg * x1.y, x0.z + sg * x1.z,
-                                   x0.w + sg * x1.w);
+      // input transform x0 +- x1 as two packed FMAs (v_pk_fma_f32) instead of four scalar ones
+      const wf32x2 sg2 = {sg, sg};
+      const wf32x2 vlo = __builtin_elementwise_fma(wf32x2{x1.x, x1.y}, sg2, wf32x2{x0.x, x0.y});
+      const wf32x2 vhi = __builtin_elementwise_fma(wf32x2{x1.z, x1.w}, sg2, wf32x2{x0.z, x0.w});
+      const float4 v = make_float4(vlo.x, vlo.y, vhi.x, vhi.y);
       float4 fb[NT];
 #pragma unroll
       for (int u = 0; u < NT; ++u) fb[u] = emsa_ld4(b + u * 32 * kWLD + co);
