@@ -82,7 +82,8 @@ double algo_flops(const EmsaConvGeom& g) {
 }
 
 #ifndef EMSA_ABL
-#define EMSA_ABL 0   // tuning only (tools/conv_bench.py): 1 = no global loads, 2 = no stores, 4 = no MFMA
+#define EMSA_ABL 0   // tuning only (tools/conv_bench.py): 1 = no global loads, 2 = no stores, 4 = no MFMA,
+                     // 8 = one K step per workgroup (fixed cost of a weight-gradient launch)
 #endif
 // Single LDS buffer + register prefetch (two barriers per step) beats double buffering on
 // MI355X for both kernels (profiles/r01_c_*): half the LDS -> twice the resident workgroups, and
@@ -735,24 +736,13 @@ struct Wgrad1dArgs {
 // (tried: A operand by ds_read_b64 over even/odd channel tiles, waves splitting K -- halves the LDS
 //  read instructions but needs 96 accumulator registers -> 2 waves/SIMD -> 57 vs 77 TFLOP/s;
 //  occupancy beats instruction count with the 64-cycle fp32 MFMA.)
-#ifndef EMSA_W1DW_WPE
-#define EMSA_W1DW_WPE 3   // Winograd variant: 64 accumulator registers; 4 waves/SIMD would spill
-#endif
 #ifndef EMSA_W1D_WPE
 #define EMSA_W1D_WPE 4
 #endif
-#ifndef EMSA_W1D_PIPE
-#define EMSA_W1D_PIPE 0   // pin the LDS reads of the next pixel pair ahead of the MFMA group
-#endif
-// WINO = Winograd F(3,2) over pixel PAIRS along the line (needs an even line length):
-//   dW_t = sum_pairs sum_i e_i d_(i+t),  e_i = dy(2p+i), d_r = x(2p-1+r)   ->   4 products per pair
-//   E = (e0, e0+e1, e0-e1, -e1)   D = (d0-d2, d1+d2, d2-d1, d1-d3)   M_k = sum_pairs E_k (x) D_k
-//   dW_0 = M0 + (M1+M2)/2    dW_1 = (M1-M2)/2    dW_2 = (M1+M2)/2 + M3
-// i.e. 4 MFMAs per pixel pair instead of 6 (the transposed form of the forward F(2,3) kernel in
-// conv_wino.hip); operands are formed on the fly from the same raw LDS rows, the output
-// transform is applied to the accumulators in registers before the atomics.
-template <int BCO, int BCI, bool WINO>
-__global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv_wgrad1d_kernel(
+// direct form (EMSA_WGRAD_WINO=0): three MFMAs per pixel and accumulator tile, taps masked at the
+// line ends with two ballot masks.  The default is the Winograd form below.
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(
     const Wgrad1dArgs p) {
   static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
   constexpr int PK = 32, XROWS = PK + 2;   // pixels per K step (64 spills: measured slower)
@@ -851,7 +841,7 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
     }
   };
 
-  constexpr int NACC = WINO ? 4 : 3;
+  constexpr int NACC = 3;
   f32x16 acc[NQ][NACC];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -871,38 +861,6 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
     mleft = mleft_n;                         // masks of THIS step (set when it was loaded)
     mright = mright_n;
     if (has_next) load_regs(s + 1);
-    if constexpr (WINO) {
-      // K index of the MFMA = pixel pair: lane half lh takes pair 2*kk + lh of the step's 16
-      const float* d = dS + wco * 32 + l31;
-      const float* x = xS + wci * 32 + l31;
-      // operands of pair kk + 1 are read from LDS BEFORE the four MFMAs of pair kk are issued,
-      // so the LDS latency hides behind 256 matrix-pipe cycles instead of the last 64
-      float e0, e1, d0, d1, d2, d3;
-      auto lds_pair = [&](int kk, float& f0, float& f1, float& g0, float& g1, float& g2,
-                          float& g3) {
-        const int row = 2 * (2 * kk + lh);           // first pixel of the pair within the step
-        f0 = d[row * BCO]; f1 = d[(row + 1) * BCO];
-        g0 = x[row * BCI];                           // xS row 0 = pixel k0 - 1
-        g1 = x[(row + 1) * BCI]; g2 = x[(row + 2) * BCI]; g3 = x[(row + 3) * BCI];
-      };
-      lds_pair(0, e0, e1, d0, d1, d2, d3);
-#pragma unroll
-      for (int kk = 0; kk < PK / 4; ++kk) {
-        const int row = 2 * (2 * kk + lh);
-        float n0 = 0.f, n1 = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-        if (kk + 1 < PK / 4) lds_pair(kk + 1, n0, n1, m0, m1, m2, m3);
-#if EMSA_W1D_PIPE
-        __builtin_amdgcn_sched_barrier(0);           // keep the reads AHEAD of the MFMA group
-#endif
-        d0 = ((mleft >> row) & 1u) ? 0.f : d0;
-        d3 = ((mright >> (row + 1)) & 1u) ? 0.f : d3;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, d0 - d2, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, d1 + d2, acc[0][1], 0, 0, 0);
-        acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, d2 - d1, acc[0][2], 0, 0, 0);
-        acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-e1, d1 - d3, acc[0][3], 0, 0, 0);
-        e0 = n0; e1 = n1; d0 = m0; d1 = m1; d2 = m2; d3 = m3;
-      }
-    } else {
     const float* d = dS + lh * BCO + wco * 32 + l31;
     const float* x = xS + lh * BCI + wci * 32 + l31;
 #pragma unroll
@@ -918,22 +876,9 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
         acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0][t], 0, 0, 0);
       }
     }
-    }
     __syncthreads();
     if (has_next) store_lds();
     __syncthreads();
-  }
-
-  if constexpr (WINO) {
-    // output transform G^T on the accumulators: acc[0][0..2] <- dW_0, dW_1, dW_2
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][0][r], m1 = acc[0][1][r], m2 = acc[0][2][r], m3 = acc[0][3][r];
-      const float hs = 0.5f * (m1 + m2);
-      acc[0][0][r] = m0 + hs;
-      acc[0][1][r] = 0.5f * (m1 - m2);
-      acc[0][2][r] = hs + m3;
-    }
   }
 
   if (p.ws != nullptr) {
@@ -985,6 +930,202 @@ __global__ __launch_bounds__(256, WINO ? EMSA_W1DW_WPE : EMSA_W1D_WPE) void conv
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Winograd F(3,2) weight gradient with the operand transforms done ONCE, when the tile enters LDS
+// ------------------------------------------------------------------------------------------
+// Over pixel PAIRS along the line (even line length; an odd line gets one virtual zero pixel):
+//   dW_t = sum_pairs sum_i e_i d_(i+t),  e_i = dy(2p+i), d_r = x(2p-1+r)   ->   4 products per pair
+//   E = (e0, e0+e1, e0-e1, -e1)   D = (d0-d2, d1+d2, d2-d1, d1-d3)   M_k = sum_pairs E_k (x) D_k
+//   dW_0 = M0 + (M1+M2)/2    dW_1 = (M1-M2)/2    dW_2 = (M1+M2)/2 + M3
+// i.e. 4 MFMAs per pixel pair instead of 6 (the transposed form of the forward F(2,3) kernel in
+// conv_wino.hip); the output transform is applied to the accumulators in registers.
+// On gfx950 the fp32 MFMAs and the vector ALU are the same hardware: every VALU instruction takes
+// its four cycles away from the matrix pipe, whichever wave issues it (tools/mfma_peak.hip:
+// 156 TFLOP/s with none, 125 with four FMAs per MFMA).  An earlier version formed
+// E and D in every consuming wave and
+// masked the line ends per pixel pair: ~14 VALU instructions per 4 MFMAs plus ~100 per K step of
+// addressing -> 69 % of the MFMA peak at best.  Here each loader thread owns one pixel PAIR and
+// four channels: it loads the pair's two dy rows and four x rows, transforms them with packed
+// math and stores E and D; the MFMA loop only reads LDS.  Line ends need no masks: the loads of
+// d0 / d3 across a line end are sent out of range and read as zero.  ~80 VALU per K step of 32
+// MFMAs.
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
+  static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
+  constexpr int PK = 32, NP = PK / 2, XROWS = PK + 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const eS = smem;                      // [NP pairs][4: e0, e0+e1, e0-e1, e1][BCO]
+  float* const dS = smem + NP * 4 * BCO;       // [NP pairs][4: D0..D3][BCI]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+  // blockIdx = (split * R + kernel row) * n_tiles + tile
+  const int tile = blockIdx.x % p.n_tiles, kr = (blockIdx.x / p.n_tiles) % p.R;
+  const int ks = blockIdx.x / (p.n_tiles * p.R);
+  const int dline = p.R == 3 ? kr - 1 : 0;         // x is read `dline` lines away (3x3 row tap)
+  const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(s_begin + p.steps_per_split, p.steps_total);
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
+  const int col4 = (tid & 15) * 4, pr = tid >> 4;  // this thread's float4 column and pixel pair
+  const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
+  // channel part of the addresses; a column beyond the tensor's channels stays out of range
+  const bool dok = co0 + col4 < p.n_ch, xok = ci0 + col4 < p.k_ch;
+  const uint32_t dadd = dok ? (uint32_t)(co0 + col4) * 4u : 0u, dmask = dok ? 0u : kOOB;
+  const uint32_t xadd = xok ? (uint32_t)(ci0 + col4) * 4u : 0u, xmask = xok ? 0u : kOOB;
+
+  float4 re[2], rx[4];
+  float4 bsum = emsa_zero4();
+  auto load_regs = [&](int s) {
+    // lane l of every wave decomposes pixel k0 + l - 1 (l < 34) once; the loading threads fetch
+    // their rows' byte offsets with wave shuffles
+    const int k = s * PK + lane - 1;
+    const bool valid = lane < XROWS && k >= 0 && k < p.M;
+    const uint32_t ku = valid ? (uint32_t)k : 0u;
+    const uint32_t img = fast_div(ku, p.div_al);
+    const uint32_t line = fast_div(ku, p.div_l);                 // = img * A + a
+    const int b_ = (int)(ku - __umul24(line, (uint32_t)p.L));
+    const int a_ = (int)(line - __umul24(img, (uint32_t)p.A));
+    const int a2 = a_ + dline;
+    const bool in_line = valid && b_ < p.Lr;
+    const uint32_t off_d = in_line
+        ? (__umul24(img, (uint32_t)p.dy_simg) + __umul24((uint32_t)a_, (uint32_t)p.dy_sa) +
+           __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * 4u : kOOB;
+    const uint32_t off_x = (in_line && a2 >= 0 && a2 < p.A)
+        ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa) +
+           __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * 4u : kOOB;
+    // as the LEFT neighbour (d0) of the next pixel a line's last pixel reads zero, as the RIGHT
+    // neighbour (d3) of the previous pixel a line's first pixel does: the tap crosses a line end
+    const uint32_t off_xl = b_ == p.L - 1 ? kOOB : off_x;
+    const uint32_t off_xr = b_ == 0 ? kOOB : off_x;
+    const int l0 = (2 * pr) * 4;                  // lane of pixel k0 + 2*pr - 1, times 4
+    const uint32_t o_e0 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 4, (int)off_d);
+    const uint32_t o_e1 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 8, (int)off_d);
+    const uint32_t o_d0 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)off_xl);
+    const uint32_t o_d1 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 4, (int)off_x);
+    const uint32_t o_d2 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 8, (int)off_x);
+    const uint32_t o_d3 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 12, (int)off_xr);
+    re[0] = buf_ld4(rs_dy, (o_e0 + dadd) | dmask);
+    re[1] = buf_ld4(rs_dy, (o_e1 + dadd) | dmask);
+    rx[0] = buf_ld4(rs_in, (o_d0 + xadd) | xmask);
+    rx[1] = buf_ld4(rs_in, (o_d1 + xadd) | xmask);
+    rx[2] = buf_ld4(rs_in, (o_d2 + xadd) | xmask);
+    rx[3] = buf_ld4(rs_in, (o_d3 + xadd) | xmask);
+  };
+  auto add4 = [](const float4& a, const float4& b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  };
+  auto sub4 = [](const float4& a, const float4& b) {
+    return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+  };
+  auto store_lds = [&]() {
+    float* e = eS + pr * 4 * BCO + col4;
+    float* d = dS + pr * 4 * BCI + col4;
+    const float4 es = add4(re[0], re[1]);
+    bsum = add4(bsum, es);                       // bias gradient = column sums of dy
+    emsa_st4(e, re[0]);
+    emsa_st4(e + BCO, es);
+    emsa_st4(e + 2 * BCO, sub4(re[0], re[1]));
+    emsa_st4(e + 3 * BCO, re[1]);
+    emsa_st4(d, sub4(rx[0], rx[2]));
+    emsa_st4(d + BCI, add4(rx[1], rx[2]));
+    emsa_st4(d + 2 * BCI, sub4(rx[2], rx[1]));
+    emsa_st4(d + 3 * BCI, sub4(rx[1], rx[3]));
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (s_begin < s_end) {
+    load_regs(s_begin);
+    store_lds();
+  }
+  __syncthreads();
+
+#if EMSA_ABL & 8
+  for (int s = s_begin; s < s_begin + 1 && s < s_end; ++s) {   // tuning: one K step only
+#else
+  for (int s = s_begin; s < s_end; ++s) {
+#endif
+    const bool has_next = s + 1 < s_end;
+    if (has_next) load_regs(s + 1);
+    // K index of the MFMA = pixel pair: lane half lh takes pair 2*kk + lh of the step's 16
+    const float* e = eS + lh * 4 * BCO + wco * 32 + l31;
+    const float* d = dS + lh * 4 * BCI + wci * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < NP / 2; ++kk) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(e[(kk * 8 + c) * BCO], d[(kk * 8 + c) * BCI],
+                                                      acc[c], 0, 0, 0);
+    }
+    __syncthreads();
+    if (has_next) store_lds();
+    __syncthreads();
+  }
+
+  // output transform G^T on the accumulators (M3 was accumulated with +e1, i.e. negated):
+  //   dW_0 = M0 + (M1+M2)/2    dW_1 = (M1-M2)/2    dW_2 = (M1+M2)/2 - M3'
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+    const float hs = 0.5f * (m1 + m2);
+    acc[0][r] = m0 + hs;
+    acc[1][r] = 0.5f * (m1 - m2);
+    acc[2][r] = hs - m3;
+  }
+
+  if (p.ws != nullptr) {
+    // deterministic split-K: this workgroup's partial tile [3][BCO][BCI] goes to the workspace
+    float* wt = p.ws + ((size_t)ks * p.n_tiles + tile) * (3 * BCO * BCI);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        wt[(t * BCO + wco * 32 + row) * BCI + wci * 32 + l31] = acc[t][r];
+      }
+  } else {
+    const int ci = ci0 + wci * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = co0 + wco * 32 + row;
+#if EMSA_ABL & 2
+        if (co < p.n_ch && ci < p.k_ch && acc[t][r] == 1.2345e30f)
+#else
+        if (co < p.n_ch && ci < p.k_ch)
+#endif
+          unsafeAtomicAdd(p.dw + ((size_t)(kr * 3 + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
+      }
+  }
+  if (do_bias) {
+    float* red = smem;   // [NP][BCO]
+    __syncthreads();     // (the K loop's LDS reads are done; red overlays eS)
+    red[pr * BCO + col4 + 0] = bsum.x;
+    red[pr * BCO + col4 + 1] = bsum.y;
+    red[pr * BCO + col4 + 2] = bsum.z;
+    red[pr * BCO + col4 + 3] = bsum.w;
+    __syncthreads();
+    if (tid < BCO) {
+      float a = 0.f;
+      for (int r = 0; r < NP; ++r) a += red[r * BCO + tid];
+      if (p.ws_bias != nullptr)
+        p.ws_bias[((size_t)ks * p.n_co_tiles + co_t) * BCO + tid] = a;
+      else if (co0 + tid < p.n_ch)
+        unsafeAtomicAdd(p.dbias + co0 + tid, a);
+    }
+  }
+}
+
 // second pass of the deterministic split-K: dw[co][ci][t] (OIHW of a 3-tap 1-D conv) =
 // sum over splits of ws[split][tile][t][co_l][ci_l]; dbias[co] = sum of ws_bias[split][co].
 // workgroup = one (tile, t, co_l) row of 64 ci (16 float4 columns) x 16 split groups; the
@@ -1002,9 +1143,18 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
     const int col = tid & 15, sg = tid >> 4;
     const float* src = ws + (size_t)tile * 12288 + row * 64 + col * 4;
     float4 a = emsa_zero4();
-    for (int sp = sg; sp < splits; sp += 16) {
-      const float4 v = emsa_ld4(src + (size_t)sp * n_tiles * 12288);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    const size_t sstride = (size_t)n_tiles * 12288;
+    // eight independent loads in flight per thread: with one (a plain loop) the few hundred
+    // workgroups of a 64-channel layer (768 partial tiles of 48 KB) are latency bound, 47 us
+    for (int sp = sg; sp < splits; sp += 128) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = sp + 16 * u < splits ? emsa_ld4(src + (size_t)(sp + 16 * u) * sstride) : emsa_zero4();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+      }
     }
     red[sg][col] = a;
     __syncthreads();
@@ -1025,15 +1175,38 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
       }
     }
   } else if (dbias != nullptr) {
-    __shared__ float redb[4][64];
+    // bias: 16 lanes x float4 = the tile's 64 channels, 16 split groups, 8 loads in flight (a
+    // plain loop over the splits was the critical path of the whole pass for 64-channel layers:
+    // 192 dependent round trips)
     const int co_t = blockIdx.x - weight_blocks;
-    const int cl = tid & 63, sg = tid >> 6;
-    float a = 0.f;
-    for (int sp = sg; sp < splits; sp += 4) a += ws_bias[((size_t)sp * n_co_tiles + co_t) * 64 + cl];
-    redb[sg][cl] = a;
+    const int col = tid & 15, sg = tid >> 4;
+    const float* src = ws_bias + (size_t)co_t * 64 + col * 4;
+    const size_t sstride = (size_t)n_co_tiles * 64;
+    float4 a = emsa_zero4();
+    for (int sp = sg; sp < splits; sp += 128) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = sp + 16 * u < splits ? emsa_ld4(src + (size_t)(sp + 16 * u) * sstride) : emsa_zero4();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+      }
+    }
+    red[sg][col] = a;
     __syncthreads();
-    if (sg == 0 && co_t * 64 + cl < n_ch)
-      dbias[co_t * 64 + cl] = redb[0][cl] + redb[1][cl] + redb[2][cl] + redb[3][cl];
+    if (sg == 0) {
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        const float4 v = red[k][col];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      const int co = co_t * 64 + col * 4;
+      if (co + 0 < n_ch) dbias[co + 0] = a.x;
+      if (co + 1 < n_ch) dbias[co + 1] = a.y;
+      if (co + 2 < n_ch) dbias[co + 2] = a.z;
+      if (co + 3 < n_ch) dbias[co + 3] = a.w;
+    }
   }
 }
 
@@ -1289,10 +1462,10 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     const int ps = prof_begin(7, algo_flops(a.g), st);
     if (pl.wino)
-      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, true>), dim3(w.n_tiles * w.R * pl.ksplit),
-                         dim3(256), lds, st, w);
+      hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
+                         dim3(256), (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
     else
-      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI, false>), dim3(w.n_tiles * w.R * pl.ksplit),
+      hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), lds, st, w);
     if (ws != nullptr)
       hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * 192 + w.n_co_tiles), dim3(256),

@@ -44,7 +44,10 @@ def main():
     tiles = [int(t) for t in sys.argv[2:]] or [-1]
     n = 32
     print(f"lib: {os.environ.get('EMSA_LIB', 'default')}")
+    only = os.environ.get('EMSA_BENCH_SHAPE')      # substring filter on the shape name
     for name, cin, cout, k, s, p, h, w in SHAPES:
+        if only and only not in name:
+            continue
         spec = Fn.ConvSpec(cin, cout, k, s, p)
         oh, ow = spec.out_hw(h, w)
         set_bytes = 4 * n * (2 * cin * h * w + 2 * cout * oh * ow)

@@ -1,0 +1,131 @@
+// Attainable fp32 MFMA rate on this GPU: registers only, no memory.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak
+// variants: waves per SIMD (1..8), independent accumulators per wave (1, 2, 4), and a loop that
+// mimics the weight-gradient kernel's inner loop (LDS reads + transform VALU between MFMA groups).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_only(float* out, int iters, float a, float b) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16 / NACC; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+// inner loop of conv_wgrad1d_kernel<..., WINO>: 6 LDS reads + transforms + 4 MFMAs per pixel pair
+__global__ __launch_bounds__(256) void mfma_lds(float* out, int iters) {
+  __shared__ float lds[66 * 64 + 64];
+  for (int i = threadIdx.x; i < 66 * 64 + 64; i += 256) lds[i] = (float)i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const float* d = lds + l31;
+  const float* x = lds + 32 * 64 + l31;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int row = 2 * (2 * kk + lh);
+      const float e0 = d[row * 64], e1 = d[(row + 1) * 64];
+      const float d0 = x[row * 64], d1 = x[(row + 1) * 64], d2 = x[(row + 2) * 64],
+                  d3 = x[(row + 3) * 64];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, d0 - d2, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 + e1, d1 + d2, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(e0 - e1, d2 - d1, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-e1, d1 - d3, acc[3], 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+
+// does VALU work overlap the matrix pipe?  NV fp32 FMAs (independent of the MFMAs) per MFMA
+template <int NV>
+__global__ __launch_bounds__(256) void mfma_valu(float* out, int iters, float a, float b) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = a + i + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], b, a);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  for (int i = 0; i < 8; ++i) s += v[i];
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+template <class F>
+double time_ms(F launch) {
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  launch(); hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / 5;
+}
+
+int main() {
+  float* out; hipMalloc(&out, 4096);
+  hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+  const int cus = pr.multiProcessorCount;
+  printf("%s: %d CUs, clock %d MHz\n", pr.gcnArchName, cus, pr.clockRate / 1000);
+  const int iters = 20000;            // x16 MFMAs per wave: ~20 ms per launch at full rate
+  for (int wps : {1, 2, 4, 6}) {
+    const int blocks = cus * wps;     // 256 threads = 4 waves = one wave per SIMD per block
+    const double fl = (double)blocks * 4 * iters * 16 * 32 * 32 * 2 * 2;
+    double m1 = time_ms([&] { hipLaunchKernelGGL(mfma_only<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    double m2 = time_ms([&] { hipLaunchKernelGGL(mfma_only<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    double m4 = time_ms([&] { hipLaunchKernelGGL(mfma_only<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    printf("waves/SIMD %d  mfma only: 1 acc %6.1f  2 acc %6.1f  4 acc %6.1f TFLOP/s\n", wps,
+           fl / m1 / 1e9, fl / m2 / 1e9, fl / m4 / 1e9);
+  }
+  for (int wps : {1, 2, 3, 4, 6}) {
+    const int blocks = cus * wps, it2 = 10000;
+    const double fl = (double)blocks * 4 * it2 * 32 * 32 * 32 * 2 * 2;
+    double m = time_ms([&] { hipLaunchKernelGGL(mfma_lds, dim3(blocks), dim3(256), 0, 0, out, it2); });
+    printf("waves/SIMD %d  wgrad-like loop (LDS + transform + 4 MFMA): %6.1f TFLOP/s\n", wps,
+           fl / m / 1e9);
+  }
+  for (int wps : {1, 3, 5}) {
+    const int blocks = cus * wps;
+    const double fl = (double)blocks * 4 * iters * 16 * 32 * 32 * 2 * 2;
+    double m0 = time_ms([&] { hipLaunchKernelGGL(mfma_valu<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    double m2 = time_ms([&] { hipLaunchKernelGGL(mfma_valu<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    double m4 = time_ms([&] { hipLaunchKernelGGL(mfma_valu<4>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    double m8 = time_ms([&] { hipLaunchKernelGGL(mfma_valu<8>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    double m12 = time_ms([&] { hipLaunchKernelGGL(mfma_valu<12>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
+    printf("waves/SIMD %d  FMAs per MFMA 0/2/4/8/12: %6.1f %6.1f %6.1f %6.1f %6.1f TFLOP/s\n", wps,
+           fl / m0 / 1e9, fl / m2 / 1e9, fl / m4 / 1e9, fl / m8 / 1e9, fl / m12 / 1e9);
+  }
+  return 0;
+}
