@@ -47,6 +47,7 @@ __device__ __forceinline__ float4 wbuf_ld4s(__amdgpu_buffer_rsrc_t r, uint32_t v
                             __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 typedef float wf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int wu32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoArgs {
   const float* in;
@@ -260,14 +261,38 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   // (px = tid/NC4 + RG*k, col4 = tid%NC4) owns PXI of the 64 output pixels x one float4 of channels
   constexpr int SLD = kWN + 4;
   constexpr int HP = kPairs / 2;
+  // The epilogue is pure VALU work and on gfx950 every VALU instruction is four cycles the fp32
+  // MFMA pipe does not get (for a 64-channel layer the K loop is only 64 MFMAs per wave), so it is
+  // written for instruction count: one pixel decomposition per LANE (fetched with wave shuffles),
+  // packed fp32 math, 32-bit buffer addressing with out-of-range offsets instead of branches.
+  constexpr uint32_t kNoPix = 0xFFFFFFFFu;
   float* const stage = smem;
   const int col4 = tid % NC4, n = n0 + col4 * 4;
   const int rgi = tid / NC4;                       // row group of this thread
   const bool nok = n < p.n_ch;
-  float4 y[PXI];
+  // lane l of every wave: element index (pixel * 1) of the tile's output pixel l = pair*2 + e
+  uint32_t lane_pix = kNoPix;
+  {
+    const int q = q0 + (lane >> 1);
+    if (q < p.MP) {
+      const int line = (int)wdiv((uint32_t)q, p.mul_pl, p.sh_pl);
+      const int pp = q - line * p.PL;
+      const int img = (int)wdiv((uint32_t)line, p.mul_a, p.sh_a);
+      const int a = line - img * p.A;
+      const int b = 2 * pp + (lane & 1);
+      if (b < p.L) lane_pix = (uint32_t)(img * p.px_simg + a * p.px_sa + b * p.px_sb);
+    }
+  }
+  wf32x2 ylo[PXI], yhi[PXI];
   uint32_t opix[PXI];          // pixel index (< 2^29, checked by emsa_conv1d_wino_supported)
   bool ok[PXI];
   const float4 bv = (nok && p.bias) ? emsa_ld4(p.bias + n) : emsa_zero4();
+  const wf32x2 blo = {bv.x, bv.y}, bhi = {bv.z, bv.w};
+  // out(e=0) = m0 + m1 + m2, out(e=1) = m1 - m2 - m3  ==  m1 + sg * (m2 + m03); e = px & 1 is a
+  // per-thread constant (RG is even)
+  const float sgo = (rgi & 1) ? -1.f : 1.f;
+  const wf32x2 sg2o = {sgo, sgo};
+  const int m03row = (rgi & 1) ? 3 : 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
   if (h) __syncthreads();                          // half 0 of the stage has been consumed
@@ -282,34 +307,17 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
 #pragma unroll
   for (int k = h * (PXI / 2); k < (h + 1) * (PXI / 2); ++k) {
     const int px = rgi + RG * k;                   // 0..63 = pair*2 + e, in [32h, 32h + 32)
-    const int pr = px >> 1, e = px & 1, prl = pr - HP * h;
+    const int prl = (px >> 1) - HP * h;
     const float4 m1 = emsa_ld4(stage + (1 * HP + prl) * SLD + col4 * 4);
     const float4 m2 = emsa_ld4(stage + (2 * HP + prl) * SLD + col4 * 4);
-    const float4 m03 = emsa_ld4(stage + ((e ? 3 : 0) * HP + prl) * SLD + col4 * 4);
-    float4 v;
-    if (e == 0) {
-      v = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z,
-                      m03.w + m1.w + m2.w);
-    } else {
-      v = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z,
-                      m1.w - m2.w - m03.w);
-    }
-    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    y[k] = v;
-    const int q = q0 + pr;
-    ok[k] = false;
-    opix[k] = 0;
-    if (q < p.MP) {
-      const int line = (int)wdiv((uint32_t)q, p.mul_pl, p.sh_pl);
-      const int pp = q - line * p.PL;
-      const int img = (int)wdiv((uint32_t)line, p.mul_a, p.sh_a);
-      const int a = line - img * p.A;
-      const int b = 2 * pp + e;
-      if (b < p.L) {
-        ok[k] = nok;
-        opix[k] = (uint32_t)(img * p.px_simg + a * p.px_sa + b * p.px_sb);
-      }
-    }
+    const float4 m03 = emsa_ld4(stage + (m03row * HP + prl) * SLD + col4 * 4);
+    const wf32x2 tlo = wf32x2{m2.x, m2.y} + wf32x2{m03.x, m03.y};
+    const wf32x2 thi = wf32x2{m2.z, m2.w} + wf32x2{m03.z, m03.w};
+    ylo[k] = __builtin_elementwise_fma(tlo, sg2o, wf32x2{m1.x, m1.y}) + blo;
+    yhi[k] = __builtin_elementwise_fma(thi, sg2o, wf32x2{m1.z, m1.w}) + bhi;
+    const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(px * 4, (int)lane_pix);
+    ok[k] = nok && o != kNoPix;
+    opix[k] = o;
   }
   }   // halves
 
@@ -319,15 +327,18 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     float* red = smem;                             // [RG row groups][kWN]
     float* tmean = smem + RG * kWN;                // [kWN]
     int* scnt = reinterpret_cast<int*>(tmean + kWN);   // [RG] valid pixels per row group
-    float4 s1 = emsa_zero4();
+    wf32x2 s1lo = {0.f, 0.f}, s1hi = {0.f, 0.f};
+    float wgt[PXI];
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < PXI; ++k)
-      if (ok[k]) {
-        s1.x += y[k].x; s1.y += y[k].y; s1.z += y[k].z; s1.w += y[k].w;
-        ++cnt;
-      }
-    emsa_st4(red + rgi * kWN + col4 * 4, s1);
+    for (int k = 0; k < PXI; ++k) {
+      wgt[k] = ok[k] ? 1.f : 0.f;
+      const wf32x2 w2 = {wgt[k], wgt[k]};
+      s1lo = __builtin_elementwise_fma(ylo[k], w2, s1lo);
+      s1hi = __builtin_elementwise_fma(yhi[k], w2, s1hi);
+      cnt += ok[k] ? 1 : 0;
+    }
+    emsa_st4(red + rgi * kWN + col4 * 4, make_float4(s1lo.x, s1lo.y, s1hi.x, s1hi.y));
     // the valid-pixel count is the same for every channel column: column 0 threads publish it
     // (n0 < n_ch for every launched tile, so their `ok` flags are the pixel validity)
     if (col4 == 0) scnt[rgi] = cnt;
@@ -347,15 +358,17 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     }
     __syncthreads();
     const float4 mu = emsa_ld4(tmean + col4 * 4);
-    float4 s2 = emsa_zero4();
+    const wf32x2 mulo = {mu.x, mu.y}, muhi = {mu.z, mu.w};
+    wf32x2 s2lo = {0.f, 0.f}, s2hi = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < PXI; ++k)
-      if (ok[k]) {
-        const float dx = y[k].x - mu.x, dy = y[k].y - mu.y, dz = y[k].z - mu.z, dw = y[k].w - mu.w;
-        s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
-      }
+    for (int k = 0; k < PXI; ++k) {
+      const wf32x2 w2 = {wgt[k], wgt[k]};
+      const wf32x2 dlo = ylo[k] - mulo, dhi = yhi[k] - muhi;
+      s2lo = __builtin_elementwise_fma(dlo * w2, dlo, s2lo);
+      s2hi = __builtin_elementwise_fma(dhi * w2, dhi, s2hi);
+    }
     __syncthreads();
-    emsa_st4(red + rgi * kWN + col4 * 4, s2);
+    emsa_st4(red + rgi * kWN + col4 * 4, make_float4(s2lo.x, s2lo.y, s2hi.x, s2hi.y));
     __syncthreads();
     if (tid < kWN && n0 + tid < p.n_ch) {
       float a2 = 0.f;
@@ -366,47 +379,69 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   }
 
   {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = emsa_zero4();
-    if (nok && p.scale) {
-      sc = emsa_ld4(p.scale + n);
-      sh = emsa_ld4(p.shift + n);
+    // every tensor touched here is < 2 GiB (checked by the launcher): byte offsets are 32-bit and
+    // an offset with the top bit set is out of range for these descriptors -- loads return zero,
+    // stores are dropped -- so dead pixels / channel columns need no branch
+    const __amdgpu_buffer_rsrc_t rs_out = wrsrc(p.out, kOOBw);
+    const __amdgpu_buffer_rsrc_t rs_res = wrsrc(p.residual, kOOBw);
+    const __amdgpu_buffer_rsrc_t rs_msk = wrsrc(p.mask_src, kOOBw);
+    const __amdgpu_buffer_rsrc_t rs_mb = wrsrc(p.mask_bits, kOOBw);
+    wf32x2 sclo = {1.f, 1.f}, schi = {1.f, 1.f}, shlo = {0.f, 0.f}, shhi = {0.f, 0.f};
+    const bool affine = p.scale != nullptr;        // uniform
+    if (affine && nok) {
+      const float4 sc = emsa_ld4(p.scale + n), sh = emsa_ld4(p.shift + n);
+      sclo = wf32x2{sc.x, sc.y}; schi = wf32x2{sc.z, sc.w};
+      shlo = wf32x2{sh.x, sh.y}; shhi = wf32x2{sh.z, sh.w};
     }
 #pragma unroll
     for (int k = 0; k < PXI; ++k) {
-      const bool live = nok && ok[k];
-      float4 v = y[k];
-      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
-      v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-      if (live && p.residual) {
-        const float4 rr = emsa_ld4(p.residual + (size_t)opix[k] * p.ld_res + n);
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      const bool live = ok[k];
+      wf32x2 vlo = ylo[k], vhi = yhi[k];
+      if (affine) {
+        vlo = __builtin_elementwise_fma(vlo, sclo, shlo);
+        vhi = __builtin_elementwise_fma(vhi, schi, shhi);
       }
-      if (live && p.mask_src) {
-        const float4 mm = emsa_ld4(p.mask_src + (size_t)opix[k] * p.ld_mask + n);
+      if (p.residual) {
+        const uint32_t off = live ? (opix[k] * (uint32_t)p.ld_res + (uint32_t)n) * 4u : kOOBw;
+        const float4 rr = wbuf_ld4(rs_res, off);
+        vlo += wf32x2{rr.x, rr.y};
+        vhi += wf32x2{rr.z, rr.w};
+      }
+      float4 v = make_float4(vlo.x, vlo.y, vhi.x, vhi.y);
+      if (p.mask_src) {
+        const uint32_t off = live ? (opix[k] * (uint32_t)p.ld_mask + (uint32_t)n) * 4u : kOOBw;
+        const float4 mm = wbuf_ld4(rs_msk, off);
         v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
         v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
       }
       if constexpr (kWN == 64) {
-        // ReLU masks as bits: the 16 lanes that share a pixel share one 64-bit word
-        if (live && p.mask_bits) {
-          const uint64_t mw = p.mask_bits[(size_t)opix[k] * p.tiles_n + nt];
-          v.x = ((mw >> col4) & 1ull) ? v.x : 0.f;
-          v.y = ((mw >> (16 + col4)) & 1ull) ? v.y : 0.f;
-          v.z = ((mw >> (32 + col4)) & 1ull) ? v.z : 0.f;
-          v.w = ((mw >> (48 + col4)) & 1ull) ? v.w : 0.f;
+        // ReLU masks as bits: the 16 lanes that share a pixel share one 64-bit word; bit
+        // comp * 16 + col4 -> x, y in the low word, z, w in the high word
+        if (p.mask_bits) {
+          const uint32_t off = live ? (opix[k] * (uint32_t)p.tiles_n + (uint32_t)nt) * 8u : kOOBw;
+          const wu32x2 mw = __builtin_bit_cast(
+              wu32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mb, (int)off, 0, 0));
+          const uint32_t t0 = mw.x >> col4, t1 = mw.y >> col4;
+          v.x = __uint_as_float(__float_as_uint(v.x) & (uint32_t)__builtin_amdgcn_sbfe((int)t0, 0, 1));
+          v.y = __uint_as_float(__float_as_uint(v.y) & (uint32_t)__builtin_amdgcn_sbfe((int)t0, 16, 1));
+          v.z = __uint_as_float(__float_as_uint(v.z) & (uint32_t)__builtin_amdgcn_sbfe((int)t1, 0, 1));
+          v.w = __uint_as_float(__float_as_uint(v.w) & (uint32_t)__builtin_amdgcn_sbfe((int)t1, 16, 1));
         }
       }
       if (p.act == EMSA_ACT_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      if (live) emsa_st4(p.out + (size_t)opix[k] * p.ld_out + n, v);
+      {
+        const uint32_t off = live ? (opix[k] * (uint32_t)p.ld_out + (uint32_t)n) * 4u : kOOBw;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, v), rs_out, (int)off, 0, 0);
+      }
       if constexpr (kWN == 64) {
         if (p.relu_bits) {                           // uniform branch: ballots see every lane
           const uint64_t b0 = __ballot(live && v.x > 0.f), b1 = __ballot(live && v.y > 0.f);
           const uint64_t b2 = __ballot(live && v.z > 0.f), b3 = __ballot(live && v.w > 0.f);
           const int sh16 = (lane >> 4) * 16;         // this pixel's 16 lanes within the wave
-          if (col4 == 0 && ok[k])
+          if (col4 == 0 && opix[k] != kNoPix)
             p.relu_bits[(size_t)opix[k] * p.tiles_n + nt] =
                 ((b0 >> sh16) & 0xFFFFull) | (((b1 >> sh16) & 0xFFFFull) << 16) |
                 (((b2 >> sh16) & 0xFFFFull) << 32) | (((b3 >> sh16) & 0xFFFFull) << 48);
@@ -659,6 +694,13 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   if (mask_bits && mask_src) return EMSA_E_ARG;
   a.tiles_m = (a.MP + kPairs - 1) / kPairs;
   a.tiles_n = (g->n_ch + wn - 1) / wn;
+  {
+    // the epilogue addresses out / residual / mask with 32-bit byte offsets below 2 GiB
+    const long px = (long)g->n_img * H * W, lim = 1L << 29;
+    if (px * g->ld_out >= lim || (residual && px * ld_res >= lim) ||
+        (mask_src && px * ld_mask >= lim) || px * a.tiles_n * 2 >= lim)
+      return EMSA_E_SHAPE;
+  }
   a.ksteps_c = (g->k_ch + kWK - 1) / kWK;
   a.ksteps = a.R * a.ksteps_c;
   a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
