@@ -43,7 +43,7 @@ const char* const kProfNames[kProfClasses] = {
     "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,4,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
     "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1>",
-    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_kernel<64,64>",
+    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_wino_kernel<64,64>",
     "conv1d_wino_kernel"};
 }  // namespace
 
@@ -148,6 +148,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// per-thread offset (VGPR) + wave-uniform offset in the instruction's scalar-offset operand: the
+// K-loop advance costs no vector instruction; kOOB in `voff` still reads zero
+__device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float4,
+                            __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 
 // gather helper: BYTE offset of (row base, tap) or kOOB
 struct Gather {
@@ -236,28 +242,36 @@ conv_igemm_kernel(const ConvArgs p) {
   float4 ra[AR], rb[BR];
 
   auto load_regs = [&]() {
+    // (tap, channel chunk) are wave-uniform: the gathered pixel offsets change once per tap, the
+    // channel advance travels in the scalar offset operand
     if (kc_n == 0) {
       const int kh = tap_n / g.kw, kw = tap_n - kh * g.kw;
 #pragma unroll
-      for (int j = 0; j < AR; ++j) a_off[j] = gather_offset(q, a_img[j], a_bh[j], a_bw[j], kh, kw);
+      for (int j = 0; j < AR; ++j) {
+        const uint32_t o = gather_offset(q, a_img[j], a_bh[j], a_bw[j], kh, kw);
+        a_off[j] = (o & kOOB) ? kOOB : o + (uint32_t)c4 * 4u;
+      }
     }
-    const int k = kc_n * kBK + c4;
-    // k >= k_ch (partial last chunk) -> out of range; kOOB + small stays out of range
-    const uint32_t kb = k < g.k_ch ? (uint32_t)k * 4u : kOOB;
-    const uint32_t wb = k < g.k_ch ? (uint32_t)tap_n * w_tap_bytes + (uint32_t)(kc_n * kBK) * 4u
-                                   : kOOB;
+    const int k0 = kc_n * kBK;
+    const uint32_t sa = (uint32_t)k0 * 4u, sb = (uint32_t)tap_n * w_tap_bytes + (uint32_t)k0 * 4u;
 #if EMSA_ABL & 1
 #pragma unroll
-    for (int j = 0; j < AR; ++j) ra[j] = make_float4(a_off[j], kb, 1.f, 2.f);
+    for (int j = 0; j < AR; ++j) ra[j] = make_float4(a_off[j], sa, 1.f, 2.f);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) rb[j] = make_float4(b_off[j], wb, 2.f, 1.f);
+    for (int j = 0; j < BR; ++j) rb[j] = make_float4(b_off[j], sb, 2.f, 1.f);
 #else
+    if (k0 + kBK <= g.k_ch) {
 #pragma unroll
-    for (int j = 0; j < AR; ++j)
-      ra[j] = buf_ld4(rs_in, ((a_off[j] | kb) & kOOB) ? kOOB : a_off[j] + kb);
+      for (int j = 0; j < AR; ++j) ra[j] = buf_ld4s(rs_in, a_off[j], sa);
 #pragma unroll
-    for (int j = 0; j < BR; ++j)
-      rb[j] = buf_ld4(rs_w, ((b_off[j] | wb) & kOOB) ? kOOB : b_off[j] + wb);
+      for (int j = 0; j < BR; ++j) rb[j] = buf_ld4s(rs_w, b_off[j], sb);
+    } else {                       // last, partial channel chunk
+      const bool cok = k0 + c4 < g.k_ch;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) ra[j] = buf_ld4s(rs_in, cok ? a_off[j] : kOOB, sa);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) rb[j] = buf_ld4s(rs_w, cok ? b_off[j] : kOOB, sb);
+    }
 #endif
     if (++kc_n == p.kchunks) {
       kc_n = 0;
