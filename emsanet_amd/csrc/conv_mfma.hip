@@ -753,6 +753,9 @@ struct Wgrad1dArgs {
 #ifndef EMSA_W1D_WPE
 #define EMSA_W1D_WPE 4
 #endif
+#ifndef EMSA_W1D_XCD
+#define EMSA_W1D_XCD 1
+#endif
 // direct form (EMSA_WGRAD_WINO=0): three MFMAs per pixel and accumulator tile, taps masked at the
 // line ends with two ballot masks.  The default is the Winograd form below.
 template <int BCO, int BCI>
@@ -974,9 +977,17 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1d
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int wco = wave & 1, wci = wave >> 1;
-  // blockIdx = (split * R + kernel row) * n_tiles + tile
-  const int tile = blockIdx.x % p.n_tiles, kr = (blockIdx.x / p.n_tiles) % p.R;
-  const int ks = blockIdx.x / (p.n_tiles * p.R);
+  // work item = (split * R + kernel row) * n_tiles + tile; every XCD (own L2) gets a contiguous
+  // range of items, i.e. ALL the tiles of a few pixel ranges: x and dy of a range are then
+  // fetched into one L2 once instead of into all eight (PMC FETCH_SIZE was 2x the algorithmic
+  // bytes with the round-robin order)
+#if EMSA_W1D_XCD
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+#else
+  const int wg = blockIdx.x;
+#endif
+  const int tile = wg % p.n_tiles, kr = (wg / p.n_tiles) % p.R;
+  const int ks = wg / (p.n_tiles * p.R);
   const int dline = p.R == 3 ? kr - 1 : 0;         // x is read `dline` lines away (3x3 row tap)
   const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
