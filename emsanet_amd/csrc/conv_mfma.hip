@@ -560,6 +560,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
+  // (kh, kw) of this workgroup's taps: uniform, computed once
+  int tkh[TT], tkw[TT];
+  bool tok[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    const int tap = tap0 + t;
+    tok[t] = tap < taps;
+    tkh[t] = tap / g.kw;
+    tkw[t] = tap - tkh[t] * g.kw;
+  }
+  // channel part of the x addresses; a column beyond the tensor's channels stays out of range
+  const bool xok = ci0 + x_c4 < g.k_ch;
+  const uint32_t xadd = xok ? (uint32_t)(ci0 + x_c4) * 4u : 0u, xmask = xok ? 0u : kOOB;
+  constexpr int TH = (TT + 1) / 2;              // taps per lane half
   auto load_regs = [&](int s) {
     const int mb = s * PK;
 #pragma unroll
@@ -580,30 +594,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #endif
       rd[j] = v;
     }
+    // x: the 16+ lanes that load one pixel row share its gathered address, so lane (r, half) of
+    // every wave computes the byte offsets of pixel mb + r for the taps t with (t & 1) == half
+    // ONCE and the loading threads fetch them with wave shuffles (per-thread decomposition and
+    // gather were ~900 VALU instructions per K step -- more issue time than the step's MFMAs)
+    const int m = mb + l31;
+    int bh = -(1 << 29), bw = 0, img_off = 0;
+    if (m < p.M) {
+      const int img = (int)fast_div((uint32_t)m, p.div_ohw);
+      const int rem = m - img * (int)p.div_ohw.d;
+      const int oh = (int)fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
+      bh = oh * q.mul_h + q.off_h;
+      bw = ow * q.mul_w + q.off_w;
+      img_off = img * (int)g.in_img_stride;
+    }
+    uint32_t goff[TH];
+#pragma unroll
+    for (int u = 0; u < TH; ++u) {
+      const int t0 = 2 * u, t1 = 2 * u + 1 < TT ? 2 * u + 1 : 2 * u;
+      const bool two = 2 * u + 1 < TT;
+      const int kh = lh ? tkh[t1] : tkh[t0], kw = lh ? tkw[t1] : tkw[t0];
+      const bool ok_t = lh ? (two && tok[t1]) : tok[t0];
+      const int hn = bh + kh * q.step_h, wn = bw + kw * q.step_w;    // (div_h = div_w = 1 here)
+      const bool ok = ok_t && hn >= 0 && hn < q.in_h && wn >= 0 && wn < q.in_w;
+      goff[u] = ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * 4u : kOOB;
+    }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
-      const int m = mb + x_r + j * (256 / XTPR);
-      const int ci = ci0 + x_c4;
-      int bh = -(1 << 29), bw = 0, img_off = 0;
-      if (m < p.M) {
-        const int img = (int)fast_div((uint32_t)m, p.div_ohw);
-        const int rem = m - img * (int)p.div_ohw.d;
-        const int oh = (int)fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
-        bh = oh * q.mul_h + q.off_h;
-        bw = ow * q.mul_w + q.off_w;
-        img_off = img * (int)g.in_img_stride;
-      }
-      const uint32_t cb = ci < g.k_ch ? (uint32_t)ci * 4u : kOOB;
+      const int r = x_r + j * (256 / XTPR);
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        const int tap = tap0 + t;
-        const int kh = tap / g.kw, kw = tap - kh * g.kw;
-        uint32_t off = tap < taps ? gather_offset(q, img_off, bh, bw, kh, kw) : kOOB;
-        off = ((off | cb) & kOOB) ? kOOB : off + cb;
+        const uint32_t o =
+            (uint32_t)__builtin_amdgcn_ds_bpermute((r + 32 * (t & 1)) * 4, (int)goff[t >> 1]);
 #if EMSA_ABL & 1
-        rx[t][j] = make_float4(off, 1.f, 2.f, 3.f);
+        rx[t][j] = make_float4(o, 1.f, 2.f, 3.f);
 #else
-        rx[t][j] = buf_ld4(rs_in, off);
+        rx[t][j] = buf_ld4(rs_in, (o + xadd) | xmask);
 #endif
       }
     }
