@@ -137,13 +137,23 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int slices, in
                                    float* running_var, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  // 32 channels x 8 slice groups per workgroup (one thread per channel walking up to 64 slices
+  // was a 10 us chain of dependent round trips, 124 times per training step)
+  __shared__ double sh[3][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
   double n = 0.0, s1 = 0.0, q = 0.0;
-  for (int sl = 0; sl < slices; ++sl) {
-    const double* o = ws + ((long)sl * c + ch) * 3;
-    n += o[0]; s1 += o[1]; q += o[2];
-  }
+  if (ch < c)
+    for (int sl = rg; sl < slices; sl += 8) {
+      const double* o = ws + ((long)sl * c + ch) * 3;
+      n += o[0]; s1 += o[1]; q += o[2];
+    }
+  sh[0][rg][cl] = n; sh[1][rg][cl] = s1; sh[2][rg][cl] = q;
+  __syncthreads();
+  if (rg != 0 || ch >= c) return;
+  n = s1 = q = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
   const double mean = n > 0.0 ? s1 / n : 0.0;
   double m2 = q - s1 * mean;
   if (m2 < 0.0) m2 = 0.0;
@@ -1119,7 +1129,7 @@ extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_partial_kernel, dim3((c + 31) / 32, slices), dim3(256), 0, st, stats, rows,
                      c, (double*)ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, st,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, st,
                      (const double*)ws, slices, c, gamma, beta, eps, momentum, running_mean,
                      running_var, scale, shift, save_mean, save_invstd);
   return emsa_launch_status();
