@@ -240,6 +240,8 @@ conv_igemm_kernel(const ConvArgs p) {
   const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 4u;
   int tap_n = 0, kc_n = 0;
   float4 ra[AR], rb[BR];
+  // kOOB for the lanes whose channels lie beyond k_ch in the last chunk of a tap
+  const uint32_t last_oob = (p.kchunks - 1) * kBK + c4 < g.k_ch ? 0u : kOOB;
 
   auto load_regs = [&]() {
     // (tap, channel chunk) are wave-uniform: the gathered pixel offsets change once per tap, the
@@ -260,18 +262,13 @@ conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < BR; ++j) rb[j] = make_float4(b_off[j], sb, 2.f, 1.f);
 #else
-    if (k0 + kBK <= g.k_ch) {
+    // partial last channel chunk: lanes beyond k_ch go out of range through a wave-uniform mask
+    // (no branch around the loads: a join behind them costs an s_waitcnt on the fresh data)
+    const uint32_t pm = k0 + kBK > g.k_ch ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-      for (int j = 0; j < AR; ++j) ra[j] = buf_ld4s(rs_in, a_off[j], sa);
+    for (int j = 0; j < AR; ++j) ra[j] = buf_ld4s(rs_in, a_off[j] | (last_oob & pm), sa);
 #pragma unroll
-      for (int j = 0; j < BR; ++j) rb[j] = buf_ld4s(rs_w, b_off[j], sb);
-    } else {                       // last, partial channel chunk
-      const bool cok = k0 + c4 < g.k_ch;
-#pragma unroll
-      for (int j = 0; j < AR; ++j) ra[j] = buf_ld4s(rs_in, cok ? a_off[j] : kOOB, sa);
-#pragma unroll
-      for (int j = 0; j < BR; ++j) rb[j] = buf_ld4s(rs_w, cok ? b_off[j] : kOOB, sb);
-    }
+    for (int j = 0; j < BR; ++j) rb[j] = buf_ld4s(rs_w, b_off[j] | (last_oob & pm), sb);
 #endif
     if (++kc_n == p.kchunks) {
       kc_n = 0;
@@ -519,8 +516,11 @@ struct WgradArgs {
   FastDiv div_ohw, div_ow;
 };
 
-template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+// ALIGNED: float4 loads of dy are legal.  A compile-time split, not a branch around the loads: a
+// control-flow join behind a load makes the compiler wait for the data at the join, i.e. before
+// the step's MFMAs.
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT, bool ALIGNED>
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
   static_assert(WCO * WCI * WT == 4, "4 waves");
   constexpr int PK = 32;                       // pixels (GEMM K) per step
   constexpr int TCO = BCO / 32 / WCO, TCI = BCI / 32 / WCI, TTW = (TT + WT - 1) / WT;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const int co = co0 + d_c4;
       float4 v = emsa_zero4();
 #if !(EMSA_ABL & 1)
-      if (p.dout_aligned) {
+      if constexpr (ALIGNED) {
         v = buf_ld4(rs_dy, (m < p.M && co < g.n_ch) ? (uint32_t)(m * g.ld_out + co) * 4u : kOOB);
       } else if (m < p.M && co < g.n_ch) {
         const float* src = p.dout + (size_t)m * g.ld_out + co;
@@ -743,6 +743,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       unsafeAtomicAdd(p.dbias + co0 + tid, a);
     }
   }
+}
+
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  if (p.dout_aligned)
+    conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, true>(p);
+  else
+    conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, false>(p);
 }
 
 // ------------------------------------------------------------------------------------------

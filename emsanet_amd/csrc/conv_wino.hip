@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
       a_voff[j] = ok ? a_base[j] + (uint32_t)(dr * p.in_sa * 4) : kOOBw;
     }
   };
+  // kOOBw for the lanes whose channels lie beyond c_in in the LAST chunk of a row
+  const uint32_t last_oob = (p.ksteps_c - 1) * kWK + c4 < p.c_in ? 0u : kOOBw;
   float4 ra[2], rb[BLD];
   auto load_regs = [&](int s) {
     // K step s = (perpendicular tap r, channel chunk), all wave-uniform
@@ -160,18 +162,15 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     const int ch = (s - r * p.ksteps_c) * kWK;                     // first input channel
     if (ch == 0) set_row(r);
     const uint32_t sa = (uint32_t)ch * 4u, sb = (uint32_t)(r * p.c_in + ch) * 4u;
-    if (ch + kWK <= p.c_in) {
+    // last, partial channel chunk (c_in not a multiple of 16): the lanes beyond c_in go out of
+    // range.  One v_and_or per load with a wave-uniform mask -- NOT a branch around the loads: a
+    // control-flow join behind them makes the compiler wait for the data right there, before the
+    // step's MFMAs (measured: +0.2 us per K step at batch 1)
+    const uint32_t pm = ch + kWK > p.c_in ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) ra[j] = wbuf_ld4s(rs_in, a_voff[j], sa);
+    for (int j = 0; j < 2; ++j) ra[j] = wbuf_ld4s(rs_in, a_voff[j] | (last_oob & pm), sa);
 #pragma unroll
-      for (int j = 0; j < BLD; ++j) rb[j] = wbuf_ld4s(rs_u, b_voff[j], sb);
-    } else {                      // last, partial channel chunk (c_in not a multiple of 16)
-      const bool cok = ch + c4 < p.c_in;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) ra[j] = wbuf_ld4s(rs_in, cok ? a_voff[j] : kOOBw, sa);
-#pragma unroll
-      for (int j = 0; j < BLD; ++j) rb[j] = wbuf_ld4s(rs_u, cok ? b_voff[j] : kOOBw, sb);
-    }
+    for (int j = 0; j < BLD; ++j) rb[j] = wbuf_ld4s(rs_u, b_voff[j] | (last_oob & pm), sb);
   };
   auto store_lds = [&]() {
 #pragma unroll

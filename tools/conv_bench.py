@@ -42,7 +42,7 @@ def timeit(fn, iters=24):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     tiles = [int(t) for t in sys.argv[2:]] or [-1]
-    n = 32
+    n = int(os.environ.get('EMSA_BENCH_N', '32'))     # batch size
     print(f"lib: {os.environ.get('EMSA_LIB', 'default')}")
     only = os.environ.get('EMSA_BENCH_SHAPE')      # substring filter on the shape name
     for name, cin, cout, k, s, p, h, w in SHAPES:
