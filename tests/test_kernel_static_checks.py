@@ -1,0 +1,29 @@
+"""Static checks of the compiled gfx950 kernels (cross-compiled, no GPU needed): no scratch
+(register spills) in any kernel, and no `s_waitcnt` that blocks an MFMA kernel's K loop on
+freshly issued global loads before the step's matrix work -- both were real, silent 5-40 %
+regressions during development."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+needs_hipcc = pytest.mark.skipif(not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')),
+                                 reason='hipcc not available')
+
+
+@needs_hipcc
+def test_no_early_waits_in_mfma_loops():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_early_waits.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'early waits: 0' in r.stdout
+
+
+@needs_hipcc
+def test_no_register_spills():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_spills.py')],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
