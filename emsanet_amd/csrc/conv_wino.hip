@@ -392,6 +392,26 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
       sclo = wf32x2{sc.x, sc.y}; schi = wf32x2{sc.z, sc.w};
       shlo = wf32x2{sh.x, sh.y}; shhi = wf32x2{sh.z, sh.w};
     }
+    // ALL the epilogue's loads first, then the math and the stores: a load issued behind a store
+    // is followed by `s_waitcnt vmcnt(0)`, which on gfx9 also waits for the store's write
+    // acknowledgement -- four serialised memory round trips per workgroup otherwise
+    float4 rres[PXI], rmsk[PXI];
+    wu32x2 rbits[PXI];
+#pragma unroll
+    for (int k = 0; k < PXI; ++k) {
+      const bool live = ok[k];
+      if (p.residual)
+        rres[k] = wbuf_ld4(rs_res, live ? (opix[k] * (uint32_t)p.ld_res + (uint32_t)n) * 4u : kOOBw);
+      if (p.mask_src)
+        rmsk[k] = wbuf_ld4(rs_msk, live ? (opix[k] * (uint32_t)p.ld_mask + (uint32_t)n) * 4u : kOOBw);
+      if constexpr (kWN == 64) {
+        if (p.mask_bits)
+          rbits[k] = __builtin_bit_cast(
+              wu32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                          rs_mb, (int)(live ? (opix[k] * (uint32_t)p.tiles_n + (uint32_t)nt) * 8u
+                                            : kOOBw), 0, 0));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < PXI; ++k) {
       const bool live = ok[k];
@@ -401,15 +421,12 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
         vhi = __builtin_elementwise_fma(vhi, schi, shhi);
       }
       if (p.residual) {
-        const uint32_t off = live ? (opix[k] * (uint32_t)p.ld_res + (uint32_t)n) * 4u : kOOBw;
-        const float4 rr = wbuf_ld4(rs_res, off);
-        vlo += wf32x2{rr.x, rr.y};
-        vhi += wf32x2{rr.z, rr.w};
+        vlo += wf32x2{rres[k].x, rres[k].y};
+        vhi += wf32x2{rres[k].z, rres[k].w};
       }
       float4 v = make_float4(vlo.x, vlo.y, vhi.x, vhi.y);
       if (p.mask_src) {
-        const uint32_t off = live ? (opix[k] * (uint32_t)p.ld_mask + (uint32_t)n) * 4u : kOOBw;
-        const float4 mm = wbuf_ld4(rs_msk, off);
+        const float4 mm = rmsk[k];
         v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
         v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
       }
@@ -417,10 +434,7 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
         // ReLU masks as bits: the 16 lanes that share a pixel share one 64-bit word; bit
         // comp * 16 + col4 -> x, y in the low word, z, w in the high word
         if (p.mask_bits) {
-          const uint32_t off = live ? (opix[k] * (uint32_t)p.tiles_n + (uint32_t)nt) * 8u : kOOBw;
-          const wu32x2 mw = __builtin_bit_cast(
-              wu32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_mb, (int)off, 0, 0));
-          const uint32_t t0 = mw.x >> col4, t1 = mw.y >> col4;
+          const uint32_t t0 = rbits[k].x >> col4, t1 = rbits[k].y >> col4;
           v.x = __uint_as_float(__float_as_uint(v.x) & (uint32_t)__builtin_amdgcn_sbfe((int)t0, 0, 1));
           v.y = __uint_as_float(__float_as_uint(v.y) & (uint32_t)__builtin_amdgcn_sbfe((int)t0, 16, 1));
           v.z = __uint_as_float(__float_as_uint(v.z) & (uint32_t)__builtin_amdgcn_sbfe((int)t1, 0, 1));
