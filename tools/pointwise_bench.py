@@ -45,10 +45,15 @@ def main():
         rows = L.emsa_bn_bwd_rows(n * h * w, c)
         part = torch.empty((2, rows, c), device=DEV)
         p = Fn._p
-        t = timeit(lambda: L.emsa_bn_bwd_reduce(p(dy), p(y), p(x), p(mean), p(inv), None, n, h * w, c, 1, p(part), Fn._stream()))
+        t = timeit(lambda: L.emsa_bn_bwd_reduce(p(dy), p(y), None, p(x), p(mean), p(inv), None, n, h * w, c, 1, p(part), Fn._stream()))
         row += f" | bwd_reduce {3 * mb / t:5.2f}"
         t = timeit(lambda: Fn.bn_bwd(dy, y, x, sc, mean, inv, None, 1, True, True))
         row += f" | bwd(reduce+apply+dres) {8 * mb / t:5.2f}"
+        _, bits = Fn.bn_act(x, sc, sh, None, None, 1, want_mask=True)
+        t = timeit(lambda: Fn.bn_act(x, sc, sh, None, None, 1, want_mask=True))
+        row += f" | bn_act+bits {2 * mb / t:5.2f} ({t:.0f}us)"
+        t = timeit(lambda: Fn.bn_bwd(dy, bits, x, sc, mean, inv, None, 1, True, True))
+        row += f" | bwd bits (6 tensors) {6 * mb / t:5.2f} ({t:.0f}us)"
         if h <= 120:
             wdw = torch.randn(c, 1, 3, 3, device=DEV)
             b = torch.randn(c, device=DEV)
