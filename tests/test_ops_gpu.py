@@ -29,6 +29,13 @@ CONVS = [
     (512, 256, (1, 1), (1, 1), (0, 0), 2, 5, 5),
     (256, 12, (1, 1), (1, 1), (0, 0), 4, 1, 1),
     (64, 64, (1, 3), (1, 1), (0, 1), 1, 30, 40),
+    # ragged: channel counts that are no multiple of the 64-wide tiles / 16-wide K chunks, odd and
+    # very short lines, fewer pixels than one K step
+    (40, 72, (1, 3), (1, 1), (0, 1), 1, 5, 7),
+    (72, 40, (3, 1), (1, 1), (1, 0), 2, 7, 5),
+    (8, 8, (1, 3), (1, 1), (0, 1), 1, 1, 2),
+    (64, 64, (3, 1), (1, 1), (1, 0), 1, 3, 3),
+    (24, 136, (3, 3), (1, 1), (1, 1), 1, 5, 3),
 ]
 
 
