@@ -21,6 +21,11 @@ SHAPES = [
     ('3x3 512->512 /32', 512, 512, (3, 3), 1, (1, 1), 15, 20),
     ('3x3 256->128 /8', 256, 128, (3, 3), 1, (1, 1), 60, 80),
     ('3x3 128->40 /4', 128, 40, (3, 3), 1, (1, 1), 120, 160),
+    # memory-bound 1x1 convs (decoder skip connections) and a stride-2 block conv
+    ('1x1 c64 /4', 64, 64, (1, 1), 1, (0, 0), 120, 160),
+    ('1x1 c128 /8', 128, 128, (1, 1), 1, (0, 0), 60, 80),
+    ('1x1 c256 /16', 256, 256, (1, 1), 1, (0, 0), 30, 40),
+    ('3x1 s2 64->128 /4', 64, 128, (3, 1), (2, 1), (1, 0), 120, 160),
 ]
 
 
