@@ -82,6 +82,61 @@ __global__ __launch_bounds__(256) void mfma_valu(float* out, int iters, float a,
   if (s == 123.456f) out[threadIdx.x] = s;
 }
 
+// K loop of conv1d_wino_kernel<64>: per step 16 MFMAs per wave fed by 8 ds_read_b128 (2 KB each) and
+// 4 packed FMAs, then barrier, 6 ds_write_b128 per thread (the 24 KB tile), barrier.  MODE bit0:
+// with the LDS writes + barriers, bit1: with the LDS reads (else operands stay in registers)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(256, 5) void wino_like(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) float lds[6144];       // 24 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < 6144; i += 256) lds[i] = (float)i;
+  __syncthreads();
+  f32x16 acc[2];
+  for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const float* a0 = lds + (0 * 32 + l31) * 16;
+  const float* a1 = lds + (2 * 32 + l31) * 16;
+  const float* b = lds + 2048 + (wave * 64 + l31) * 16;
+  float4 st = make_float4(1.f, 2.f, 3.f, 4.f);
+  float4 x0 = make_float4(1.f, 2.f, 3.f, 4.f), x1 = x0, f0 = x0, f1 = x0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int co = ((lh + 2 * t) << 2) ^ (((l31 >> 2) & 3) << 2);
+      if (MODE & 2) {
+        x0 = *reinterpret_cast<const float4*>(a0 + co);
+        x1 = *reinterpret_cast<const float4*>(a1 + co);
+        f0 = *reinterpret_cast<const float4*>(b + co);
+        f1 = *reinterpret_cast<const float4*>(b + 32 * 16 + co);
+      }
+      const f32x2 sg = {-1.f, -1.f};
+      const f32x2 vlo = __builtin_elementwise_fma(f32x2{x1.x, x1.y}, sg, f32x2{x0.x, x0.y});
+      const f32x2 vhi = __builtin_elementwise_fma(f32x2{x1.z, x1.w}, sg, f32x2{x0.z, x0.w});
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vlo.x, f0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vlo.x, f1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vlo.y, f0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vlo.y, f1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vhi.x, f0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vhi.x, f1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vhi.y, f0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vhi.y, f1.w, acc[1], 0, 0, 0);
+    }
+    if (MODE & 1) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        *reinterpret_cast<float4*>(lds + ((tid >> 2) + 64 * j) * 16 + (tid & 3) * 4) = st;
+      __syncthreads();
+    }
+    asm volatile("" ::: "memory");
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
 template <class F>
 double time_ms(F launch) {
   hipEvent_t a, b;
@@ -126,6 +181,15 @@ int main() {
     double m12 = time_ms([&] { hipLaunchKernelGGL(mfma_valu<12>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); });
     printf("waves/SIMD %d  FMAs per MFMA 0/2/4/8/12: %6.1f %6.1f %6.1f %6.1f %6.1f TFLOP/s\n", wps,
            fl / m0 / 1e9, fl / m2 / 1e9, fl / m4 / 1e9, fl / m8 / 1e9, fl / m12 / 1e9);
+  }
+  for (int wps : {1, 3, 5}) {
+    const int blocks = cus * wps, it2 = 20000;
+    const double fl = (double)blocks * 4 * it2 * 16 * 32 * 32 * 2 * 2;
+    double m0 = time_ms([&] { hipLaunchKernelGGL(wino_like<0>, dim3(blocks), dim3(256), 0, 0, out, it2); });
+    double m2 = time_ms([&] { hipLaunchKernelGGL(wino_like<2>, dim3(blocks), dim3(256), 0, 0, out, it2); });
+    double m3 = time_ms([&] { hipLaunchKernelGGL(wino_like<3>, dim3(blocks), dim3(256), 0, 0, out, it2); });
+    printf("workgroups/CU %d  Winograd K loop: MFMA+transform %6.1f  +LDS reads %6.1f  +LDS writes, 2 barriers %6.1f TFLOP/s\n",
+           wps, fl / m0 / 1e9, fl / m2 / 1e9, fl / m3 / 1e9);
   }
   return 0;
 }
