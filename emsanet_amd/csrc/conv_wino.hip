@@ -86,6 +86,10 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
 // precision): the operands are rounded to bf16 when they leave LDS and one
 // v_mfma_f32_32x32x16_bf16 replaces eight fp32 MFMAs; accumulation, the Winograd transforms and
 // everything in HBM stay fp32.
+#ifndef EMSA_WINO_PRIO
+#define EMSA_WINO_PRIO 2   // 0 = no s_setprio, 1 = raised around the MFMA cluster, 2 = also: the next step's loads
+                          // issue at the highest priority (measured +1..2 %)
+#endif
 template <int kWN, bool BF16 = false>   // kWN: output channels per workgroup, 64 (2 MFMA tiles per wave) or 32
 __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(const WinoArgs p) {
   constexpr int NT = kWN / 32;                    // accumulator tiles per wave
@@ -195,6 +199,9 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   __syncthreads();
   for (int s = 0; s < p.ksteps; ++s) {
     const bool has_next = s + 1 < p.ksteps;
+#if EMSA_WINO_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);           // the next step's loads go out first
+#endif
     if (has_next) load_regs(s + 1);
     // rows ra_*32 + l31 etc.: the swizzle term depends on (l31 >> 2) & 3 only (row bases are
     // multiples of 32); logical chunk of step t = lh + 2*t
@@ -202,7 +209,9 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     const float* a0 = As + (ra_ * kPairs + l31) * kWLD;
     const float* a1 = As + (rb_ * kPairs + l31) * kWLD;
     const float* b = Bs + (wave * kWN + l31) * kWLD;
+#if EMSA_WINO_PRIO != 0
     __builtin_amdgcn_s_setprio(1);
+#endif
     if constexpr (BF16) {
       // this lane's 8 k values of the step: chunks lh and lh + 2 (the same permutation for A and B)
       const int c0 = (lh << 2) ^ sw, c1 = ((lh + 2) << 2) ^ sw;
@@ -248,7 +257,9 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, fb[u].w, acc[u], 0, 0, 0);
     }
     }
+#if EMSA_WINO_PRIO != 0
     __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
     if (has_next) store_lds();
     __syncthreads();
