@@ -304,6 +304,40 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   const wf32x2 sg2o = {sgo, sgo};
   const int m03row = (rgi & 1) ? 3 : 0;
 #pragma unroll
+  for (int k = 0; k < PXI; ++k) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((rgi + RG * k) * 4, (int)lane_pix);
+    ok[k] = nok && o != kNoPix;
+    opix[k] = o;
+  }
+  // every tensor touched by the epilogue is < 2 GiB (checked by the launcher): byte offsets are
+  // 32-bit and an offset with the top bit set is out of range for these descriptors -- loads
+  // return zero, stores are dropped -- so dead pixels / channel columns need no branch
+  const __amdgpu_buffer_rsrc_t rs_out = wrsrc(p.out, kOOBw);
+  const __amdgpu_buffer_rsrc_t rs_res = wrsrc(p.residual, kOOBw);
+  const __amdgpu_buffer_rsrc_t rs_msk = wrsrc(p.mask_src, kOOBw);
+  const __amdgpu_buffer_rsrc_t rs_mb = wrsrc(p.mask_bits, kOOBw);
+  // ALL the epilogue's loads are issued HERE, before the accumulators are staged through LDS:
+  // their latency hides behind the staging and the statistics, and none of them sits behind a
+  // store (a load behind a store is followed by `s_waitcnt vmcnt(0)`, which on gfx9 also waits
+  // for the store's write acknowledgement -- four serialised round trips per workgroup)
+  float4 rres[PXI], rmsk[PXI];
+  wu32x2 rbits[PXI];
+#pragma unroll
+  for (int k = 0; k < PXI; ++k) {
+    const bool live = ok[k];
+    if (p.residual)
+      rres[k] = wbuf_ld4(rs_res, live ? (opix[k] * (uint32_t)p.ld_res + (uint32_t)n) * 4u : kOOBw);
+    if (p.mask_src)
+      rmsk[k] = wbuf_ld4(rs_msk, live ? (opix[k] * (uint32_t)p.ld_mask + (uint32_t)n) * 4u : kOOBw);
+    if constexpr (kWN == 64) {
+      if (p.mask_bits)
+        rbits[k] = __builtin_bit_cast(
+            wu32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        rs_mb, (int)(live ? (opix[k] * (uint32_t)p.tiles_n + (uint32_t)nt) * 8u
+                                          : kOOBw), 0, 0));
+    }
+  }
+#pragma unroll
   for (int h = 0; h < 2; ++h) {
   if (h) __syncthreads();                          // half 0 of the stage has been consumed
 #pragma unroll
@@ -325,9 +359,6 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
     const wf32x2 thi = wf32x2{m2.z, m2.w} + wf32x2{m03.z, m03.w};
     ylo[k] = __builtin_elementwise_fma(tlo, sg2o, wf32x2{m1.x, m1.y}) + blo;
     yhi[k] = __builtin_elementwise_fma(thi, sg2o, wf32x2{m1.z, m1.w}) + bhi;
-    const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(px * 4, (int)lane_pix);
-    ok[k] = nok && o != kNoPix;
-    opix[k] = o;
   }
   }   // halves
 
@@ -389,39 +420,12 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
   }
 
   {
-    // every tensor touched here is < 2 GiB (checked by the launcher): byte offsets are 32-bit and
-    // an offset with the top bit set is out of range for these descriptors -- loads return zero,
-    // stores are dropped -- so dead pixels / channel columns need no branch
-    const __amdgpu_buffer_rsrc_t rs_out = wrsrc(p.out, kOOBw);
-    const __amdgpu_buffer_rsrc_t rs_res = wrsrc(p.residual, kOOBw);
-    const __amdgpu_buffer_rsrc_t rs_msk = wrsrc(p.mask_src, kOOBw);
-    const __amdgpu_buffer_rsrc_t rs_mb = wrsrc(p.mask_bits, kOOBw);
     wf32x2 sclo = {1.f, 1.f}, schi = {1.f, 1.f}, shlo = {0.f, 0.f}, shhi = {0.f, 0.f};
     const bool affine = p.scale != nullptr;        // uniform
     if (affine && nok) {
       const float4 sc = emsa_ld4(p.scale + n), sh = emsa_ld4(p.shift + n);
       sclo = wf32x2{sc.x, sc.y}; schi = wf32x2{sc.z, sc.w};
       shlo = wf32x2{sh.x, sh.y}; shhi = wf32x2{sh.z, sh.w};
-    }
-    // ALL the epilogue's loads first, then the math and the stores: a load issued behind a store
-    // is followed by `s_waitcnt vmcnt(0)`, which on gfx9 also waits for the store's write
-    // acknowledgement -- four serialised memory round trips per workgroup otherwise
-    float4 rres[PXI], rmsk[PXI];
-    wu32x2 rbits[PXI];
-#pragma unroll
-    for (int k = 0; k < PXI; ++k) {
-      const bool live = ok[k];
-      if (p.residual)
-        rres[k] = wbuf_ld4(rs_res, live ? (opix[k] * (uint32_t)p.ld_res + (uint32_t)n) * 4u : kOOBw);
-      if (p.mask_src)
-        rmsk[k] = wbuf_ld4(rs_msk, live ? (opix[k] * (uint32_t)p.ld_mask + (uint32_t)n) * 4u : kOOBw);
-      if constexpr (kWN == 64) {
-        if (p.mask_bits)
-          rbits[k] = __builtin_bit_cast(
-              wu32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                          rs_mb, (int)(live ? (opix[k] * (uint32_t)p.tiles_n + (uint32_t)nt) * 8u
-                                            : kOOBw), 0, 0));
-      }
     }
 #pragma unroll
     for (int k = 0; k < PXI; ++k) {
