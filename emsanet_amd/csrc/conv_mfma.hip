@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(
   if (p.ws != nullptr) {
     // deterministic split-K: this workgroup's partial tile [3][BCO][BCI] goes to the workspace
     // with plain (coalesced along ci) stores; wgrad1d_reduce_kernel sums the splits
-    float* wt = p.ws + ((size_t)ks * p.n_tiles + tile) * (3 * BCO * BCI);
+    float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (3 * BCO * BCI);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1d
 
   if (p.ws != nullptr) {
     // deterministic split-K: this workgroup's partial tile [3][BCO][BCI] goes to the workspace
-    float* wt = p.ws + ((size_t)ks * p.n_tiles + tile) * (3 * BCO * BCI);
+    float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (3 * BCO * BCI);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -1192,17 +1192,19 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1d
 // flight was slower on every layer shape: most split groups idle when there are few splits.)
 __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
     const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
-    int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, float* __restrict__ dw,
+    int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
     float* __restrict__ dbias) {
   __shared__ float4 red[16][16];
   const int tid = threadIdx.x;
-  const int weight_blocks = n_tiles * 192;
+  const int weight_blocks = n_tiles * R * 192;
   if ((int)blockIdx.x < weight_blocks) {
-    const int tile = blockIdx.x / 192, row = blockIdx.x % 192;      // row = t*64 + co_l
+    // workgroup = (kernel row kr, tile, row = t*64 + co_l); ws[split][kr][tile][t][co_l][ci_l]
+    const int kt = blockIdx.x / 192, row = blockIdx.x % 192;
+    const int kr = kt / n_tiles, tile = kt % n_tiles;
     const int col = tid & 15, sg = tid >> 4;
-    const float* src = ws + (size_t)tile * 12288 + row * 64 + col * 4;
+    const float* src = ws + (size_t)kt * 12288 + row * 64 + col * 4;
     float4 a = emsa_zero4();
-    const size_t sstride = (size_t)n_tiles * 12288;
+    const size_t sstride = (size_t)R * n_tiles * 12288;
     // eight independent loads in flight per thread: with one (a plain loop) the few hundred
     // workgroups of a 64-channel layer (768 partial tiles of 48 KB) are latency bound, 47 us
     for (int sp = sg; sp < splits; sp += 128) {
@@ -1226,11 +1228,13 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
       const int t = row >> 6, co = (tile / n_ci_tiles) * 64 + (row & 63);
       const int ci = (tile % n_ci_tiles) * 64 + col * 4;
       if (co < n_ch) {
-        float* o = dw + ((size_t)co * k_ch + ci) * 3 + t;
+        // OIHW: [co][ci][kr][t] (R = 1: the 3 taps of a 1-D conv; R = 3: a 3x3 kernel)
+        float* o = dw + (((size_t)co * k_ch + ci) * R + kr) * 3 + t;
+        const int cs = 3 * R;
         if (ci + 0 < k_ch) o[0] = a.x;
-        if (ci + 1 < k_ch) o[3] = a.y;
-        if (ci + 2 < k_ch) o[6] = a.z;
-        if (ci + 3 < k_ch) o[9] = a.w;
+        if (ci + 1 < k_ch) o[cs] = a.y;
+        if (ci + 2 < k_ch) o[2 * cs] = a.z;
+        if (ci + 3 < k_ch) o[3 * cs] = a.w;
       }
     }
   } else if (dbias != nullptr) {
@@ -1488,9 +1492,8 @@ extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
   if (!geom_ok(g)) return 0;
   Wgrad1dPlan pl;
   if (!plan_wgrad1d(g, dout_is_aligned(g, nullptr), pl)) return 0;
-  if (pl.w.R != 1) return 0;            // 3x3: atomics into the packed layout
-  return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * 12288 + (int64_t)pl.w.n_co_tiles * 64) *
-         (int64_t)sizeof(float);
+  return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * pl.w.R * 12288 +
+                               (int64_t)pl.w.n_co_tiles * 64) * (int64_t)sizeof(float);
 }
 
 extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout,
@@ -1511,12 +1514,12 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   const int taps = g->kh * g->kw;
   Wgrad1dPlan pl;
   const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl);
-  if (ws != nullptr && (!one_d || pl.w.R != 1)) return EMSA_E_SHAPE;   // ws_bytes(g) was 0
+  if (ws != nullptr && !one_d) return EMSA_E_SHAPE;   // ws_bytes(g) was 0
   if (one_d) {
     Wgrad1dArgs& w = pl.w;
     w.in = in; w.dout = dout; w.dw = dw; w.dbias = dbias;
     w.ws = ws;
-    w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * 12288 : nullptr;
+    w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * 12288 : nullptr;
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     const int ps = prof_begin(7, algo_flops(a.g), st);
@@ -1527,9 +1530,9 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
       hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), lds, st, w);
     if (ws != nullptr)
-      hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * 192 + w.n_co_tiles), dim3(256),
-                         0, st, ws, w.ws_bias, pl.ksplit, w.n_tiles, w.n_ci_tiles, w.n_co_tiles,
-                         w.n_ch, w.k_ch, dw, dbias);
+      hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * w.R * 192 + w.n_co_tiles),
+                         dim3(256), 0, st, ws, w.ws_bias, pl.ksplit, w.n_tiles, w.n_ci_tiles,
+                         w.n_co_tiles, w.n_ch, w.k_ch, w.R, dw, dbias);
     prof_end(ps, st);
     return emsa_launch_status();
   }

@@ -93,7 +93,7 @@ int emsa_conv_stats_rows(const EmsaConvGeom* g);
  *   ws     NULL: split-K partial sums are accumulated with fp32 atomics into dw in the packed
  *          layout [tap][n][c] (emsa_unpack_wgrad converts) and into dbias; BOTH MUST BE ZEROED by
  *          the caller.
- *          non-NULL (only when emsa_conv_wgrad_ws_bytes(g) > 0: the stride-1 3-tap 1-D convs;
+ *          non-NULL (only when emsa_conv_wgrad_ws_bytes(g) > 0: the stride-1 3-tap 1-D and 3x3 convs;
  *          at least that many bytes): deterministic two-pass form -- the partial tiles are stored
  *          to ws and a reduce kernel writes dw directly in the reference's OIHW parameter layout
  *          [n][c][tap] and dbias; no zeroing, no unpack pass, bit-reproducible.                */

@@ -246,17 +246,17 @@ def test_conv_wgrad(cfg):
     torch.cuda.synchronize()
     close(dw, wt.grad, what='wgrad')
     close(db, b.grad, what='bgrad')
-    # deterministic two-pass form (1-D stride-1 convs): OIHW directly, bit-reproducible
+    # deterministic two-pass form (stride-1 3-tap and 3x3 convs): OIHW directly, bit-reproducible
     like = wt.detach().float().to(DEV)
     dw2, db2, packed2 = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True)
     if not packed2:
-        assert k in ((3, 1), (1, 3)) and s == (1, 1)
+        assert k in ((3, 1), (1, 3), (3, 3)) and s == (1, 1)
         close(dw2, wt.grad, what='wgrad two-pass')
         close(db2, b.grad, what='bgrad two-pass')
         dw3, db3, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True)
         assert torch.equal(dw2, dw3) and torch.equal(db2, db3)
     else:
-        assert not (k in ((3, 1), (1, 3)) and s == (1, 1))
+        assert not (k in ((3, 1), (1, 3), (3, 3)) and s == (1, 1))
 
 
 def test_conv_wgrad_split_k_large():
