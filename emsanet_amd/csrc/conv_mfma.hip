@@ -1000,13 +1000,22 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(
 // math and stores E and D; the MFMA loop only reads LDS.  Line ends need no masks: the loads of
 // d0 / d3 across a line end are sent out of range and read as zero.  ~80 VALU per K step of 32
 // MFMAs.
-template <int BCO, int BCI>
+// BF16 (EMSA_BF16_MFMA=1, NOT the default and never the headline: BASELINE config 3's mixed
+// precision): E and D are rounded to bf16 as they enter LDS ([comp][channel][pair], pair fastest)
+// and one v_mfma_f32_32x32x16_bf16 per component covers the step's 16 pixel pairs; accumulation,
+// the transforms and everything in HBM stay fp32.
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+template <int BCO, int BCI, bool BF16 = false>
 __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
   static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
   constexpr int PK = 32, NP = PK / 2, XROWS = PK + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const eS = smem;                      // [NP pairs][4: e0, e0+e1, e0-e1, e1][BCO]
   float* const dS = smem + NP * 4 * BCO;       // [NP pairs][4: D0..D3][BCI]
+  // BF16: [4 comps][64 channels][kBL = 20 (16 pairs + pad: 8-byte aligned rows)] bf16 each
+  constexpr int kBL = 20;
+  __bf16* const eH = reinterpret_cast<__bf16*>(smem);
+  __bf16* const dH = eH + 4 * BCO * kBL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -1085,6 +1094,22 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1d
     float* d = dS + pr * 4 * BCI + col4;
     const float4 es = add4(re[0], re[1]);
     bsum = add4(bsum, es);                       // bias gradient = column sums of dy
+    if constexpr (BF16) {
+      auto st4h = [&](__bf16* o, const float4& v) {
+        o[0] = (__bf16)v.x; o[kBL] = (__bf16)v.y; o[2 * kBL] = (__bf16)v.z; o[3 * kBL] = (__bf16)v.w;
+      };
+      __bf16* eo = eH + col4 * kBL + pr;
+      __bf16* dq = dH + col4 * kBL + pr;
+      st4h(eo, re[0]);
+      st4h(eo + BCO * kBL, es);
+      st4h(eo + 2 * BCO * kBL, sub4(re[0], re[1]));
+      st4h(eo + 3 * BCO * kBL, re[1]);
+      st4h(dq, sub4(rx[0], rx[2]));
+      st4h(dq + BCI * kBL, add4(rx[1], rx[2]));
+      st4h(dq + 2 * BCI * kBL, sub4(rx[2], rx[1]));
+      st4h(dq + 3 * BCI * kBL, sub4(rx[1], rx[3]));
+      return;
+    }
     emsa_st4(e, re[0]);
     emsa_st4(e + BCO, es);
     emsa_st4(e + 2 * BCO, sub4(re[0], re[1]));
@@ -1115,6 +1140,19 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1d
     const bool has_next = s + 1 < s_end;
     if (has_next) load_regs(s + 1);
     // K index of the MFMA = pixel pair: lane half lh takes pair 2*kk + lh of the step's 16
+    if constexpr (BF16) {
+      // lane (l31, lh): channel row l31 of its 32x32 tile, pairs 8*lh .. 8*lh + 7 (16 bytes)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint2* ea = reinterpret_cast<const uint2*>(eH + (c * BCO + wco * 32 + l31) * kBL + 8 * lh);
+        const uint2* da = reinterpret_cast<const uint2*>(dH + (c * BCI + wci * 32 + l31) * kBL + 8 * lh);
+        const uint2 e0 = ea[0], e1 = ea[1], d0 = da[0], d1 = da[1];
+        const uint4 eu = make_uint4(e0.x, e0.y, e1.x, e1.y), du = make_uint4(d0.x, d0.y, d1.x, d1.y);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, eu),
+                                                         __builtin_bit_cast(gbf16x8, du), acc[c],
+                                                         0, 0, 0);
+      }
+    } else {
     const float* e = eS + lh * 4 * BCO + wco * 32 + l31;
     const float* d = dS + lh * 4 * BCI + wci * 32 + l31;
 #pragma unroll
@@ -1123,6 +1161,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1d
       for (int c = 0; c < 4; ++c)
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(e[(kk * 8 + c) * BCO], d[(kk * 8 + c) * BCI],
                                                       acc[c], 0, 0, 0);
+    }
     }
     __syncthreads();
     if (has_next) store_lds();
@@ -1523,7 +1562,15 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     const int ps = prof_begin(7, algo_flops(a.g), st);
-    if (pl.wino)
+    static const bool bf16 = [] {
+      const char* e = getenv("EMSA_BF16_MFMA");
+      return e && e[0] == '1';
+    }();
+    if (pl.wino && bf16)
+      hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true>),
+                         dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
+                         (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
+    else if (pl.wino)
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
     else

@@ -550,6 +550,20 @@ for cin, cout, k in ((64, 64, (1, 3)), (256, 128, (3, 1)), (128, 40, (3, 3))):
     err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     worst = max(worst, err)
     assert 1e-5 < err < 2e-2, err      # really bf16 (not the fp32 path), and bf16-accurate
+    # weight gradient (Winograd F(3,2) kernel, operands rounded to bf16 at the LDS store)
+    wt64 = wt.double().requires_grad_(True)
+    b64 = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    yy = F.conv2d(x.double(), wt64, b64, padding=(k[0] // 2, k[1] // 2))
+    dy = rnd(*yy.shape, seed=7)
+    yy.backward(dy.double())
+    like = wt.to(DEV)
+    dw, db, packed = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True)
+    assert not packed
+    errw = (dw.cpu().double() - wt64.grad).abs().max().item() / wt64.grad.abs().max().item()
+    errb = (db.cpu().double() - b64.grad).abs().max().item() / b64.grad.abs().max().item()
+    assert 1e-5 < errw < 2e-2, errw
+    assert errb < 1e-4, errb           # the bias gradient is summed in fp32
+    worst = max(worst, errw)
 print("BF16_OK %.2e" % worst)
 '''
     env = dict(os.environ, EMSA_BF16_MFMA='1')
