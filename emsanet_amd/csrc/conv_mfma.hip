@@ -42,7 +42,7 @@ int g_prof_seen[kProfClasses] = {0};
 const char* const kProfNames[kProfClasses] = {
     "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,4,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
-    "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1>",
+    "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1> (unused)",
     "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_wino_kernel<64,64>",
     "conv1d_wino_kernel"};
 }  // namespace
@@ -1585,7 +1585,8 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   }
   if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2>(a, st);
   if (taps == 1) {
-    if (g->n_ch >= 128 && g->k_ch >= 128) return launch_wgrad<128, 128, 1, 2, 2, 1>(a, st);
+    // (a 128x128 tile was measured slower for the 1x1 convs: 96 / 82 us vs 66 / 63 us at 128 /
+    //  256 channels -- four times the split-K partial-tile volume per workgroup)
     return launch_wgrad<64, 64, 1, 2, 2, 1>(a, st);
   }
   return launch_wgrad<64, 64, 3, 2, 2, 1>(a, st);
