@@ -10,7 +10,10 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 256 * 8;
+#ifndef EMSA_PW_BLOCKS_PER_CU
+#define EMSA_PW_BLOCKS_PER_CU 8
+#endif
+constexpr int kMaxBlocks = 256 * EMSA_PW_BLOCKS_PER_CU;
 
 inline int grid_for(long work_items) {
   long b = (work_items + kThreads - 1) / kThreads;
