@@ -1295,7 +1295,10 @@ extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32, kBwdSlices), dim3(256), 0, st, partial,
                      rows, rows_alloc, c);
   const long total4 = pixels * (c / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads),
+  // four workgroups per CU (the other streaming kernels: eight): measured -0.3 ms per step
+  int ap_grid = grid_for(total4);
+  if (ap_grid > 256 * 4) ap_grid = 256 * 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ap_grid), dim3(kThreads),
                      (size_t)2 * c * sizeof(float), st, dy, y, mask_bits, x, gamma, save_mean,
                      save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / 4, total4,
                      1.0f / (float)pixels, act, train, dx, dres);
