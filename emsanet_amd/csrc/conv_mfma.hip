@@ -787,6 +787,9 @@ struct Wgrad1dArgs {
 #ifndef EMSA_W1D_WPE
 #define EMSA_W1D_WPE 4
 #endif
+#ifndef EMSA_W1DW_WPE
+#define EMSA_W1DW_WPE 4   // waves per SIMD the Winograd weight-gradient kernel is compiled for
+#endif
 #ifndef EMSA_W1D_XCD
 #define EMSA_W1D_XCD 1
 #endif
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(
 // the transforms and everything in HBM stay fp32.
 typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
 template <int BCO, int BCI, bool BF16 = false>
-__global__ __launch_bounds__(256, 4) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
+__global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
   static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
   constexpr int PK = 32, NP = PK / 2, XROWS = PK + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
