@@ -48,9 +48,13 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='do not bracket conv launches with HIP events (A/B of the overhead)')
-    ap.add_argument('--timing-every', type=int, default=4,
-                    help='bracket every n-th launch of each conv kernel class with HIP events')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--timing-every', type=int, default=5,
+                    help='bracket every n-th launch of each conv kernel class with HIP events '
+                         '(5: coprime to the 4 launches an NBt1D block issues per class, so every '
+                         'position of the block is sampled)')
+    ap.add_argument('--cpu-seconds', type=float, default=45.0,
+                    help='bound of the timed part of the CPU baseline (3 warm-up + up to 10 timed '
+                         'iterations, SURVEY 8d; at least 3 timed)')
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
     ap.add_argument('--force-dist', action='store_true',
                     help='validation: RCCL process group + bucketed all-reduce path with ONE rank')
@@ -62,6 +66,9 @@ def parse():
                     help='complete training step: all task losses on device (semantic / scene CE, '
                          'instance MSE / L1 / von Mises, multi-scale, reference weights) and '
                          'loss.backward() instead of fixed output cotangents')
+    ap.add_argument('--grad-dtype', default='f32', choices=('f32', 'bf16'),
+                    help='dtype of the gradient all-reduce buckets on the wire (bf16: half the xGMI '
+                         'bytes, SURVEY 8e)')
     ap.add_argument('--graph', action='store_true',
                     help='with --eval: replay the whole-model hipGraph (BASELINE config 5 shape)')
     return ap.parse_args()
@@ -139,24 +146,56 @@ def cpu_baseline(args):
             p.grad = None
         flat = flatten_outputs(o(batch))
         torch.autograd.backward(flat, [torch.full_like(t, 1e-3) for t in flat])
+    # 3 warm-up + 10 timed iterations; bounded so that the default run stays within
+    # minutes on a slow host (warm-up: at most 30 s after the first iteration, timed: at least
+    # 3 iterations, then until --cpu-seconds)
     t0 = time.time()
-    step()                      # warm-up (allocator, oneDNN primitive cache)
+    n_warm = 0
+    while n_warm < 3 and (n_warm == 0 or time.time() - t0 < 30.0):
+        step()                  # warm-up (allocator, oneDNN primitive cache, thread pool)
+        n_warm += 1
     warm = time.time() - t0
-    n, t0 = 0, time.time()
-    while True:
+    times = []
+    t0 = time.time()
+    while len(times) < 10 and (len(times) < 3 or time.time() - t0 < args.cpu_seconds):
+        t1 = time.time()
         step()
-        n += 1
-        if time.time() - t0 >= args.cpu_seconds or n >= 10:
-            break
+        times.append(time.time() - t1)
     dt = time.time() - t0
+    n = len(times)
     return {'value': round(n * bs / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} fwd+bwd iteration(s) of the PyTorch-CPU oracle, bs={bs}, '
+            'best_iteration_value': round(bs / min(times), 4),
+            'sample': f'{n} timed fwd+bwd iteration(s) of the PyTorch-CPU oracle, bs={bs}, '
                       f'{args.width}x{args.height} RGB-D, all heads, train mode, fp32 oneDNN, '
-                      f'after 1 warm-up iteration ({warm:.1f}s)'}
+                      f'{cores} threads, after {n_warm} warm-up iteration(s) ({warm:.1f}s)'}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: become the launcher -- one process
+    per GPU through torch.distributed.run on 127.0.0.1 (the same command line the driver uses),
+    stdout (rank 0's JSON line) passed through."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get('EMSA_DIST_BACKEND', 'nccl') == 'nccl':
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible (RCCL needs one "
+                         "device per rank; EMSA_DIST_BACKEND=gloo rehearses the flow on one GPU)")
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     # stdout carries exactly ONE JSON line (rank 0): everything libraries print to fd 1 while the
     # benchmark runs (RCCL prints its version banner there) is routed to stderr
     sys.stdout.flush()
@@ -175,8 +214,7 @@ def run(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one process per GPU")
     assert torch.cuda.is_available(), "bench.py needs an AMD GPU"
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -210,7 +248,10 @@ def run(args):
     else:
         model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    buckets = GradientBuckets(params, force_collectives=args.force_dist)
+    # FusedSGD folds the 1/world averaging into its update kernel; torch's optimizer needs it done
+    comm_dtype = {'f32': None, 'bf16': torch.bfloat16}[args.grad_dtype]
+    buckets = GradientBuckets(params, force_collectives=args.force_dist,
+                              average=args.torch_optimizer, comm_dtype=comm_dtype)
     # LR rule of the reference: 0.01 * batch/8 (args.py:1338-1344); tiny here so that the random
     # net stays finite over the benchmark steps
     if args.torch_optimizer:
@@ -265,6 +306,7 @@ def run(args):
 
     for _ in range(args.warmup):
         step()
+    buckets.reset_stats()
     timing = not args.no_kernel_timing
     L.emsa_prof_reset()
     L.emsa_prof_enable(args.timing_every if timing else 0)
@@ -275,10 +317,28 @@ def run(args):
     barrier()
     dt = time.perf_counter() - t0
     L.emsa_prof_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    comm = None
+    if dist.is_initialized():
+        # evidence that the ranks really ran and exchanged: every rank reports (rank, device index,
+        # its own wall time, the time its compute stream waited for un-hidden collectives)
+        exposed = buckets.exposed_comm_ms()
+        mine = torch.tensor([float(rank), float(local_rank), dt, -1.0 if exposed is None else exposed],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [r.tolist() for r in allr]
+        st = buckets.stats
+        steps_seen = max(1, st['steps'])
+        comm = {'backend': dist.get_backend(), 'ranks_seen': sorted(int(r[0]) for r in rows),
+                'devices': [int(r[1]) for r in rows],
+                'per_rank_ms_per_step': [round(1e3 * r[2] / args.steps, 2) for r in rows],
+                'exposed_comm_ms_per_step': [None if r[3] < 0 else round(r[3], 3) for r in rows],
+                'allreduce_bytes_per_step': st['bytes'] // steps_seen,
+                'collectives_per_step': st['collectives'] // steps_seen,
+                'bucket_dtype': args.grad_dtype,
+                'grads_written_in_place': st['direct_tensors'] // steps_seen,
+                'grads_gathered_by_copy': st['gathered_tensors'] // steps_seen}
+        dt = max(r[2] for r in rows)
 
     if rank != 0:
         if dist.is_initialized():
@@ -369,6 +429,7 @@ def run(args):
         'model_tflops_effective': round(step_gflop * world * args.steps / dt / 1e3, 2)
         if step_gflop else None,
         'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        'comm': comm,
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args)

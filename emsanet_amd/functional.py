@@ -157,9 +157,10 @@ def pack_weight_pair(w):
     return buf[0], buf[1]
 
 
-def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off=0):
+def unpack_wgrad(dwp, like, cout_total=None, cout_off=0, cin_total=None, cin_off=0, out=None):
+    """`out`: contiguous destination with the parameter's shape (e.g. its flat-bucket view)"""
     cout, cin, kh, kw = like.shape if like.dim() == 4 else (like.shape[0], like.shape[1], 1, 1)
-    dw = _empty(tuple(like.shape), like.device)
+    dw = out if out is not None else _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_unpack_wgrad(_p(dwp), _p(dw), cout, cin, kh, kw, cout_total or cout,
                                        cout_off, cin_total or cin, cin_off, _stream()),
           'emsa_unpack_wgrad')
@@ -270,10 +271,12 @@ def deterministic_wgrad():
     return os.environ.get('EMSA_DETERMINISTIC', '1') != '0'
 
 
-def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None):
+def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db_out=None):
     """weight (+bias) gradient.  returns (dw, dbias or None, packed):
     packed=False: dw is already in the parameter layout [cout][cin][kh][kw] (deterministic
-    two-pass kernel of the 1-D convs, needs `like` = the weight for the shape);
+    two-pass kernel of the 1-D convs, needs `like` = the weight for the shape); `dw_out` /
+    `db_out` (contiguous, parameter-shaped, 16-byte aligned: the flat gradient-bucket views)
+    receive the result directly;
     packed=True: dw is the flat packed [tap][cout][cin] accumulator (-> unpack_wgrad)."""
     if two_pass is None:
         two_pass = deterministic_wgrad()
@@ -285,13 +288,18 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None):
     nb = spec.cout if want_bias else 0
     ws_bytes = L.emsa_conv_wgrad_ws_bytes(g) if (like is not None and two_pass) else 0
     if ws_bytes > 0:
-        buf = _empty((nw + nb,), x.device)
         ws = _empty((ws_bytes // 4,), x.device)
+        if dw_out is not None and (db_out is not None or not want_bias):
+            dw, db = dw_out.view(-1), db_out
+        else:
+            buf = _empty((nw + nb,), x.device)
+            dw = buf[:nw]
+            db = buf[nw:] if want_bias else None
     else:
         buf = torch.zeros(nw + nb, device=x.device, dtype=torch.float32)
         ws = None
-    dw = buf[:nw]
-    db = buf[nw:] if want_bias else None
+        dw = buf[:nw]
+        db = buf[nw:] if want_bias else None
     check(L.emsa_conv_wgrad(g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _stream()),
           'emsa_conv_wgrad')
     if ws is not None:
@@ -366,12 +374,12 @@ def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift):
     return out
 
 
-def stem_wgrad(xp, dy, spec, n, h, w, like):
+def stem_wgrad(xp, dy, spec, n, h, w, like, out=None):
     g = spec.geom(n, h, w, ld_of(dy))
     dwp = torch.zeros(7 * spec.cout * 32, device=dy.device, dtype=torch.float32)
     check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), None, None, _stream()),
           'emsa_conv_wgrad(stem)')
-    dw = _empty(tuple(like.shape), like.device)
+    dw = out if out is not None else _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
           'emsa_stem_unpack_wgrad')
     return dw

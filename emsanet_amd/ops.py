@@ -18,6 +18,7 @@ from . import _lib
 from . import functional as Fn
 from ._lib import check
 from .functional import ACT_NONE, ACT_RELU
+from .parallel import grad_target
 
 # debug: set to a list to record (tag, tensor clone) for every backward's inputs and outputs
 TRACE = None
@@ -227,9 +228,16 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
 def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None):
     """-> dx (or None), dw (OIHW), dbias (or None)"""
     conv = crt.conv
-    dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight)
+    # the gradients go straight into their flat all-reduce / optimizer bucket views when
+    # GradientBuckets manages the parameters (no gather copy later)
+    tw = grad_target(conv.weight)
+    tb = grad_target(conv.bias) if conv.bias is not None else None
+    dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight,
+                                   dw_out=tw, db_out=tb)
     if packed:
-        dw = Fn.unpack_wgrad(dw, conv.weight)
+        dw = Fn.unpack_wgrad(dw, conv.weight, out=tw)
+    elif tw is not None and dw.data_ptr() == tw.data_ptr():
+        dw = tw
     dx = None
     if need_dx:
         dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual,
@@ -468,8 +476,10 @@ class MultiConvFunction(Function):
         grads = []
         for m, co, ci in rt.placements:
             w4 = rt._w4(m)
-            dw = Fn.unpack_wgrad(dwp, w4, s.cout, co, s.cin, ci)
-            grads.append(dw.reshape(m.weight.shape))
+            tw = grad_target(m.weight)
+            dw = Fn.unpack_wgrad(dwp, w4, s.cout, co, s.cin, ci,
+                                 out=tw.view(w4.shape) if tw is not None else None)
+            grads.append(tw if tw is not None else dw.reshape(m.weight.shape))
             if m.bias is not None:
                 grads.append(db[co:co + m.bias.shape[0]].clone())
         dx = None
@@ -528,7 +538,8 @@ class StemFunction(Function):
         dout = Fn.as_act(dout, dense=True)
         dy, _, dg, db = Fn.bn_bwd(dout, mask, y, rt.brt.bn.weight.detach(), mean, invstd, None,
                                   ACT_RELU, ctx.bn_train, want_dres=False)
-        dw = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight)
+        dw = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight,
+                           out=grad_target(rt.conv.weight))
         # gradient w.r.t. the network input is not produced (the reference never needs it:
         # /root/reference/main.py:597-599 back-propagates into parameters only)
         return None, None, dw, dg, db

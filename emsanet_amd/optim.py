@@ -7,8 +7,9 @@ Optimizer step and learning-rate schedule of the reference's training loop on de
   /root/reference/emsanet/optimizer.py:29-36 configures it, but executed as ONE kernel per flat
   bucket (`emsa_sgd_nesterov`, csrc/pointwise.hip) on the flat gradient buffers of
   `GradientBuckets`: parameters and momentum live in flat buffers with the same layout (the
-  nn.Parameters become views, so `state_dict()` / `load_state_dict()` are unchanged), the
-  1/world_size averaging of the all-reduced gradients is folded into the update.
+  nn.Parameters become views, so `state_dict()` / `load_state_dict()` are unchanged); with
+  `GradientBuckets(average=False)` the 1/world_size averaging of the all-reduced gradient sums is
+  folded into the update (`grad_scale` argument of the kernel).
 * `one_cycle(step, ...)`: the schedule of /root/reference/emsanet/lr_scheduler.py:23-31 --
   torch's OneCycleLR(max_lr, total_steps=n_epochs, div_factor=25, pct_start=0.1,
   anneal_strategy='cos', final_div_factor=1e4), stepped once per EPOCH, INCLUDING the momentum
@@ -71,8 +72,9 @@ class FusedSGD:
     @torch.no_grad()
     def step(self):
         b = self.buckets
-        # the collectives leave the SUM in the flat buffers when GradientBuckets does not average
-        scale = 1.0
+        # GradientBuckets(average=False) leaves the world SUM in the flat buffers: the 1/world
+        # averaging is folded into the update kernel (no separate pass over the 254 MB)
+        scale = 1.0 / b.world if (b.active and not b.average and b.world > 1) else 1.0
         L = _lib.lib()
         for (flat_g, ps, views), fp, fm in zip(b.buckets, self.flat_params, self.flat_momentum):
             stray = [(v, p.grad) for v, p in zip(views, ps)

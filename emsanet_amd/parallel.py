@@ -11,25 +11,48 @@ rank runs an independent bs/GPU shard (BatchNorm uses local statistics, as the r
 `GradientBuckets` groups the parameters (reverse layer order) into a few large flat buffers
 (32 MiB by default: xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large
 collectives beat many small ones).  From the autograd post-accumulate hook of the LAST gradient
-of a bucket it gathers the bucket's gradients with one multi-tensor copy and launches an
-asynchronous all-reduce, so the exchange overlaps the remaining backward pass; afterwards
-`param.grad` are views of the reduced buffer.  `finish()` waits and averages.  With a single
-process nothing is copied or reduced at all.
+of a bucket it launches an asynchronous all-reduce, so the exchange overlaps the remaining
+backward pass; afterwards `param.grad` are views of the reduced buffer.  The backward kernels
+write the large gradients (conv weights) STRAIGHT into their bucket views (`grad_target`), only
+gradients that were produced elsewhere are gathered with one multi-tensor copy.  `finish()`
+waits and averages (or leaves the sum for `FusedSGD`, which folds 1/world into its update).
+`comm_dtype=torch.bfloat16` exchanges the buckets as bf16 (half the xGMI bytes).
+With a single process nothing is copied or reduced at all.
 """
 import torch
 import torch.distributed as dist
 
 
+def grad_target(p):
+    """The flat-bucket view this parameter's gradient should be written into by the backward
+    kernel that produces it (so that neither the all-reduce nor the fused optimizer needs a
+    gather copy) -- or None: no buckets, a gradient already exists (accumulation: autograd must
+    add, so the kernel may not overwrite), or the view was already handed out since `reset()`."""
+    slot = getattr(p, '_emsa_grad_slot', None)
+    if slot is None or p.grad is not None:
+        return None
+    view, owner = slot
+    if owner._taken.get(p) == owner._epoch:
+        return None
+    owner._taken[p] = owner._epoch
+    return view
+
+
 class GradientBuckets:
-    """usage per step:  buckets.reset(); loss.backward(); buckets.finish(); optimizer.step()"""
+    """usage per step:  buckets.reset(); loss.backward(); buckets.finish(); optimizer.step()
+
+    Two backward passes between `reset()` and `finish()` (gradient accumulation) are an error when
+    collectives are active: a bucket is all-reduced as soon as its last gradient of the FIRST pass
+    exists, so a later gradient would silently stay local.  The hook raises in that case."""
 
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True,
-                 force_collectives=False):
+                 force_collectives=False, comm_dtype=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collectives: run the gather + all-reduce path even with one rank (validation)
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.average = average
+        self.comm_dtype = comm_dtype
         params = [p for p in params if p.requires_grad]
         self.params = params
         # reverse registration order ~ order in which backward produces gradients
@@ -44,12 +67,22 @@ class GradientBuckets:
                 cur, cur_bytes = [], 0
         if cur:
             self._close(cur)
-        self._pending = [0] * len(self.buckets)
+        nb = len(self.buckets)
+        self._arrived = [0] * nb
+        self._launched = [False] * nb
         self._handles = []
+        self._comm = [None] * nb       # bf16 staging buffers (comm_dtype)
         self._bucket_of = {}
-        for bi, (_, ps, _) in enumerate(self.buckets):
-            for p in ps:
+        self._epoch = 0
+        self._taken = {}
+        # evidence for bench.py: what was exchanged and how much of it was NOT hidden behind backward
+        self.stats = {'steps': 0, 'collectives': 0, 'bytes': 0, 'gathered_tensors': 0,
+                      'direct_tensors': 0}
+        self._exposed = []             # (event before the wait, event after) per step
+        for bi, (_, ps, views) in enumerate(self.buckets):
+            for p, v in zip(ps, views):
                 self._bucket_of[p] = bi
+                p._emsa_grad_slot = (v, self)
                 if self.active:
                     p.register_post_accumulate_grad_hook(self._hook)
         self.reset()
@@ -73,42 +106,90 @@ class GradientBuckets:
         parameter (742 tiny kernels per step for EMSANet)."""
         for p in self.params:
             p.grad = None
-        for bi, (_, ps, _) in enumerate(self.buckets):
-            self._pending[bi] = len(ps)
+        for bi in range(len(self.buckets)):
+            self._arrived[bi] = 0
+            self._launched[bi] = False
         self._handles = []
+        self._epoch += 1
 
     def _launch(self, bi):
         flat, ps, views = self.buckets[bi]
         have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
         if len(have) != len(ps):
-            flat.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+            # (a parameter without a gradient this step contributes zeros; its stale bucket
+            #  content must not be exchanged)
+            missing = [v for v, p in zip(views, ps) if p.grad is None]
+            torch._foreach_zero_(missing)
+        stray = [(v, g) for v, g in have if g.data_ptr() != v.data_ptr()]
+        if stray:
+            torch._foreach_copy_([v for v, _ in stray], [g for _, g in stray])
+        self.stats['gathered_tensors'] += len(stray)
+        self.stats['direct_tensors'] += len(have) - len(stray)
+        buf = flat
+        if self.comm_dtype is not None and self.comm_dtype != flat.dtype:
+            if self._comm[bi] is None:
+                self._comm[bi] = torch.empty_like(flat, dtype=self.comm_dtype)
+            buf = self._comm[bi]
+            buf.copy_(flat)
+        self._handles.append((bi, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True)))
+        self.stats['collectives'] += 1
+        self.stats['bytes'] += buf.numel() * buf.element_size()
         for v, p in zip(views, ps):
-            p.grad = v                    # optimizer reads the (soon averaged) bucket view
-        self._pending[bi] = -1
+            p.grad = v                    # optimizer reads the (soon reduced) bucket view
+        self._launched[bi] = True
 
     def _hook(self, p):
-        # one multi-tensor gather + one asynchronous all-reduce per bucket, fired as soon as the
-        # bucket's last gradient exists -> the exchange overlaps the remaining backward pass
+        # one asynchronous all-reduce per bucket, fired as soon as the bucket's last gradient
+        # exists -> the exchange overlaps the remaining backward pass
         bi = self._bucket_of[p]
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0:
+        if self._launched[bi]:
+            raise RuntimeError(
+                "GradientBuckets: a gradient arrived for a bucket that was already all-reduced in "
+                "this step (second backward pass without reset()? gradient accumulation is not "
+                "supported with overlapped collectives: call reset() before every backward)")
+        self._arrived[bi] += 1
+        if self._arrived[bi] == len(self.buckets[bi][1]):
             self._launch(bi)
 
     def finish(self):
-        """call after backward: wait for the collectives; gradients become the world average"""
+        """call after backward: wait for the collectives; gradients become the world average
+        (`average=True`) or stay the world SUM (`average=False`: FusedSGD folds 1/world in)"""
         if self.active:
             for bi in range(len(self.buckets)):
-                if self._pending[bi] >= 0:      # some parameter received no gradient this step
+                if not self._launched[bi]:      # some parameter received no gradient this step
                     self._launch(bi)
-            for h in self._handles:
+            timed = torch.cuda.is_available() and self.buckets[0][0].is_cuda
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            for bi, h in self._handles:
                 h.wait()
+                if self._comm[bi] is not None:
+                    self.buckets[bi][0].copy_(self._comm[bi])
             if self.average and self.world > 1:
                 torch._foreach_mul_([f for f, _, _ in self.buckets], 1.0 / self.world)
+            if timed:
+                e1.record()
+                self._exposed.append((e0, e1))
+                if len(self._exposed) > 64:
+                    self._exposed.pop(0)
+            self.stats['steps'] += 1
         self._handles = []
+
+    def exposed_comm_ms(self):
+        """mean time per step the compute stream spent in finish() waiting for collectives that
+        the backward pass did not hide (plus the bf16 copy-back / averaging kernels); call after
+        a device synchronisation"""
+        if not self._exposed:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+
+    def reset_stats(self):
+        for k in self.stats:
+            self.stats[k] = 0
+        self._exposed = []
 
     def n_bytes(self):
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets)
@@ -118,5 +199,10 @@ def broadcast_parameters(module, src=0, process_group=None):
     """make every replica start from rank `src`'s parameters and buffers"""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=process_group)
+    with torch.no_grad():
+        params = list(module.parameters())
+        for t in params + list(module.buffers()):
+            dist.broadcast(t.detach(), src=src, group=process_group)
+        # the broadcast wrote in place through detached aliases: tell autograd -- and with it the
+        # engine's packed-weight caches, which key on `_version` -- that the parameters changed
+        torch.autograd.graph.increment_version(params)

@@ -98,3 +98,105 @@ def test_single_process_is_passthrough():
     assert b.n_bytes() == sum((p.numel() + 3) // 4 * 4 for p in net.parameters()) * 4
     for p, q in zip(net.parameters(), ref.parameters()):
         assert torch.equal(p.grad, q.grad)
+
+
+def _worker_modes(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from emsanet_amd.parallel import GradientBuckets
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(8, 3, 6, 6, generator=g)
+    y = torch.randn(8, 5, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+
+    # (1) a second backward pass without reset() must raise instead of silently diverging
+    net = _net()
+    b = GradientBuckets(list(net.parameters()), bucket_bytes=256)
+    b.reset()
+    ((net(xs) - ys) ** 2).mean().backward()
+    try:
+        ((net(xs) - ys) ** 2).mean().backward()
+        raised = False
+    except RuntimeError as e:
+        raised = 'already all-reduced' in str(e)
+    b.finish()
+
+    # (2) average=False leaves the world SUM (FusedSGD folds 1/world into its update)
+    net2 = _net()
+    b2 = GradientBuckets(list(net2.parameters()), bucket_bytes=1 << 20, average=False)
+    b2.reset()
+    ((net2(xs) - ys) ** 2).mean().backward()
+    b2.finish()
+    sums = [p.grad.clone() for p in net2.parameters()]
+
+    # (3) bf16 buckets on the wire
+    net3 = _net()
+    b3 = GradientBuckets(list(net3.parameters()), bucket_bytes=1 << 20, comm_dtype=torch.bfloat16)
+    b3.reset()
+    ((net3(xs) - ys) ** 2).mean().backward()
+    b3.finish()
+    if rank == 0:
+        ret['raised'] = raised
+        ret['sums'] = sums
+        ret['bf16'] = [p.grad.clone() for p in net3.parameters()]
+        ret['stats'] = dict(b3.stats)
+        ret['bytes_f32'] = b2.stats['bytes']
+    dist.destroy_process_group()
+
+
+def test_bucket_modes_two_ranks():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_modes, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret['raised'], "second backward without reset() must raise"
+    net = _net()
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(8, 3, 6, 6, generator=g)
+    y = torch.randn(8, 5, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    for s, a, p in zip(ret['sums'], ret['bf16'], net.parameters()):
+        assert torch.allclose(s, 2.0 * p.grad, rtol=1e-5, atol=1e-7)         # SUM of 2 shard means
+        assert torch.allclose(a, p.grad, rtol=2e-2, atol=1e-3 * float(p.grad.abs().max()))
+    assert ret['stats']['collectives'] == 1 and ret['stats']['steps'] == 1
+    assert ret['stats']['bytes'] * 2 == ret['bytes_f32']                       # half the bytes
+
+
+def test_grad_target_hands_out_each_view_once_per_step():
+    sys.path.insert(0, ROOT)
+    from emsanet_amd.parallel import GradientBuckets, grad_target
+    net = _net()
+    ps = list(net.parameters())
+    assert grad_target(ps[0]) is None                  # no buckets: kernels allocate
+    b = GradientBuckets(ps, bucket_bytes=1 << 20)
+    v = grad_target(ps[0])
+    assert v is not None and v.shape == ps[0].shape and v.data_ptr() % 16 == 0
+    assert grad_target(ps[0]) is None                  # only once per step
+    b.reset()
+    assert grad_target(ps[0]) is not None
+    ps[1].grad = torch.zeros_like(ps[1])
+    assert grad_target(ps[1]) is None                  # accumulation: autograd must add
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher re-executes itself through
+    torch.distributed.run (one process per GPU) instead of exiting"""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import subprocess
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, 'call', lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '3'])
+    assert bench.self_launch(argparse.Namespace(gpus=8)) == 0
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert '--nproc-per-node=8' in cmd and '127.0.0.1' in cmd
+    assert cmd[-4:] == ['--gpus', '8', '--steps', '3'] and cmd[-5].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    monkeypatch.delenv('EMSA_DIST_BACKEND', raising=False)
+    with pytest.raises(SystemExit):
+        bench.self_launch(argparse.Namespace(gpus=8))
