@@ -310,6 +310,8 @@ def run(args):
     timing = not args.no_kernel_timing
     L.emsa_prof_reset()
     L.emsa_prof_enable(args.timing_every if timing else 0)
+    from emsanet_amd import functional as Fn
+    Fn.PROF_REAL_FLOPS = timing      # padded / merged convs report their real FLOPs (stem 7x7x3 ...)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -317,6 +319,7 @@ def run(args):
     barrier()
     dt = time.perf_counter() - t0
     L.emsa_prof_enable(0)
+    Fn.PROF_REAL_FLOPS = False
     comm = None
     if dist.is_initialized():
         # evidence that the ranks really ran and exchanged: every rank reports (rank, device index,

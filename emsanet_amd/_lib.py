@@ -90,8 +90,8 @@ SIGNATURES = {
     'emsa_adaptive_avgpool_bwd': (c_int, [_P, _P] + [c_int32] * 6 + [_P]),
     'emsa_bilinear_fwd': (c_int, [_P, _P] + [c_int32] * 7 + [_P]),
     'emsa_bilinear_bwd': (c_int, [_P, _P] + [c_int32] * 7 + [_P]),
-    'emsa_head_act_fwd': (c_int, [_P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
-    'emsa_head_act_bwd': (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
+    'emsa_head_act_fwd': (c_int, [_P, _P, c_int64] + [c_int32] * 5 + [_P]),
+    'emsa_head_act_bwd': (c_int, [_P, _P, _P, _P, c_int64] + [c_int32] * 5 + [_P]),
     'emsa_copy_channels': (c_int, [_P, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_axpy': (c_int, [_P, _P, c_int64, c_float, _P]),
     'emsa_ce_semantic_blocks': (c_int, [c_int64]),
@@ -118,6 +118,7 @@ SIGNATURES = {
                                        c_int64, c_float, _P, _P, _P, c_int32, _P, c_int32, _P,
                                        c_int32, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
+    'emsa_prof_next_flops': (c_int, [ctypes.c_double]),
     'emsa_prof_reset': (c_int, []),
     'emsa_prof_seen': (c_int, [c_int32]),
     'emsa_prof_name': (c_char_p, [c_int32]),

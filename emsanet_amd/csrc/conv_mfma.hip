@@ -39,6 +39,7 @@ std::vector<ProfSlotImpl> g_prof_pool;
 size_t g_prof_used = 0;
 int g_prof_every = 0;          // 0 = off, n = bracket every n-th launch of each kernel class
 int g_prof_seen[kProfClasses] = {0};
+double g_prof_next_flops = 0.0;   // one-shot override of the next sampled launch's FLOP count
 const char* const kProfNames[kProfClasses] = {
     "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,4,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
@@ -49,6 +50,9 @@ const char* const kProfNames[kProfClasses] = {
 
 int emsa_prof_begin(int cls, double flops, hipStream_t st) {
   if (g_prof_every <= 0) return -1;
+  struct ClearOverride {            // the override applies to exactly one launch, sampled or not
+    ~ClearOverride() { g_prof_next_flops = 0.0; }
+  } clear_override;
   if ((g_prof_seen[cls]++ % g_prof_every) != 0) return -1;
   if (g_prof_used == g_prof_pool.size()) {
     ProfSlotImpl s;
@@ -58,7 +62,7 @@ int emsa_prof_begin(int cls, double flops, hipStream_t st) {
   const int id = (int)g_prof_used++;
   ProfSlotImpl* s = &g_prof_pool[id];
   s->cls = cls;
-  s->flops = flops;
+  s->flops = g_prof_next_flops > 0.0 ? g_prof_next_flops : flops;
   (void)hipEventRecord(s->a, st);
   return id;
 }
@@ -1598,6 +1602,13 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
 // ---- profiling C-ABI -------------------------------------------------------------------------
 extern "C" int emsa_prof_enable(int32_t every) {
   g_prof_every = every > 0 ? every : 0;
+  return EMSA_OK;
+}
+// The kernels count 2 * pixels * k_ch * n_ch * taps on the channel counts they RUN on; a conv whose
+// GEMM is zero-padded (stem: 7x7x3 real taps inside 7 x 32, block-diagonal task heads, channel-
+// padded 40 -> 40 / 5 -> 8 heads) declares its real direct-convolution FLOPs for the next launch.
+extern "C" int emsa_prof_next_flops(double flops) {
+  g_prof_next_flops = g_prof_every > 0 ? flops : 0.0;
   return EMSA_OK;
 }
 extern "C" int emsa_prof_reset(void) {

@@ -1035,24 +1035,43 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
 // ------------------------------------------------------------------------------------------
 // head activations, copies
 // ------------------------------------------------------------------------------------------
+// channels [0, n_sig): sigmoid; [n_sig, n_sig + n_tanh): tanh; channels [norm_off, norm_off +
+// n_norm) (n_norm 0 or 2: the orientation biternion, oracle Spec.ORIENTATION_L2_NORMALIZE) are
+// L2-normalised over the channel pair like F.normalize(dim=1, eps=1e-12); the rest passes through
 __global__ void head_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total,
-                                    int c, int n_sig, int n_tanh) {
+                                    int c, int n_sig, int n_tanh, int norm_off, int n_norm) {
+  const int o = norm_off, ot = n_sig + n_tanh;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % c);
     const float v = x[i];
-    y[i] = ch < n_sig ? 1.f / (1.f + expf(-v)) : ch < n_sig + n_tanh ? tanhf(v) : v;
+    float r = ch < n_sig ? 1.f / (1.f + expf(-v)) : ch < ot ? tanhf(v) : v;
+    if (ch >= o && ch < o + n_norm) {
+      const float u = x[i + (ch == o ? 1 : -1)];
+      r = v / fmaxf(sqrtf(v * v + u * u), 1e-12f);
+    }
+    y[i] = r;
   }
 }
 
 __global__ void head_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                    float* __restrict__ dx, long total, int c, int n_sig,
-                                    int n_tanh) {
+                                    const float* __restrict__ x, float* __restrict__ dx,
+                                    long total, int c, int n_sig, int n_tanh, int norm_off,
+                                    int n_norm) {
+  const int o = norm_off, ot = n_sig + n_tanh;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % c);
     const float g = dy[i], v = y[i];
-    dx[i] = ch < n_sig ? g * v * (1.f - v) : ch < n_sig + n_tanh ? g * (1.f - v * v) : g;
+    float r = ch < n_sig ? g * v * (1.f - v) : ch < ot ? g * (1.f - v * v) : g;
+    if (ch >= o && ch < o + n_norm) {
+      // y = x / max(|x|, eps):  dx = (g - y (y . g)) / |x|   (|x| > eps), g / eps otherwise
+      const long j = i + (ch == o ? 1 : -1);
+      const float xa = x[i], xb = x[j];
+      const float nrm = sqrtf(xa * xa + xb * xb);
+      r = nrm > 1e-12f ? (g - v * (v * g + y[j] * dy[j])) / nrm : g / 1e-12f;
+    }
+    dx[i] = r;
   }
 }
 
@@ -1502,19 +1521,27 @@ extern "C" int emsa_bilinear_bwd(const float* dy, float* dx, int32_t n, int32_t 
 }
 
 extern "C" int emsa_head_act_fwd(const float* x, float* y, int64_t pixels, int32_t c,
-                                 int32_t n_sig, int32_t n_tanh, void* stream) {
+                                 int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm,
+                                 void* stream) {
   if (!x || !y) return EMSA_E_ARG;
+  if ((n_norm != 0 && n_norm != 2) || n_sig < 0 || n_tanh < 0 || n_sig + n_tanh > c ||
+      (n_norm && (norm_off < n_sig + n_tanh || norm_off + n_norm > c)))
+    return EMSA_E_SHAPE;
   const long total = (long)pixels * c;
   hipLaunchKernelGGL(head_act_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, y, total, c, n_sig, n_tanh);
+                     (hipStream_t)stream, x, y, total, c, n_sig, n_tanh, norm_off, n_norm);
   return emsa_launch_status();
 }
-extern "C" int emsa_head_act_bwd(const float* dy, const float* y, float* dx, int64_t pixels,
-                                 int32_t c, int32_t n_sig, int32_t n_tanh, void* stream) {
-  if (!dy || !y || !dx) return EMSA_E_ARG;
+extern "C" int emsa_head_act_bwd(const float* dy, const float* y, const float* x, float* dx,
+                                 int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh,
+                                 int32_t norm_off, int32_t n_norm, void* stream) {
+  if (!dy || !y || !dx || (n_norm && !x)) return EMSA_E_ARG;
+  if ((n_norm != 0 && n_norm != 2) || n_sig < 0 || n_tanh < 0 || n_sig + n_tanh > c ||
+      (n_norm && (norm_off < n_sig + n_tanh || norm_off + n_norm > c)))
+    return EMSA_E_SHAPE;
   const long total = (long)pixels * c;
   hipLaunchKernelGGL(head_act_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dy, y, dx, total, c, n_sig, n_tanh);
+                     (hipStream_t)stream, dy, y, x, dx, total, c, n_sig, n_tanh, norm_off, n_norm);
   return emsa_launch_status();
 }
 

@@ -6,9 +6,9 @@ the decoder classes the reference imports from `nicr_mt_scene_analysis.model.dec
 (reference lines 10-23) rebuilt on the HIP operators.
 
 Supported: the 'emsanet' decoder type for the semantic and instance(+orientation) tasks and the
-scene-classification head -- the full multi-task configuration of BASELINE.json.  The
-'segformermlp' decoders, the normal decoder and the eval-time panoptic merge are outside the hot
-path and raise NotImplementedError.
+scene-classification head, the `PanopticHelper` wrapper with the eval-time panoptic merge --
+the full multi-task configuration of BASELINE.json.  The 'segformermlp' decoders and the normal
+decoder are outside the hot path and raise NotImplementedError.
 """
 from collections import OrderedDict
 from typing import Tuple, Union
@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import ops
-from .nn import ConvNormAct, LearnedUpsampling, NonBottleneck1D, make_plain_conv_rt, plain_conv
+from .nn import (ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt,
+                 plain_conv)
 from .postprocessing import InstancePostprocessing, PanopticPostprocessing, softmax_argmax
 
 KNOWN_DECODERS = (
@@ -33,7 +34,8 @@ class SemanticSideHead(nn.Module):
 
     def __init__(self, c, n_classes):
         super().__init__()
-        self.conv = nn.Conv2d(c, n_classes, 1)
+        k = Spec.SIDE_OUTPUT_KERNEL
+        self.conv = nn.Conv2d(c, n_classes, k, padding=k // 2)
         self._rt = make_plain_conv_rt(self.conv)
 
     def forward(self, x):
@@ -47,12 +49,13 @@ class InstanceSideHead(nn.Module):
     def __init__(self, c, with_orientation):
         super().__init__()
         outs = (1, 2, 2) if with_orientation else (1, 2)
-        self.task_convs = nn.ModuleList([nn.Conv2d(c, o, 1) for o in outs])
+        k = Spec.SIDE_OUTPUT_KERNEL
+        self.task_convs = nn.ModuleList([nn.Conv2d(c, o, k, padding=k // 2) for o in outs])
         placements, co = [], 0
         for conv, o in zip(self.task_convs, outs):
             placements.append((conv, co, 0))
             co += o
-        self._rt = ops.MultiConvRT(placements, Fn.pad4(sum(outs)), c, 1, 0)
+        self._rt = ops.MultiConvRT(placements, Fn.pad4(sum(outs)), c, k, k // 2)
 
     def forward(self, x):
         return ops.MultiConvFunction.apply(x, self._rt, *self._rt.params())
@@ -68,7 +71,8 @@ class DecoderModule(nn.Module):
         self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
                                       for _ in range(n_blocks)])
         self.upsampling = LearnedUpsampling(c)
-        self.skip_fusion = ConvNormAct(skip_c, c, 1) if skip_c != c else None
+        fuse = Spec.SKIP_FUSION_1X1 == 'always' or (Spec.SKIP_FUSION_1X1 and skip_c != c)
+        self.skip_fusion = ConvNormAct(skip_c, c, 1) if fuse else None
 
     def forward(self, x, skip, side_head):
         x = self.blocks(self.conv3x3(x))
@@ -173,17 +177,19 @@ class InstanceDecoder(DecoderBody):
         self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
         self.sigmoid_for_center = sigmoid_for_center
         self.tanh_for_offset = tanh_for_offset
+        self.normalize_orientation = bool(Spec.ORIENTATION_L2_NORMALIZE) and with_orientation
 
     def _split(self, y):
         n_sig = 1 if self.sigmoid_for_center else 0
         n_tanh = 2 if self.tanh_for_offset else 0
-        if n_sig or n_tanh:
+        n_norm = 2 if self.normalize_orientation else 0
+        if n_sig or n_tanh or n_norm:
             if n_tanh and not n_sig:
                 raise NotImplementedError("tanh offsets without sigmoid centres")
             # activation + split in one autograd node (its backward assembles the task gradients
             # with strided channel copies instead of autograd's zero-filled slice gradients)
             sizes = (1, 2, 2) if self.with_orientation else (1, 2)
-            return ops.HeadActFunction.apply(y, n_sig, n_tanh, sizes)
+            return ops.HeadActFunction.apply(y, n_sig, n_tanh, sizes, n_norm)
         center, offset = y[:, 0:1], y[:, 1:3]
         if not self.with_orientation:
             return center, offset

@@ -85,6 +85,16 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# bench.py sets this while it samples kernel times: convs that run on zero-padded channel counts
+# (stem, merged / padded heads) then declare their REAL direct-convolution FLOPs per launch
+PROF_REAL_FLOPS = False
+
+
+def prof_flops(flops):
+    if PROF_REAL_FLOPS:
+        _lib.lib().emsa_prof_next_flops(float(flops))
+
+
 class ConvSpec:
     """Geometry of one nn.Conv2d (OIHW parameter of shape [cout, cin, kh, kw])."""
 
@@ -350,7 +360,7 @@ def stem_pack_weight(w):
     return wp
 
 
-def stem_fwd(xp, wpk, spec, n, h, w, want_stats=True):
+def stem_fwd(xp, wpk, spec, n, h, w, want_stats=True, bias=None):
     oh, ow = spec.out_hw(h, w)
     out = act_empty(n, spec.cout, oh, ow, xp.device)
     g = spec.geom(n, h, w, spec.cout)
@@ -359,30 +369,38 @@ def stem_fwd(xp, wpk, spec, n, h, w, want_stats=True):
     if want_stats:
         rows = L.emsa_conv_stats_rows(g)
         stats = _empty((3, rows, spec.cout), xp.device)
-    check(L.emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), None, _p(stats), None, None, None, 0,
+    prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
+    check(L.emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), _p(bias), _p(stats), None, None, None, 0,
                             None, 0, ACT_NONE, _stream()), 'emsa_conv_igemm(stem)')
     return out, stats
 
 
-def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift):
+def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift, bias=None):
     oh, ow = spec.out_hw(h, w)
     out = act_empty(n, spec.cout, oh, ow, xp.device)
     g = spec.geom(n, h, w, spec.cout)
-    check(_lib.lib().emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), None, None, _p(scale), _p(shift),
-                                     None, 0, None, 0, ACT_RELU, _stream()),
+    prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
+    check(_lib.lib().emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), _p(bias), None, _p(scale),
+                                     _p(shift), None, 0, None, 0, ACT_RELU, _stream()),
           'emsa_conv_igemm(stem)')
     return out
 
 
-def stem_wgrad(xp, dy, spec, n, h, w, like, out=None):
+def stem_wgrad(xp, dy, spec, n, h, w, like, out=None, want_bias=False):
+    """-> dw (OIHW), or (dw, dbias) with want_bias"""
     g = spec.geom(n, h, w, ld_of(dy))
-    dwp = torch.zeros(7 * spec.cout * 32, device=dy.device, dtype=torch.float32)
-    check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), None, None, _stream()),
+    buf = torch.zeros(7 * spec.cout * 32 + (spec.cout if want_bias else 0), device=dy.device,
+                      dtype=torch.float32)
+    dwp = buf[:7 * spec.cout * 32]
+    db = buf[7 * spec.cout * 32:] if want_bias else None
+    oh, ow = spec.out_hw(h, w)
+    prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
+    check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), _p(db), None, _stream()),
           'emsa_conv_wgrad(stem)')
     dw = out if out is not None else _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
           'emsa_stem_unpack_wgrad')
-    return dw
+    return (dw, db) if want_bias else dw
 
 
 # ---------------------------------------------------------------------------------------------
@@ -598,21 +616,21 @@ def bilinear_bwd(dy, in_hw):
     return dx
 
 
-def head_act_fwd(x, n_sig, n_tanh):
+def head_act_fwd(x, n_sig, n_tanh, n_norm=0, norm_off=3):
     n, c, h, w = x.shape
     assert ld_of(x) == c
     y = act_empty(n, c, h, w, x.device)
-    check(_lib.lib().emsa_head_act_fwd(_p(x), _p(y), n * h * w, c, n_sig, n_tanh, _stream()),
-          'emsa_head_act_fwd')
+    check(_lib.lib().emsa_head_act_fwd(_p(x), _p(y), n * h * w, c, n_sig, n_tanh, norm_off,
+                                       n_norm, _stream()), 'emsa_head_act_fwd')
     return y
 
 
-def head_act_bwd(dy, y, n_sig, n_tanh):
+def head_act_bwd(dy, y, n_sig, n_tanh, n_norm=0, x=None, norm_off=3):
     n, c, h, w = y.shape
     assert ld_of(dy) == c
     dx = act_empty(n, c, h, w, y.device)
-    check(_lib.lib().emsa_head_act_bwd(_p(dy), _p(y), _p(dx), n * h * w, c, n_sig, n_tanh,
-                                       _stream()), 'emsa_head_act_bwd')
+    check(_lib.lib().emsa_head_act_bwd(_p(dy), _p(y), _p(x), _p(dx), n * h * w, c, n_sig, n_tanh,
+                                       norm_off, n_norm, _stream()), 'emsa_head_act_bwd')
     return dx
 
 

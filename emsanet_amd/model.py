@@ -69,13 +69,35 @@ class EMSANet(nn.Module):
         self.decoders = get_decoders(args, n_channels_in=c_enc, downsampling_in=ds_enc,
                                      **head_options)
 
-        # initialisation (model.py:162-190)
-        if 'encoder-fusion' in args.he_init and self.encoder.two:
-            for m in self.encoder.fusion_modules.modules():
-                if isinstance(m, nn.Conv2d):
+        # initialisation (model.py:162-190): He init of the selected parts -- convolution / linear
+        # WEIGHTS only, biases keep PyTorch's default (args.py:633-637) -- then the last BatchNorm
+        # gamma of every decoder block := 0
+        from .decoder import DecoderModule
+        from .nn import LearnedUpsampling, SEAddUniRGB
+
+        def he_(root, skip=()):
+            banned = {id(c) for b in root.modules() if isinstance(b, skip) for c in b.modules()} \
+                if skip else set()
+            for m in root.modules():
+                if isinstance(m, (nn.Conv2d, nn.Linear)) and id(m) not in banned:
                     nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-                    if m.bias is not None:
-                        nn.init.zeros_(m.bias)
+
+        for part in args.he_init:
+            if part == 'encoder-fusion':
+                for m in self.encoder.modules():
+                    if isinstance(m, SEAddUniRGB):
+                        he_(m)
+            elif part == 'encoder-decoder-fusion':
+                for m in self.decoders.modules():
+                    if isinstance(m, DecoderModule) and m.skip_fusion is not None:
+                        he_(m.skip_fusion)
+            elif part == 'context-module':
+                he_(self.context_module)
+            elif part == 'decoder':
+                he_(self.decoders, skip=(LearnedUpsampling,))      # blacklist=(Upsampling,)
+            else:
+                raise ValueError(f"he_init part '{part}' (choices: encoder-fusion, "
+                                 "encoder-decoder-fusion, context-module, decoder; args.py:626-638)")
         if not args.no_zero_init_decoder_residuals:
             for m in self.decoders.modules():
                 if isinstance(m, NonBottleneck1D):
@@ -101,6 +123,9 @@ class EMSANet(nn.Module):
             if isinstance(crt, ops.ConvRT):
                 rts.append(crt)
         self._pack_plan = ops.PackPlan(rts)
+        # BatchNorm step counters are kept on the host and written to the buffers when a
+        # state_dict is taken (no per-layer counter kernel in the training step)
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: ops.flush_bn_counters())
 
     def _dropout_seed(self):
         return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF

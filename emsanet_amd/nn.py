@@ -22,12 +22,21 @@ from .functional import ACT_NONE, ACT_RELU
 
 
 class Spec:
-    """[U] constants of SURVEY.md App. A (same values as the oracle's Spec)."""
+    """[U] constants of SURVEY.md App. A -- the SAME table as the oracle's `Spec`
+    (oracle/emsanet_oracle.py): every micro-detail of the un-vendored upstream library that could
+    not be read off /root/reference is a switch here, read when a module is CONSTRUCTED, so a
+    correction costs one line on each side (tests/test_model_gpu.py flips each of them)."""
     BLOCK_BN_EPS = 1e-3
     DEFAULT_BN_EPS = 1e-5
     BN_MOMENTUM = 0.1
     SE_REDUCTION = 16
     PPM_BINS = (1, 5)
+    STEM_BIAS = False                  # bias on the 7x7 stem convolution
+    DW_UPSAMPLE_BIAS = True            # bias on the depth-wise 3x3 of 'learned-3x3-zeropad'
+    SIDE_OUTPUT_KERNEL = 1             # kernel size of the side-output heads (1 or 3)
+    SKIP_FUSION_1X1 = True             # True: 1x1 conv+BN+ReLU on the rgb skip when the channel
+    #                                    counts differ; 'always': also when they match; False: never
+    ORIENTATION_L2_NORMALIZE = False   # L2-normalise the 2-channel orientation output
     RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
                      'resnet101': (3, 4, 23, 3)}
 
@@ -103,7 +112,7 @@ class ResNetNBt1D(nn.Module):
         if name not in Spec.RESNET_LAYERS:
             raise NotImplementedError(f"backbone '{name}' (only NBt1D ResNet-18/34/101)")
         layers = Spec.RESNET_LAYERS[name]
-        self.conv1 = nn.Conv2d(n_input_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.conv1 = nn.Conv2d(n_input_channels, 64, 7, stride=2, padding=3, bias=Spec.STEM_BIAS)
         self.bn1 = nn.BatchNorm2d(64, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM)
         cin = 64
         for i, (c, n) in enumerate(zip((64, 128, 256, 512), layers)):
@@ -122,7 +131,7 @@ class ResNetNBt1D(nn.Module):
             if _fast_eval(self):
                 return ops.stem_eval(x, self._stem)
             return ops.StemFunction.apply(x, self._stem, self.conv1.weight, self.bn1.weight,
-                                          self.bn1.bias)
+                                          self.bn1.bias, self.conv1.bias)
         if i == 1:
             x = ops.MaxPoolFunction.apply(x)
         return getattr(self, f'layer{i}')(x)
@@ -214,11 +223,12 @@ class LearnedUpsampling(nn.Module):
 
     def __init__(self, c, c_pad=None):
         super().__init__()
-        self.conv = nn.Conv2d(c, c, 3, padding=1, groups=c, bias=True)
+        self.conv = nn.Conv2d(c, c, 3, padding=1, groups=c, bias=Spec.DW_UPSAMPLE_BIAS)
         w = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.
         with torch.no_grad():
             self.conv.weight.copy_(w.expand(c, 1, 3, 3))
-            self.conv.bias.zero_()
+            if self.conv.bias is not None:
+                self.conv.bias.zero_()
         self.c, self.c_pad = c, c_pad or c
 
     def _padded(self):
@@ -226,7 +236,8 @@ class LearnedUpsampling(nn.Module):
         if self.c_pad != self.c:
             # parameter-sized glue (a few hundred floats); autograd routes the slice back
             w = torch.cat([w, w.new_zeros(self.c_pad - self.c, 1, 3, 3)], 0)
-            b = torch.cat([b, b.new_zeros(self.c_pad - self.c)], 0)
+            if b is not None:
+                b = torch.cat([b, b.new_zeros(self.c_pad - self.c)], 0)
         return w, b
 
     def forward(self, x, skip=None):

@@ -9,6 +9,7 @@ per conv+BN+act, per SE fusion, per learned upsampling ...  Every Function only 
 into libemsanet_hip.so (emsanet_amd/functional.py); autograd is used for graph bookkeeping only.
 """
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -22,6 +23,16 @@ from .parallel import grad_target
 
 # debug: set to a list to record (tag, tensor clone) for every backward's inputs and outputs
 TRACE = None
+# tests: set to a list to record every sign decision of the forward pass (ReLU outputs > 0) in
+# execution order -- tests/test_model_gpu.py replays them inside the fp64 oracle so that the
+# engine's gradients can be compared at a TIGHT tolerance (same piecewise-linear branch on both
+# sides; without it a single ReLU flipped by fp32 roundoff moves every upstream gradient by ~1e-2)
+MASK_TRACE = None
+
+
+def _trace_mask(tag, t):
+    if MASK_TRACE is not None:
+        MASK_TRACE.append((tag, t > 0))
 
 
 def _traced(fn):
@@ -176,11 +187,25 @@ class PackPlan:
         self._key = key
 
 
+_BN_RTS = weakref.WeakSet()
+
+
+def flush_bn_counters():
+    """add the host-side training-step counts to the `num_batches_tracked` buffers (called from
+    the model's state_dict pre-hook)"""
+    for rt in list(_BN_RTS):
+        if rt.pending_batches and rt.bn.num_batches_tracked is not None:
+            rt.bn.num_batches_tracked += rt.pending_batches
+        rt.pending_batches = 0
+
+
 class BNRT:
     """nn.BatchNorm2d used as a parameter/buffer container."""
 
     def __init__(self, bn):
         self.bn = bn
+        self.pending_batches = 0
+        _BN_RTS.add(self)
 
     def batch_stats(self):
         # torch semantics: batch statistics in training mode or when no running stats exist
@@ -199,6 +224,10 @@ class BNRT:
         if self.batch_stats():
             rm, rv = self.running()
             mom = bn.momentum if bn.momentum is not None else 0.1
+            if rm is not None and bn.num_batches_tracked is not None:
+                # nn.BatchNorm2d.forward is never called: keep its step counter like torch does
+                # (checkpoints carry it); counted on the host, flushed by `flush_bn_counters`
+                self.pending_batches += 1
             return Fn.bn_finalize(stats, count, g, b, bn.eps, mom, rm, rv)
         scale, shift, invstd = Fn.bn_fold(g, b, bn.running_mean, bn.running_var, bn.eps)
         return scale, shift, bn.running_mean, invstd
@@ -290,6 +319,9 @@ class NBt1DFunction(Function):
             idn, yd, md, isd = x, None, None, None
         out, y4, m2, is2, k2 = _conv_bn_forward(y3, rt.c13_2, rt.bn2, ACT_RELU, drop=drop,
                                                 residual=idn)
+        if MASK_TRACE is not None:
+            for tag, t in (('nbt.y1', y1), ('nbt.a2', a2), ('nbt.y3', y3), ('nbt.out', out)):
+                _trace_mask(tag, t)
         ctx.rt, ctx.drop = rt, drop
         ctx.save_for_backward(x)
         # the ReLU masks of the two BatchNorm outputs travel as bit masks (k1, k2): the block
@@ -360,6 +392,8 @@ class ConvBNActFunction(Function):
     def forward(ctx, x, crt, brt, act, weight, gamma, beta):
         x = Fn.as_act(x)
         out, y, mean, invstd, mask = _conv_bn_forward(x, crt, brt, act)
+        if act == ACT_RELU:
+            _trace_mask('conv_bn_act', out)
         ctx.crt, ctx.brt, ctx.act = crt, brt, act
         ctx.save_for_backward(x)
         ctx.saved = (y, mean, invstd, mask)
@@ -424,8 +458,14 @@ class MultiConvRT:
                 if self.wino else None
         return self._wp, self._bias
 
+    def real_flops(self, x):
+        """direct-convolution FLOPs of the REAL (un-padded, un-merged) convolutions on `x`"""
+        n, _, h, w = x.shape
+        return 2.0 * n * h * w * sum(m.weight.numel() for m, _, _ in self.placements)
+
     def forward(self, x):
         wp, bias = self.packed()
+        Fn.prof_flops(self.real_flops(x))
         if self.wino:
             return Fn.conv_fwd(x, None, self.spec, bias=bias, wino_u=self._u)
         return Fn.conv_fwd(x, wp, self.spec, bias=bias)
@@ -435,7 +475,9 @@ class MultiConvRT:
         if self.wino:
             s = self.spec
             ud = Fn.pack_wino_packed(wpd, s.cin, s.cout, Fn.wino_rows(s), flip=True)
+            Fn.prof_flops(self.real_flops(dy))
             return Fn.conv_dgrad(dy, None, s, in_hw, wino_u=ud)
+        Fn.prof_flops(self.real_flops(dy))
         return Fn.conv_dgrad(dy, wpd, self.spec, in_hw)
 
     def packed_dgrad(self):
@@ -472,6 +514,7 @@ class MultiConvFunction(Function):
         (x,) = ctx.saved_tensors
         dy = Fn.as_act(dy)
         s = rt.spec
+        Fn.prof_flops(rt.real_flops(x))
         dwp, db, _ = Fn.conv_wgrad(x, dy, s, rt.has_bias)
         grads = []
         for m, co, ci in rt.placements:
@@ -509,22 +552,25 @@ class StemRT:
 
 class StemFunction(Function):
     @staticmethod
-    def forward(ctx, x_nchw, rt, weight, gamma, beta):
+    def forward(ctx, x_nchw, rt, weight, gamma, beta, bias=None):
         n, c, h, w = x_nchw.shape
         xp = Fn.stem_pack_input(x_nchw.detach().float())
         brt = rt.brt
+        b = bias.detach() if bias is not None else None      # [U] Spec.STEM_BIAS
         if brt.batch_stats():
-            y, stats = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=True)
+            y, stats = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=True, bias=b)
             count = y.shape[0] * y.shape[2] * y.shape[3]
         else:
-            y, _ = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=False)
+            y, _ = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=False, bias=b)
             stats, count = None, 0
         scale, shift, mean, invstd = brt.forward_stats(stats, count)
         out, mask = Fn.bn_act(y, scale, shift, None, None, ACT_RELU, want_mask=True)
+        _trace_mask('stem', out)
         ctx.rt = rt
         ctx.hw = (n, h, w)
         ctx.saved = (xp, y, mean, invstd, mask)
         ctx.bn_train = brt.batch_stats()
+        ctx.has_bias = bias is not None
         return out
 
     @staticmethod
@@ -538,18 +584,20 @@ class StemFunction(Function):
         dout = Fn.as_act(dout, dense=True)
         dy, _, dg, db = Fn.bn_bwd(dout, mask, y, rt.brt.bn.weight.detach(), mean, invstd, None,
                                   ACT_RELU, ctx.bn_train, want_dres=False)
-        dw = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight,
-                           out=grad_target(rt.conv.weight))
+        res = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight,
+                            out=grad_target(rt.conv.weight), want_bias=ctx.has_bias)
+        dw, dbias = res if ctx.has_bias else (res, None)
         # gradient w.r.t. the network input is not produced (the reference never needs it:
         # /root/reference/main.py:597-599 back-propagates into parameters only)
-        return None, None, dw, dg, db
+        return None, None, dw, dg, db, dbias
 
 
 def stem_eval(x_nchw, rt):
     n, c, h, w = x_nchw.shape
     xp = Fn.stem_pack_input(x_nchw.float())
     s, t = rt.brt.folded()
-    return Fn.stem_fwd_folded(xp, rt.packed(), rt.spec, n, h, w, s, t)
+    b = rt.conv.bias.detach() if rt.conv.bias is not None else None
+    return Fn.stem_fwd_folded(xp, rt.packed(), rt.spec, n, h, w, s, t, bias=b)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -588,6 +636,8 @@ class SEAddFunction(Function):
         gr, gd = Fn.channel_mean(rgb), Fn.channel_mean(depth)
         hr, sr = Fn.se_mlp_fwd(gr, flat(w1r), b1r.detach(), flat(w2r), b2r.detach())
         hd, sd = Fn.se_mlp_fwd(gd, flat(w1d), b1d.detach(), flat(w2d), b2d.detach())
+        _trace_mask('se.rgb', hr)
+        _trace_mask('se.depth', hd)
         out = Fn.se_scale_add(rgb, sr, depth, sd)
         ctx.save_for_backward(rgb, depth)
         ctx.saved = (gr, gd, hr, sr, hd, sd, flat(w1r), flat(w2r), flat(w1d), flat(w2d))
@@ -700,17 +750,19 @@ class PPMConcatFunction(Function):
 # head activations
 # ---------------------------------------------------------------------------------------------
 class HeadActFunction(Function):
-    """sigmoid / tanh on the leading channels of the (channel-padded) instance head output and the
-    split into the task tensors.  The outputs are channel-slice VIEWS of one activated tensor;
-    backward gathers their gradients into one padded tensor with strided channel copies -- slicing
-    outside (autograd's SliceBackward) materialised a zero-filled full-size tensor per task and
-    added them up: three fills, three copies and two adds of the 315 MB full-resolution tensor."""
+    """sigmoid / tanh (/ L2 normalisation of the orientation pair) on the leading channels of the
+    (channel-padded) instance head output and the split into the task tensors.  The outputs are
+    channel-slice VIEWS of one activated tensor; backward gathers their gradients into one padded
+    tensor with strided channel copies -- slicing outside (autograd's SliceBackward) materialised
+    a zero-filled full-size tensor per task and added them up: three fills, three copies and two
+    adds of the 315 MB full-resolution tensor."""
 
     @staticmethod
-    def forward(ctx, x, n_sig, n_tanh, sizes):
-        y = Fn.head_act_fwd(Fn.as_act(x, dense=True), n_sig, n_tanh)
-        ctx.save_for_backward(y)
-        ctx.cfg = (n_sig, n_tanh)
+    def forward(ctx, x, n_sig, n_tanh, sizes, n_norm=0):
+        x = Fn.as_act(x, dense=True)
+        y = Fn.head_act_fwd(x, n_sig, n_tanh, n_norm)
+        ctx.save_for_backward(y, x if n_norm else None)
+        ctx.cfg = (n_sig, n_tanh, n_norm)
         ctx.sizes = tuple(sizes)
         outs, o = [], 0
         for sz in sizes:
@@ -722,7 +774,7 @@ class HeadActFunction(Function):
     @once_differentiable
     @_traced
     def backward(ctx, *dys):
-        (y,) = ctx.saved_tensors
+        y, x = ctx.saved_tensors
         n, c, h, w = y.shape
         dy = Fn.act_empty(n, c, h, w, y.device)
         o = 0
@@ -731,4 +783,4 @@ class HeadActFunction(Function):
             o += sz
         if o < c:
             dy[:, o:].zero_()                      # padding channels carry no gradient
-        return Fn.head_act_bwd(dy, y, *ctx.cfg), None, None, None
+        return Fn.head_act_bwd(dy, y, *ctx.cfg, x=x), None, None, None, None

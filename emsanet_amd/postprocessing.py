@@ -138,6 +138,23 @@ def normalize_depth(depth_u16, mean, std, keep_invalid_zero=True):
     return out
 
 
+_THING_TABLES = {}
+
+
+def thing_table(classes_is_thing, device):
+    """uint8 is-thing lookup table on `device`, created ONCE per (classes, device): building it per
+    call was a synchronous pageable host-to-device copy, which stream capture (hipGraph) rejects"""
+    key = (tuple(bool(t) for t in classes_is_thing), str(device))
+    t = _THING_TABLES.get(key)
+    if t is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise _lib.EmsaError("is-thing table requested for the first time inside a stream "
+                                 "capture: run the post-processing once before capturing")
+        t = torch.tensor([1 if b else 0 for b in key[0]], dtype=torch.uint8, device=device)
+        _THING_TABLES[key] = t
+    return t
+
+
 def panoptic_merge(semantic_idx, instance_ids, classes_is_thing, top_k=64, label_divisor=1000):
     """Panoptic-DeepLab merge on device.  semantic_idx (N,H,W) int64 in [0, C); instance_ids
     (N,H,W) int32 from `instance_assign` on the thing pixels -> dict(semantic (-1 = void),
@@ -145,7 +162,7 @@ def panoptic_merge(semantic_idx, instance_ids, classes_is_thing, top_k=64, label
     n, h, w = semantic_idx.shape
     dev = semantic_idx.device
     nc = len(classes_is_thing)
-    thing = torch.tensor([1 if t else 0 for t in classes_is_thing], dtype=torch.uint8, device=dev)
+    thing = thing_table(classes_is_thing, dev)
     sem = semantic_idx.contiguous()
     ids = instance_ids.contiguous()
     ws_votes = torch.empty(n * (top_k + 1) * nc, device=dev, dtype=torch.int32)
@@ -172,7 +189,7 @@ class PanopticPostprocessing:
 
     def __call__(self, semantic_logits, center, offset):
         score, idx = softmax_argmax(semantic_logits)
-        thing = torch.tensor(self.is_thing, device=idx.device)[idx]          # (N,H,W) bool
+        thing = thing_table(self.is_thing, idx.device).bool()[idx]           # (N,H,W) bool
         r = {'semantic_segmentation_score': score, 'semantic_segmentation_idx': idx,
              'panoptic_foreground_mask': thing}
         inst = InstancePostprocessing(self.inst.threshold, self.inst.kernel, True, self.inst.top_k,

@@ -15,8 +15,14 @@ the same cases, decided on the same key fragments, ending in `load_state_dict(st
   5. scene head with a different number of classes keeps the model's own weights         [80-91]
   6. semantic head 37 (SUNRGB-D) <-> 40 (NYUv2/ScanNet/Hypersim) classes: copy / keep the
      first 37 channels; any remaining shape mismatch keeps the model's weights   [93-119,147-160]
-The ScanNet 20/200-class benchmark remapping (:121-145) needs the un-vendored datasets package
-and raises NotImplementedError.
+  7. ScanNet, not in benchmark mode: a head trained on the 40 (549) dataset classes is cut down
+     to the 20 (200) benchmark classes with the dataset's class mapping                [121-145]
+     The mapping tables (`ScanNet.SEMANTIC_CLASSES_40_MAPPING_TO_BENCHMARK`, `..._549_..._200`)
+     live in the un-vendored `nicr_scene_analysis_datasets` package, so the mapping is PASSED IN
+     (`scannet_mapping={class_in_dataset: class_in_benchmark}`, void = key 0, ignored = value 0 --
+     the structure the reference iterates over); without it only the checkpoints that need the
+     table (40 / 549 channels into a smaller head) raise, everything else falls through to the
+     keep-the-model's-weights rule like in the reference.
 """
 import torch
 
@@ -25,7 +31,7 @@ def _has(key, *fragments):
     return all(f in key for f in fragments)
 
 
-def load_weights(args, model, state_dict, verbose=True):
+def load_weights(args, model, state_dict, verbose=True, scannet_mapping=None):
     log = print if verbose else (lambda *a, **k: None)
     own = model.state_dict()
     sd = {k.replace('fused_encoders.', 'encoder.'): v for k, v in state_dict.items()}   # case 1
@@ -79,9 +85,24 @@ def load_weights(args, model, state_dict, verbose=True):
                     sd[k] = sd[k][:37]
         elif (dataset.startswith('scannet')
               and not getattr(args, 'validation_scannet_benchmark_mode', False)):
-            if any(sd[k].shape != own[k].shape for k in sem):
-                raise NotImplementedError(
-                    "ScanNet benchmark class remapping needs nicr_scene_analysis_datasets")
+            mapping = scannet_mapping if scannet_mapping is not None \
+                else getattr(args, 'scannet_semantic_mapping', None)
+            if mapping is not None:
+                mask = torch.tensor([c_benchmark != 0                   # class is not ignored
+                                     for c_data, c_benchmark in mapping.items()
+                                     if c_data != 0], dtype=torch.bool)  # skip void class
+                for k in sem:
+                    if sd[k].shape[0] == mask.shape[0]:
+                        log(f"Removing channels for ignored classes in '{k}'.")
+                        sd[k] = sd[k][mask.to(sd[k].device)]
+            else:
+                need = [k for k in sem if sd[k].shape[0] in (40, 549)
+                        and sd[k].shape[0] != own[k].shape[0]]
+                if need:
+                    raise NotImplementedError(
+                        f"'{need[0]}' has {sd[need[0]].shape[0]} classes: cutting it down to the "
+                        "ScanNet benchmark classes needs the class mapping of "
+                        "nicr_scene_analysis_datasets -- pass it as scannet_mapping=")
         for k in sem:
             if sd[k].shape != own[k].shape:
                 log(f"Removing '{k}' from loaded state dict as the shape does not match: "

@@ -284,11 +284,15 @@ int emsa_bilinear_bwd(const float* dy, float* dx, int32_t n, int32_t ih, int32_t
                       int32_t ow, int32_t c, int32_t ld_dy, void* stream);
 
 /* instance head activations (sigmoid centre, tanh offset; emsanet/model.py:122-137):
- * channels [0,n_sig) sigmoid, [n_sig, n_sig+n_tanh) tanh, rest identity                       */
+ * channels [0,n_sig) sigmoid, [n_sig, n_sig+n_tanh) tanh, channels [norm_off, norm_off+n_norm)
+ * (n_norm 0 or 2, behind the sigmoid/tanh channels) L2-normalised over the pair (orientation biternion; [U] switch ORIENTATION_L2_NORMALIZE of the
+ * oracle's Spec, F.normalize(dim=1, eps=1e-12) semantics), rest identity.  bwd needs the forward
+ * input x only when n_norm > 0.                                                                */
 int emsa_head_act_fwd(const float* x, float* y, int64_t pixels, int32_t c, int32_t n_sig,
-                      int32_t n_tanh, void* stream);
-int emsa_head_act_bwd(const float* dy, const float* y, float* dx, int64_t pixels, int32_t c,
-                      int32_t n_sig, int32_t n_tanh, void* stream);
+                      int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream);
+int emsa_head_act_bwd(const float* dy, const float* y, const float* x, float* dx, int64_t pixels,
+                      int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm,
+                      void* stream);
 
 /* plain copies with strides (channel slice <-> dense), and y += x */
 int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y, int64_t pixels,
@@ -408,6 +412,9 @@ int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int6
  * total_flops = ALGORITHMIC direct-convolution FLOPs (2*pixels*k_ch*n_ch*taps).
  * ------------------------------------------------------------------------------------------ */
 int emsa_prof_enable(int32_t every);   /* 0 = off; n = bracket every n-th launch per class */
+/* one-shot: algorithmic FLOPs of the NEXT conv launch (convs whose GEMM runs on zero-padded
+ * channel counts report their real direct-convolution FLOPs: stem 7x7x3, block-diagonal heads) */
+int emsa_prof_next_flops(double flops);
 int emsa_prof_reset(void);
 int emsa_prof_seen(int32_t cls);       /* launches of the class since reset (sampled or not) */
 const char* emsa_prof_name(int32_t cls);

@@ -42,6 +42,7 @@ class Spec:
     DW_UPSAMPLE_BIAS = True      # [U] ESANet 'learned-3x3-zeropad'
     SIDE_OUTPUT_KERNEL = 1       # [U] 1x1 conv side heads
     SKIP_FUSION_1X1 = True       # [U] 1x1 conv + BN + act on the rgb skip when channels differ
+    #                              ('always': also when they match; False: never)
     ORIENTATION_L2_NORMALIZE = False   # [U] raw 2-ch biternion
     RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
                      'resnet101': (3, 4, 23, 3)}   # NBt1D has expansion 1 -> 64/128/256/512
@@ -257,7 +258,8 @@ class SemanticSideHead(nn.Module):
     # semantic keys the reference's checkpoint surgery resizes (weights.py:95-119,147-160)
     def __init__(self, c, n_classes):
         super().__init__()
-        self.conv = nn.Conv2d(c, n_classes, Spec.SIDE_OUTPUT_KERNEL)
+        self.conv = nn.Conv2d(c, n_classes, Spec.SIDE_OUTPUT_KERNEL,
+                              padding=Spec.SIDE_OUTPUT_KERNEL // 2)
 
     def forward(self, x):
         return self.conv(x)
@@ -269,7 +271,8 @@ class InstanceSideHead(nn.Module):
     def __init__(self, c, with_orientation):
         super().__init__()
         outs = (1, 2, 2) if with_orientation else (1, 2)
-        self.task_convs = nn.ModuleList([nn.Conv2d(c, o, Spec.SIDE_OUTPUT_KERNEL) for o in outs])
+        k = Spec.SIDE_OUTPUT_KERNEL
+        self.task_convs = nn.ModuleList([nn.Conv2d(c, o, k, padding=k // 2) for o in outs])
 
     def forward(self, x):
         return torch.cat([conv(x) for conv in self.task_convs], dim=1)
@@ -282,7 +285,7 @@ class DecoderModule(nn.Module):
         self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
                                       for _ in range(n_blocks)])
         self.upsampling = LearnedUpsampling(c)
-        if Spec.SKIP_FUSION_1X1 and skip_c != c:
+        if Spec.SKIP_FUSION_1X1 == 'always' or (Spec.SKIP_FUSION_1X1 and skip_c != c):
             self.skip_fusion = ConvNormAct(skip_c, c, 1)
         else:
             self.skip_fusion = None
@@ -476,9 +479,8 @@ class EMSANetOracle(nn.Module):
         if 'encoder-fusion' in args.he_init and self.encoder.two:
             for m in self.encoder.fusion_modules.modules():
                 if isinstance(m, nn.Conv2d):
+                    # weights only: biases keep PyTorch's default (args.py:633-637)
                     nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-                    if m.bias is not None:
-                        nn.init.zeros_(m.bias)
         if not args.no_zero_init_decoder_residuals:
             for m in self.decoders.modules():
                 if isinstance(m, NonBottleneck1D):

@@ -274,3 +274,64 @@ def test_dry_run_panoptic_helper(fake_lib, monkeypatch):
         assert p.grad is not None, k
     # the surgery case "semantic-only model fed a panoptic checkpoint" still applies to these keys
     from emsanet_amd.weights import load_weights        # noqa: F401
+
+
+def test_he_init_parts_and_bias_defaults():
+    """/root/reference/emsanet/model.py:162-185 + args.py:626-638: every whitelisted part is
+    He-initialised (weights only), unknown parts raise"""
+    from emsanet_amd import full_args
+    torch.manual_seed(0)
+    base = _model(full_args(he_init=()))
+    torch.manual_seed(0)
+    m = _model(full_args(he_init=('encoder-fusion', 'encoder-decoder-fusion', 'context-module',
+                                  'decoder')))
+    sb, sm = base.state_dict(), m.state_dict()
+
+    def changed(frag, kind):
+        ks = [k for k in sm if frag in k and k.endswith(kind) and sm[k].dim() > 1]
+        assert ks, frag
+        return [not torch.equal(sm[k], sb[k]) for k in ks]
+    assert all(changed('fusion_modules', 'weight'))
+    assert all(changed('skip_fusion.conv', 'weight'))
+    assert all(changed('context_module', 'conv.weight'))
+    assert all(changed('decoder_modules.0.conv3x3.conv', 'weight'))
+    # biases keep PyTorch's default; the learned upsampling keeps its bilinear kernel
+    for k in sm:
+        if k.endswith('.bias') and 'fusion_modules' in k:
+            assert torch.equal(sm[k], sb[k]), k
+        if 'upsampling' in k:
+            assert torch.equal(sm[k], sb[k]), k
+        if k.startswith('encoder.backbone'):
+            assert torch.equal(sm[k], sb[k]), k
+    with pytest.raises(ValueError):
+        _model(full_args(he_init=('bogus',)))
+
+
+def test_spec_switches_change_the_structure_like_the_oracle(monkeypatch):
+    """the five [U] switches that used to be hard-coded in the engine are table-driven on both
+    sides: after a flip the state dicts still agree key for key"""
+    from emsanet_amd import full_args, nn as enn, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from oracle import emsanet_oracle as O
+    flips = dict(STEM_BIAS=True, DW_UPSAMPLE_BIAS=False, SIDE_OUTPUT_KERNEL=3,
+                 SKIP_FUSION_1X1='always', ORIENTATION_L2_NORMALIZE=True)
+    for name, val in flips.items():
+        monkeypatch.setattr(enn.Spec, name, val)
+        monkeypatch.setattr(O.Spec, name, val)
+        args = full_args(input_height=64, input_width=64)
+        if name == 'SKIP_FUSION_1X1':
+            args.semantic_decoder_n_channels = (256, 128, 64)       # == skip channels
+            args.instance_decoder_n_channels = (256, 128, 64)
+        m, o = EMSANet(args, nyuv2_config()), O.EMSANetOracle(args, nyuv2_config())
+        sm, so = m.state_dict(), o.state_dict()
+        assert list(sm) == list(so), name
+        assert all(sm[k].shape == so[k].shape for k in sm), name
+        if name == 'STEM_BIAS':
+            assert 'encoder.backbone_rgb.conv1.bias' in sm
+        if name == 'DW_UPSAMPLE_BIAS':
+            assert not any('upsampling' in k and k.endswith('bias') for k in sm)
+        if name == 'SIDE_OUTPUT_KERNEL':
+            assert sm['decoders.semantic_decoder.side_output_heads.0.conv.weight'].shape[-1] == 3
+        if name == 'SKIP_FUSION_1X1':
+            assert 'decoders.semantic_decoder.decoder_modules.0.skip_fusion.conv.weight' in sm
+        monkeypatch.undo()

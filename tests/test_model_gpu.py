@@ -420,3 +420,170 @@ def test_full_size_batch_consistency_and_determinism():
         outs.append([t.clone() for t in (o[0][0], *o[1][0], o[2][0])])
     for a, b in zip(*outs):
         assert torch.equal(a, b), 'train-mode forward is not bit-reproducible'
+
+
+# ---------------------------------------------------------------------------------------------
+# mask-pinned gradient parity: the oracle replays the ENGINE's ReLU sign decisions
+# ---------------------------------------------------------------------------------------------
+class _PinnedRelu:
+    """Replacement for torch.nn.functional.relu inside the oracle: call i multiplies by the i-th
+    sign mask the engine recorded in its own forward (emsanet_amd.ops.MASK_TRACE).  Both sides
+    then sit on the SAME piecewise-linear branch of the network, so gradients can be compared at
+    a tight tolerance instead of through the chaos yardstick above.  Counts how many decisions
+    the oracle would have taken differently (fp32 roundoff at |x| ~ 1e-6)."""
+
+    def __init__(self, trace):
+        self.trace, self.i, self.flips, self.total = trace, 0, 0, 0
+
+    def __call__(self, x, inplace=False):
+        tag, m = self.trace[self.i]
+        self.i += 1
+        m = m.cpu()
+        assert m.numel() == x.numel(), f"mask {self.i - 1} ({tag}): {tuple(m.shape)} vs {tuple(x.shape)}"
+        m = m.reshape(x.shape)
+        self.flips += int(((x.detach() > 0) != m).sum())
+        self.total += m.numel()
+        return x * m.to(x.dtype)
+
+
+def _pinned_grad_parity(args, bs, seed, monkeypatch, tol_out, tol_grad, oracle_dtype=torch.float64,
+                        check_buffers=True):
+    """train-mode forward + backward of the engine vs the oracle on the engine's ReLU branch:
+    every raw output within tol_out, EVERY parameter gradient within tol_grad (relative L2;
+    gradients that are mathematically ~0 are compared against the global scale)"""
+    import torch.nn.functional as F
+    from emsanet_amd import nyuv2_config, ops
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
+    cfg = nyuv2_config()
+    oracle = EMSANetOracle(args, cfg)
+    sd = deterministic_state_dict(oracle, 0)
+    oracle.load_state_dict(sd)
+    oracle = oracle.to(oracle_dtype)
+    model = EMSANet(args, cfg)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    for m in (model, oracle):
+        m.train()
+        m.dropout_seed = seed
+    batch = synthetic_batch(bs, args.input_height, args.input_width)
+    ops.MASK_TRACE = []
+    try:
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+        trace = ops.MASK_TRACE
+    finally:
+        ops.MASK_TRACE = None
+    pinned = _PinnedRelu(trace)
+    monkeypatch.setattr(F, 'relu', pinned)
+    ref = oracle({k: v.to(oracle_dtype) for k, v in batch.items()})
+    assert pinned.i == len(trace), f"oracle made {pinned.i} ReLU calls, engine {len(trace)}"
+    fo, fr = _flatten(out), _flatten(ref)
+    assert len(fo) == len(fr)
+    for i, (a, b) in enumerate(zip(fo, fr)):
+        e = _rel(a, b)
+        assert e <= tol_out, f"output {i}: rel err {e:.3e} > {tol_out:.1e}"
+    _argmax_check(fo[0], fr[0].double(), 'semantic (train)')
+    cots = [rnd(*t.shape, seed=100 + i, scale=1e-1) for i, t in enumerate(fr)]
+    torch.autograd.backward(fo, [c.to(DEV) for c in cots])
+    torch.autograd.backward(fr, [c.to(oracle_dtype) for c in cots])
+    monkeypatch.undo()
+    pr = dict(oracle.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in pr.values() if p.grad is not None)
+    worst, worst_k, n = 0.0, None, 0
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        r = pr[k].grad.double()
+        g = p.grad.detach().cpu().double()
+        # relative L2 with a floor on the denominator: a gradient that is mathematically zero
+        # (conv bias in front of a train-mode BatchNorm) is compared on the global scale
+        den = max(r.norm().item(), 1e-6 * gmax * r.numel() ** 0.5)
+        e = (g - r).norm().item() / den
+        n += 1
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"pinned parity: {n} gradients, worst rel-L2 {worst:.2e} ({worst_k}); "
+          f"{pinned.flips} of {pinned.total} ReLU decisions differ from the oracle's own")
+    assert worst <= tol_grad, f"gradient {worst_k}: rel-L2 {worst:.3e} > {tol_grad:.1e}"
+    assert pinned.flips <= 1e-5 * pinned.total + 2, "engine forward disagrees on too many signs"
+    if check_buffers:
+        rb = dict(oracle.named_buffers())
+        for k, b in model.named_buffers():
+            if 'running' in k:
+                close(b, rb[k], tol=1e-3, what=f'buffer {k}')
+    return worst
+
+
+def test_pinned_gradients_small(monkeypatch):
+    """96x128 bs 4, all heads: all 742 gradients at 1e-3 relative L2 (was: distribution gate with
+    max <= 0.1)"""
+    from emsanet_amd import full_args
+    _pinned_grad_parity(full_args(input_height=96, input_width=128), 4, 1234, monkeypatch,
+                        tol_out=TOL, tol_grad=1e-3)
+
+
+def test_pinned_gradients_baseline_resolution(monkeypatch):
+    """BASELINE configs[1] shape: 640x480 RGB-D, all heads, train mode, bs=2 (what the fp64 CPU
+    oracle finishes in seconds): every output and every one of the 742 gradients vs fp64"""
+    from emsanet_amd import full_args
+    _pinned_grad_parity(full_args(), 2, 77, monkeypatch, tol_out=TOL, tol_grad=1e-3)
+
+
+def test_pinned_gradients_config4_r101_train(monkeypatch):
+    """BASELINE configs[3]: ResNet-101-NBt1D dual encoder at 960x736, TRAIN step, bs=2, vs the
+    fp32 CPU oracle on the engine's ReLU branch (fp64 at this size takes minutes)"""
+    from emsanet_amd import full_args
+    args = full_args(input_height=736, input_width=960, rgb_encoder_backbone='resnet101',
+                     depth_encoder_backbone='resnet101')
+    _pinned_grad_parity(args, 2, 5, monkeypatch, tol_out=2 * TOL, tol_grad=5e-3,
+                        oracle_dtype=torch.float32)
+
+
+@pytest.mark.parametrize('name,val', [('STEM_BIAS', True), ('DW_UPSAMPLE_BIAS', False),
+                                      ('SIDE_OUTPUT_KERNEL', 3), ('SKIP_FUSION_1X1', 'always'),
+                                      ('ORIENTATION_L2_NORMALIZE', True)])
+def test_spec_switch_flips(name, val, monkeypatch):
+    """each [U] switch of SURVEY App. A flipped on BOTH sides: engine == oracle, fwd + bwd"""
+    from emsanet_amd import full_args, nn as enn
+    from oracle import emsanet_oracle as O
+    monkeypatch.setattr(enn.Spec, name, val)
+    monkeypatch.setattr(O.Spec, name, val)
+    args = full_args(input_height=64, input_width=96)
+    if name == 'SKIP_FUSION_1X1':
+        args.semantic_decoder_n_channels = (256, 128, 64)
+        args.instance_decoder_n_channels = (256, 128, 64)
+    _pinned_grad_parity(args, 3, 11, monkeypatch, tol_out=TOL, tol_grad=1e-3)
+
+
+def test_load_weights_surgery_then_forward(monkeypatch):
+    """f-2 on the device: a checkpoint WITH orientation and 37 semantic classes goes through
+    `load_weights` (orientation removal + 37 -> 40 class reuse, weights.py:28-56,95-107) into an
+    engine without orientation; its eval forward equals the oracle loaded with the same
+    surgically altered state dict"""
+    from emsanet_amd import DatasetConfig, full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.weights import load_weights
+    from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
+    src_args = full_args(input_height=64, input_width=96)
+    src = EMSANetOracle(src_args, DatasetConfig(37, 10))
+    ckpt = deterministic_state_dict(src, 3)
+    ckpt = {k.replace('encoder.', 'fused_encoders.', 1) if k.startswith('encoder.') else k: v
+            for k, v in ckpt.items()}
+    args = full_args(input_height=64, input_width=96, tasks=('semantic', 'scene', 'instance'))
+    args.dataset = 'nyuv2'
+    torch.manual_seed(0)
+    model = EMSANet(args, nyuv2_config())
+    load_weights(args, model, {k: v.clone() for k, v in ckpt.items()}, verbose=False)
+    oracle = EMSANetOracle(args, nyuv2_config())
+    oracle.load_state_dict(model.state_dict())          # strict: same keys and shapes
+    own = model.state_dict()
+    k = 'decoders.semantic_decoder.head.conv.weight'
+    assert own[k].shape[0] == 40 and torch.equal(own[k][:37], ckpt[k])
+    k = 'decoders.instance_decoder.head.shared_conv.conv.weight'
+    assert own[k].shape[0] == 64 and torch.equal(own[k], ckpt[k][:64])
+    model.to(DEV).eval(), oracle.eval()
+    batch = synthetic_batch(2, 64, 96)
+    with torch.no_grad():
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+        ref = oracle(batch)
+    for i, (a, b) in enumerate(zip(_flatten(out), _flatten(ref))):
+        close(a, b, tol=TOL, what=f'output {i} after load_weights')

@@ -511,6 +511,27 @@ def test_head_act():
     close(xg.grad, ref, what='head act bwd')
 
 
+def test_head_act_l2_normalised_orientation():
+    """[U] switch ORIENTATION_L2_NORMALIZE: the orientation pair is F.normalize(dim=1)'d"""
+    from emsanet_amd import ops
+    x = rnd(2, 8, 6, 7, seed=1).double()
+    x[0, 3:5, 0, 0] = 0.0                        # a zero vector: eps branch
+    x.requires_grad_(True)
+    y = torch.cat([torch.sigmoid(x[:, :1]), torch.tanh(x[:, 1:3]),
+                   torch.nn.functional.normalize(x[:, 3:5], dim=1), x[:, 5:]], 1)
+    dy = rnd(*y.shape, seed=2)
+    dy[0, 3:5, 0, 0] = 0.0                       # (the eps branch's 1e12 gain is not a parity case)
+    y.backward(dy.double())
+    xg = to_act(x.detach().float()).requires_grad_(True)
+    c, o, r = ops.HeadActFunction.apply(xg, 1, 2, (1, 2, 2), 2)
+    close(torch.cat([c, o, r], 1), y[:, :5], what='head act + normalise')
+    torch.autograd.backward([c, o, r], [dy[:, :1].contiguous().to(DEV), dy[:, 1:3].contiguous().to(DEV),
+                                        dy[:, 3:5].contiguous().to(DEV)])
+    ref = x.grad.clone()
+    ref[:, 5:] = 0
+    close(xg.grad, ref, what='head act + normalise bwd')
+
+
 def test_copy_axpy():
     Fn = _fn()
     x = rnd(2, 12, 3, 5, seed=1)
