@@ -117,6 +117,26 @@ SIGNATURES = {
     'emsa_instance_loss_bwd': (c_int, [_P, c_int32, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P,
                                        c_int64, c_float, _P, _P, _P, c_int32, _P, c_int32, _P,
                                        c_int32, _P]),
+    'emsa_bn_act_fwd_t': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
+    'emsa_bn_bwd_reduce_t': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, _P, _P]),
+    'emsa_bn_bwd_apply_t': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    'emsa_maxpool3x3s2_fwd_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_maxpool3x3s2_bwd_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_se_scale_add_fwd_t': (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_se_scale_bwd_apply_t': (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_up2x_dw3x3_fwd_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_up2x_dw3x3_bwd_data_t': (c_int, [c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_up2x_dw3x3_bwd_weight_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_adaptive_avgpool_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_adaptive_avgpool_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_bilinear_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_bilinear_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_head_act_fwd_t': (c_int, [c_int32, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_head_act_bwd_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_stem_pack_input_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_channel_mean_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_se_scale_bwd_reduce_t': (c_int, [c_int32, _P, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_cast_channels': (c_int, [c_int32, _P, c_int32, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
     'emsa_prof_next_flops': (c_int, [ctypes.c_double]),
     'emsa_prof_reset': (c_int, []),

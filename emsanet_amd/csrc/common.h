@@ -33,6 +33,49 @@ __device__ __forceinline__ void emsa_st4(float* p, float4 v) {
 }
 __device__ __forceinline__ float4 emsa_zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- 16-bit activation storage (BASELINE configs 3 / 5: bf16 training, fp16|bf16 inference) ------
+// Kernels templated on the STORAGE type T of their activation tensors read / write through these
+// overloads; all arithmetic stays fp32 in registers.  Four consecutive channels = one 8-byte access
+// for the 16-bit types (16 bytes for float); conversions are single v_cvt_pk instructions on gfx950.
+typedef __bf16 emsa_bf16;
+typedef _Float16 emsa_f16;
+typedef __bf16 emsa_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 emsa_f16x4 __attribute__((ext_vector_type(4)));
+typedef float emsa_f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 emsa_ld4(const emsa_bf16* p) {
+  const emsa_f32x4v v = __builtin_convertvector(*reinterpret_cast<const emsa_bf16x4*>(p), emsa_f32x4v);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 emsa_ld4(const emsa_f16* p) {
+  const emsa_f32x4v v = __builtin_convertvector(*reinterpret_cast<const emsa_f16x4*>(p), emsa_f32x4v);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void emsa_st4(emsa_bf16* p, float4 v) {
+  const emsa_f32x4v f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<emsa_bf16x4*>(p) = __builtin_convertvector(f, emsa_bf16x4);
+}
+__device__ __forceinline__ void emsa_st4(emsa_f16* p, float4 v) {
+  const emsa_f32x4v f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<emsa_f16x4*>(p) = __builtin_convertvector(f, emsa_f16x4);
+}
+// scalar element access
+__device__ __forceinline__ float emsa_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float emsa_ld1(const emsa_bf16* p) { return (float)*p; }
+__device__ __forceinline__ float emsa_ld1(const emsa_f16* p) { return (float)*p; }
+__device__ __forceinline__ void emsa_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void emsa_st1(emsa_bf16* p, float v) { *p = (emsa_bf16)v; }
+__device__ __forceinline__ void emsa_st1(emsa_f16* p, float v) { *p = (emsa_f16)v; }
+
+// run `body` (a generic lambda taking a type tag) with the storage type selected by `dtype`
+#define EMSA_DISPATCH_DTYPE(dtype, T, ...)                              \
+  switch (dtype) {                                                      \
+    case EMSA_DT_F32: { using T = float; __VA_ARGS__; } break;          \
+    case EMSA_DT_BF16: { using T = emsa_bf16; __VA_ARGS__; } break;     \
+    case EMSA_DT_F16: { using T = emsa_f16; __VA_ARGS__; } break;       \
+    default: return EMSA_E_ARG;                                         \
+  }
+
 // counter-based hash shared with oracle/emsanet_oracle.py (_lowbias32)
 __host__ __device__ __forceinline__ uint32_t emsa_lowbias32(uint32_t x) {
   x ^= x >> 16;

@@ -55,7 +55,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 }
 
 // stem: NCHW -> zero padded NHWC4 [n][h][w+8][4]
-__global__ void stem_pack_input_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+template <typename T>
+__global__ void stem_pack_input_kernel(const float* __restrict__ x, T* __restrict__ y, int n,
                                        int c, int h, int w) {
   const int wp = w + 8;
   const long total = (long)n * h * wp;
@@ -187,10 +188,11 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
   }
 }
 
-__global__ void bn_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ drop,
-                                  const float* __restrict__ residual, long hw, int c4n, long total4,
+                                  const T* __restrict__ residual, long hw, int c4n, long total4,
                                   int act, uint64_t* __restrict__ mask_bits) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
        i += (long)gridDim.x * blockDim.x) {
@@ -267,9 +269,10 @@ __device__ __forceinline__ void column_reduce(long p0, long p1, int c4n, F f, fl
   }
 }
 
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                      const uint64_t* __restrict__ mask_bits,
-                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                     const T* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ invstd,
                                      const float* __restrict__ drop, long pixels, long hw, int c4n,
                                      int act, int rows_alloc, float* __restrict__ partial) {
@@ -346,9 +349,10 @@ __global__ void bn_bwd_sum_kernel(float* __restrict__ partial, int rows, int row
   }
 }
 
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                     const uint64_t* __restrict__ mask_bits,
-                                    const float* __restrict__ x, const float* __restrict__ gamma,
+                                    const T* __restrict__ x, const float* __restrict__ gamma,
                                     const float* __restrict__ mean,
                                     const float* __restrict__ invstd,
                                     const float* __restrict__ drop,
@@ -356,7 +360,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     int rows_alloc, float* __restrict__ dbeta_out,
                                     float* __restrict__ dgamma_out, long hw, int c4n,
                                     long total4, float inv_count, int act, int train,
-                                    float* __restrict__ dx, float* __restrict__ dres) {
+                                    T* __restrict__ dx, T* __restrict__ dres) {
   // level 2 of the (sum dy, sum dy*xhat) reduction: merge the slice sums of bn_bwd_sum_kernel
   extern __shared__ __attribute__((aligned(16))) float sums[];   // [2][c]
   float* const dbeta = sums;
@@ -430,7 +434,8 @@ __global__ void dropout2d_mask_kernel(float* mask, int n, int c, float p, uint32
 // ------------------------------------------------------------------------------------------
 // max pool 3x3 s2 p1
 // ------------------------------------------------------------------------------------------
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                    int8_t* __restrict__ idx, int n, int h, int w, int c4n) {
   const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;
   const long total = (long)n * oh_n * ow_n * c4n;
@@ -463,8 +468,9 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* __restrict__ idx,
-                                   float* __restrict__ dx, int n, int h, int w, int c4n) {
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ idx,
+                                   T* __restrict__ dx, int n, int h, int w, int c4n) {
   const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;
   const long total = (long)n * h * w * c4n;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -502,7 +508,8 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int8_t* _
 // stage 1: ws[n][split][c] = sum_{hw chunk} a*b (b may be NULL -> sum a); stage 2 sums the splits
 // in a fixed order -> bit-reproducible (no atomics: the SE weighting feeds every later layer, and
 // run-to-run noise there flips ReLU masks downstream)
-__global__ void channel_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename T>
+__global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                    float* __restrict__ ws, long hw, int c4n, int splits) {
   const int img = blockIdx.x / splits, sp = blockIdx.x % splits;
   const long chunk = (hw + splits - 1) / splits;
@@ -699,9 +706,10 @@ __global__ void se_mlp_bwd_kernel(const float* __restrict__ gap, const float* __
   }
 }
 
-__global__ void se_scale_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ sa,
-                                        const float* __restrict__ b, const float* __restrict__ sb,
-                                        float* __restrict__ out, long hw, int c4n, long total4) {
+template <typename T>
+__global__ void se_scale_add_fwd_kernel(const T* __restrict__ a, const float* __restrict__ sa,
+                                        const T* __restrict__ b, const float* __restrict__ sb,
+                                        T* __restrict__ out, long hw, int c4n, long total4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
        i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % c4n);
@@ -716,10 +724,11 @@ __global__ void se_scale_add_fwd_kernel(const float* __restrict__ a, const float
   }
 }
 
-__global__ void se_scale_bwd_apply_kernel(const float* __restrict__ dout,
+template <typename T>
+__global__ void se_scale_bwd_apply_kernel(const T* __restrict__ dout,
                                           const float* __restrict__ s,
                                           const float* __restrict__ dgap,
-                                          const float* __restrict__ extra, float* __restrict__ dx,
+                                          const T* __restrict__ extra, T* __restrict__ dx,
                                           long hw, int c4n, long total4, float inv_hw) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
        i += (long)gridDim.x * blockDim.x) {
@@ -750,9 +759,12 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 // ih-1+ (a+kh)/2 ... : with r = (a + kh + 1) >> 1 in {0,1,2} selecting input row ih-1+r.  So the
 // quad needs the 3x3 input neighbourhood once (9 float4 loads for 4 outputs) and per output the
 // 9 taps collapse onto 2x2 / 2x3 / 3x2 / ... neighbourhood entries.
-__global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wdw,
-                                   const float* __restrict__ bias, const float* __restrict__ skip,
-                                   float* __restrict__ y, int n, int h, int w, int c4n) {
+// T = storage type of x / skip, TO = storage type of y (the last up-sampling of a head writes the
+// model's fp32 output straight from 16-bit features)
+template <typename T, typename TO>
+__global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
+                                   const float* __restrict__ bias, const T* __restrict__ skip,
+                                   TO* __restrict__ y, int n, int h, int w, int c4n) {
   // the depth-wise weights [c][9], transposed to [9][c] in LDS once per workgroup: 9 ds_read_b128
   // per thread instead of 36 strided scalar global loads (the kernel was load-instruction bound)
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -810,8 +822,9 @@ __global__ void up2x_dw_fwd_kernel(const float* __restrict__ x, const float* __r
 
 // dx(ih,iw) = sum over the 4x4 output neighbourhood (2ih-1 .. 2ih+2) of dy * (collapsed taps):
 // output (oh,ow) touches input row ih through taps kh with ((oh+kh-1)>>1) == ih.
-__global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
-                                        const float* __restrict__ wdw, float* __restrict__ dx,
+template <typename T, typename TO>
+__global__ void up2x_dw_bwd_data_kernel(const TO* __restrict__ dy,
+                                        const float* __restrict__ wdw, T* __restrict__ dx,
                                         int n, int h, int w, int c4n) {
   // collapsed taps per (p, q) of the 4x4 output neighbourhood, [16][c] in LDS once per workgroup:
   // taps kh with oh+kh-1 in {2ih, 2ih+1}  <=>  kh in {2-p, 3-p} intersect [0,2] (same for kw, q)
@@ -860,7 +873,8 @@ __global__ void up2x_dw_bwd_data_kernel(const float* __restrict__ dy,
 // dw[c][9] += sum dy*up(x) ; db[c] += sum dy.  block = c4n columns x lanes over a chunk of INPUT
 // pixels; one thread visits an input pixel, loads its 3x3 neighbourhood once and the 2x2 output
 // quad's dy, and accumulates all 9 taps of the 4 outputs (13 loads per 36x4 FMAs).
-__global__ void up2x_dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T, typename TO>
+__global__ void up2x_dw_bwd_weight_kernel(const TO* __restrict__ dy, const T* __restrict__ x,
                                           float* __restrict__ dwt, float* __restrict__ db, int n,
                                           int h, int w, int c4n, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float wred[];   // [lanes][10][c4n*4]
@@ -930,7 +944,8 @@ __device__ __forceinline__ void bin_range(int i, int size, int bins, int& b0, in
   b1 = ((i + 1) * size + bins - 1) / bins;
 }
 
-__global__ void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ void adaptive_avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                             int n, int h, int w, int c, int bins) {
   const long total = (long)n * bins * bins * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -945,12 +960,13 @@ __global__ void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, float* 
     bin_range(bj, w, bins, w0, w1);
     float a = 0.f;
     for (int hh = h0; hh < h1; ++hh)
-      for (int ww = w0; ww < w1; ++ww) a += x[(((long)img * h + hh) * w + ww) * c + ch];
-    y[i] = a / (float)((h1 - h0) * (w1 - w0));
+      for (int ww = w0; ww < w1; ++ww) a += emsa_ld1(x + (((long)img * h + hh) * w + ww) * c + ch);
+    emsa_st1(y + i, a / (float)((h1 - h0) * (w1 - w0)));
   }
 }
 
-__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
                                             int n, int h, int w, int c, int bins, int accumulate) {
   const long total = (long)n * h * w * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -969,11 +985,11 @@ __global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float*
         int w0, w1;
         bin_range(bj, w, bins, w0, w1);
         if (ww < w0 || ww >= w1) continue;
-        a += dy[(((long)img * bins + bi) * bins + bj) * c + ch] /
+        a += emsa_ld1(dy + (((long)img * bins + bi) * bins + bj) * c + ch) /
              (float)((h1 - h0) * (w1 - w0));
       }
     }
-    dx[i] = accumulate ? dx[i] + a : a;
+    emsa_st1(dx + i, accumulate ? emsa_ld1(dx + i) + a : a);
   }
 }
 
@@ -987,7 +1003,8 @@ __device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, in
   l = s - (float)i0;
 }
 
-__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n,
                                     int ih, int iw, int oh, int ow, int c, int ld_y) {
   const long total = (long)n * oh * ow * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -1001,15 +1018,17 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restri
     float lh, lw;
     bilinear_src(yo, ih, oh, h0, h1, lh);
     bilinear_src(xo, iw, ow, w0, w1, lw);
-    const float* b = x + (long)img * ih * iw * c + ch;
-    const float v00 = b[((long)h0 * iw + w0) * c], v01 = b[((long)h0 * iw + w1) * c];
-    const float v10 = b[((long)h1 * iw + w0) * c], v11 = b[((long)h1 * iw + w1) * c];
-    y[(((long)img * oh + yo) * ow + xo) * ld_y + ch] =
-        (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+    const T* b = x + (long)img * ih * iw * c + ch;
+    const float v00 = emsa_ld1(b + ((long)h0 * iw + w0) * c), v01 = emsa_ld1(b + ((long)h0 * iw + w1) * c);
+    const float v10 = emsa_ld1(b + ((long)h1 * iw + w0) * c), v11 = emsa_ld1(b + ((long)h1 * iw + w1) * c);
+    emsa_st1(y + (((long)img * oh + yo) * ow + xo) * ld_y + ch,
+             (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11));
   }
 }
 
-__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int n,
+// dx is ALWAYS fp32 (scattered atomics; a few KB at the /32 pyramid-pooling resolution)
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dx, int n,
                                     int ih, int iw, int oh, int ow, int c, int ld_dy) {
   const long total = (long)n * oh * ow * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -1023,7 +1042,7 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
     float lh, lw;
     bilinear_src(yo, ih, oh, h0, h1, lh);
     bilinear_src(xo, iw, ow, w0, w1, lw);
-    const float g = dy[(((long)img * oh + yo) * ow + xo) * ld_dy + ch];
+    const float g = emsa_ld1(dy + (((long)img * oh + yo) * ow + xo) * ld_dy + ch);
     float* b = dx + (long)img * ih * iw * c + ch;
     unsafeAtomicAdd(b + ((long)h0 * iw + w0) * c, g * (1.f - lh) * (1.f - lw));
     unsafeAtomicAdd(b + ((long)h0 * iw + w1) * c, g * (1.f - lh) * lw);
@@ -1038,51 +1057,54 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
 // channels [0, n_sig): sigmoid; [n_sig, n_sig + n_tanh): tanh; channels [norm_off, norm_off +
 // n_norm) (n_norm 0 or 2: the orientation biternion, oracle Spec.ORIENTATION_L2_NORMALIZE) are
 // L2-normalised over the channel pair like F.normalize(dim=1, eps=1e-12); the rest passes through
-__global__ void head_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long total,
+template <typename T, typename TO>
+__global__ void head_act_fwd_kernel(const T* __restrict__ x, TO* __restrict__ y, long total,
                                     int c, int n_sig, int n_tanh, int norm_off, int n_norm) {
   const int o = norm_off, ot = n_sig + n_tanh;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % c);
-    const float v = x[i];
+    const float v = emsa_ld1(x + i);
     float r = ch < n_sig ? 1.f / (1.f + expf(-v)) : ch < ot ? tanhf(v) : v;
     if (ch >= o && ch < o + n_norm) {
-      const float u = x[i + (ch == o ? 1 : -1)];
+      const float u = emsa_ld1(x + i + (ch == o ? 1 : -1));
       r = v / fmaxf(sqrtf(v * v + u * u), 1e-12f);
     }
-    y[i] = r;
+    emsa_st1(y + i, r);
   }
 }
 
-__global__ void head_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                    const float* __restrict__ x, float* __restrict__ dx,
+template <typename T, typename TO>
+__global__ void head_act_bwd_kernel(const TO* __restrict__ dy, const TO* __restrict__ y,
+                                    const T* __restrict__ x, T* __restrict__ dx,
                                     long total, int c, int n_sig, int n_tanh, int norm_off,
                                     int n_norm) {
   const int o = norm_off, ot = n_sig + n_tanh;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % c);
-    const float g = dy[i], v = y[i];
+    const float g = emsa_ld1(dy + i), v = emsa_ld1(y + i);
     float r = ch < n_sig ? g * v * (1.f - v) : ch < ot ? g * (1.f - v * v) : g;
     if (ch >= o && ch < o + n_norm) {
       // y = x / max(|x|, eps):  dx = (g - y (y . g)) / |x|   (|x| > eps), g / eps otherwise
       const long j = i + (ch == o ? 1 : -1);
-      const float xa = x[i], xb = x[j];
+      const float xa = emsa_ld1(x + i), xb = emsa_ld1(x + j);
       const float nrm = sqrtf(xa * xa + xb * xb);
-      r = nrm > 1e-12f ? (g - v * (v * g + y[j] * dy[j])) / nrm : g / 1e-12f;
+      r = nrm > 1e-12f ? (g - v * (v * g + emsa_ld1(y + j) * emsa_ld1(dy + j))) / nrm : g / 1e-12f;
     }
-    dx[i] = r;
+    emsa_st1(dx + i, r);
   }
 }
 
-__global__ void copy_channels_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y,
+template <typename TS, typename TD>
+__global__ void copy_channels_kernel(const TS* __restrict__ x, int ld_x, TD* __restrict__ y,
                                      int ld_y, long pixels, int c) {
   const long total = pixels * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const long p = i / c;
     const int ch = (int)(i % c);
-    y[p * ld_y + ch] = x[p * ld_x + ch];
+    emsa_st1(y + p * ld_y + ch, emsa_ld1(x + p * ld_x + ch));
   }
 }
 
@@ -1188,14 +1210,26 @@ extern "C" int emsa_unpack_wgrad(const float* dwp, float* dw, int32_t cout, int3
                      stream);
 }
 
-extern "C" int emsa_stem_pack_input(const float* x, float* xp, int32_t n, int32_t c, int32_t h,
-                                    int32_t w, void* stream) {
+template <typename T>
+static int stem_pack_input_impl(const float* x, T* xp, int32_t n, int32_t c, int32_t h, int32_t w,
+                                void* stream) {
   if (!x || !xp) return EMSA_E_ARG;
   if (c < 1 || c > 4) return EMSA_E_SHAPE;
   const long total = (long)n * h * (w + 8);
-  hipLaunchKernelGGL(stem_pack_input_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((stem_pack_input_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, xp, n, c, h, w);
   return emsa_launch_status();
+}
+extern "C" int emsa_stem_pack_input(const float* x, float* xp, int32_t n, int32_t c, int32_t h,
+                                    int32_t w, void* stream) {
+  return stem_pack_input_impl<float>(x, xp, n, c, h, w, stream);
+}
+// the network input stays fp32 NCHW (emsanet/model.py:192); the packed NHWC4 image is written in
+// the engine's storage type
+extern "C" int emsa_stem_pack_input_t(int32_t dtype, const float* x, void* xp, int32_t n, int32_t c,
+                                      int32_t h, int32_t w, void* stream) {
+  EMSA_DISPATCH_DTYPE(dtype, T, return stem_pack_input_impl<T>(x, (T*)xp, n, c, h, w, stream));
+  return EMSA_E_ARG;
 }
 extern "C" int emsa_stem_pack_weight(const float* w, float* wp, int32_t cout, int32_t cin,
                                      void* stream) {
@@ -1251,17 +1285,26 @@ extern "C" int64_t emsa_relu_mask_words(int64_t elements) {
   return ((elements / 4 + 63) / 64) * 4;
 }
 
-extern "C" int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift,
-                               const float* drop, const float* residual, int32_t n_img,
-                               int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits,
-                               void* stream) {
+template <typename T>
+static int bn_act_fwd_impl(const T* x, T* y, const float* scale, const float* shift, const float* drop, const T* residual, int32_t n_img, int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits, void* stream) {
   if (!x || !y || !scale || !shift) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total4 = (long)n_img * hw * (c / 4);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(grid_for(total4)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, scale, shift, drop, residual, (long)hw, c / 4,
                      total4, act, mask_bits);
   return emsa_launch_status();
+}
+extern "C" int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift, const float* drop, const float* residual, int32_t n_img, int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits, void* stream) {
+  return bn_act_fwd_impl<float>(x, y, scale, shift, drop, residual, n_img, hw, c, act, mask_bits, stream);
+}
+extern "C" int emsa_bn_act_fwd_t(int32_t dtype, const void* x, void* y, const float* scale, const float* shift, const float* drop, const void* residual, int32_t n_img, int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return bn_act_fwd_impl<float>((const float*)x, (float*)y, scale, shift, drop, (const float*)residual, n_img, hw, c, act, mask_bits, stream); }
+    case EMSA_DT_BF16: { return bn_act_fwd_impl<emsa_bf16>((const emsa_bf16*)x, (emsa_bf16*)y, scale, shift, drop, (const emsa_bf16*)residual, n_img, hw, c, act, mask_bits, stream); }
+    case EMSA_DT_F16: { return bn_act_fwd_impl<emsa_f16>((const emsa_f16*)x, (emsa_f16*)y, scale, shift, drop, (const emsa_f16*)residual, n_img, hw, c, act, mask_bits, stream); }
+    default: return EMSA_E_ARG;
+  }
 }
 
 // number of partial rows (= blocks of the reduce kernel) for `pixels` pixels of `c` channels:
@@ -1279,11 +1322,8 @@ extern "C" int emsa_bn_bwd_rows(int64_t pixels, int32_t c) {
   return bn_bwd_rows_for((long)pixels, c) + kBwdSlices;
 }
 
-extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const uint64_t* mask_bits,
-                                  const float* x, const float* save_mean,
-                                  const float* save_invstd, const float* drop, int32_t n_img,
-                                  int64_t hw, int32_t c, int32_t act, float* partial,
-                                  void* stream) {
+template <typename T>
+static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* save_mean, const float* save_invstd, const float* drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream) {
   if (!dy || !x || !save_mean || !save_invstd || !partial) return EMSA_E_ARG;
   if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
@@ -1291,18 +1331,25 @@ extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const uint64_
   const int rows = bn_bwd_rows_for(pixels, c);
   const int c4n = c / 4, lanes = kThreads / c4n;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
                      dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act,
                      rows + kBwdSlices, partial);
   return emsa_launch_status();
 }
+extern "C" int emsa_bn_bwd_reduce(const float* dy, const float* y, const uint64_t* mask_bits, const float* x, const float* save_mean, const float* save_invstd, const float* drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream) {
+  return bn_bwd_reduce_impl<float>(dy, y, mask_bits, x, save_mean, save_invstd, drop, n_img, hw, c, act, partial, stream);
+}
+extern "C" int emsa_bn_bwd_reduce_t(int32_t dtype, const void* dy, const void* y, const uint64_t* mask_bits, const void* x, const float* save_mean, const float* save_invstd, const float* drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return bn_bwd_reduce_impl<float>((const float*)dy, (const float*)y, mask_bits, (const float*)x, save_mean, save_invstd, drop, n_img, hw, c, act, partial, stream); }
+    case EMSA_DT_BF16: { return bn_bwd_reduce_impl<emsa_bf16>((const emsa_bf16*)dy, (const emsa_bf16*)y, mask_bits, (const emsa_bf16*)x, save_mean, save_invstd, drop, n_img, hw, c, act, partial, stream); }
+    case EMSA_DT_F16: { return bn_bwd_reduce_impl<emsa_f16>((const emsa_f16*)dy, (const emsa_f16*)y, mask_bits, (const emsa_f16*)x, save_mean, save_invstd, drop, n_img, hw, c, act, partial, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
 
-extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t* mask_bits,
-                                 const float* x, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, const float* drop,
-                                 float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw,
-                                 int32_t c, int32_t act, int32_t train, float* dx, float* dres,
-                                 float* dgamma, float* dbeta, void* stream) {
+template <typename T>
+static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, T* dx, T* dres, float* dgamma, float* dbeta, void* stream) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
     return EMSA_E_ARG;
   if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
@@ -1317,11 +1364,22 @@ extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t
   // four workgroups per CU (the other streaming kernels: eight): measured -0.3 ms per step
   int ap_grid = grid_for(total4);
   if (ap_grid > 256 * 4) ap_grid = 256 * 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ap_grid), dim3(kThreads),
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ap_grid), dim3(kThreads),
                      (size_t)2 * c * sizeof(float), st, dy, y, mask_bits, x, gamma, save_mean,
                      save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / 4, total4,
                      1.0f / (float)pixels, act, train, dx, dres);
   return emsa_launch_status();
+}
+extern "C" int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t* mask_bits, const float* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+  return bn_bwd_apply_impl<float>(dy, y, mask_bits, x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, dx, dres, dgamma, dbeta, stream);
+}
+extern "C" int emsa_bn_bwd_apply_t(int32_t dtype, const void* dy, const void* y, const uint64_t* mask_bits, const void* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, void* dx, void* dres, float* dgamma, float* dbeta, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return bn_bwd_apply_impl<float>((const float*)dy, (const float*)y, mask_bits, (const float*)x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, (float*)dx, (float*)dres, dgamma, dbeta, stream); }
+    case EMSA_DT_BF16: { return bn_bwd_apply_impl<emsa_bf16>((const emsa_bf16*)dy, (const emsa_bf16*)y, mask_bits, (const emsa_bf16*)x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, (emsa_bf16*)dx, (emsa_bf16*)dres, dgamma, dbeta, stream); }
+    case EMSA_DT_F16: { return bn_bwd_apply_impl<emsa_f16>((const emsa_f16*)dy, (const emsa_f16*)y, mask_bits, (const emsa_f16*)x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, (emsa_f16*)dx, (emsa_f16*)dres, dgamma, dbeta, stream); }
+    default: return EMSA_E_ARG;
+  }
 }
 
 extern "C" int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, uint32_t seed,
@@ -1332,23 +1390,45 @@ extern "C" int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, u
   return emsa_launch_status();
 }
 
-extern "C" int emsa_maxpool3x3s2_fwd(const float* x, float* y, int8_t* idx, int32_t n, int32_t h,
-                                     int32_t w, int32_t c, void* stream) {
+template <typename T>
+static int maxpool3x3s2_fwd_impl(const T* x, T* y, int8_t* idx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!x || !y || !idx) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, idx, n, h, w, c / 4);
   return emsa_launch_status();
 }
-extern "C" int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t n,
-                                     int32_t h, int32_t w, int32_t c, void* stream) {
+extern "C" int emsa_maxpool3x3s2_fwd(const float* x, float* y, int8_t* idx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return maxpool3x3s2_fwd_impl<float>(x, y, idx, n, h, w, c, stream);
+}
+extern "C" int emsa_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, int8_t* idx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return maxpool3x3s2_fwd_impl<float>((const float*)x, (float*)y, idx, n, h, w, c, stream); }
+    case EMSA_DT_BF16: { return maxpool3x3s2_fwd_impl<emsa_bf16>((const emsa_bf16*)x, (emsa_bf16*)y, idx, n, h, w, c, stream); }
+    case EMSA_DT_F16: { return maxpool3x3s2_fwd_impl<emsa_f16>((const emsa_f16*)x, (emsa_f16*)y, idx, n, h, w, c, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T>
+static int maxpool3x3s2_bwd_impl(const T* dy, const int8_t* idx, T* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!dy || !dx || !idx) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * h * w * (c / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, dy, idx, dx, n, h, w, c / 4);
   return emsa_launch_status();
+}
+extern "C" int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return maxpool3x3s2_bwd_impl<float>(dy, idx, dx, n, h, w, c, stream);
+}
+extern "C" int emsa_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const int8_t* idx, void* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return maxpool3x3s2_bwd_impl<float>((const float*)dy, idx, (float*)dx, n, h, w, c, stream); }
+    case EMSA_DT_BF16: { return maxpool3x3s2_bwd_impl<emsa_bf16>((const emsa_bf16*)dy, idx, (emsa_bf16*)dx, n, h, w, c, stream); }
+    case EMSA_DT_F16: { return maxpool3x3s2_bwd_impl<emsa_f16>((const emsa_f16*)dy, idx, (emsa_f16*)dx, n, h, w, c, stream); }
+    default: return EMSA_E_ARG;
+  }
 }
 
 static int channel_splits(long hw) {
@@ -1358,14 +1438,15 @@ static int channel_splits(long hw) {
   return splits;
 }
 
-static int channel_dot(const float* a, const float* b, float* out, float* ws, int n, long hw,
+template <typename T>
+static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, long hw,
                        int c, float scale, hipStream_t st) {
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const int splits = channel_splits(hw);
   const int c4n = c / 4, lanes = kThreads / c4n;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
-  hipLaunchKernelGGL(channel_dot_kernel, dim3(n * splits), dim3(kThreads), lds, st, a, b, ws, hw,
-                     c4n, splits);
+  hipLaunchKernelGGL((channel_dot_kernel<T>), dim3(n * splits), dim3(kThreads), lds, st, a, b, ws,
+                     hw, c4n, splits);
   hipLaunchKernelGGL(channel_dot_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, ws,
                      out, n, c, splits, scale);
   return emsa_launch_status();
@@ -1377,12 +1458,29 @@ extern "C" int emsa_channel_ws_floats(int32_t n, int64_t hw, int32_t c) {
 extern "C" int emsa_channel_mean(const float* x, float* gap, float* ws, int32_t n, int64_t hw,
                                  int32_t c, void* stream) {
   if (!x || !gap || !ws) return EMSA_E_ARG;
-  return channel_dot(x, nullptr, gap, ws, n, (long)hw, c, 1.0f / (float)hw, (hipStream_t)stream);
+  return channel_dot<float>(x, nullptr, gap, ws, n, (long)hw, c, 1.0f / (float)hw,
+                            (hipStream_t)stream);
+}
+extern "C" int emsa_channel_mean_t(int32_t dtype, const void* x, float* gap, float* ws, int32_t n,
+                                   int64_t hw, int32_t c, void* stream) {
+  if (!x || !gap || !ws) return EMSA_E_ARG;
+  EMSA_DISPATCH_DTYPE(dtype, T, return channel_dot<T>((const T*)x, (const T*)nullptr, gap, ws, n,
+                                                      (long)hw, c, 1.0f / (float)hw,
+                                                      (hipStream_t)stream));
+  return EMSA_E_ARG;
 }
 extern "C" int emsa_se_scale_bwd_reduce(const float* dout, const float* x, float* ds, float* ws,
                                         int32_t n, int64_t hw, int32_t c, void* stream) {
   if (!dout || !x || !ds || !ws) return EMSA_E_ARG;
-  return channel_dot(dout, x, ds, ws, n, (long)hw, c, 1.0f, (hipStream_t)stream);
+  return channel_dot<float>(dout, x, ds, ws, n, (long)hw, c, 1.0f, (hipStream_t)stream);
+}
+extern "C" int emsa_se_scale_bwd_reduce_t(int32_t dtype, const void* dout, const void* x, float* ds,
+                                          float* ws, int32_t n, int64_t hw, int32_t c,
+                                          void* stream) {
+  if (!dout || !x || !ds || !ws) return EMSA_E_ARG;
+  EMSA_DISPATCH_DTYPE(dtype, T, return channel_dot<T>((const T*)dout, (const T*)x, ds, ws, n,
+                                                      (long)hw, c, 1.0f, (hipStream_t)stream));
+  return EMSA_E_ARG;
 }
 
 extern "C" int emsa_se_mlp_fwd(const float* gap, const float* w1, const float* b1,
@@ -1418,52 +1516,92 @@ extern "C" int emsa_se_mlp_bwd(const float* gap, const float* w1, const float* w
   return emsa_launch_status();
 }
 
-extern "C" int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b,
-                                     const float* sb, float* out, int32_t n, int64_t hw,
-                                     int32_t c, void* stream) {
+template <typename T>
+static int se_scale_add_fwd_impl(const T* a, const float* sa, const T* b, const float* sb, T* out, int32_t n, int64_t hw, int32_t c, void* stream) {
   if (!a || !sa || !out || ((b == nullptr) != (sb == nullptr))) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total4 = (long)n * hw * (c / 4);
-  hipLaunchKernelGGL(se_scale_add_fwd_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((se_scale_add_fwd_kernel<T>), dim3(grid_for(total4)), dim3(kThreads), 0,
                      (hipStream_t)stream, a, sa, b, sb, out, (long)hw, c / 4, total4);
   return emsa_launch_status();
 }
-extern "C" int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap,
-                                       const float* dx_extra, float* dx, int32_t n, int64_t hw,
-                                       int32_t c, void* stream) {
+extern "C" int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b, const float* sb, float* out, int32_t n, int64_t hw, int32_t c, void* stream) {
+  return se_scale_add_fwd_impl<float>(a, sa, b, sb, out, n, hw, c, stream);
+}
+extern "C" int emsa_se_scale_add_fwd_t(int32_t dtype, const void* a, const float* sa, const void* b, const float* sb, void* out, int32_t n, int64_t hw, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return se_scale_add_fwd_impl<float>((const float*)a, sa, (const float*)b, sb, (float*)out, n, hw, c, stream); }
+    case EMSA_DT_BF16: { return se_scale_add_fwd_impl<emsa_bf16>((const emsa_bf16*)a, sa, (const emsa_bf16*)b, sb, (emsa_bf16*)out, n, hw, c, stream); }
+    case EMSA_DT_F16: { return se_scale_add_fwd_impl<emsa_f16>((const emsa_f16*)a, sa, (const emsa_f16*)b, sb, (emsa_f16*)out, n, hw, c, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T>
+static int se_scale_bwd_apply_impl(const T* dout, const float* s, const float* dgap, const T* dx_extra, T* dx, int32_t n, int64_t hw, int32_t c, void* stream) {
   if (!dout || !s || !dgap || !dx) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total4 = (long)n * hw * (c / 4);
-  hipLaunchKernelGGL(se_scale_bwd_apply_kernel, dim3(grid_for(total4)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((se_scale_bwd_apply_kernel<T>), dim3(grid_for(total4)), dim3(kThreads), 0,
                      (hipStream_t)stream, dout, s, dgap, dx_extra, dx, (long)hw, c / 4, total4,
                      1.0f / (float)hw);
   return emsa_launch_status();
 }
+extern "C" int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap, const float* dx_extra, float* dx, int32_t n, int64_t hw, int32_t c, void* stream) {
+  return se_scale_bwd_apply_impl<float>(dout, s, dgap, dx_extra, dx, n, hw, c, stream);
+}
+extern "C" int emsa_se_scale_bwd_apply_t(int32_t dtype, const void* dout, const float* s, const float* dgap, const void* dx_extra, void* dx, int32_t n, int64_t hw, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return se_scale_bwd_apply_impl<float>((const float*)dout, s, dgap, (const float*)dx_extra, (float*)dx, n, hw, c, stream); }
+    case EMSA_DT_BF16: { return se_scale_bwd_apply_impl<emsa_bf16>((const emsa_bf16*)dout, s, dgap, (const emsa_bf16*)dx_extra, (emsa_bf16*)dx, n, hw, c, stream); }
+    case EMSA_DT_F16: { return se_scale_bwd_apply_impl<emsa_f16>((const emsa_f16*)dout, s, dgap, (const emsa_f16*)dx_extra, (emsa_f16*)dx, n, hw, c, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
 
-extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias,
-                                   const float* skip, float* y, int32_t n, int32_t h, int32_t w,
-                                   int32_t c, void* stream) {
+template <typename T, typename TO>
+static int up2x_dw3x3_fwd_impl(const T* x, const float* wdw, const float* bias, const T* skip, TO* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!x || !wdw || !y) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * 4 * h * w * (c / 4);
-  hipLaunchKernelGGL(up2x_dw_fwd_kernel, dim3(grid_for(total)), dim3(kThreads),
+  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
                      (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
                      h, w, c / 4);
   return emsa_launch_status();
 }
-extern "C" int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float* dx, int32_t n,
-                                        int32_t h, int32_t w, int32_t c, void* stream) {
+extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias, const float* skip, float* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return up2x_dw3x3_fwd_impl<float, float>(x, wdw, bias, skip, y, n, h, w, c, stream);
+}
+extern "C" int emsa_up2x_dw3x3_fwd_t(int32_t dtype, int32_t out_f32, const void* x, const float* wdw, const float* bias, const void* skip, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { if (out_f32) { using TO_ = float; return up2x_dw3x3_fwd_impl<float, float>((const float*)x, wdw, bias, (const float*)skip, (TO_*)y, n, h, w, c, stream); } else { using TO_ = float; return up2x_dw3x3_fwd_impl<float, float>((const float*)x, wdw, bias, (const float*)skip, (TO_*)y, n, h, w, c, stream); } }
+    case EMSA_DT_BF16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_fwd_impl<emsa_bf16, float>((const emsa_bf16*)x, wdw, bias, (const emsa_bf16*)skip, (TO_*)y, n, h, w, c, stream); } else { using TO_ = emsa_bf16; return up2x_dw3x3_fwd_impl<emsa_bf16, emsa_bf16>((const emsa_bf16*)x, wdw, bias, (const emsa_bf16*)skip, (TO_*)y, n, h, w, c, stream); } }
+    case EMSA_DT_F16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_fwd_impl<emsa_f16, float>((const emsa_f16*)x, wdw, bias, (const emsa_f16*)skip, (TO_*)y, n, h, w, c, stream); } else { using TO_ = emsa_f16; return up2x_dw3x3_fwd_impl<emsa_f16, emsa_f16>((const emsa_f16*)x, wdw, bias, (const emsa_f16*)skip, (TO_*)y, n, h, w, c, stream); } }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T, typename TO>
+static int up2x_dw3x3_bwd_data_impl(const TO* dy, const float* wdw, T* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!dy || !wdw || !dx) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * h * w * (c / 4);
-  hipLaunchKernelGGL(up2x_dw_bwd_data_kernel, dim3(grid_for(total)), dim3(kThreads),
+  hipLaunchKernelGGL((up2x_dw_bwd_data_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
                      (size_t)16 * c * sizeof(float), (hipStream_t)stream, dy, wdw, dx, n, h, w,
                      c / 4);
   return emsa_launch_status();
 }
-extern "C" int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db,
-                                          int32_t n, int32_t h, int32_t w, int32_t c,
-                                          void* stream) {
+extern "C" int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return up2x_dw3x3_bwd_data_impl<float, float>(dy, wdw, dx, n, h, w, c, stream);
+}
+extern "C" int emsa_up2x_dw3x3_bwd_data_t(int32_t dtype, int32_t out_f32, const void* dy, const float* wdw, void* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_data_impl<float, float>((const TO_*)dy, wdw, (float*)dx, n, h, w, c, stream); } else { using TO_ = float; return up2x_dw3x3_bwd_data_impl<float, float>((const TO_*)dy, wdw, (float*)dx, n, h, w, c, stream); } }
+    case EMSA_DT_BF16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_data_impl<emsa_bf16, float>((const TO_*)dy, wdw, (emsa_bf16*)dx, n, h, w, c, stream); } else { using TO_ = emsa_bf16; return up2x_dw3x3_bwd_data_impl<emsa_bf16, emsa_bf16>((const TO_*)dy, wdw, (emsa_bf16*)dx, n, h, w, c, stream); } }
+    case EMSA_DT_F16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_data_impl<emsa_f16, float>((const TO_*)dy, wdw, (emsa_f16*)dx, n, h, w, c, stream); } else { using TO_ = emsa_f16; return up2x_dw3x3_bwd_data_impl<emsa_f16, emsa_f16>((const TO_*)dy, wdw, (emsa_f16*)dx, n, h, w, c, stream); } }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T, typename TO>
+static int up2x_dw3x3_bwd_weight_impl(const TO* dy, const T* x, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!dy || !x || !dw || !db) return EMSA_E_ARG;
   if (!c4_ok(c) || c > 512) return EMSA_E_SHAPE;
   const long pixels = (long)n * h * w;
@@ -1474,83 +1612,172 @@ extern "C" int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float
   const size_t lds = (size_t)lanes * 10 * c * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_weight_kernel,
+    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_weight_kernel<T, TO>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(up2x_dw_bwd_weight_kernel, dim3(nblocks), dim3(kThreads), lds,
+  hipLaunchKernelGGL((up2x_dw_bwd_weight_kernel<T, TO>), dim3(nblocks), dim3(kThreads), lds,
                      (hipStream_t)stream, dy, x, dw, db, n, h, w, c / 4, nblocks);
   return emsa_launch_status();
 }
+extern "C" int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return up2x_dw3x3_bwd_weight_impl<float, float>(dy, x, dw, db, n, h, w, c, stream);
+}
+extern "C" int emsa_up2x_dw3x3_bwd_weight_t(int32_t dtype, int32_t out_f32, const void* dy, const void* x, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<float, float>((const TO_*)dy, (const float*)x, dw, db, n, h, w, c, stream); } else { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<float, float>((const TO_*)dy, (const float*)x, dw, db, n, h, w, c, stream); } }
+    case EMSA_DT_BF16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<emsa_bf16, float>((const TO_*)dy, (const emsa_bf16*)x, dw, db, n, h, w, c, stream); } else { using TO_ = emsa_bf16; return up2x_dw3x3_bwd_weight_impl<emsa_bf16, emsa_bf16>((const TO_*)dy, (const emsa_bf16*)x, dw, db, n, h, w, c, stream); } }
+    case EMSA_DT_F16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<emsa_f16, float>((const TO_*)dy, (const emsa_f16*)x, dw, db, n, h, w, c, stream); } else { using TO_ = emsa_f16; return up2x_dw3x3_bwd_weight_impl<emsa_f16, emsa_f16>((const TO_*)dy, (const emsa_f16*)x, dw, db, n, h, w, c, stream); } }
+    default: return EMSA_E_ARG;
+  }
+}
 
-extern "C" int emsa_adaptive_avgpool_fwd(const float* x, float* y, int32_t n, int32_t h,
-                                         int32_t w, int32_t c, int32_t bins, void* stream) {
+template <typename T>
+static int adaptive_avgpool_fwd_impl(const T* x, T* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bins, void* stream) {
   if (!x || !y) return EMSA_E_ARG;
   const long total = (long)n * bins * bins * c;
-  hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((adaptive_avgpool_fwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, n, h, w, c, bins);
   return emsa_launch_status();
 }
-extern "C" int emsa_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t n, int32_t h,
-                                         int32_t w, int32_t c, int32_t bins, int32_t accumulate,
-                                         void* stream) {
+extern "C" int emsa_adaptive_avgpool_fwd(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bins, void* stream) {
+  return adaptive_avgpool_fwd_impl<float>(x, y, n, h, w, c, bins, stream);
+}
+extern "C" int emsa_adaptive_avgpool_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bins, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return adaptive_avgpool_fwd_impl<float>((const float*)x, (float*)y, n, h, w, c, bins, stream); }
+    case EMSA_DT_BF16: { return adaptive_avgpool_fwd_impl<emsa_bf16>((const emsa_bf16*)x, (emsa_bf16*)y, n, h, w, c, bins, stream); }
+    case EMSA_DT_F16: { return adaptive_avgpool_fwd_impl<emsa_f16>((const emsa_f16*)x, (emsa_f16*)y, n, h, w, c, bins, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T>
+static int adaptive_avgpool_bwd_impl(const T* dy, T* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bins, int32_t accumulate, void* stream) {
   if (!dy || !dx) return EMSA_E_ARG;
   const long total = (long)n * h * w * c;
-  hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((adaptive_avgpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, dy, dx, n, h, w, c, bins, accumulate);
   return emsa_launch_status();
 }
-extern "C" int emsa_bilinear_fwd(const float* x, float* y, int32_t n, int32_t ih, int32_t iw,
-                                 int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
+extern "C" int emsa_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bins, int32_t accumulate, void* stream) {
+  return adaptive_avgpool_bwd_impl<float>(dy, dx, n, h, w, c, bins, accumulate, stream);
+}
+extern "C" int emsa_adaptive_avgpool_bwd_t(int32_t dtype, const void* dy, void* dx, int32_t n, int32_t h, int32_t w, int32_t c, int32_t bins, int32_t accumulate, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return adaptive_avgpool_bwd_impl<float>((const float*)dy, (float*)dx, n, h, w, c, bins, accumulate, stream); }
+    case EMSA_DT_BF16: { return adaptive_avgpool_bwd_impl<emsa_bf16>((const emsa_bf16*)dy, (emsa_bf16*)dx, n, h, w, c, bins, accumulate, stream); }
+    case EMSA_DT_F16: { return adaptive_avgpool_bwd_impl<emsa_f16>((const emsa_f16*)dy, (emsa_f16*)dx, n, h, w, c, bins, accumulate, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T>
+static int bilinear_fwd_impl(const T* x, T* y, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
   if (!x || !y) return EMSA_E_ARG;
   const long total = (long)n * oh * ow * c;
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, n, ih, iw, oh, ow, c, ld_y);
   return emsa_launch_status();
 }
-extern "C" int emsa_bilinear_bwd(const float* dy, float* dx, int32_t n, int32_t ih, int32_t iw,
-                                 int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
+extern "C" int emsa_bilinear_fwd(const float* x, float* y, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
+  return bilinear_fwd_impl<float>(x, y, n, ih, iw, oh, ow, c, ld_y, stream);
+}
+extern "C" int emsa_bilinear_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return bilinear_fwd_impl<float>((const float*)x, (float*)y, n, ih, iw, oh, ow, c, ld_y, stream); }
+    case EMSA_DT_BF16: { return bilinear_fwd_impl<emsa_bf16>((const emsa_bf16*)x, (emsa_bf16*)y, n, ih, iw, oh, ow, c, ld_y, stream); }
+    case EMSA_DT_F16: { return bilinear_fwd_impl<emsa_f16>((const emsa_f16*)x, (emsa_f16*)y, n, ih, iw, oh, ow, c, ld_y, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T>
+static int bilinear_bwd_impl(const T* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
   if (!dy || !dx) return EMSA_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(dx, 0, (size_t)n * ih * iw * c * sizeof(float), st) != hipSuccess)
     return EMSA_E_LAUNCH;
   const long total = (long)n * oh * ow * c;
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, dy, dx, n,
+  hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, dy, dx, n,
                      ih, iw, oh, ow, c, ld_dy);
   return emsa_launch_status();
 }
+extern "C" int emsa_bilinear_bwd(const float* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
+  return bilinear_bwd_impl<float>(dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream);
+}
+extern "C" int emsa_bilinear_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { return bilinear_bwd_impl<float>((const float*)dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream); }
+    case EMSA_DT_BF16: { return bilinear_bwd_impl<emsa_bf16>((const emsa_bf16*)dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream); }
+    case EMSA_DT_F16: { return bilinear_bwd_impl<emsa_f16>((const emsa_f16*)dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
 
-extern "C" int emsa_head_act_fwd(const float* x, float* y, int64_t pixels, int32_t c,
-                                 int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm,
-                                 void* stream) {
+template <typename T, typename TO>
+static int head_act_fwd_impl(const T* x, TO* y, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {
   if (!x || !y) return EMSA_E_ARG;
   if ((n_norm != 0 && n_norm != 2) || n_sig < 0 || n_tanh < 0 || n_sig + n_tanh > c ||
       (n_norm && (norm_off < n_sig + n_tanh || norm_off + n_norm > c)))
     return EMSA_E_SHAPE;
   const long total = (long)pixels * c;
-  hipLaunchKernelGGL(head_act_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((head_act_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, total, c, n_sig, n_tanh, norm_off, n_norm);
   return emsa_launch_status();
 }
-extern "C" int emsa_head_act_bwd(const float* dy, const float* y, const float* x, float* dx,
-                                 int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh,
-                                 int32_t norm_off, int32_t n_norm, void* stream) {
+extern "C" int emsa_head_act_fwd(const float* x, float* y, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {
+  return head_act_fwd_impl<float, float>(x, y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream);
+}
+extern "C" int emsa_head_act_fwd_t(int32_t dtype, int32_t out_f32, const void* x, void* y, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { if (out_f32) { using TO_ = float; return head_act_fwd_impl<float, float>((const float*)x, (TO_*)y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } else { using TO_ = float; return head_act_fwd_impl<float, float>((const float*)x, (TO_*)y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } }
+    case EMSA_DT_BF16: { if (out_f32) { using TO_ = float; return head_act_fwd_impl<emsa_bf16, float>((const emsa_bf16*)x, (TO_*)y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } else { using TO_ = emsa_bf16; return head_act_fwd_impl<emsa_bf16, emsa_bf16>((const emsa_bf16*)x, (TO_*)y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } }
+    case EMSA_DT_F16: { if (out_f32) { using TO_ = float; return head_act_fwd_impl<emsa_f16, float>((const emsa_f16*)x, (TO_*)y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } else { using TO_ = emsa_f16; return head_act_fwd_impl<emsa_f16, emsa_f16>((const emsa_f16*)x, (TO_*)y, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T, typename TO>
+static int head_act_bwd_impl(const TO* dy, const TO* y, const T* x, T* dx, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {
   if (!dy || !y || !dx || (n_norm && !x)) return EMSA_E_ARG;
   if ((n_norm != 0 && n_norm != 2) || n_sig < 0 || n_tanh < 0 || n_sig + n_tanh > c ||
       (n_norm && (norm_off < n_sig + n_tanh || norm_off + n_norm > c)))
     return EMSA_E_SHAPE;
   const long total = (long)pixels * c;
-  hipLaunchKernelGGL(head_act_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
+  hipLaunchKernelGGL((head_act_bwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, dy, y, x, dx, total, c, n_sig, n_tanh, norm_off, n_norm);
   return emsa_launch_status();
 }
+extern "C" int emsa_head_act_bwd(const float* dy, const float* y, const float* x, float* dx, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {
+  return head_act_bwd_impl<float, float>(dy, y, x, dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream);
+}
+extern "C" int emsa_head_act_bwd_t(int32_t dtype, int32_t out_f32, const void* dy, const void* y, const void* x, void* dx, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: { if (out_f32) { using TO_ = float; return head_act_bwd_impl<float, float>((const TO_*)dy, (const TO_*)y, (const float*)x, (float*)dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } else { using TO_ = float; return head_act_bwd_impl<float, float>((const TO_*)dy, (const TO_*)y, (const float*)x, (float*)dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } }
+    case EMSA_DT_BF16: { if (out_f32) { using TO_ = float; return head_act_bwd_impl<emsa_bf16, float>((const TO_*)dy, (const TO_*)y, (const emsa_bf16*)x, (emsa_bf16*)dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } else { using TO_ = emsa_bf16; return head_act_bwd_impl<emsa_bf16, emsa_bf16>((const TO_*)dy, (const TO_*)y, (const emsa_bf16*)x, (emsa_bf16*)dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } }
+    case EMSA_DT_F16: { if (out_f32) { using TO_ = float; return head_act_bwd_impl<emsa_f16, float>((const TO_*)dy, (const TO_*)y, (const emsa_f16*)x, (emsa_f16*)dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } else { using TO_ = emsa_f16; return head_act_bwd_impl<emsa_f16, emsa_f16>((const TO_*)dy, (const TO_*)y, (const emsa_f16*)x, (emsa_f16*)dx, pixels, c, n_sig, n_tanh, norm_off, n_norm, stream); } }
+    default: return EMSA_E_ARG;
+  }
+}
 
+template <typename TS, typename TD>
+static int copy_channels_impl(const TS* x, int32_t ld_x, TD* y, int32_t ld_y, int64_t pixels,
+                              int32_t c, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  hipLaunchKernelGGL((copy_channels_kernel<TS, TD>), dim3(grid_for((long)pixels * c)),
+                     dim3(kThreads), 0, (hipStream_t)stream, x, ld_x, y, ld_y, (long)pixels, c);
+  return emsa_launch_status();
+}
 extern "C" int emsa_copy_channels(const float* x, int32_t ld_x, float* y, int32_t ld_y,
                                   int64_t pixels, int32_t c, void* stream) {
-  if (!x || !y) return EMSA_E_ARG;
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for((long)pixels * c)), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, ld_x, y, ld_y, (long)pixels, c);
-  return emsa_launch_status();
+  return copy_channels_impl<float, float>(x, ld_x, y, ld_y, pixels, c, stream);
+}
+// strided channel copy with conversion between storage types (fp32 <-> 16-bit at the model
+// boundary: side outputs, scene logits and their cotangents)
+extern "C" int emsa_cast_channels(int32_t src_dtype, const void* x, int32_t ld_x, int32_t dst_dtype,
+                                  void* y, int32_t ld_y, int64_t pixels, int32_t c, void* stream) {
+  EMSA_DISPATCH_DTYPE(src_dtype, TS, {
+    EMSA_DISPATCH_DTYPE(dst_dtype, TD, return copy_channels_impl<TS, TD>(
+                                           (const TS*)x, ld_x, (TD*)y, ld_y, pixels, c, stream));
+  });
+  return EMSA_E_ARG;
 }
 extern "C" int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream) {
   if (!x || !y) return EMSA_E_ARG;

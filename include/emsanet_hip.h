@@ -34,6 +34,15 @@ extern "C" {
 #define EMSA_ACT_NONE 0
 #define EMSA_ACT_RELU 1
 
+/* storage type of the activation tensors of the `_t` ("typed") entry points: BASELINE configs[2]
+ * (bf16 mixed-precision training) and configs[4] (16-bit inference).  Arithmetic is fp32 in
+ * registers / fp32 MFMA accumulation everywhere; parameters, BatchNorm statistics, SE vectors and
+ * weight gradients stay fp32.  Every `emsa_X_t(dtype, ...)` has the argument list of `emsa_X(...)`
+ * with the activation pointers typed `void*`; EMSA_DT_F32 selects the fp32 kernels. */
+#define EMSA_DT_F32 0
+#define EMSA_DT_BF16 1
+#define EMSA_DT_F16 2
+
 /* library identity: returns the gfx arch string the kernels were compiled for ("gfx950") */
 const char* emsa_arch(void);
 int emsa_version(void);
@@ -402,6 +411,63 @@ int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t total, float
 int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                       float momentum, float weight_decay, float grad_scale, int32_t first_step,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Typed ("_t") forms of the HBM-bound kernels: same semantics and argument order as the fp32 entry
+ * points above, activation tensors in the storage type `dtype` (EMSA_DT_*).  Kernels at the model
+ * boundary take `out_f32`: the tensors on the OUTPUT side of the op (y of a forward kernel, dy / y
+ * of its backward kernels) are fp32 while the features are 16-bit -- the last up-sampling of a head
+ * and the head activations write the model's fp32 outputs directly.  emsa_bilinear_bwd_t always
+ * accumulates into an fp32 dx (scattered atomics at the /32 pyramid resolution).
+ * emsa_cast_channels: strided channel-slice copy with conversion between storage types.
+ * ------------------------------------------------------------------------------------------ */
+int emsa_bn_act_fwd_t(int32_t dtype, const void* x, void* y, const float* scale, const float*
+    shift, const float* drop, const void* residual, int32_t n_img, int64_t hw, int32_t c,
+    int32_t act, uint64_t* mask_bits, void* stream);
+int emsa_bn_bwd_reduce_t(int32_t dtype, const void* dy, const void* y, const uint64_t*
+    mask_bits, const void* x, const float* save_mean, const float* save_invstd, const float*
+    drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream);
+int emsa_bn_bwd_apply_t(int32_t dtype, const void* dy, const void* y, const uint64_t* mask_bits,
+    const void* x, const float* gamma, const float* save_mean, const float* save_invstd, const
+    float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c,
+    int32_t act, int32_t train, void* dx, void* dres, float* dgamma, float* dbeta, void*
+    stream);
+int emsa_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, int8_t* idx, int32_t n,
+    int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const int8_t* idx, void* dx, int32_t
+    n, int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_se_scale_add_fwd_t(int32_t dtype, const void* a, const float* sa, const void* b, const
+    float* sb, void* out, int32_t n, int64_t hw, int32_t c, void* stream);
+int emsa_se_scale_bwd_apply_t(int32_t dtype, const void* dout, const float* s, const float*
+    dgap, const void* dx_extra, void* dx, int32_t n, int64_t hw, int32_t c, void* stream);
+int emsa_up2x_dw3x3_fwd_t(int32_t dtype, int32_t out_f32, const void* x, const float* wdw, const
+    float* bias, const void* skip, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void*
+    stream);
+int emsa_up2x_dw3x3_bwd_data_t(int32_t dtype, int32_t out_f32, const void* dy, const float* wdw,
+    void* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_up2x_dw3x3_bwd_weight_t(int32_t dtype, int32_t out_f32, const void* dy, const void* x,
+    float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_adaptive_avgpool_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t h,
+    int32_t w, int32_t c, int32_t bins, void* stream);
+int emsa_adaptive_avgpool_bwd_t(int32_t dtype, const void* dy, void* dx, int32_t n, int32_t h,
+    int32_t w, int32_t c, int32_t bins, int32_t accumulate, void* stream);
+int emsa_bilinear_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t ih, int32_t
+    iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream);
+int emsa_bilinear_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int32_t ih, int32_t
+    iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream);
+int emsa_head_act_fwd_t(int32_t dtype, int32_t out_f32, const void* x, void* y, int64_t pixels,
+    int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream);
+int emsa_head_act_bwd_t(int32_t dtype, int32_t out_f32, const void* dy, const void* y, const
+    void* x, void* dx, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t
+    norm_off, int32_t n_norm, void* stream);
+int emsa_stem_pack_input_t(int32_t dtype, const float* x, void* xp, int32_t n, int32_t c,
+    int32_t h, int32_t w, void* stream);
+int emsa_channel_mean_t(int32_t dtype, const void* x, float* gap, float* ws, int32_t n, int64_t
+    hw, int32_t c, void* stream);
+int emsa_se_scale_bwd_reduce_t(int32_t dtype, const void* dout, const void* x, float* ds, float*
+    ws, int32_t n, int64_t hw, int32_t c, void* stream);
+int emsa_cast_channels(int32_t src_dtype, const void* x, int32_t ld_x, int32_t dst_dtype, void*
+    y, int32_t ld_y, int64_t pixels, int32_t c, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every n-th
