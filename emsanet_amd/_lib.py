@@ -137,6 +137,12 @@ SIGNATURES = {
     'emsa_channel_mean_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_se_scale_bwd_reduce_t': (c_int, [c_int32, _P, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_cast_channels': (c_int, [c_int32, _P, c_int32, c_int32, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_conv_stats_rows_t': (c_int, [c_int32, _GP]),
+    'emsa_conv_igemm_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
+                                  c_int32, _P]),
+    'emsa_conv_wgrad_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P]),
+    'emsa_pack_weight_t': (c_int, [c_int32, _P, _P, _P] + [c_int32] * 8 + [_P]),
+    'emsa_stem_pack_weight_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
     'emsa_prof_next_flops': (c_int, [ctypes.c_double]),
     'emsa_prof_reset': (c_int, []),

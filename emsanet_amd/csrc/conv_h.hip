@@ -1,0 +1,484 @@
+// Implicit-GEMM convolution with 16-bit operands on the CDNA4 matrix cores
+// (v_mfma_f32_32x32x16_bf16 / _f16, fp32 accumulation): the forward convolutions and data gradients
+// of BASELINE.json configs[2] (bf16 mixed-precision training) and configs[4] (16-bit inference).
+//
+//   emsa_conv_igemm_t : out[m][n] = epi( sum_{tap,c} in[gather(m,tap)][c] * w[tap][n][c] )
+//
+// Same gather geometry, same fused epilogue (bias, BatchNorm statistics partials from the fp32
+// accumulators, folded BatchNorm, residual, ReLU, ReLU-backward mask) and the same C-ABI shape as
+// emsa_conv_igemm (conv_mfma.hip); what differs is everything the 16x faster matrix pipe changes:
+//   * at 2.5 PFLOP/s the 64/128-channel layers are HBM-bound (arithmetic intensity 96 / 192 FLOP/B
+//     against a ridge of ~400) and the 256/512-channel ones LDS/issue-bound, never MFMA-bound, so
+//     the kernel is built around bytes: activations, weights and LDS tiles are 16-bit, one K step
+//     is 64 channels (a 128-byte line per pixel row and 16-byte accesses per lane everywhere),
+//     Winograd is NOT used (it saves matrix instructions, which are free here, and costs
+//     transforms + precision);
+//   * one MFMA consumes 8 consecutive k per lane = one ds_read_b128, so no K permutation trick is
+//     needed; LDS rows are padded to 144 bytes (36 banks) -> the 16-lane groups of ds_read_b128
+//     cover all 64 banks, staging writes are 8 lanes x 16 B per row;
+//   * wave tile 64x32 / 64x64 (2x1 / 2x2 MFMA tiles): per 16-deep k sub-step 3-4 ds_read_b128 feed
+//     2-4 MFMAs of 32 cycles, which keeps the LDS pipe below the matrix pipe's issue time;
+//   * the epilogue converts to the storage type and stores 16 bytes (8 channels) per lane; the
+//     accumulators are staged through LDS one wave-row at a time so that the epilogue's LDS never
+//     exceeds the main loop's.
+#include <cstdlib>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int kHK = 64;               // channels per K step
+constexpr int kHLD = kHK + 8;         // padded LDS row (elements): 144 B
+constexpr int kHRowLanes = kHK / 8;   // lanes (16 B each) per staged row
+
+typedef unsigned int hu32x4 __attribute__((ext_vector_type(4)));
+typedef float hf32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+constexpr uint32_t kHOOB = 0x80000000u;
+
+template <typename T> struct Vec8;
+template <> struct Vec8<emsa_bf16> { typedef hbf16x8 type; };
+template <> struct Vec8<emsa_f16> { typedef hf16x8 type; };
+
+__device__ __forceinline__ f32x16 mfma16(hbf16x8 a, hbf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(hf16x8 a, hf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+struct HFastDiv {
+  uint32_t mul, shift, d;
+};
+inline HFastDiv h_make_fastdiv(uint32_t d) {
+  HFastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.mul = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ uint32_t h_fast_div(uint32_t n, const HFastDiv& f) {
+  return (__umulhi(n, f.mul) + n) >> f.shift;
+}
+
+struct ConvHArgs {
+  EmsaConvGeom g;
+  const void* in;
+  const void* w;
+  void* out;
+  const float* bias;
+  float* stats;
+  const float* scale;
+  const float* shift;
+  const void* residual;
+  const void* mask_src;
+  int ld_res, ld_mask, act;
+  int M, tiles_m, tiles_n, kchunks;
+  uint32_t in_bytes, w_bytes;
+  HFastDiv div_ohw, div_ow;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t h_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// per-thread offset (VGPR) + wave-uniform offset in the scalar-offset operand; kHOOB reads zero
+__device__ __forceinline__ hu32x4 h_ld16s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+
+struct HGather {
+  int mul_h, off_h, step_h, div_h, mul_w, off_w, step_w, div_w, in_h, in_w;
+  int row_stride, px_stride;
+};
+// BYTE offset (2-byte elements) of the gathered pixel, or kHOOB
+__device__ __forceinline__ uint32_t h_gather(const HGather& q, int img_off, int bh, int bw, int kh,
+                                             int kw) {
+  int hn = bh + kh * q.step_h, wn = bw + kw * q.step_w;
+  bool ok = true;
+  if (q.div_h > 1) {      // strided data gradient only (wave-uniform branch)
+    ok = ok && (hn % q.div_h == 0);
+    hn /= q.div_h;
+  }
+  if (q.div_w > 1) {
+    ok = ok && (wn % q.div_w == 0);
+    wn /= q.div_w;
+  }
+  ok = ok && hn >= 0 && hn < q.in_h && wn >= 0 && wn < q.in_w;
+  return ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * 2u : kHOOB;
+}
+
+template <int BM, int BN, int WM, int WN, typename T>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 4 : 2) void conv_h_kernel(
+    const ConvHArgs p) {
+  static_assert(WM * WN == 4, "4 waves");
+  typedef typename Vec8<T>::type V8;
+  constexpr int NT = 256;
+  constexpr int kRowsPerPass = NT / kHRowLanes;                   // 32
+  static_assert(BM % kRowsPerPass == 0 && BN % kRowsPerPass == 0, "loader mapping");
+  constexpr int AR = BM / kRowsPerPass, BR = BN / kRowsPerPass;   // 16-byte loads per thread
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* const As = reinterpret_cast<T*>(smem_raw);     // [BM][kHLD]
+  T* const Bs = As + BM * kHLD;                     // [BN][kHLD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const EmsaConvGeom& g = p.g;
+  HGather q;
+  q.mul_h = g.mul_h; q.off_h = g.off_h; q.step_h = g.step_h; q.div_h = g.div_h;
+  q.mul_w = g.mul_w; q.off_w = g.off_w; q.step_w = g.step_w; q.div_w = g.div_w;
+  q.in_h = g.in_h; q.in_w = g.in_w;
+  q.row_stride = (int)g.in_row_stride; q.px_stride = g.in_px_stride;
+
+  // ---- loader state ---------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rs_in = h_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_w = h_rsrc(p.w, p.w_bytes);
+  const int rl = tid / kHRowLanes, c8 = (tid % kHRowLanes) * 8;
+  int a_bh[AR], a_bw[AR], a_img[AR];
+  uint32_t a_off[AR], b_off[BR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int m = m0 + rl + kRowsPerPass * j;
+    if (m < p.M) {
+      const int img = (int)h_fast_div((uint32_t)m, p.div_ohw);
+      const int rem = m - img * (int)p.div_ohw.d;
+      const int oh = (int)h_fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
+      a_bh[j] = oh * q.mul_h + q.off_h;
+      a_bw[j] = ow * q.mul_w + q.off_w;
+      a_img[j] = img * (int)g.in_img_stride;
+    } else {
+      a_bh[j] = -(1 << 29);
+      a_bw[j] = 0;
+      a_img[j] = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + rl + kRowsPerPass * j;
+    b_off[j] = n < g.n_ch ? (uint32_t)(n * g.k_ch + c8) * 2u : kHOOB;
+  }
+  const int taps = g.kh * g.kw;
+  const int steps = taps * p.kchunks;
+  const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 2u;
+  int tap_n = 0, kc_n = 0;
+  hu32x4 ra[AR], rb[BR];
+  // kHOOB for the lanes whose channels lie beyond k_ch in the last chunk of a tap
+  const uint32_t last_oob = (p.kchunks - 1) * kHK + c8 < g.k_ch ? 0u : kHOOB;
+
+  auto load_regs = [&]() {
+    // (tap, channel chunk) are wave-uniform: the gathered pixel offsets change once per tap, the
+    // channel advance travels in the scalar offset operand
+    if (kc_n == 0) {
+      const int kh = tap_n / g.kw, kw = tap_n - kh * g.kw;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        const uint32_t o = h_gather(q, a_img[j], a_bh[j], a_bw[j], kh, kw);
+        a_off[j] = (o & kHOOB) ? kHOOB : o + (uint32_t)c8 * 2u;
+      }
+    }
+    const int k0 = kc_n * kHK;
+    const uint32_t sa = (uint32_t)k0 * 2u, sb = (uint32_t)tap_n * w_tap_bytes + (uint32_t)k0 * 2u;
+    // partial last channel chunk: lanes beyond k_ch go out of range through a wave-uniform mask
+    // (no branch around the loads: a join behind them costs an s_waitcnt on the fresh data)
+    const uint32_t pm = k0 + kHK > g.k_ch ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) ra[j] = h_ld16s(rs_in, a_off[j] | (last_oob & pm), sa);
+#pragma unroll
+    for (int j = 0; j < BR; ++j) rb[j] = h_ld16s(rs_w, b_off[j] | (last_oob & pm), sb);
+    if (++kc_n == p.kchunks) {
+      kc_n = 0;
+      ++tap_n;
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int j = 0; j < AR; ++j)
+      *reinterpret_cast<hu32x4*>(As + (rl + kRowsPerPass * j) * kHLD + c8) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      *reinterpret_cast<hu32x4*>(Bs + (rl + kRowsPerPass * j) * kHLD + c8) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_regs();
+  store_lds();
+  __syncthreads();
+
+  for (int s = 0; s < steps; ++s) {
+    const bool has_next = s + 1 < steps;
+    if (has_next) load_regs();
+    const T* a = As + (wm * TM * 32 + l31) * kHLD + lh * 8;
+    const T* b = Bs + (wn * TN * 32 + l31) * kHLD + lh * 8;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < kHK / 16; ++ks) {
+      V8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const V8*>(a + i * 32 * kHLD + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const V8*>(b + j * 32 * kHLD + ks * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();                 // every wave is done reading the buffer
+    if (has_next) store_lds();
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  const bool want_stats = p.stats != nullptr;
+  float bvv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + l31;
+    bvv[j] = (n < g.n_ch && p.bias) ? p.bias[n] : 0.f;
+  }
+  if (want_stats) {
+    // Per-tile (count, sum, M2 about the tile mean) of the fp32 accumulators (+bias) -> merged with
+    // Chan's formula in emsa_bn_finalize.  Deterministic (no atomics).
+    float* red = smem;              // [WM][BN]; main-loop LDS reads are all behind a barrier
+    float* tmean = smem + WM * BN;  // [BN]
+    const int cnt = min(BM, p.M - m0);
+    float s1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m0 + row < p.M) a1 += acc[i][j][r] + bvv[j];
+        }
+      s1[j] = a1 + __shfl_xor(a1, 32);
+      if (lh == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s1[j];
+    }
+    __syncthreads();
+    for (int col = tid; col < BN; col += NT) {
+      float a1 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WM; ++w_) a1 += red[w_ * BN + col];
+      tmean[col] = a1 / (float)cnt;
+      const int n = n0 + col;
+      if (n < g.n_ch) {
+        p.stats[((size_t)0 * p.tiles_m + mt) * g.n_ch + n] = a1;
+        p.stats[((size_t)2 * p.tiles_m + mt) * g.n_ch + n] = (float)cnt;
+      }
+    }
+    __syncthreads();
+    float s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float mu = tmean[(wn * TN + j) * 32 + l31];
+      float q2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m0 + row < p.M) {
+            const float d = acc[i][j][r] + bvv[j] - mu;
+            q2 += d * d;
+          }
+        }
+      s2[j] = q2 + __shfl_xor(q2, 32);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (lh == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s2[j];
+    __syncthreads();
+    for (int col = tid; col < BN; col += NT) {
+      const int n = n0 + col;
+      if (n < g.n_ch) {
+        float a2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) a2 += red[w_ * BN + col];
+        p.stats[((size_t)1 * p.tiles_m + mt) * g.n_ch + n] = a2;
+      }
+    }
+  }
+
+  // ---- output pass: one wave-row (BM / WM pixel rows) at a time through an fp32 LDS stage -------
+  constexpr int SLD = BN + 4;
+  constexpr int HR = BM / WM;                      // rows per stage pass
+  constexpr int C8 = BN / 8, RPP = NT / C8;        // 8-channel columns, rows per pass of the block
+  float* const stage = smem;                       // [HR][SLD] <= LDS of the main loop
+  const int col8 = tid % C8, row0 = tid / C8;
+  const int n = n0 + col8 * 8;
+  const bool nok = n < g.n_ch;
+  float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sc1 = sc0, sh0 = emsa_zero4(), sh1 = sh0;
+  if (p.scale && nok) {
+    sc0 = emsa_ld4(p.scale + n); sc1 = emsa_ld4(p.scale + n + 4);
+    sh0 = emsa_ld4(p.shift + n); sh1 = emsa_ld4(p.shift + n + 4);
+  }
+  const T* const res = reinterpret_cast<const T*>(p.residual);
+  const T* const msk = reinterpret_cast<const T*>(p.mask_src);
+  T* const outp = reinterpret_cast<T*>(p.out);
+#pragma unroll
+  for (int h = 0; h < WM; ++h) {
+    __syncthreads();                               // statistics / previous pass are done with LDS
+    if (wm == h) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;       // within the wave-row
+            stage[row * SLD + (wn * TN + j) * 32 + l31] = acc[i][j][r] + bvv[j];
+          }
+    }
+    __syncthreads();
+    if (nok) {
+#pragma unroll 2
+      for (int row = row0; row < HR; row += RPP) {
+        const int m = m0 + h * HR + row;
+        if (m >= p.M) break;
+        const float4 v0 = emsa_ld4(stage + row * SLD + col8 * 8);
+        const float4 v1 = emsa_ld4(stage + row * SLD + col8 * 8 + 4);
+        hf32x8 v = {v0.x * sc0.x + sh0.x, v0.y * sc0.y + sh0.y, v0.z * sc0.z + sh0.z,
+                    v0.w * sc0.w + sh0.w, v1.x * sc1.x + sh1.x, v1.y * sc1.y + sh1.y,
+                    v1.z * sc1.z + sh1.z, v1.w * sc1.w + sh1.w};
+        if (res) {
+          const V8 rr = *reinterpret_cast<const V8*>(res + (size_t)m * p.ld_res + n);
+          v += __builtin_convertvector(rr, hf32x8);
+        }
+        if (msk) {
+          const hf32x8 mm =
+              __builtin_convertvector(*reinterpret_cast<const V8*>(msk + (size_t)m * p.ld_mask + n), hf32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = mm[e] > 0.f ? v[e] : 0.f;
+        }
+        if (p.act == EMSA_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<V8*>(outp + (size_t)m * g.ld_out + n) = __builtin_convertvector(v, V8);
+      }
+    }
+  }
+}
+
+enum HTile { HT_128x64 = 0, HT_128x128, HT_64x64, HT_COUNT };
+int ht_bm(HTile t) { return t == HT_64x64 ? 64 : 128; }
+int ht_bn(HTile t) { return t == HT_128x128 ? 128 : 64; }
+
+// EMSA_CONVH_TILE=0..2 forces a tile configuration (tests / tuning)
+HTile pick_htile(long M, int n_ch) {
+  const char* e = getenv("EMSA_CONVH_TILE");
+  const int f = (e && *e) ? atoi(e) : -1;
+  if (f >= 0 && f < HT_COUNT) return (HTile)f;
+  if (M < 128 * 512) return HT_64x64;             // few pixels (low resolutions, batch 1): more tiles
+  if (n_ch >= 128) return HT_128x128;
+  return HT_128x64;
+}
+
+bool h_geom_ok(const EmsaConvGeom* g) {
+  if (!g) return false;
+  // 16-byte accesses of 2-byte elements: channel counts and strides in multiples of 8
+  if (g->k_ch <= 0 || g->n_ch <= 0 || (g->k_ch & 7) || (g->n_ch & 7) || (g->ld_out & 7)) return false;
+  if ((g->in_px_stride & 7) || (g->in_row_stride & 7) || (g->in_img_stride & 7)) return false;
+  if (g->div_h < 1 || g->div_w < 1 || g->kh < 1 || g->kw < 1) return false;
+  const long in_elems = (long)g->n_img * g->in_img_stride;
+  const long out_elems = (long)g->n_img * g->out_h * g->out_w * (long)g->ld_out;
+  if (in_elems >= (1L << 30) || out_elems >= (1L << 31)) return false;   // descriptors < 2 GiB
+  if ((long)g->kh * g->kw * g->n_ch * g->k_ch >= (1L << 30)) return false;
+  return true;
+}
+
+template <int BM, int BN, int WM, int WN, typename T>
+int launch_h(const ConvHArgs& a, hipStream_t st) {
+  constexpr size_t lds_main = (size_t)(BM + BN) * kHLD * 2;
+  constexpr size_t lds_epi = (size_t)(BM / WM) * (BN + 4) * sizeof(float);
+  constexpr size_t lds_stat = (size_t)(WM + 1) * BN * sizeof(float);
+  constexpr size_t lds0 = lds_main > lds_epi ? lds_main : lds_epi;
+  constexpr size_t lds = lds0 > lds_stat ? lds0 : lds_stat;
+  const int grid = a.tiles_m * a.tiles_n;
+  const double flops = 2.0 * a.g.n_img *
+                       ((a.g.div_h > 1 || a.g.div_w > 1) ? (double)a.g.in_h * a.g.in_w
+                                                         : (double)a.g.out_h * a.g.out_w) *
+                       a.g.k_ch * a.g.n_ch * a.g.kh * a.g.kw;
+  const int ps = emsa_prof_begin(kProfClassConvH, flops, st);
+  hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T>), dim3(grid), dim3(256), lds, st, a);
+  emsa_prof_end(ps, st);
+  return emsa_launch_status();
+}
+
+template <typename T>
+int conv_h_dispatch(const ConvHArgs& a, HTile t, hipStream_t st) {
+  switch (t) {
+    case HT_128x128: return launch_h<128, 128, 2, 2, T>(a, st);
+    case HT_64x64: return launch_h<64, 64, 2, 2, T>(a, st);
+    default: return launch_h<128, 64, 2, 2, T>(a, st);
+  }
+}
+
+}  // namespace
+
+extern "C" int emsa_conv_stats_rows_t(int32_t dtype, const EmsaConvGeom* g) {
+  if (dtype == EMSA_DT_F32) return emsa_conv_stats_rows(g);
+  if (!h_geom_ok(g)) return EMSA_E_SHAPE;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  const HTile t = pick_htile(M, g->n_ch);
+  return (int)((M + ht_bm(t) - 1) / ht_bm(t));
+}
+
+extern "C" int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                 const void* w, void* out, const float* bias, float* stats,
+                                 const float* scale, const float* shift, const void* residual,
+                                 int32_t ld_res, const void* mask_src, int32_t ld_mask,
+                                 int32_t act, void* stream) {
+  if (dtype == EMSA_DT_F32)
+    return emsa_conv_igemm(g, (const float*)in, (const float*)w, (float*)out, bias, stats, scale,
+                           shift, (const float*)residual, ld_res, (const float*)mask_src, ld_mask,
+                           act, stream);
+  if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
+  if (!h_geom_ok(g)) return EMSA_E_SHAPE;
+  if (!in || !w || !out) return EMSA_E_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!al16(in) || !al16(w) || !al16(out) || !al16(bias) || !al16(scale) || !al16(shift) ||
+      (residual && (!al16(residual) || (ld_res & 7))) ||
+      (mask_src && (!al16(mask_src) || (ld_mask & 7))))
+    return EMSA_E_SHAPE;
+  ConvHArgs a;
+  a.g = *g;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats;
+  a.scale = scale; a.shift = shift; a.residual = residual; a.mask_src = mask_src;
+  a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  a.M = (int)M;
+  const HTile t = pick_htile(M, g->n_ch);
+  a.tiles_m = (int)((M + ht_bm(t) - 1) / ht_bm(t));
+  a.tiles_n = (g->n_ch + ht_bn(t) - 1) / ht_bn(t);
+  a.kchunks = (g->k_ch + kHK - 1) / kHK;
+  a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * 2);
+  a.w_bytes = (uint32_t)((size_t)g->kh * g->kw * g->n_ch * g->k_ch * 2);
+  a.div_ohw = h_make_fastdiv((uint32_t)(g->out_h * g->out_w));
+  a.div_ow = h_make_fastdiv((uint32_t)g->out_w);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMSA_DT_BF16) return conv_h_dispatch<emsa_bf16>(a, t, st);
+  return conv_h_dispatch<emsa_f16>(a, t, st);
+}

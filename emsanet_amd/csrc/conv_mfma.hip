@@ -22,6 +22,7 @@
 //     folded eval BatchNorm, residual add, ReLU and the ReLU-backward mask.
 #include "common.h"
 
+#include <type_traits>
 #include <vector>
 
 #include "prof.h"
@@ -45,7 +46,7 @@ const char* const kProfNames[kProfClasses] = {
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
     "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1> (unused)",
     "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_wino_kernel<64,64>",
-    "conv1d_wino_kernel"};
+    "conv1d_wino_kernel", "conv_h_kernel (16-bit igemm)", "wgrad kernels on 16-bit activations"};
 }  // namespace
 
 int emsa_prof_begin(int cls, double flops, hipStream_t st) {
@@ -157,6 +158,32 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byt
 __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(float4,
                             __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+// Four consecutive channels of an activation in storage type T (16 bytes for float, 8 for the
+// 16-bit types: the weight-gradient kernels below read the bf16 activations of the mixed-precision
+// training path through the same loaders).  The load returns the RAW registers; the conversion to
+// fp32 happens where the prefetched registers are consumed (store_lds) -- converting right behind
+// the load would put an s_waitcnt on the fresh data in front of the step's MFMAs.
+typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
+template <typename T> struct Raw4 { typedef u32x2w type; };
+template <> struct Raw4<float> { typedef float4 type; };
+template <typename T>
+__device__ __forceinline__ typename Raw4<T>::type buf_ld4raw(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  if constexpr (sizeof(T) == 4) {
+    return buf_ld4(r, byte_off);
+  } else {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+  }
+}
+__device__ __forceinline__ float4 raw_f4(const float4& v, float*) { return v; }
+__device__ __forceinline__ float4 raw_f4(const u32x2w& raw, emsa_bf16*) {
+  return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xFFFF0000u),
+                     __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ float4 raw_f4(const u32x2w& raw, emsa_f16*) {
+  const emsa_f16x4 h = __builtin_bit_cast(emsa_f16x4, raw);
+  return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
 }
 
 // gather helper: BYTE offset of (row base, tap) or kOOB
@@ -523,8 +550,9 @@ struct WgradArgs {
 // ALIGNED: float4 loads of dy are legal.  A compile-time split, not a branch around the loads: a
 // control-flow join behind a load makes the compiler wait for the data at the join, i.e. before
 // the step's MFMAs.
-template <int BCO, int BCI, int TT, int WCO, int WCI, int WT, bool ALIGNED>
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT, bool ALIGNED, typename T = float>
 __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
+  constexpr uint32_t ES = sizeof(T);            // bytes per activation element
   static_assert(WCO * WCI * WT == 4, "4 waves");
   constexpr int PK = 32;                       // pixels (GEMM K) per step
   constexpr int TCO = BCO / 32 / WCO, TCI = BCI / 32 / WCI, TTW = (TT + WT - 1) / WT;
@@ -559,7 +587,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
   const int x_c4 = (tid % XTPR) * 4, x_r = tid / XTPR;
   const bool do_bias = p.dbias != nullptr && ci_t == 0 && tg == 0;
 
-  float4 rd[DR], rx[TT][XR];
+  typename Raw4<T>::type rd[DR], rx[TT][XR];
   float4 bsum = emsa_zero4();
 
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
@@ -576,7 +604,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
   }
   // channel part of the x addresses; a column beyond the tensor's channels stays out of range
   const bool xok = ci0 + x_c4 < g.k_ch;
-  const uint32_t xadd = xok ? (uint32_t)(ci0 + x_c4) * 4u : 0u, xmask = xok ? 0u : kOOB;
+  const uint32_t xadd = xok ? (uint32_t)(ci0 + x_c4) * ES : 0u, xmask = xok ? 0u : kOOB;
   constexpr int TH = (TT + 1) / 2;              // taps per lane half
   auto load_regs = [&](int s) {
     const int mb = s * PK;
@@ -584,19 +612,19 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
     for (int j = 0; j < DR; ++j) {
       const int m = mb + d_r + j * (256 / DTPR);
       const int co = co0 + d_c4;
-      float4 v = emsa_zero4();
-#if !(EMSA_ABL & 1)
       if constexpr (ALIGNED) {
-        v = buf_ld4(rs_dy, (m < p.M && co < g.n_ch) ? (uint32_t)(m * g.ld_out + co) * 4u : kOOB);
-      } else if (m < p.M && co < g.n_ch) {
-        const float* src = p.dout + (size_t)m * g.ld_out + co;
-        v.x = src[0];
-        if (co + 1 < g.n_ch) v.y = src[1];
-        if (co + 2 < g.n_ch) v.z = src[2];
-        if (co + 3 < g.n_ch) v.w = src[3];
+        rd[j] = buf_ld4raw<T>(rs_dy, (m < p.M && co < g.n_ch) ? (uint32_t)(m * g.ld_out + co) * ES : kOOB);
+      } else if constexpr (sizeof(T) == 4) {
+        float4 v = emsa_zero4();
+        if (m < p.M && co < g.n_ch) {
+          const float* src = p.dout + (size_t)m * g.ld_out + co;
+          v.x = src[0];
+          if (co + 1 < g.n_ch) v.y = src[1];
+          if (co + 2 < g.n_ch) v.z = src[2];
+          if (co + 3 < g.n_ch) v.w = src[3];
+        }
+        rd[j] = v;
       }
-#endif
-      rd[j] = v;
     }
     // x: the 16+ lanes that load one pixel row share its gathered address, so lane (r, half) of
     // every wave computes the byte offsets of pixel mb + r for the taps t with (t & 1) == half
@@ -621,7 +649,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
       const bool ok_t = lh ? (two && tok[t1]) : tok[t0];
       const int hn = bh + kh * q.step_h, wn = bw + kw * q.step_w;    // (div_h = div_w = 1 here)
       const bool ok = ok_t && hn >= 0 && hn < q.in_h && wn >= 0 && wn < q.in_w;
-      goff[u] = ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * 4u : kOOB;
+      goff[u] = ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * ES : kOOB;
     }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
@@ -630,11 +658,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
       for (int t = 0; t < TT; ++t) {
         const uint32_t o =
             (uint32_t)__builtin_amdgcn_ds_bpermute((r + 32 * (t & 1)) * 4, (int)goff[t >> 1]);
-#if EMSA_ABL & 1
-        rx[t][j] = make_float4(o, 1.f, 2.f, 3.f);
-#else
-        rx[t][j] = buf_ld4(rs_in, (o + xadd) | xmask);
-#endif
+        rx[t][j] = buf_ld4raw<T>(rs_in, (o + xadd) | xmask);
       }
     }
   };
@@ -646,14 +670,16 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
       // (the bias gradient = column sums of dy is accumulated HERE, where the prefetched
       //  registers are consumed anyway: summing right behind the load puts the wave to sleep
       //  on s_waitcnt until the next step's data has arrived, before this step's MFMAs)
-      bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;
-      emsa_st4(d + (d_r + j * (256 / DTPR)) * BCO + d_c4, rd[j]);
+      const float4 dv = raw_f4(rd[j], (T*)nullptr);
+      bsum.x += dv.x; bsum.y += dv.y; bsum.z += dv.z; bsum.w += dv.w;
+      emsa_st4(d + (d_r + j * (256 / DTPR)) * BCO + d_c4, dv);
     }
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int j = 0; j < XR; ++j)
-        emsa_st4(x + t * PK * BCI + (x_r + j * (256 / XTPR)) * BCI + x_c4, rx[t][j]);
+        emsa_st4(x + t * PK * BCI + (x_r + j * (256 / XTPR)) * BCI + x_c4,
+                 raw_f4(rx[t][j], (T*)nullptr));
   };
 
   f32x16 acc[TCO][TCI][TTW];
@@ -749,12 +775,16 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& p) {
   }
 }
 
-template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT, typename T = float>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
-  if (p.dout_aligned)
-    conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, true>(p);
-  else
-    conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, false>(p);
+  if constexpr (sizeof(T) == 4) {
+    if (p.dout_aligned)
+      conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, true, T>(p);
+    else
+      conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, false, T>(p);
+  } else {
+    conv_wgrad_body<BCO, BCI, TT, WCO, WCI, WT, true, T>(p);    // (the launcher requires alignment)
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1012,9 +1042,10 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(
 // and one v_mfma_f32_32x32x16_bf16 per component covers the step's 16 pixel pairs; accumulation,
 // the transforms and everything in HBM stay fp32.
 typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
-template <int BCO, int BCI, bool BF16 = false>
+template <int BCO, int BCI, bool BF16 = false, typename T = float>
 __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
   static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
+  constexpr uint32_t ES = sizeof(T);            // bytes per activation element
   constexpr int PK = 32, NP = PK / 2, XROWS = PK + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const eS = smem;                      // [NP pairs][4: e0, e0+e1, e0-e1, e1][BCO]
@@ -1049,10 +1080,10 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
   const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
   // channel part of the addresses; a column beyond the tensor's channels stays out of range
   const bool dok = co0 + col4 < p.n_ch, xok = ci0 + col4 < p.k_ch;
-  const uint32_t dadd = dok ? (uint32_t)(co0 + col4) * 4u : 0u, dmask = dok ? 0u : kOOB;
-  const uint32_t xadd = xok ? (uint32_t)(ci0 + col4) * 4u : 0u, xmask = xok ? 0u : kOOB;
+  const uint32_t dadd = dok ? (uint32_t)(co0 + col4) * ES : 0u, dmask = dok ? 0u : kOOB;
+  const uint32_t xadd = xok ? (uint32_t)(ci0 + col4) * ES : 0u, xmask = xok ? 0u : kOOB;
 
-  float4 re[2], rx[4];
+  typename Raw4<T>::type re_raw[2], rx_raw[4];
   float4 bsum = emsa_zero4();
   auto load_regs = [&](int s) {
     // lane l of every wave decomposes pixel k0 + l - 1 (l < 34) once; the loading threads fetch
@@ -1068,10 +1099,10 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
     const bool in_line = valid && b_ < p.Lr;
     const uint32_t off_d = in_line
         ? (__umul24(img, (uint32_t)p.dy_simg) + __umul24((uint32_t)a_, (uint32_t)p.dy_sa) +
-           __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * 4u : kOOB;
+           __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * ES : kOOB;
     const uint32_t off_x = (in_line && a2 >= 0 && a2 < p.A)
         ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa) +
-           __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * 4u : kOOB;
+           __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * ES : kOOB;
     // as the LEFT neighbour (d0) of the next pixel a line's last pixel reads zero, as the RIGHT
     // neighbour (d3) of the previous pixel a line's first pixel does: the tap crosses a line end
     const uint32_t off_xl = b_ == p.L - 1 ? kOOB : off_x;
@@ -1083,12 +1114,12 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
     const uint32_t o_d1 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 4, (int)off_x);
     const uint32_t o_d2 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 8, (int)off_x);
     const uint32_t o_d3 = (uint32_t)__builtin_amdgcn_ds_bpermute(l0 + 12, (int)off_xr);
-    re[0] = buf_ld4(rs_dy, (o_e0 + dadd) | dmask);
-    re[1] = buf_ld4(rs_dy, (o_e1 + dadd) | dmask);
-    rx[0] = buf_ld4(rs_in, (o_d0 + xadd) | xmask);
-    rx[1] = buf_ld4(rs_in, (o_d1 + xadd) | xmask);
-    rx[2] = buf_ld4(rs_in, (o_d2 + xadd) | xmask);
-    rx[3] = buf_ld4(rs_in, (o_d3 + xadd) | xmask);
+    re_raw[0] = buf_ld4raw<T>(rs_dy, (o_e0 + dadd) | dmask);
+    re_raw[1] = buf_ld4raw<T>(rs_dy, (o_e1 + dadd) | dmask);
+    rx_raw[0] = buf_ld4raw<T>(rs_in, (o_d0 + xadd) | xmask);
+    rx_raw[1] = buf_ld4raw<T>(rs_in, (o_d1 + xadd) | xmask);
+    rx_raw[2] = buf_ld4raw<T>(rs_in, (o_d2 + xadd) | xmask);
+    rx_raw[3] = buf_ld4raw<T>(rs_in, (o_d3 + xadd) | xmask);
   };
   auto add4 = [](const float4& a, const float4& b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
@@ -1097,6 +1128,9 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
     return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
   };
   auto store_lds = [&]() {
+    const float4 re[2] = {raw_f4(re_raw[0], (T*)nullptr), raw_f4(re_raw[1], (T*)nullptr)};
+    const float4 rx[4] = {raw_f4(rx_raw[0], (T*)nullptr), raw_f4(rx_raw[1], (T*)nullptr),
+                          raw_f4(rx_raw[2], (T*)nullptr), raw_f4(rx_raw[3], (T*)nullptr)};
     float* e = eS + pr * 4 * BCO + col4;
     float* d = dS + pr * 4 * BCI + col4;
     const float4 es = add4(re[0], re[1]);
@@ -1381,12 +1415,12 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
   return emsa_launch_status();
 }
 
-template <int BCO, int BCI, int TT, int WCO, int WCI, int WT>
+template <int BCO, int BCI, int TT, int WCO, int WCI, int WT, typename T = float>
 int launch_wgrad(WgradArgs a, hipStream_t st) {
   constexpr size_t lds = (size_t)((EMSA_SB & 2) ? 1 : 2) * (32 * BCO + TT * 32 * BCI) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>,
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT, T>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
@@ -1402,9 +1436,9 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   if (ksplit < 1) ksplit = 1;
   a.steps_per_split = (a.steps_total + ksplit - 1) / ksplit;
   ksplit = (a.steps_total + a.steps_per_split - 1) / a.steps_per_split;
-  constexpr int cls = TT == 7 ? 4 : TT == 3 ? 7 : BCO == 128 ? 5 : 6;
+  constexpr int cls = sizeof(T) != 4 ? kProfClassWgradH : TT == 7 ? 4 : TT == 3 ? 7 : BCO == 128 ? 5 : 6;
   const int ps = prof_begin(cls, algo_flops(a.g), st);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT>), dim3(a.n_tiles * ksplit),
+  hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, TT, WCO, WCI, WT, T>), dim3(a.n_tiles * ksplit),
                      dim3(256), lds, st, a);
   prof_end(ps, st);
   return emsa_launch_status();
@@ -1464,7 +1498,7 @@ struct Wgrad1dPlan {
   int ksplit;
   bool wino;
 };
-bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
+bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, size_t esize = sizeof(float)) {
   // a 3x3 conv = three row taps, each a 3-tap 1-D weight gradient along W on x shifted by a line
   const bool sq = g->kh == 3 && g->kw == 3 && g->off_w == -1 && g->off_h == -1;
   const bool along_w = (g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0) || sq;
@@ -1503,8 +1537,8 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl) {
   pl.wino = wino_on;
   w.L = (pl.wino && (w.Lr & 1)) ? w.Lr + 1 : w.Lr;
   w.M = g->n_img * A * w.L;
-  w.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
-  w.dout_bytes = (uint32_t)((size_t)g->n_img * H * W * g->ld_out * sizeof(float));
+  w.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * esize);
+  w.dout_bytes = (uint32_t)((size_t)g->n_img * H * W * g->ld_out * esize);
   w.div_al = make_fastdiv((uint32_t)(A * w.L));
   w.div_l = make_fastdiv((uint32_t)w.L);
   w.n_co_tiles = (g->n_ch + 63) / 64;
@@ -1542,8 +1576,14 @@ extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
                                (int64_t)pl.w.n_co_tiles * 64) * (int64_t)sizeof(float);
 }
 
-extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout,
-                               float* dw, float* dbias, float* ws, void* stream) {
+namespace {
+template <typename T>
+int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float* dw, float* dbias,
+                    float* ws, void* stream) {
+  constexpr bool kHalf = sizeof(T) != 4;
+  // (the argument structs carry byte addresses; the kernels read them through typed loaders)
+  const float* in = reinterpret_cast<const float*>(in_t);
+  const float* dout = reinterpret_cast<const float*>(dout_t);
   if (!geom_ok(g)) return EMSA_E_SHAPE;
   if (!in || !dout || !dw) return EMSA_E_ARG;
   if (g->div_h != 1 || g->div_w != 1) return EMSA_E_SHAPE;
@@ -1552,14 +1592,15 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
   a.in = in; a.dout = dout; a.dw = dw; a.dbias = dbias;
   a.M = g->n_img * g->out_h * g->out_w;
   a.dout_aligned = dout_is_aligned(g, dout);
-  a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
-  a.dout_bytes = (uint32_t)((size_t)a.M * g->ld_out * sizeof(float));
+  if (kHalf && (!a.dout_aligned || (((uintptr_t)in) & 7))) return EMSA_E_SHAPE;
+  a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(T));
+  a.dout_bytes = (uint32_t)((size_t)a.M * g->ld_out * sizeof(T));
   a.div_ohw = make_fastdiv((uint32_t)(g->out_h * g->out_w));
   a.div_ow = make_fastdiv((uint32_t)g->out_w);
   hipStream_t st = (hipStream_t)stream;
   const int taps = g->kh * g->kw;
   Wgrad1dPlan pl;
-  const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl);
+  const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl, sizeof(T)) && (!kHalf || pl.wino);
   if (ws != nullptr && !one_d) return EMSA_E_SHAPE;   // ws_bytes(g) was 0
   if (one_d) {
     Wgrad1dArgs& w = pl.w;
@@ -1568,12 +1609,18 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * 12288 : nullptr;
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
-    const int ps = prof_begin(7, algo_flops(a.g), st);
+    const int ps = prof_begin(kHalf ? kProfClassWgradH : 7, algo_flops(a.g), st);
     static const bool bf16 = [] {
       const char* e = getenv("EMSA_BF16_MFMA");
       return e && e[0] == '1';
     }();
-    if (pl.wino && bf16)
+    if constexpr (kHalf) {
+      // 16-bit activations: operands are bf16 already; E / D are formed in fp32 and rounded to bf16
+      // as they enter LDS, one v_mfma_f32_32x32x16_bf16 per Winograd component and K step
+      hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true, T>),
+                         dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
+                         (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
+    } else if (pl.wino && bf16)
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true>),
                          dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
                          (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
@@ -1590,13 +1637,32 @@ extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const flo
     prof_end(ps, st);
     return emsa_launch_status();
   }
-  if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2>(a, st);
+  if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2, T>(a, st);
   if (taps == 1) {
     // (a 128x128 tile was measured slower for the 1x1 convs: 96 / 82 us vs 66 / 63 us at 128 /
     //  256 channels -- four times the split-K partial-tile volume per workgroup)
-    return launch_wgrad<64, 64, 1, 2, 2, 1>(a, st);
+    return launch_wgrad<64, 64, 1, 2, 2, 1, T>(a, st);
   }
-  return launch_wgrad<64, 64, 3, 2, 2, 1>(a, st);
+  return launch_wgrad<64, 64, 3, 2, 2, 1, T>(a, st);
+}
+}  // namespace
+
+extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout,
+                               float* dw, float* dbias, float* ws, void* stream) {
+  return conv_wgrad_impl<float>(g, in, dout, dw, dbias, ws, stream);
+}
+
+// weight (+bias) gradient from activations in storage type `dtype` (training: EMSA_DT_BF16); the
+// gradients are fp32 (master weights), the workspace contract is that of emsa_conv_wgrad
+extern "C" int emsa_conv_wgrad_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                 const void* dout, float* dw, float* dbias, float* ws,
+                                 void* stream) {
+  if (dtype == EMSA_DT_F32)
+    return conv_wgrad_impl<float>(g, (const float*)in, (const float*)dout, dw, dbias, ws, stream);
+  if (dtype == EMSA_DT_BF16)
+    return conv_wgrad_impl<emsa_bf16>(g, (const emsa_bf16*)in, (const emsa_bf16*)dout, dw, dbias,
+                                      ws, stream);
+  return EMSA_E_ARG;
 }
 
 // ---- profiling C-ABI -------------------------------------------------------------------------

@@ -535,6 +535,15 @@ __global__ void pack_wino_packed_kernel(const float* __restrict__ wp, float* __r
 // job j owns workgroups [first_block[j], first_block[j+1]); kind 0: OIHW -> packed implicit-GEMM
 // layouts (dst0 = [tap][cout][cin], dst1 = [tap][cin][cout]); kind 1: OIHW -> Winograd U
 // (dst0 forward, dst1 data gradient; rows = 3 for a 3x3 kernel); NULL outputs are skipped
+// kind 2 / 3: as kind 0 with bf16 / fp16 outputs (operands of conv_h.hip)
+__device__ __forceinline__ void pack_store(float* base, size_t idx, float v, int kind) {
+  if (kind == 2)
+    reinterpret_cast<emsa_bf16*>(base)[idx] = (emsa_bf16)v;
+  else if (kind == 3)
+    reinterpret_cast<emsa_f16*>(base)[idx] = (emsa_f16)v;
+  else
+    base[idx] = v;
+}
 __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __restrict__ jobs,
                                                          int n_jobs) {
   // 32 (co) x 32 (ci) tiles: reads and forward-layout writes run along ci, the transposed
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
       } else {
         const float v = ok ? jb.src[((size_t)co * cin + ci) * taps + r] : 0.f;
         vals[k][0] = v;
-        if (ok && jb.dst0) jb.dst0[((size_t)r * cout + co) * cin + ci] = v;
+        if (ok && jb.dst0) pack_store(jb.dst0, ((size_t)r * cout + co) * cin + ci, v, jb.kind);
       }
     }
     if (jb.dst1) {
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
             jb.dst1[2 * NK + o] = tr[2][tx][ty + 8 * k];
             jb.dst1[3 * NK + o] = tr[0][tx][ty + 8 * k];
           } else {
-            jb.dst1[((size_t)r * cin + ci) * cout + co] = tr[0][tx][ty + 8 * k];
+            pack_store(jb.dst1, ((size_t)r * cin + ci) * cout + co, tr[0][tx][ty + 8 * k], jb.kind);
           }
         }
       }

@@ -54,6 +54,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
   }
 }
 
+// 16-bit operands of conv_h.hip from the fp32 OIHW parameter: dst = [tap][cout_total][cin_total],
+// dst2 = [tap][cin_total][cout_total] (either may be NULL)
+template <typename T>
+__global__ void pack_weight_t_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                     T* __restrict__ dst2, int cout, int cin, int taps,
+                                     int cout_total, int cout_off, int cin_total, int cin_off) {
+  const long total = (long)cout * cin * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long r = i / taps;
+    const int ci = (int)(r % cin), co = (int)(r / cin);
+    const float v = src[i];
+    if (dst) emsa_st1(dst + ((long)tap * cout_total + cout_off + co) * cin_total + cin_off + ci, v);
+    if (dst2) emsa_st1(dst2 + ((long)tap * cin_total + cin_off + ci) * cout_total + cout_off + co, v);
+  }
+}
+
 // stem: NCHW -> zero padded NHWC4 [n][h][w+8][4]
 template <typename T>
 __global__ void stem_pack_input_kernel(const float* __restrict__ x, T* __restrict__ y, int n,
@@ -80,7 +98,8 @@ __global__ void stem_pack_input_kernel(const float* __restrict__ x, T* __restric
 }
 
 // stem weights: OIHW [cout][cin][7][7] <-> [7(kh)][cout][32 = 8(kw) x 4(c)]
-__global__ void stem_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp,
+template <typename T>
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wp,
                                         int cout, int cin, int unpack) {
   const int total = 7 * cout * 32;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -88,10 +107,10 @@ __global__ void stem_pack_weight_kernel(const float* __restrict__ w, float* __re
     const int kw = k / 4, c = k % 4;
     const bool real = kw < 7 && c < cin;
     if (!unpack) {
-      wp[i] = real ? w[((co * cin + c) * 7 + kh) * 7 + kw] : 0.f;
+      emsa_st1(wp + i, real ? w[((co * cin + c) * 7 + kh) * 7 + kw] : 0.f);
     } else if (real) {
       // here `w` is the packed gradient and `wp` the OIHW destination
-      wp[((co * cin + c) * 7 + kh) * 7 + kw] = w[i];
+      emsa_st1(wp + ((co * cin + c) * 7 + kh) * 7 + kw, w[i]);
     }
   }
 }
@@ -1235,16 +1254,43 @@ extern "C" int emsa_stem_pack_weight(const float* w, float* wp, int32_t cout, in
                                      void* stream) {
   if (!w || !wp) return EMSA_E_ARG;
   if (cin < 1 || cin > 4) return EMSA_E_SHAPE;
-  hipLaunchKernelGGL(stem_pack_weight_kernel, dim3(grid_for(7L * cout * 32)), dim3(kThreads), 0,
-                     (hipStream_t)stream, w, wp, cout, cin, 0);
+  hipLaunchKernelGGL(stem_pack_weight_kernel<float>, dim3(grid_for(7L * cout * 32)), dim3(kThreads),
+                     0, (hipStream_t)stream, w, wp, cout, cin, 0);
+  return emsa_launch_status();
+}
+extern "C" int emsa_stem_pack_weight_t(int32_t dtype, const float* w, void* wp, int32_t cout,
+                                       int32_t cin, void* stream) {
+  if (!w || !wp) return EMSA_E_ARG;
+  if (cin < 1 || cin > 4) return EMSA_E_SHAPE;
+  EMSA_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL(stem_pack_weight_kernel<T>, dim3(grid_for(7L * cout * 32)), dim3(kThreads),
+                       0, (hipStream_t)stream, w, (T*)wp, cout, cin, 0);
+  });
+  return emsa_launch_status();
+}
+// fp32 OIHW parameter -> 16-bit packed operand layouts of emsa_conv_igemm_t (forward
+// [tap][cout_total][cin_total] and / or data gradient [tap][cin_total][cout_total]; a destination
+// may be NULL; padding rows / columns of a merged or channel-padded conv must be zeroed by the caller)
+extern "C" int emsa_pack_weight_t(int32_t dtype, const float* w, void* wp_fwd, void* wp_dgrad,
+                                  int32_t cout, int32_t cin, int32_t kh, int32_t kw,
+                                  int32_t cout_total, int32_t cout_off, int32_t cin_total,
+                                  int32_t cin_off, void* stream) {
+  if (!w || (!wp_fwd && !wp_dgrad)) return EMSA_E_ARG;
+  if (cout_off + cout > cout_total || cin_off + cin > cin_total) return EMSA_E_SHAPE;
+  const long total = (long)cout * cin * kh * kw;
+  EMSA_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL(pack_weight_t_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       (hipStream_t)stream, w, (T*)wp_fwd, (T*)wp_dgrad, cout, cin, kh * kw,
+                       cout_total, cout_off, cin_total, cin_off);
+  });
   return emsa_launch_status();
 }
 extern "C" int emsa_stem_unpack_wgrad(const float* dwp, float* dw, int32_t cout, int32_t cin,
                                       void* stream) {
   if (!dwp || !dw) return EMSA_E_ARG;
   if (cin < 1 || cin > 4) return EMSA_E_SHAPE;
-  hipLaunchKernelGGL(stem_pack_weight_kernel, dim3(grid_for(7L * cout * 32)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dwp, dw, cout, cin, 1);
+  hipLaunchKernelGGL(stem_pack_weight_kernel<float>, dim3(grid_for(7L * cout * 32)), dim3(kThreads),
+                     0, (hipStream_t)stream, dwp, dw, cout, cin, 1);
   return emsa_launch_status();
 }
 

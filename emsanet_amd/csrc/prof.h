@@ -4,8 +4,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-constexpr int kProfClasses = 9;
+constexpr int kProfClasses = 11;
 constexpr int kProfClassWino = 8;
+constexpr int kProfClassConvH = 9;     // 16-bit implicit GEMM (conv_h.hip)
+constexpr int kProfClassWgradH = 10;   // weight gradients on 16-bit activations
 
 // returns a slot id (or -1 when this launch is not sampled); `flops` = algorithmic FLOPs
 int emsa_prof_begin(int cls, double flops, hipStream_t st);

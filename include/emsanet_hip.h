@@ -413,6 +413,33 @@ int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int6
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 16-bit convolution family (BASELINE configs[2] bf16 mixed-precision training, configs[4] 16-bit
+ * inference; the reference trains / times fp32 and fp16-TensorRT, README.md:176-181).
+ *
+ * emsa_conv_igemm_t: forward conv / data gradient on v_mfma_f32_32x32x16_{bf16,f16} with fp32
+ *   accumulation; `in`, `w`, `out`, `residual`, `mask_src` are tensors of `dtype`, `w` is the packed
+ *   [tap][n_ch][k_ch] operand in `dtype` (emsa_pack_weight_t / emsa_pack_batch kinds 2, 3),
+ *   bias / scale / shift and the BatchNorm statistics partials (taken from the fp32 accumulators)
+ *   are fp32.  k_ch, n_ch, ld_* must be multiples of 8 (16-byte accesses).  EMSA_DT_F32 forwards
+ *   to emsa_conv_igemm.  emsa_conv_stats_rows_t: statistics rows of that launch.
+ * emsa_conv_wgrad_t: weight (+bias) gradient from `dtype` activations (bf16) into fp32 gradients;
+ *   same workspace contract as emsa_conv_wgrad (emsa_conv_wgrad_ws_bytes).
+ * emsa_pack_weight_t / emsa_stem_pack_weight_t: fp32 OIHW parameter -> 16-bit packed operands.
+ * ------------------------------------------------------------------------------------------ */
+int emsa_conv_stats_rows_t(int32_t dtype, const EmsaConvGeom* g);
+int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* w,
+                      void* out, const float* bias, float* stats, const float* scale,
+                      const float* shift, const void* residual, int32_t ld_res,
+                      const void* mask_src, int32_t ld_mask, int32_t act, void* stream);
+int emsa_conv_wgrad_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* dout,
+                      float* dw, float* dbias, float* ws, void* stream);
+int emsa_pack_weight_t(int32_t dtype, const float* w, void* wp_fwd, void* wp_dgrad, int32_t cout,
+                       int32_t cin, int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
+                       int32_t cin_total, int32_t cin_off, void* stream);
+int emsa_stem_pack_weight_t(int32_t dtype, const float* w, void* wp, int32_t cout, int32_t cin,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Typed ("_t") forms of the HBM-bound kernels: same semantics and argument order as the fp32 entry
  * points above, activation tensors in the storage type `dtype` (EMSA_DT_*).  Kernels at the model
  * boundary take `out_f32`: the tensors on the OUTPUT side of the op (y of a forward kernel, dy / y

@@ -23,7 +23,7 @@ def isa(src):
 
 def main():
     bad = 0
-    for f in ('conv_mfma.hip', 'conv_wino.hip'):
+    for f in ('conv_mfma.hip', 'conv_wino.hip', 'conv_h.hip'):
         text = isa(os.path.join(CSRC, f))
         for m in re.finditer(r'^(_Z\S+):.*?s_endpgm', text, re.S | re.M):
             lines = m.group(0).split('\n')
