@@ -74,6 +74,9 @@ _DEFAULTS = {
     'he_init': (('encoder-fusion',), 626),
     'no_zero_init_decoder_residuals': (False, 640),
     'debug': (False, 1116),
+    # NOT a reference option (line 0): storage type of the engine's activations, see
+    # EMSANet.set_compute_dtype ('float32' = the reference's arithmetic)
+    'compute_dtype': ('float32', 0),
 }
 
 FULL_TASKS = ('semantic', 'scene', 'instance', 'orientation')

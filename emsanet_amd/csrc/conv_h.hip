@@ -399,7 +399,14 @@ bool h_geom_ok(const EmsaConvGeom* g) {
   if (!g) return false;
   // 16-byte accesses of 2-byte elements: channel counts and strides in multiples of 8
   if (g->k_ch <= 0 || g->n_ch <= 0 || (g->k_ch & 7) || (g->n_ch & 7) || (g->ld_out & 7)) return false;
-  if ((g->in_px_stride & 7) || (g->in_row_stride & 7) || (g->in_img_stride & 7)) return false;
+  if ((g->in_row_stride & 7) || (g->in_img_stride & 7)) return false;
+  if (g->in_px_stride & 7) {
+    // a 4-element pixel (the stem's zero-padded NHWC4 image) is fine when every gathered column
+    // is even: the 16-byte accesses then start on 8-element boundaries
+    const bool even_cols = (g->mul_w % 2 == 0) && (g->off_w % 2 == 0) &&
+                           (g->kw == 1 || g->step_w % 2 == 0) && g->div_w == 1;
+    if ((g->in_px_stride & 3) || !even_cols) return false;
+  }
   if (g->div_h < 1 || g->div_w < 1 || g->kh < 1 || g->kw < 1) return false;
   const long in_elems = (long)g->n_img * g->in_img_stride;
   const long out_elems = (long)g->n_img * g->out_h * g->out_w * (long)g->ld_out;

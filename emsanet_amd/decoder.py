@@ -55,7 +55,7 @@ class InstanceSideHead(nn.Module):
         for conv, o in zip(self.task_convs, outs):
             placements.append((conv, co, 0))
             co += o
-        self._rt = ops.MultiConvRT(placements, Fn.pad4(sum(outs)), c, k, k // 2)
+        self._rt = ops.MultiConvRT(placements, Fn.pad8(sum(outs)), c, k, k // 2)
 
     def forward(self, x):
         return ops.MultiConvFunction.apply(x, self._rt, *self._rt.params())
@@ -109,14 +109,15 @@ class SemanticHead(nn.Module):
     def __init__(self, c, n_classes):
         super().__init__()
         self.conv = nn.Conv2d(c, n_classes, 3, padding=1)
-        cp = Fn.pad4(n_classes)
+        cp = Fn.pad8(n_classes)
         self.upsampling = nn.Sequential(LearnedUpsampling(n_classes, cp),
                                         LearnedUpsampling(n_classes, cp))
         self._rt = make_plain_conv_rt(self.conv)
 
     def forward(self, x):
         y = plain_conv(self._rt, x)
-        return self.upsampling[1](self.upsampling[0](y))
+        # the full-resolution logits leave the engine as fp32 whatever the features' storage type
+        return self.upsampling[1](self.upsampling[0](y), out_f32=True)
 
 
 class SemanticDecoder(DecoderBody):
@@ -131,7 +132,7 @@ class SemanticDecoder(DecoderBody):
         x, sides = self.body(x[0], skips)
         nc = self.n_classes
         out = self.head(x)[:, :nc]
-        sides = tuple(s[:, :nc] for s in sides) if self.training else ()
+        sides = tuple(ops.to_float(s)[:, :nc] for s in sides) if self.training else ()
         if not do_postprocessing:
             return out, sides
         r = {'semantic_output': out, 'semantic_side_outputs': sides}
@@ -151,7 +152,7 @@ class InstanceHead(nn.Module):
         outs = (1, 2, 2) if with_orientation else (1, 2)
         self.outs = outs
         self.n_out = sum(outs)
-        cp = Fn.pad4(self.n_out)
+        cp = Fn.pad8(self.n_out)
         self.shared_conv = ConvNormAct(c, n_per_task * len(outs), 3)
         self.task_convs = nn.ModuleList([nn.Conv2d(n_per_task, o, 3, padding=1) for o in outs])
         self.upsampling = nn.Sequential(LearnedUpsampling(self.n_out, cp),
@@ -190,6 +191,7 @@ class InstanceDecoder(DecoderBody):
             # with strided channel copies instead of autograd's zero-filled slice gradients)
             sizes = (1, 2, 2) if self.with_orientation else (1, 2)
             return ops.HeadActFunction.apply(y, n_sig, n_tanh, sizes, n_norm)
+        y = ops.to_float(y)
         center, offset = y[:, 0:1], y[:, 1:3]
         if not self.with_orientation:
             return center, offset
@@ -252,11 +254,11 @@ class SceneClassificationDecoder(nn.Module):
         self.n_classes = n_classes
         self.side_output_downscales = ()
         self.postprocessing = None
-        self._rt = ops.MultiConvRT([(self.head, 0, 0)], Fn.pad4(n_classes), cin, 1, 0)
+        self._rt = ops.MultiConvRT([(self.head, 0, 0)], Fn.pad8(n_classes), cin, 1, 0)
 
     def forward(self, x, skips, batch=None, do_postprocessing=False):
         feat = x[1][0]                      # GAP branch of the context module (B, C, 1, 1)
-        y = ops.MultiConvFunction.apply(feat, self._rt, *self._rt.params())
+        y = ops.to_float(ops.MultiConvFunction.apply(feat, self._rt, *self._rt.params()))
         out = y.flatten(1)[:, :self.n_classes]
         if not do_postprocessing:
             return out, ()

@@ -33,15 +33,37 @@ def _empty(shape, device, dtype=torch.float32):
     return t
 
 
-def act_empty(n, c, h, w, device, ld=None):
+# storage types of the activation tensors (EMSA_DT_* of include/emsanet_hip.h): fp32 is the
+# reference's arithmetic (BASELINE configs[1]), bf16 the mixed-precision training path (configs[2]),
+# bf16 / fp16 the 16-bit inference path (configs[4])
+DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def dt(t):
+    """EMSA_DT_* code of an activation tensor"""
+    try:
+        return DT[t.dtype]
+    except KeyError:
+        raise _lib.EmsaError(f"activation dtype {t.dtype} (the engine stores fp32, bf16 or fp16)")
+
+
+def call_t(name, code, *args):
+    """emsa_<name>(...) for fp32 activations, emsa_<name>_t(dtype, ...) for the 16-bit ones"""
+    L = _lib.lib()
+    if code == 0:
+        return getattr(L, name)(*args)
+    return getattr(L, name + '_t')(code, *args)
+
+
+def act_empty(n, c, h, w, device, ld=None, dtype=torch.float32):
     """(N,C,H,W) view over fresh NHWC memory (optionally a slice of an ld-wide buffer)."""
     if ld is None or ld == c:
-        return _empty((n, h, w, c), device).permute(0, 3, 1, 2)
-    return _empty((n, h, w, ld), device)[..., :c].permute(0, 3, 1, 2)
+        return _empty((n, h, w, c), device, dtype).permute(0, 3, 1, 2)
+    return _empty((n, h, w, ld), device, dtype)[..., :c].permute(0, 3, 1, 2)
 
 
-def act_zeros(n, c, h, w, device):
-    return torch.zeros((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+def act_zeros(n, c, h, w, device, dtype=torch.float32):
+    return torch.zeros((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
 
 
 def ld_of(t):
@@ -58,7 +80,7 @@ def ld_of(t):
 
 def to_nhwc(t):
     """Boundary helper: accept any layout of a logical NCHW tensor, return dense NHWC memory."""
-    if t.dtype != torch.float32:
+    if t.dtype not in DT:
         t = t.float()
     n, c, h, w = t.shape
     try:
@@ -71,7 +93,7 @@ def to_nhwc(t):
 
 def as_act(t, dense=False):
     """t itself when it already is an NHWC activation (dense if requested), else a dense copy."""
-    if t.dtype == torch.float32:
+    if t.dtype in DT:
         try:
             ld = ld_of(t)
             if not dense or ld == t.shape[1]:
@@ -137,6 +159,34 @@ class ConvSpec:
 
 def pad4(c):
     return (c + 3) // 4 * 4
+
+
+def pad8(c):
+    """channel padding of the narrow heads: multiples of 8 so that the 16-bit kernels' 16-byte
+    accesses (8 channels) apply to them too"""
+    return (c + 7) // 8 * 8
+
+
+def pack_weight_t(w, dtype, fwd=True, dgrad=False, cout_total=None, cout_off=0, cin_total=None,
+                  cin_off=0, out_fwd=None, out_dgrad=None):
+    """fp32 OIHW parameter -> 16-bit packed operands of emsa_conv_igemm_t: forward
+    [tap][cout_total][cin_total] and / or data gradient [tap][cin_total][cout_total]"""
+    cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+    cout_total = cout_total or cout
+    cin_total = cin_total or cin
+    n = kh * kw * cout_total * cin_total
+    padded = cout_total != cout or cin_total != cin
+    mk = (lambda: torch.zeros(n, device=w.device, dtype=dtype)) if padded \
+        else (lambda: _empty((n,), w.device, dtype))
+    if fwd and out_fwd is None:
+        out_fwd = mk()
+    if dgrad and out_dgrad is None:
+        out_dgrad = mk()
+    check(_lib.lib().emsa_pack_weight_t(DT[dtype], _p(w.contiguous()), _p(out_fwd) if fwd else None,
+                                        _p(out_dgrad) if dgrad else None, cout, cin, kh, kw,
+                                        cout_total, cout_off, cin_total, cin_off, _stream()),
+          'emsa_pack_weight_t')
+    return out_fwd if fwd else None, out_dgrad if dgrad else None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -215,18 +265,25 @@ def pack_wino_packed(wp, n_ch, k_ch, rows, flip):
 
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
              act=ACT_NONE, out=None, wino_u=None, want_relu_bits=False):
-    """wp = packed [tap][cout][cin] weights (MFMA implicit GEMM) -- or wino_u = Winograd weights
-    of an eligible conv (emsa_conv1d_wino).  want_relu_bits (Winograd kernel with act = ReLU):
-    additionally returns (out > 0) as a bit mask for `conv_dgrad(mask_bits=...)`, else None."""
+    """wp = packed [tap][cout][cin] weights in the dtype of `x` (MFMA implicit GEMM) -- or, fp32
+    only, wino_u = Winograd weights of an eligible conv (emsa_conv1d_wino).  want_relu_bits
+    (Winograd kernel with act = ReLU): additionally returns (out > 0) as a bit mask for
+    `conv_dgrad(mask_bits=...)`, else None."""
     n, c, h, w = x.shape
     oh, ow = spec.out_hw(h, w)
+    code = dt(x)
     if out is None:
-        out = act_empty(n, spec.cout, oh, ow, x.device)
+        out = act_empty(n, spec.cout, oh, ow, x.device, dtype=x.dtype)
     g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(out))
     L = _lib.lib()
     stats = None
+    if code != 0:
+        wino_u = None                       # the 16-bit path is the implicit GEMM of conv_h.hip
     if want_stats:
-        rows = (L.emsa_conv1d_wino_stats_rows if wino_u is not None else L.emsa_conv_stats_rows)(g)
+        if wino_u is not None:
+            rows = L.emsa_conv1d_wino_stats_rows(g)
+        else:
+            rows = call_t('emsa_conv_stats_rows', code, g)
         if rows <= 0:
             check(rows or -1, 'emsa_conv_stats_rows')
         stats = _empty((3, rows, spec.cout), x.device)
@@ -240,8 +297,11 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
                                  _p(shift), _p(residual), lr, None, 0, act, None, _p(bits),
                                  _stream()), 'emsa_conv1d_wino')
     else:
-        check(L.emsa_conv_igemm(g, _p(x), _p(wp), _p(out), _p(bias), _p(stats), _p(scale),
-                                _p(shift), _p(residual), lr, None, 0, act, _stream()),
+        if wp is None or wp.dtype != x.dtype:
+            raise _lib.EmsaError(f"conv weights packed as {None if wp is None else wp.dtype} for "
+                                 f"{x.dtype} activations")
+        check(call_t('emsa_conv_igemm', code, g, _p(x), _p(wp), _p(out), _p(bias), _p(stats),
+                     _p(scale), _p(shift), _p(residual), lr, None, 0, act, _stream()),
               'emsa_conv_igemm')
     res = (out, stats) if want_stats else out
     return (res, bits) if want_relu_bits else res
@@ -253,11 +313,14 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
     (`mask_bits`, Winograd kernel only) -- and `+ residual`."""
     n = dy.shape[0]
     h, w = in_hw
+    code = dt(dy)
     if out is None:
-        out = act_empty(n, spec.cin, h, w, dy.device)
+        out = act_empty(n, spec.cin, h, w, dy.device, dtype=dy.dtype)
     g = spec.geom_dgrad(n, h, w, ld_of(dy), ld_of(out))
     L = _lib.lib()
     lr = ld_of(residual) if residual is not None else 0
+    if code != 0:
+        wino_u = None
     if wino_u is not None:
         if mask_bits is not None:
             mask_src = None
@@ -266,9 +329,11 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
                                  _p(residual), lr, _p(mask_src), lm, ACT_NONE, _p(mask_bits), None,
                                  _stream()), 'emsa_conv1d_wino(dgrad)')
     else:
+        if wpd is None or wpd.dtype != dy.dtype:
+            raise _lib.EmsaError("data-gradient weights are not packed in the gradient's dtype")
         lm = ld_of(mask_src) if mask_src is not None else 0
-        check(L.emsa_conv_igemm(g, _p(dy), _p(wpd), _p(out), None, None, None, None,
-                                _p(residual), lr, _p(mask_src), lm, ACT_NONE, _stream()),
+        check(call_t('emsa_conv_igemm', code, g, _p(dy), _p(wpd), _p(out), None, None, None, None,
+                     _p(residual), lr, _p(mask_src), lm, ACT_NONE, _stream()),
               'emsa_conv_igemm(dgrad)')
     return out
 
@@ -310,7 +375,9 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db
         ws = None
         dw = buf[:nw]
         db = buf[nw:] if want_bias else None
-    check(L.emsa_conv_wgrad(g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _stream()),
+    if x.dtype != dy.dtype:
+        raise _lib.EmsaError(f"weight gradient of {x.dtype} activations with a {dy.dtype} gradient")
+    check(call_t('emsa_conv_wgrad', dt(x), g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _stream()),
           'emsa_conv_wgrad')
     if ws is not None:
         return dw.view(like.shape), db, False
@@ -343,45 +410,45 @@ class StemSpec:
         return g
 
 
-def stem_pack_input(x_nchw):
+def stem_pack_input(x_nchw, dtype=torch.float32):
     x = x_nchw.contiguous()
     n, c, h, w = x.shape
-    xp = _empty((n, h, w + 8, 4), x.device)
-    check(_lib.lib().emsa_stem_pack_input(_p(x), _p(xp), n, c, h, w, _stream()),
+    xp = _empty((n, h, w + 8, 4), x.device, dtype)
+    check(call_t('emsa_stem_pack_input', DT[dtype], _p(x), _p(xp), n, c, h, w, _stream()),
           'emsa_stem_pack_input')
     return xp
 
 
-def stem_pack_weight(w):
+def stem_pack_weight(w, dtype=torch.float32):
     cout, cin = w.shape[:2]
-    wp = _empty(7 * cout * 32, w.device)
-    check(_lib.lib().emsa_stem_pack_weight(_p(w), _p(wp), cout, cin, _stream()),
+    wp = _empty(7 * cout * 32, w.device, dtype)
+    check(call_t('emsa_stem_pack_weight', DT[dtype], _p(w), _p(wp), cout, cin, _stream()),
           'emsa_stem_pack_weight')
     return wp
 
 
 def stem_fwd(xp, wpk, spec, n, h, w, want_stats=True, bias=None):
     oh, ow = spec.out_hw(h, w)
-    out = act_empty(n, spec.cout, oh, ow, xp.device)
+    out = act_empty(n, spec.cout, oh, ow, xp.device, dtype=xp.dtype)
     g = spec.geom(n, h, w, spec.cout)
-    L = _lib.lib()
+    code = dt(xp)
     stats = None
     if want_stats:
-        rows = L.emsa_conv_stats_rows(g)
+        rows = call_t('emsa_conv_stats_rows', code, g)
         stats = _empty((3, rows, spec.cout), xp.device)
     prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
-    check(L.emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), _p(bias), _p(stats), None, None, None, 0,
-                            None, 0, ACT_NONE, _stream()), 'emsa_conv_igemm(stem)')
+    check(call_t('emsa_conv_igemm', code, g, _p(xp), _p(wpk), _p(out), _p(bias), _p(stats), None,
+                 None, None, 0, None, 0, ACT_NONE, _stream()), 'emsa_conv_igemm(stem)')
     return out, stats
 
 
 def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift, bias=None):
     oh, ow = spec.out_hw(h, w)
-    out = act_empty(n, spec.cout, oh, ow, xp.device)
+    out = act_empty(n, spec.cout, oh, ow, xp.device, dtype=xp.dtype)
     g = spec.geom(n, h, w, spec.cout)
     prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
-    check(_lib.lib().emsa_conv_igemm(g, _p(xp), _p(wpk), _p(out), _p(bias), None, _p(scale),
-                                     _p(shift), None, 0, None, 0, ACT_RELU, _stream()),
+    check(call_t('emsa_conv_igemm', dt(xp), g, _p(xp), _p(wpk), _p(out), _p(bias), None, _p(scale),
+                 _p(shift), None, 0, None, 0, ACT_RELU, _stream()),
           'emsa_conv_igemm(stem)')
     return out
 
@@ -395,7 +462,7 @@ def stem_wgrad(xp, dy, spec, n, h, w, like, out=None, want_bias=False):
     db = buf[7 * spec.cout * 32:] if want_bias else None
     oh, ow = spec.out_hw(h, w)
     prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
-    check(_lib.lib().emsa_conv_wgrad(g, _p(xp), _p(dy), _p(dwp), _p(db), None, _stream()),
+    check(call_t('emsa_conv_wgrad', dt(dy), g, _p(xp), _p(dy), _p(dwp), _p(db), None, _stream()),
           'emsa_conv_wgrad(stem)')
     dw = out if out is not None else _empty(tuple(like.shape), like.device)
     check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
@@ -430,14 +497,14 @@ def bn_act(x, scale, shift, drop=None, residual=None, act=ACT_NONE, want_mask=Fa
     (int64 words) that `bn_bwd` reads instead of y  -> y or (y, mask)"""
     n, c, h, w = x.shape
     assert ld_of(x) == c and (residual is None or ld_of(residual) == c)
-    y = act_empty(n, c, h, w, x.device)
+    y = act_empty(n, c, h, w, x.device, dtype=x.dtype)
     L = _lib.lib()
     bits = None
     if want_mask and act == ACT_RELU:
         bits = torch.empty(L.emsa_relu_mask_words(n * c * h * w), device=x.device,
                            dtype=torch.int64)
-    check(L.emsa_bn_act_fwd(_p(x), _p(y), _p(scale), _p(shift), _p(drop), _p(residual),
-                            n, h * w, c, act, _p(bits), _stream()), 'emsa_bn_act_fwd')
+    check(call_t('emsa_bn_act_fwd', dt(x), _p(x), _p(y), _p(scale), _p(shift), _p(drop),
+                 _p(residual), n, h * w, c, act, _p(bits), _stream()), 'emsa_bn_act_fwd')
     return (y, bits) if want_mask else y
 
 
@@ -445,22 +512,22 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
     """returns dx, dres (or None), dgamma, dbeta.  `y` = the activation output (ReLU mask y > 0)
     or the int64 bit mask `bn_act(..., want_mask=True)` produced"""
     n, c, h, w = x.shape
-    assert ld_of(x) == c and ld_of(dy) == c
+    assert ld_of(x) == c and ld_of(dy) == c and dy.dtype == x.dtype
     L = _lib.lib()
+    code = dt(x)
     bits = None
     if y is not None and y.dtype == torch.int64:
         y, bits = None, y
     rows = L.emsa_bn_bwd_rows(n * h * w, c)
     partial = _empty((2, rows, c), x.device)
-    check(L.emsa_bn_bwd_reduce(_p(dy), _p(y), _p(bits), _p(x), _p(mean), _p(invstd), _p(drop), n,
-                               h * w, c, act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
-    dx = act_empty(n, c, h, w, x.device)
-    dres = act_empty(n, c, h, w, x.device) if want_dres else None
+    check(call_t('emsa_bn_bwd_reduce', code, _p(dy), _p(y), _p(bits), _p(x), _p(mean), _p(invstd),
+                 _p(drop), n, h * w, c, act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
+    dx = act_empty(n, c, h, w, x.device, dtype=x.dtype)
+    dres = act_empty(n, c, h, w, x.device, dtype=x.dtype) if want_dres else None
     dgb = _empty((2, c), x.device)
-    check(L.emsa_bn_bwd_apply(_p(dy), _p(y), _p(bits), _p(x), _p(gamma), _p(mean), _p(invstd),
-                              _p(drop),
-                              _p(partial), rows, n, h * w, c, act, 1 if train else 0, _p(dx),
-                              _p(dres), _p(dgb[0]), _p(dgb[1]), _stream()), 'emsa_bn_bwd_apply')
+    check(call_t('emsa_bn_bwd_apply', code, _p(dy), _p(y), _p(bits), _p(x), _p(gamma), _p(mean),
+                 _p(invstd), _p(drop), _p(partial), rows, n, h * w, c, act, 1 if train else 0,
+                 _p(dx), _p(dres), _p(dgb[0]), _p(dgb[1]), _stream()), 'emsa_bn_bwd_apply')
     return dx, dres, dgb[0], dgb[1]
 
 
@@ -478,9 +545,9 @@ def maxpool_fwd(x):
     n, c, h, w = x.shape
     assert ld_of(x) == c
     oh, ow = (h + 1) // 2, (w + 1) // 2
-    y = act_empty(n, c, oh, ow, x.device)
+    y = act_empty(n, c, oh, ow, x.device, dtype=x.dtype)
     idx = _empty((n, oh, ow, c), x.device, torch.int8)
-    check(_lib.lib().emsa_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _stream()),
+    check(call_t('emsa_maxpool3x3s2_fwd', dt(x), _p(x), _p(y), _p(idx), n, h, w, c, _stream()),
           'emsa_maxpool3x3s2_fwd')
     return y, idx
 
@@ -489,8 +556,8 @@ def maxpool_bwd(dy, idx, in_hw):
     n, c = dy.shape[:2]
     h, w = in_hw
     assert ld_of(dy) == c
-    dx = act_empty(n, c, h, w, dy.device)
-    check(_lib.lib().emsa_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, _stream()),
+    dx = act_empty(n, c, h, w, dy.device, dtype=dy.dtype)
+    check(call_t('emsa_maxpool3x3s2_bwd', dt(dy), _p(dy), _p(idx), _p(dx), n, h, w, c, _stream()),
           'emsa_maxpool3x3s2_bwd')
     return dx
 
@@ -500,7 +567,7 @@ def channel_mean(x):
     assert ld_of(x) == c
     gap = _empty((n, c), x.device)
     ws = _empty((_lib.lib().emsa_channel_ws_floats(n, h * w, c),), x.device)
-    check(_lib.lib().emsa_channel_mean(_p(x), _p(gap), _p(ws), n, h * w, c, _stream()),
+    check(call_t('emsa_channel_mean', dt(x), _p(x), _p(gap), _p(ws), n, h * w, c, _stream()),
           'emsa_channel_mean')
     return gap
 
@@ -532,68 +599,83 @@ def se_mlp_bwd(gap, w1, w2, hid, s, ds):
 
 def se_scale_add(a, sa, b=None, sb=None):
     n, c, h, w = a.shape
-    out = act_empty(n, c, h, w, a.device)
-    check(_lib.lib().emsa_se_scale_add_fwd(_p(a), _p(sa), _p(b), _p(sb), _p(out), n, h * w, c,
-                                           _stream()), 'emsa_se_scale_add_fwd')
+    out = act_empty(n, c, h, w, a.device, dtype=a.dtype)
+    check(call_t('emsa_se_scale_add_fwd', dt(a), _p(a), _p(sa), _p(b), _p(sb), _p(out), n, h * w,
+                 c, _stream()), 'emsa_se_scale_add_fwd')
     return out
 
 
 def se_scale_bwd_reduce(dout, x):
     n, c, h, w = x.shape
+    assert dout.dtype == x.dtype
     ds = _empty((n, c), x.device)
     ws = _empty((_lib.lib().emsa_channel_ws_floats(n, h * w, c),), x.device)
-    check(_lib.lib().emsa_se_scale_bwd_reduce(_p(dout), _p(x), _p(ds), _p(ws), n, h * w, c,
-                                              _stream()), 'emsa_se_scale_bwd_reduce')
+    check(call_t('emsa_se_scale_bwd_reduce', dt(x), _p(dout), _p(x), _p(ds), _p(ws), n, h * w, c,
+                 _stream()), 'emsa_se_scale_bwd_reduce')
     return ds
 
 
 def se_scale_bwd_apply(dout, s, dgap, extra=None):
     n, c, h, w = dout.shape
-    dx = act_empty(n, c, h, w, dout.device)
-    check(_lib.lib().emsa_se_scale_bwd_apply(_p(dout), _p(s), _p(dgap), _p(extra), _p(dx), n,
-                                             h * w, c, _stream()), 'emsa_se_scale_bwd_apply')
+    dx = act_empty(n, c, h, w, dout.device, dtype=dout.dtype)
+    check(call_t('emsa_se_scale_bwd_apply', dt(dout), _p(dout), _p(s), _p(dgap), _p(extra), _p(dx),
+                 n, h * w, c, _stream()), 'emsa_se_scale_bwd_apply')
     return dx
 
 
-def up2x_dw_fwd(x, wdw, bias, skip=None):
+def _two(name, feat, out_f32, *args):
+    """kernels at the model boundary: features in the dtype of `feat`, output-side tensors fp32
+    when `out_f32` (always the case for an fp32 engine)"""
+    code = dt(feat)
+    L = _lib.lib()
+    if code == 0:
+        return getattr(L, name)(*args)
+    return getattr(L, name + '_t')(code, 1 if out_f32 else 0, *args)
+
+
+def up2x_dw_fwd(x, wdw, bias, skip=None, out_f32=False):
+    """out_f32: write the result as fp32 from 16-bit features (last up-sampling of a head)"""
     n, c, h, w = x.shape
-    assert ld_of(x) == c and (skip is None or ld_of(skip) == c)
-    y = act_empty(n, c, 2 * h, 2 * w, x.device)
-    check(_lib.lib().emsa_up2x_dw3x3_fwd(_p(x), _p(wdw), _p(bias), _p(skip), _p(y), n, h, w, c,
-                                         _stream()), 'emsa_up2x_dw3x3_fwd')
+    assert ld_of(x) == c and (skip is None or (ld_of(skip) == c and skip.dtype == x.dtype))
+    y = act_empty(n, c, 2 * h, 2 * w, x.device,
+                  dtype=torch.float32 if out_f32 else x.dtype)
+    check(_two('emsa_up2x_dw3x3_fwd', x, out_f32, _p(x), _p(wdw), _p(bias), _p(skip), _p(y), n, h,
+               w, c, _stream()), 'emsa_up2x_dw3x3_fwd')
     return y
 
 
 def up2x_dw_bwd(dy, x, wdw, need_dx=True):
     n, c, h, w = x.shape
     assert ld_of(dy) == c
-    L = _lib.lib()
+    out_f32 = dy.dtype == torch.float32
+    if not out_f32 and dy.dtype != x.dtype:
+        raise _lib.EmsaError(f"up-sampling gradient {dy.dtype} for {x.dtype} features")
     dx = None
     if need_dx:
-        dx = act_empty(n, c, h, w, x.device)
-        check(L.emsa_up2x_dw3x3_bwd_data(_p(dy), _p(wdw), _p(dx), n, h, w, c, _stream()),
-              'emsa_up2x_dw3x3_bwd_data')
+        dx = act_empty(n, c, h, w, x.device, dtype=x.dtype)
+        check(_two('emsa_up2x_dw3x3_bwd_data', x, out_f32, _p(dy), _p(wdw), _p(dx), n, h, w, c,
+                   _stream()), 'emsa_up2x_dw3x3_bwd_data')
     dwb = torch.zeros(c * 10, device=x.device, dtype=torch.float32)
     dw, db = dwb[:c * 9], dwb[c * 9:]
-    check(L.emsa_up2x_dw3x3_bwd_weight(_p(dy), _p(x), _p(dw), _p(db), n, h, w, c, _stream()),
-          'emsa_up2x_dw3x3_bwd_weight')
+    check(_two('emsa_up2x_dw3x3_bwd_weight', x, out_f32, _p(dy), _p(x), _p(dw), _p(db), n, h, w, c,
+               _stream()), 'emsa_up2x_dw3x3_bwd_weight')
     return dx, dw, db
 
 
 def adaptive_avgpool_fwd(x, bins):
     n, c, h, w = x.shape
     assert ld_of(x) == c
-    y = act_empty(n, c, bins, bins, x.device)
-    check(_lib.lib().emsa_adaptive_avgpool_fwd(_p(x), _p(y), n, h, w, c, bins, _stream()),
+    y = act_empty(n, c, bins, bins, x.device, dtype=x.dtype)
+    check(call_t('emsa_adaptive_avgpool_fwd', dt(x), _p(x), _p(y), n, h, w, c, bins, _stream()),
           'emsa_adaptive_avgpool_fwd')
     return y
 
 
 def adaptive_avgpool_bwd(dy, dx, bins, accumulate):
     n, c, h, w = dx.shape
-    check(_lib.lib().emsa_adaptive_avgpool_bwd(_p(dy), _p(dx), n, h, w, c, bins,
-                                               1 if accumulate else 0, _stream()),
-          'emsa_adaptive_avgpool_bwd')
+    assert dy.dtype == dx.dtype
+    check(call_t('emsa_adaptive_avgpool_bwd', dt(dx), _p(dy), _p(dx), n, h, w, c, bins,
+                 1 if accumulate else 0, _stream()), 'emsa_adaptive_avgpool_bwd')
     return dx
 
 
@@ -601,45 +683,64 @@ def bilinear_fwd(x, out):
     """x (N,C,ih,iw) dense -> out (N,C,oh,ow) possibly a channel slice"""
     n, c, ih, iw = x.shape
     oh, ow = out.shape[2:]
-    assert ld_of(x) == c
-    check(_lib.lib().emsa_bilinear_fwd(_p(x), _p(out), n, ih, iw, oh, ow, c, ld_of(out),
-                                       _stream()), 'emsa_bilinear_fwd')
+    assert ld_of(x) == c and out.dtype == x.dtype
+    check(call_t('emsa_bilinear_fwd', dt(x), _p(x), _p(out), n, ih, iw, oh, ow, c, ld_of(out),
+                 _stream()), 'emsa_bilinear_fwd')
     return out
 
 
 def bilinear_bwd(dy, in_hw):
+    """scattered fp32 atomics into a zeroed fp32 dx (a few KB at the pyramid-pooling resolution),
+    returned in the dtype of dy"""
     n, c, oh, ow = dy.shape
     ih, iw = in_hw
-    dx = act_empty(n, c, ih, iw, dy.device)
-    check(_lib.lib().emsa_bilinear_bwd(_p(dy), _p(dx), n, ih, iw, oh, ow, c, ld_of(dy),
-                                       _stream()), 'emsa_bilinear_bwd')
+    dx = act_zeros(n, c, ih, iw, dy.device)
+    check(call_t('emsa_bilinear_bwd', dt(dy), _p(dy), _p(dx), n, ih, iw, oh, ow, c, ld_of(dy),
+                 _stream()), 'emsa_bilinear_bwd')
+    if dy.dtype != torch.float32:
+        dx = cast(dx, dy.dtype)
     return dx
 
 
 def head_act_fwd(x, n_sig, n_tanh, n_norm=0, norm_off=3):
+    """16-bit features -> fp32 outputs (the model's instance outputs), fp32 -> fp32"""
     n, c, h, w = x.shape
     assert ld_of(x) == c
     y = act_empty(n, c, h, w, x.device)
-    check(_lib.lib().emsa_head_act_fwd(_p(x), _p(y), n * h * w, c, n_sig, n_tanh, norm_off,
-                                       n_norm, _stream()), 'emsa_head_act_fwd')
+    check(_two('emsa_head_act_fwd', x, True, _p(x), _p(y), n * h * w, c, n_sig, n_tanh, norm_off,
+               n_norm, _stream()), 'emsa_head_act_fwd')
     return y
 
 
-def head_act_bwd(dy, y, n_sig, n_tanh, n_norm=0, x=None, norm_off=3):
+def head_act_bwd(dy, y, n_sig, n_tanh, n_norm=0, x=None, norm_off=3, dtype=torch.float32):
+    """dy, y fp32 (output side) -> dx in `dtype` (the features' storage type)"""
     n, c, h, w = y.shape
-    assert ld_of(dy) == c
-    dx = act_empty(n, c, h, w, y.device)
-    check(_lib.lib().emsa_head_act_bwd(_p(dy), _p(y), _p(x), _p(dx), n * h * w, c, n_sig, n_tanh,
-                                       norm_off, n_norm, _stream()), 'emsa_head_act_bwd')
+    assert ld_of(dy) == c and dy.dtype == torch.float32 and y.dtype == torch.float32
+    dx = act_empty(n, c, h, w, y.device, dtype=dtype)
+    check(_two('emsa_head_act_bwd', dx, True, _p(dy), _p(y), _p(x), _p(dx), n * h * w, c, n_sig,
+               n_tanh, norm_off, n_norm, _stream()), 'emsa_head_act_bwd')
     return dx
 
 
 def copy_channels(src, dst):
-    """copy an activation (possibly a channel slice) into another (possibly a slice)."""
+    """copy an activation (possibly a channel slice) into another (possibly a slice); the storage
+    types may differ (conversion on the fly)."""
     n, c, h, w = src.shape
-    check(_lib.lib().emsa_copy_channels(_p(src), ld_of(src), _p(dst), ld_of(dst), n * h * w, c,
-                                        _stream()), 'emsa_copy_channels')
+    if src.dtype == dst.dtype == torch.float32:
+        check(_lib.lib().emsa_copy_channels(_p(src), ld_of(src), _p(dst), ld_of(dst), n * h * w, c,
+                                            _stream()), 'emsa_copy_channels')
+    else:
+        check(_lib.lib().emsa_cast_channels(dt(src), _p(src), ld_of(src), dt(dst), _p(dst),
+                                            ld_of(dst), n * h * w, c, _stream()),
+              'emsa_cast_channels')
     return dst
+
+
+def cast(x, dtype):
+    """dense copy of an activation in another storage type"""
+    x = as_act(x)
+    n, c, h, w = x.shape
+    return copy_channels(x, act_empty(n, c, h, w, x.device, dtype=dtype))
 
 
 def axpy_(y, x, alpha=1.0):

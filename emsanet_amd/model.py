@@ -123,9 +123,29 @@ class EMSANet(nn.Module):
             if isinstance(crt, ops.ConvRT):
                 rts.append(crt)
         self._pack_plan = ops.PackPlan(rts)
+        # storage type of the activations (NOT a reference option: the reference has no mixed
+        # precision): 'float32' = the reference's arithmetic (default), 'bfloat16' =
+        # BASELINE configs[2] mixed-precision training, 'bfloat16' / 'float16' = configs[4] inference
+        self.compute_dtype = torch.float32
+        self.set_compute_dtype(getattr(args, 'compute_dtype', 'float32'))
         # BatchNorm step counters are kept on the host and written to the buffers when a
         # state_dict is taken (no per-layer counter kernel in the training step)
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: ops.flush_bn_counters())
+
+    def set_compute_dtype(self, dtype):
+        """activations (and the packed conv operands) are stored as `dtype`; parameters, BatchNorm
+        statistics, SE vectors, gradients of parameters and the model's outputs stay fp32, all
+        accumulation is fp32.  fp16 has no loss scaling here: inference only."""
+        if isinstance(dtype, str):
+            dtype = {'float32': torch.float32, 'fp32': torch.float32, 'bfloat16': torch.bfloat16,
+                     'bf16': torch.bfloat16, 'float16': torch.float16, 'fp16': torch.float16}[dtype]
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"compute dtype {dtype}")
+        self.compute_dtype = dtype
+        for bb in (self.encoder.backbone_rgb, self.encoder.backbone_depth):
+            if bb is not None:
+                bb.compute_dtype = dtype
+        return self
 
     def _dropout_seed(self):
         return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF
@@ -144,7 +164,10 @@ class EMSANet(nn.Module):
                 raise _lib.EmsaError(
                     f"batch['{name}'] lives on {t.device}: the EMSANet engine only runs on an "
                     "AMD GPU (no CPU fallback)")
-        self._pack_plan.refresh()
+        if self.compute_dtype == torch.float16 and self.training:
+            raise _lib.EmsaError("float16 storage is an inference mode (no loss scaling); train "
+                                 "in bfloat16 or float32")
+        self._pack_plan.refresh(self.compute_dtype)
 
         deep, skips = self.encoder(feeds)
         # the context module sees the fused rgb stream, or the only stream there is

@@ -125,13 +125,16 @@ class ResNetNBt1D(nn.Module):
         self.stage_channels = (64, 64, 128, 256, 512)
         self.stage_downsamplings = (2, 4, 8, 16, 32)
         self._stem = ops.StemRT(self.conv1, self.bn1)
+        # storage type of the activations this backbone produces (set by EMSANet.set_compute_dtype):
+        # the fp32 network input is converted when the stem packs it
+        self.compute_dtype = torch.float32
 
     def forward_stage(self, i, x):
         if i == 0:
             if _fast_eval(self):
-                return ops.stem_eval(x, self._stem)
+                return ops.stem_eval(x, self._stem, self.compute_dtype)
             return ops.StemFunction.apply(x, self._stem, self.conv1.weight, self.bn1.weight,
-                                          self.bn1.bias, self.conv1.bias)
+                                          self.bn1.bias, self.conv1.bias, self.compute_dtype)
         if i == 1:
             x = ops.MaxPoolFunction.apply(x)
         return getattr(self, f'layer{i}')(x)
@@ -240,16 +243,17 @@ class LearnedUpsampling(nn.Module):
                 b = torch.cat([b, b.new_zeros(self.c_pad - self.c)], 0)
         return w, b
 
-    def forward(self, x, skip=None):
+    def forward(self, x, skip=None, out_f32=False):
         w, b = self._padded()
-        return ops.UpsampleDWFunction.apply(x, w, b, skip)
+        return ops.UpsampleDWFunction.apply(x, w, b, skip, out_f32)
 
 
 def make_plain_conv_rt(conv):
     """runtime for an nn.Conv2d (+bias) evaluated by the MFMA kernel with its output channels
-    zero-padded to a multiple of 4; `plain_conv` returns the PADDED tensor (callers slice)."""
+    zero-padded to a multiple of 8 (16-byte accesses also for 16-bit storage); `plain_conv`
+    returns the PADDED tensor (callers slice)."""
     k = conv.kernel_size[0]
-    return ops.MultiConvRT([(conv, 0, 0)], Fn.pad4(conv.out_channels), conv.in_channels, k,
+    return ops.MultiConvRT([(conv, 0, 0)], Fn.pad8(conv.out_channels), conv.in_channels, k,
                            conv.padding[0])
 
 

@@ -58,7 +58,9 @@ def _traced(fn):
 # runtime views of parameter containers
 # ---------------------------------------------------------------------------------------------
 class ConvRT:
-    """nn.Conv2d used as a parameter container + cached packed weights."""
+    """nn.Conv2d used as a parameter container + cached packed weights.  fp32 activations run on
+    the fp32 kernels (Winograd where eligible); 16-bit activations on conv_h.hip with the weights
+    packed in the activations' dtype (the fp32 parameter stays the master copy)."""
 
     def __init__(self, conv):
         self.conv = conv
@@ -73,6 +75,7 @@ class ConvRT:
         self._keyu = None
         self._u = None
         self._ud = None
+        self._h = {}              # 16-bit packs: dtype -> [key, fwd, key_d, dgrad]
 
     def _wino_weights(self):
         w = self.conv.weight
@@ -84,6 +87,8 @@ class ConvRT:
 
     def forward(self, x, **kw):
         """conv forward through the best kernel for this layer (fused-epilogue kwargs of conv_fwd)"""
+        if x.dtype != torch.float32:
+            return Fn.conv_fwd(x, self.packed(x.dtype), self.spec, **kw)
         if self.wino:
             return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
         return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
@@ -91,6 +96,8 @@ class ConvRT:
     def dgrad(self, dy, in_hw, mask_bits=None, **kw):
         """mask_bits: the ReLU mask of the producing layer as bits (conv_fwd(want_relu_bits));
         used by the Winograd kernel, otherwise the float `mask_src` applies"""
+        if dy.dtype != torch.float32:
+            return Fn.conv_dgrad(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw, **kw)
         if self.wino:
             u, ud = self._wino_weights()
             if ud is None:
@@ -98,9 +105,17 @@ class ConvRT:
             return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, mask_bits=mask_bits, **kw)
         return Fn.conv_dgrad(dy, self.packed_dgrad(), self.spec, in_hw, **kw)
 
-    def packed(self):
+    def packed(self, dtype=torch.float32):
         w = self.conv.weight
         key = (w._version, w.data_ptr())
+        if dtype != torch.float32:
+            ent = self._h.setdefault(dtype, [None, None, None, None])
+            if ent[0] != key:
+                ent[1], d = Fn.pack_weight_t(w.detach(), dtype, fwd=True, dgrad=w.requires_grad)
+                ent[0] = key
+                if d is not None:
+                    ent[2], ent[3] = key, d
+            return ent[1]
         if key != self._key:
             if w.requires_grad:
                 # trainable: the data-gradient layout will be needed too -> one launch for both
@@ -111,9 +126,15 @@ class ConvRT:
             self._key = key
         return self._wp
 
-    def packed_dgrad(self):
+    def packed_dgrad(self, dtype=torch.float32):
         w = self.conv.weight
         key = (w._version, w.data_ptr())
+        if dtype != torch.float32:
+            ent = self._h.setdefault(dtype, [None, None, None, None])
+            if ent[2] != key:
+                ent[3] = Fn.pack_weight_t(w.detach(), dtype, fwd=False, dgrad=True)[1]
+                ent[2] = key
+            return ent[3]
         if key != self._keyd:
             self._wpd = Fn.pack_weight(w.detach(), 'dgrad')
             self._keyd = key
@@ -121,11 +142,12 @@ class ConvRT:
 
 
 class PackPlan:
-    """All weight transforms of a model (packed implicit-GEMM layouts, Winograd U) in ONE launch
-    per optimizer step instead of one ~5 us kernel per layer (380 launches = 2.3 ms per step).
-    `refresh()` (called at the start of the model's forward) re-packs every registered ConvRT
-    when any weight changed and installs the results as the ConvRTs' own caches, so their
-    per-layer fallbacks (`packed()`, `_wino_weights()`) find fresh entries and launch nothing."""
+    """All weight transforms of a model (packed implicit-GEMM layouts, Winograd U, or the 16-bit
+    operands of the mixed-precision path) in ONE launch per optimizer step instead of one ~5 us
+    kernel per layer (380 launches = 2.3 ms per step).  `refresh(dtype)` (called at the start of
+    the model's forward) re-packs every registered ConvRT when any weight changed and installs the
+    results as the ConvRTs' own caches, so their per-layer fallbacks (`packed()`,
+    `_wino_weights()`) find fresh entries and launch nothing."""
 
     def __init__(self, rts):
         self.rts = [rt for rt in rts if isinstance(rt, ConvRT)]
@@ -135,50 +157,57 @@ class PackPlan:
         self._n_blocks = 0
         self._arena = None
         self._views = None
+        self._dtype = None
 
-    def _build(self, dev):
-        import ctypes
+    def _build(self, dev, dtype):
         n = len(self.rts)
         jobs = (_lib.EmsaPackJob * n)()
+        half = dtype != torch.float32
+        esz = 2 if half else 4
         sizes = []
         for rt in self.rts:
             w = rt.conv.weight
             numel = w.numel()
-            per = numel * 4 // 3 if rt.wino else numel          # U has 4 components per 3 taps
-            sizes.append((per, per if w.requires_grad else 0))
-        arena = Fn._empty((sum(a + b for a, b in sizes),), dev)
+            per = numel if half else (numel * 4 // 3 if rt.wino else numel)   # U: 4 comps per 3 taps
+            per_b = (per * esz + 15) // 16 * 16            # every pack starts 16-byte aligned
+            sizes.append((per, per_b, per_b if w.requires_grad else 0))
+        arena = torch.empty(sum(a + b for _, a, b in sizes), device=dev, dtype=torch.uint8)
         views, off, blk = [], 0, 0
-        for j, (rt, (a, b)) in enumerate(zip(self.rts, sizes)):
+        for j, (rt, (per, a, b)) in enumerate(zip(self.rts, sizes)):
             w = rt.conv.weight
-            v0 = arena[off:off + a]
-            v1 = arena[off + a:off + a + b] if b else None
+            v0 = arena[off:off + per * esz].view(dtype)
+            v1 = arena[off + a:off + a + per * esz].view(dtype) if b else None
             off += a + b
             views.append((v0, v1))
             cout, cin, kh, kw = w.shape
+            kind = Fn.DT[dtype] + 1 if half else (1 if rt.wino else 0)   # 2 = bf16, 3 = fp16
             jobs[j] = _lib.EmsaPackJob(w.data_ptr(), v0.data_ptr(), v1.data_ptr() if b else None,
-                                       cout, cin, kh, kw, 1 if rt.wino else 0, blk)
+                                       cout, cin, kh, kw, kind, blk)
             blk += max(1, min(64, (w.numel() + 2047) // 2048))
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self._jobs, self._n_blocks, self._arena, self._views = raw, blk, arena, views
         self._ptrs = tuple(rt.conv.weight.data_ptr() for rt in self.rts)
+        self._dtype = dtype
 
-    def refresh(self):
+    def refresh(self, dtype=torch.float32):
         if not self.rts:
             return
         ws = [rt.conv.weight for rt in self.rts]
-        key = tuple((w._version, w.data_ptr(), w.requires_grad) for w in ws)
+        key = (dtype,) + tuple((w._version, w.data_ptr(), w.requires_grad) for w in ws)
         if key == self._key:
             return
         if not ws[0].is_cuda:
             return                                   # host-side dry runs: per-layer path
-        if self._ptrs != tuple(w.data_ptr() for w in ws) or \
+        if self._dtype != dtype or self._ptrs != tuple(w.data_ptr() for w in ws) or \
                 any((v1 is None) == w.requires_grad for (_, v1), w in zip(self._views or [], ws)):
-            self._build(ws[0].device)
+            self._build(ws[0].device, dtype)
         check(_lib.lib().emsa_pack_batch(self._jobs.data_ptr(), len(self.rts), self._n_blocks,
                                          Fn._stream()), 'emsa_pack_batch')
         for rt, (v0, v1), w in zip(self.rts, self._views, ws):
             k = (w._version, w.data_ptr())
-            if rt.wino:
+            if dtype != torch.float32:
+                rt._h[dtype] = [k, v0, k if v1 is not None else None, v1]
+            elif rt.wino:
                 rt._u, rt._ud, rt._keyu = v0, v1, k
             else:
                 rt._wp, rt._key = v0, k
@@ -433,6 +462,7 @@ class MultiConvRT:
         self._wp = None
         self._bias = None
         self._u = None
+        self._h = {}                 # 16-bit packs: dtype -> (key, wp, bias)
         self.has_bias = any(m.bias is not None for m, _, _ in placements)
         # 3x3 stride-1 merged convs (the task heads) run on the Winograd kernel as well
         self.wino = Fn.wino_eligible(self.spec) and os.environ.get('EMSA_WINO', '1') != '0'
@@ -441,51 +471,80 @@ class MultiConvRT:
         w = m.weight
         return w if w.dim() == 4 else w[:, :, None, None]
 
+    def _key_now(self):
+        return tuple((m.weight._version, m.weight.data_ptr(),
+                      m.bias._version if m.bias is not None else 0) for m, _, _ in self.placements)
+
+    def _bias_vec(self, dev):
+        bias = torch.zeros(self.spec.cout, device=dev, dtype=torch.float32)
+        for m, co, _ in self.placements:
+            if m.bias is not None:
+                bias[co:co + m.bias.shape[0]].copy_(m.bias.detach())
+        return bias
+
     def packed(self):
-        key = tuple((m.weight._version, m.weight.data_ptr(),
-                     m.bias._version if m.bias is not None else 0) for m, _, _ in self.placements)
+        key = self._key_now()
         if key != self._key:
             s = self.spec
             wp = torch.zeros(s.kh * s.kw * s.cout * s.cin, device=self.placements[0][0].weight.device,
                              dtype=torch.float32)
-            bias = torch.zeros(s.cout, device=wp.device, dtype=torch.float32) if self.has_bias else None
             for m, co, ci in self.placements:
                 Fn.pack_weight(self._w4(m).detach(), 'fwd', s.cout, co, s.cin, ci, out=wp)
-                if m.bias is not None:
-                    bias[co:co + m.bias.shape[0]].copy_(m.bias.detach())
+            bias = self._bias_vec(wp.device) if self.has_bias else None
             self._wp, self._bias, self._key = wp, bias, key
             self._u = Fn.pack_wino_packed(wp, s.cout, s.cin, Fn.wino_rows(s), flip=False) \
                 if self.wino else None
         return self._wp, self._bias
+
+    def packed_t(self, dtype):
+        """16-bit forward operand [tap][cout][cin] (+ fp32 bias vector)"""
+        key = self._key_now()
+        ent = self._h.get(dtype)
+        if ent is None or ent[0] != key:
+            s = self.spec
+            dev = self.placements[0][0].weight.device
+            wp = torch.zeros(s.kh * s.kw * s.cout * s.cin, device=dev, dtype=dtype)
+            for m, co, ci in self.placements:
+                Fn.pack_weight_t(self._w4(m).detach(), dtype, True, False, s.cout, co, s.cin, ci,
+                                 out_fwd=wp)
+            ent = (key, wp, self._bias_vec(dev) if self.has_bias else None)
+            self._h[dtype] = ent
+        return ent[1], ent[2]
+
+    def forward(self, x):
+        Fn.prof_flops(self.real_flops(x))
+        if x.dtype != torch.float32:
+            wp, bias = self.packed_t(x.dtype)
+            return Fn.conv_fwd(x, wp, self.spec, bias=bias)
+        wp, bias = self.packed()
+        if self.wino:
+            return Fn.conv_fwd(x, None, self.spec, bias=bias, wino_u=self._u)
+        return Fn.conv_fwd(x, wp, self.spec, bias=bias)
 
     def real_flops(self, x):
         """direct-convolution FLOPs of the REAL (un-padded, un-merged) convolutions on `x`"""
         n, _, h, w = x.shape
         return 2.0 * n * h * w * sum(m.weight.numel() for m, _, _ in self.placements)
 
-    def forward(self, x):
-        wp, bias = self.packed()
-        Fn.prof_flops(self.real_flops(x))
-        if self.wino:
-            return Fn.conv_fwd(x, None, self.spec, bias=bias, wino_u=self._u)
-        return Fn.conv_fwd(x, wp, self.spec, bias=bias)
-
     def dgrad(self, dy, in_hw):
-        wpd = self.packed_dgrad()
-        if self.wino:
+        Fn.prof_flops(self.real_flops(dy))
+        wpd = self.packed_dgrad(dy.dtype)
+        if self.wino and dy.dtype == torch.float32:
             s = self.spec
             ud = Fn.pack_wino_packed(wpd, s.cin, s.cout, Fn.wino_rows(s), flip=True)
-            Fn.prof_flops(self.real_flops(dy))
             return Fn.conv_dgrad(dy, None, s, in_hw, wino_u=ud)
-        Fn.prof_flops(self.real_flops(dy))
         return Fn.conv_dgrad(dy, wpd, self.spec, in_hw)
 
-    def packed_dgrad(self):
+    def packed_dgrad(self, dtype=torch.float32):
         s = self.spec
         wp = torch.zeros(s.kh * s.kw * s.cout * s.cin, device=self.placements[0][0].weight.device,
-                         dtype=torch.float32)
+                         dtype=dtype)
         for m, co, ci in self.placements:
-            Fn.pack_weight(self._w4(m).detach(), 'dgrad', s.cout, co, s.cin, ci, out=wp)
+            if dtype == torch.float32:
+                Fn.pack_weight(self._w4(m).detach(), 'dgrad', s.cout, co, s.cin, ci, out=wp)
+            else:
+                Fn.pack_weight_t(self._w4(m).detach(), dtype, False, True, s.cout, co, s.cin, ci,
+                                 out_dgrad=wp)
         return wp
 
     def params(self):
@@ -538,30 +597,31 @@ class StemRT:
     def __init__(self, conv, bn):
         self.conv, self.brt = conv, BNRT(bn)
         self.spec = Fn.StemSpec(conv.in_channels, conv.out_channels)
-        self._key = None
-        self._wp = None
+        self._packs = {}             # dtype -> (key, packed weights)
 
-    def packed(self):
+    def packed(self, dtype=torch.float32):
         w = self.conv.weight
         key = (w._version, w.data_ptr())
-        if key != self._key:
-            self._wp = Fn.stem_pack_weight(w.detach())
-            self._key = key
-        return self._wp
+        ent = self._packs.get(dtype)
+        if ent is None or ent[0] != key:
+            ent = (key, Fn.stem_pack_weight(w.detach(), dtype))
+            self._packs[dtype] = ent
+        return ent[1]
 
 
 class StemFunction(Function):
     @staticmethod
-    def forward(ctx, x_nchw, rt, weight, gamma, beta, bias=None):
+    def forward(ctx, x_nchw, rt, weight, gamma, beta, bias=None, dtype=torch.float32):
         n, c, h, w = x_nchw.shape
-        xp = Fn.stem_pack_input(x_nchw.detach().float())
+        xp = Fn.stem_pack_input(x_nchw.detach().float(), dtype)
         brt = rt.brt
         b = bias.detach() if bias is not None else None      # [U] Spec.STEM_BIAS
+        wpk = rt.packed(dtype)
         if brt.batch_stats():
-            y, stats = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=True, bias=b)
+            y, stats = Fn.stem_fwd(xp, wpk, rt.spec, n, h, w, want_stats=True, bias=b)
             count = y.shape[0] * y.shape[2] * y.shape[3]
         else:
-            y, _ = Fn.stem_fwd(xp, rt.packed(), rt.spec, n, h, w, want_stats=False, bias=b)
+            y, _ = Fn.stem_fwd(xp, wpk, rt.spec, n, h, w, want_stats=False, bias=b)
             stats, count = None, 0
         scale, shift, mean, invstd = brt.forward_stats(stats, count)
         out, mask = Fn.bn_act(y, scale, shift, None, None, ACT_RELU, want_mask=True)
@@ -589,15 +649,15 @@ class StemFunction(Function):
         dw, dbias = res if ctx.has_bias else (res, None)
         # gradient w.r.t. the network input is not produced (the reference never needs it:
         # /root/reference/main.py:597-599 back-propagates into parameters only)
-        return None, None, dw, dg, db, dbias
+        return None, None, dw, dg, db, dbias, None
 
 
-def stem_eval(x_nchw, rt):
+def stem_eval(x_nchw, rt, dtype=torch.float32):
     n, c, h, w = x_nchw.shape
-    xp = Fn.stem_pack_input(x_nchw.float())
+    xp = Fn.stem_pack_input(x_nchw.float(), dtype)
     s, t = rt.brt.folded()
     b = rt.conv.bias.detach() if rt.conv.bias is not None else None
-    return Fn.stem_fwd_folded(xp, rt.packed(), rt.spec, n, h, w, s, t, bias=b)
+    return Fn.stem_fwd_folded(xp, rt.packed(dtype), rt.spec, n, h, w, s, t, bias=b)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -667,15 +727,18 @@ class SEAddFunction(Function):
 # learned upsampling (nearest x2 + depth-wise 3x3) with optional fused skip add
 # ---------------------------------------------------------------------------------------------
 class UpsampleDWFunction(Function):
-    """`wdw`/`bias` are the (possibly zero-padded) [c,1,3,3] / [c] tensors the kernel reads."""
+    """`wdw`/`bias` are the (possibly zero-padded) [c,1,3,3] / [c] tensors the kernel reads.
+    out_f32: the result is written as fp32 from 16-bit features (the last up-sampling of a head
+    produces the model's fp32 output directly; its cotangent arrives as fp32 too)."""
 
     @staticmethod
-    def forward(ctx, x, wdw, bias, skip):
+    def forward(ctx, x, wdw, bias, skip, out_f32=False):
         x = Fn.as_act(x, dense=True)
         if skip is not None:
             skip = Fn.as_act(skip, dense=True)
         w = wdw.detach().contiguous()
-        y = Fn.up2x_dw_fwd(x, w, bias.detach() if bias is not None else None, skip)
+        y = Fn.up2x_dw_fwd(x, w, bias.detach() if bias is not None else None, skip,
+                           out_f32=out_f32 and x.dtype != torch.float32)
         ctx.save_for_backward(x, w)
         ctx.has = (bias is not None, skip is not None)
         ctx.wshape = wdw.shape
@@ -689,7 +752,10 @@ class UpsampleDWFunction(Function):
         dy = Fn.as_act(dy, dense=True)
         dx, dw, db = Fn.up2x_dw_bwd(dy, x, w, need_dx=ctx.needs_input_grad[0])
         has_bias, has_skip = ctx.has
-        return dx, dw.reshape(ctx.wshape), (db if has_bias else None), (dy if has_skip else None)
+        dskip = None
+        if has_skip:
+            dskip = dy if dy.dtype == x.dtype else Fn.cast(dy, x.dtype)
+        return dx, dw.reshape(ctx.wshape), (db if has_bias else None), dskip, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -707,8 +773,9 @@ class AdaptiveAvgPoolFunction(Function):
     @_traced
     def backward(ctx, dy):
         n, c, h, w = ctx.shape
-        dx = Fn.act_empty(n, c, h, w, dy.device)
-        Fn.adaptive_avgpool_bwd(Fn.as_act(dy, dense=True), dx, ctx.bins, accumulate=False)
+        dy = Fn.as_act(dy, dense=True)
+        dx = Fn.act_empty(n, c, h, w, dy.device, dtype=dy.dtype)
+        Fn.adaptive_avgpool_bwd(dy, dx, ctx.bins, accumulate=False)
         return dx, None
 
 
@@ -721,7 +788,7 @@ class PPMConcatFunction(Function):
         ys = [Fn.as_act(y, dense=True) for y in ys]
         n, c, h, w = x.shape
         total = c + sum(y.shape[1] for y in ys)
-        buf = Fn.act_empty(n, total, h, w, x.device)
+        buf = Fn.act_empty(n, total, h, w, x.device, dtype=x.dtype)
         Fn.copy_channels(x, buf[:, :c])
         off = c
         for y in ys:
@@ -737,7 +804,7 @@ class PPMConcatFunction(Function):
         dbuf = Fn.as_act(dbuf)
         c, yshapes = ctx.meta
         n, _, h, w = dbuf.shape
-        dx = Fn.act_empty(n, c, h, w, dbuf.device)
+        dx = Fn.act_empty(n, c, h, w, dbuf.device, dtype=dbuf.dtype)
         Fn.copy_channels(dbuf[:, :c], dx)
         off, dys = c, []
         for ys in yshapes:
@@ -763,6 +830,7 @@ class HeadActFunction(Function):
         y = Fn.head_act_fwd(x, n_sig, n_tanh, n_norm)
         ctx.save_for_backward(y, x if n_norm else None)
         ctx.cfg = (n_sig, n_tanh, n_norm)
+        ctx.dtype = x.dtype
         ctx.sizes = tuple(sizes)
         outs, o = [], 0
         for sz in sizes:
@@ -779,8 +847,28 @@ class HeadActFunction(Function):
         dy = Fn.act_empty(n, c, h, w, y.device)
         o = 0
         for sz, g in zip(ctx.sizes, dys):
-            Fn.copy_channels(Fn.as_act(g), dy[:, o:o + sz])
+            Fn.copy_channels(Fn.as_act(g.float()), dy[:, o:o + sz])
             o += sz
         if o < c:
             dy[:, o:].zero_()                      # padding channels carry no gradient
-        return Fn.head_act_bwd(dy, y, *ctx.cfg, x=x), None, None, None, None
+        return Fn.head_act_bwd(dy, y, *ctx.cfg, x=x, dtype=ctx.dtype), None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# storage-type boundary: small 16-bit tensors leave the engine as fp32 (side outputs, scene logits)
+# ---------------------------------------------------------------------------------------------
+class CastFunction(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return Fn.cast(x, dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return Fn.cast(dy, ctx.src), None
+
+
+def to_float(x):
+    """fp32 view of an engine tensor (identity for the fp32 engine)"""
+    return x if x.dtype == torch.float32 else CastFunction.apply(x, torch.float32)

@@ -1,0 +1,307 @@
+"""GPU parity of the 16-bit kernel family (BASELINE configs[2] bf16 training, configs[4] 16-bit
+inference) against plain PyTorch CPU references in fp64.
+
+The reference of every op is computed in fp64 FROM THE SAME 16-BIT-ROUNDED INPUTS (and, for the
+convolutions, 16-bit-rounded weights) the kernel reads, so what is left is the kernel's own error:
+fp32 accumulation (negligible) + ONE rounding of the result to the storage type.  Stated tolerance:
+    bf16 storage: 2^-8 relative per element  -> 6e-3 of the tensor's max magnitude
+    fp16 storage: 2^-11                      -> 1e-3
+    fp32 results computed from 16-bit inputs (statistics, weight gradients, SE vectors): 2e-4,
+    except the Winograd F(3,2) weight gradient, whose transformed operands (sums of two inputs) are
+    rounded to bf16 once more: 1e-2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import DEV, close, rnd
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+TOL = {torch.bfloat16: 6e-3, torch.float16: 1e-3}
+
+
+def _fn():
+    from emsanet_amd import functional as Fn
+    return Fn
+
+
+def q(t, dtype):
+    """value of `t` after rounding to `dtype`, as fp64 on the CPU"""
+    return t.to(dtype).double()
+
+
+def act16(t_nchw, dtype):
+    """CPU NCHW fp32 tensor -> GPU activation in `dtype` (logical NCHW, NHWC memory)"""
+    return t_nchw.to(dtype).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+CONVS = [
+    # cin, cout, kernel, stride, padding, n, h, w
+    (64, 64, (3, 1), (1, 1), (1, 0), 2, 12, 20),
+    (64, 64, (1, 3), (1, 1), (0, 1), 2, 12, 20),
+    (128, 128, (1, 3), (1, 1), (0, 1), 3, 9, 13),
+    (64, 128, (3, 1), (2, 1), (1, 0), 2, 12, 20),
+    (128, 128, (1, 3), (1, 2), (0, 1), 2, 6, 20),
+    (64, 128, (1, 1), (2, 2), (0, 0), 2, 12, 20),
+    (256, 128, (3, 3), (1, 1), (1, 1), 2, 8, 10),
+    (128, 40, (3, 3), (1, 1), (1, 1), 2, 8, 10),
+    (96, 8, (3, 3), (1, 1), (1, 1), 2, 8, 10),
+    (512, 256, (1, 1), (1, 1), (0, 0), 2, 5, 5),
+    (256, 16, (1, 1), (1, 1), (0, 0), 4, 1, 1),
+    (512, 512, (3, 1), (1, 1), (1, 0), 1, 15, 20),
+    # ragged: channel counts off the 64-wide tiles / 64-deep K steps, odd and tiny images
+    (40, 72, (1, 3), (1, 1), (0, 1), 1, 5, 7),
+    (72, 40, (3, 1), (1, 1), (1, 0), 2, 7, 5),
+    (8, 8, (1, 3), (1, 1), (0, 1), 1, 1, 2),
+    (24, 136, (3, 3), (1, 1), (1, 1), 1, 5, 3),
+    # enough pixels for the 128-row tiles
+    (64, 64, (1, 3), (1, 1), (0, 1), 4, 120, 160),
+    (128, 128, (3, 1), (1, 1), (1, 0), 4, 60, 80),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2])
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv16_fwd(cfg, tile, dtype, monkeypatch):
+    Fn = _fn()
+    if tile >= 0:
+        monkeypatch.setenv('EMSA_CONVH_TILE', str(tile))
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    b = rnd(cout, seed=3)
+    ref = F.conv2d(q(x, dtype), q(wt, dtype), b.double(), stride=s, padding=p)
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
+    y, stats = Fn.conv_fwd(act16(x, dtype), wp, spec, bias=b.to(DEV), want_stats=True)
+    torch.cuda.synchronize()
+    assert y.dtype == dtype
+    close(y, ref, tol=TOL[dtype], what='conv16')
+    # BatchNorm statistics come from the fp32 accumulators (before the rounding of the output)
+    cnt = ref.numel() / cout
+    assert float(stats[2][:, 0].sum()) == cnt
+    mean = stats[0].sum(0) / cnt
+    close(mean, ref.mean((0, 2, 3)), tol=2e-4, what='stats mean')
+    tile_mean = stats[0] / stats[2]
+    m2 = stats[1].sum(0) + (stats[2] * (tile_mean - mean[None]) ** 2).sum(0)
+    close(m2 / cnt, ref.var((0, 2, 3), unbiased=False), tol=4e-4, what='stats var')
+    # fused epilogue: folded BN + residual + relu
+    sc, sh = rnd(cout, seed=4), rnd(cout, seed=5)
+    res = rnd(*ref.shape, seed=6)
+    y2 = Fn.conv_fwd(act16(x, dtype), wp, spec, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV),
+                     residual=act16(res, dtype), act=Fn.ACT_RELU)
+    ref2 = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+                  + q(res, dtype))
+    close(y2, ref2, tol=TOL[dtype], what='conv16 epilogue')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('tile', [-1, 1])
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv16_dgrad(cfg, tile, dtype, monkeypatch):
+    Fn = _fn()
+    if tile >= 0:
+        monkeypatch.setenv('EMSA_CONVH_TILE', str(tile))
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    y = F.conv2d(x, q(wt, dtype), None, stride=s, padding=p)
+    dy = rnd(*y.shape, seed=7)
+    y.backward(q(dy, dtype))
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    _, wpd = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=False, dgrad=True)
+    dx = Fn.conv_dgrad(act16(dy, dtype), wpd, spec, (h, w))
+    torch.cuda.synchronize()
+    close(dx, x.grad, tol=TOL[dtype], what='dgrad16')
+    mask = rnd(n, cin, h, w, seed=8)
+    res = rnd(n, cin, h, w, seed=9)
+    dx2 = Fn.conv_dgrad(act16(dy, dtype), wpd, spec, (h, w), mask_src=act16(mask, dtype))
+    close(dx2, x.grad * (q(mask, dtype) > 0), tol=TOL[dtype], what='dgrad16 mask')
+    dx3 = Fn.conv_dgrad(act16(dy, dtype), wpd, spec, (h, w), residual=act16(res, dtype))
+    close(dx3, x.grad + q(res, dtype), tol=TOL[dtype], what='dgrad16 residual')
+
+
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv16_wgrad(cfg):
+    """fp32 weight / bias gradients from bf16 activations"""
+    Fn = _fn()
+    dtype = torch.bfloat16
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1).double().requires_grad_(True)
+    b = rnd(cout, seed=3).double().requires_grad_(True)
+    y = F.conv2d(q(x, dtype), wt, b, stride=s, padding=p)
+    dy = rnd(*y.shape, seed=7)
+    y.backward(q(dy, dtype))
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    like = torch.empty(cout, cin, *k, device=DEV)
+    for two_pass in (True, False):
+        dw, db, packed = Fn.conv_wgrad(act16(x, dtype), act16(dy, dtype), spec, True, like=like,
+                                       two_pass=two_pass)
+        if packed:
+            dw = Fn.unpack_wgrad(dw, like)
+        torch.cuda.synchronize()
+        wino = Fn.wino_eligible(spec)       # Winograd F(3,2): operands rounded to bf16 once more
+        close(dw, wt.grad, tol=1e-2 if wino else 2e-4, what=f'wgrad16 (two_pass={two_pass})')
+        close(db, b.grad, tol=2e-4, what='dbias16')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_stem16(dtype):
+    """7x7/2 stem on the fp32 NCHW network input: packed to 16-bit NHWC4, conv_h kernel, BN stats"""
+    Fn = _fn()
+    for cin in (3, 1):
+        n, h, w = 2, 32, 48
+        x = rnd(n, cin, h, w, seed=1)
+        wt = rnd(64, cin, 7, 7, seed=2, scale=0.1)
+        ref = F.conv2d(q(x, dtype), q(wt, dtype), None, stride=2, padding=3)
+        spec = Fn.StemSpec(cin, 64)
+        xp = Fn.stem_pack_input(x.to(DEV), dtype)
+        wp = Fn.stem_pack_weight(wt.to(DEV), dtype)
+        y, stats = Fn.stem_fwd(xp, wp, spec, n, h, w, want_stats=True)
+        torch.cuda.synchronize()
+        close(y, ref, tol=TOL[dtype], what='stem16')
+        close(stats[0].sum(0) / (ref.numel() / 64), ref.mean((0, 2, 3)), tol=2e-4, what='stem mean')
+        if dtype == torch.bfloat16:
+            wd = wt.double().requires_grad_(True)
+            yy = F.conv2d(q(x, dtype), wd, None, stride=2, padding=3)
+            dy = rnd(*yy.shape, seed=5)
+            yy.backward(q(dy, dtype))
+            dw = Fn.stem_wgrad(xp, act16(dy, dtype), spec, n, h, w, wt.to(DEV))
+            close(dw, wd.grad, tol=2e-4, what='stem16 wgrad')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_act_and_backward16(dtype):
+    Fn = _fn()
+    n, c, h, w = 3, 64, 9, 7
+    x = rnd(n, c, h, w, seed=1)
+    res = rnd(n, c, h, w, seed=2)
+    sc, sh = rnd(c, seed=3), rnd(c, seed=4)
+    drop = (rnd(n, c, seed=5) > 0).float() * 1.25
+    xq = q(x, dtype).requires_grad_(True)
+    rq = q(res, dtype).requires_grad_(True)
+    ref = F.relu((xq * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+                 * drop.double()[:, :, None, None] + rq)
+    y, bits = Fn.bn_act(act16(x, dtype), sc.to(DEV), sh.to(DEV), drop.to(DEV), act16(res, dtype),
+                        Fn.ACT_RELU, want_mask=True)
+    assert y.dtype == dtype
+    close(y, ref, tol=TOL[dtype], what='bn_act16')
+    # backward through batch-statistics BatchNorm + dropout + residual + ReLU (eval-style check of
+    # the fused formula against autograd on the same rounded tensors)
+    gamma = rnd(c, seed=6).abs() + 0.5
+    xq2 = q(x, dtype).requires_grad_(True)
+    mean = xq2.mean((0, 2, 3))
+    var = xq2.var((0, 2, 3), unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-3)
+    xhat = (xq2 - mean[None, :, None, None]) * invstd[None, :, None, None]
+    beta = rnd(c, seed=7).double()
+    rq2 = q(res, dtype).requires_grad_(True)
+    out = F.relu((xhat * gamma.double()[None, :, None, None] + beta[None, :, None, None])
+                 * drop.double()[:, :, None, None] + rq2)
+    dy = rnd(n, c, h, w, seed=8)
+    out.backward(q(dy, dtype))
+    scale = (gamma.double() * invstd).float()
+    shift = (beta - mean * gamma.double() * invstd).float()
+    y2, bits2 = Fn.bn_act(act16(x, dtype), scale.to(DEV), shift.to(DEV), drop.to(DEV),
+                          act16(res, dtype), Fn.ACT_RELU, want_mask=True)
+    dx, dres, dg, db = Fn.bn_bwd(act16(dy, dtype), bits2, act16(x, dtype), gamma.to(DEV),
+                                 mean.float().to(DEV), invstd.float().to(DEV), drop.to(DEV),
+                                 Fn.ACT_RELU, True, want_dres=True)
+    # the engine's ReLU mask is taken on ITS forward values: compare where both agree on the sign
+    same = ((y2.float().cpu() > 0) == (out.detach() > 0))
+    assert same.float().mean() > 0.995
+    close(dres.float().cpu() * same, rq2.grad * same, tol=TOL[dtype], what='bn16 dres')
+    close(dx.float().cpu() * same, xq2.grad * same, tol=3 * TOL[dtype], what='bn16 dx')
+    assert dg.dtype == torch.float32 and db.dtype == torch.float32
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_pool_se_upsample_ppm16(dtype):
+    Fn = _fn()
+    n, c, h, w = 2, 64, 10, 12
+    x = rnd(n, c, h, w, seed=1)
+    xq = q(x, dtype)
+    # max pool 3x3/2 + backward
+    xr = xq.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    y, idx = Fn.maxpool_fwd(act16(x, dtype))
+    close(y, ref, tol=0, what='maxpool16')               # a max of stored values: exact
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(q(dy, dtype))
+    close(Fn.maxpool_bwd(act16(dy, dtype), idx, (h, w)), xr.grad, tol=TOL[dtype], what='maxpool16 bwd')
+    # SE pieces
+    gap = Fn.channel_mean(act16(x, dtype))
+    close(gap, xq.mean((2, 3)), tol=2e-4, what='channel mean16')
+    sa, sb = torch.rand(n, c) + 0.1, torch.rand(n, c) + 0.1
+    x2 = rnd(n, c, h, w, seed=3)
+    out = Fn.se_scale_add(act16(x, dtype), sa.to(DEV), act16(x2, dtype), sb.to(DEV))
+    close(out, xq * sa.double()[:, :, None, None] + q(x2, dtype) * sb.double()[:, :, None, None],
+          tol=TOL[dtype], what='se_scale_add16')
+    ds = Fn.se_scale_bwd_reduce(act16(x2, dtype), act16(x, dtype))
+    close(ds, (q(x2, dtype) * xq).sum((2, 3)), tol=2e-4, what='se reduce16')
+    dgap = rnd(n, c, seed=4)
+    dxs = Fn.se_scale_bwd_apply(act16(x2, dtype), sa.to(DEV), dgap.to(DEV))
+    close(dxs, q(x2, dtype) * sa.double()[:, :, None, None] + dgap.double()[:, :, None, None] / (h * w),
+          tol=TOL[dtype], what='se apply16')
+    # learned x2 up-sampling: 16-bit -> 16-bit with skip, and 16-bit -> fp32 (model boundary)
+    wdw = rnd(c, 1, 3, 3, seed=5, scale=0.3)
+    bias = rnd(c, seed=6)
+    skip = rnd(n, c, 2 * h, 2 * w, seed=7)
+    xr = xq.clone().requires_grad_(True)
+    wr = wdw.double().requires_grad_(True)
+    up = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, bias.double(), padding=1,
+                  groups=c)
+    y16 = Fn.up2x_dw_fwd(act16(x, dtype), wdw.to(DEV), bias.to(DEV), act16(skip, dtype))
+    close(y16, up + q(skip, dtype), tol=TOL[dtype], what='up2x16')
+    y32 = Fn.up2x_dw_fwd(act16(x, dtype), wdw.to(DEV), bias.to(DEV), None, out_f32=True)
+    assert y32.dtype == torch.float32
+    close(y32, up, tol=2e-4, what='up2x16 -> fp32')
+    dyu = rnd(*up.shape, seed=8)
+    up.backward(dyu.double())                              # fp32 cotangent (model boundary)
+    from util import to_act
+    dx, dw, db = Fn.up2x_dw_bwd(to_act(dyu), act16(x, dtype), wdw.to(DEV).contiguous())
+    assert dx.dtype == dtype
+    close(dx, xr.grad, tol=TOL[dtype], what='up2x16 dx (fp32 dy)')
+    close(dw.view(c, 1, 3, 3), wr.grad, tol=2e-4, what='up2x16 dw')
+    # pyramid pooling pieces
+    close(Fn.adaptive_avgpool_fwd(act16(x, dtype), 5), F.adaptive_avg_pool2d(xq, 5), tol=TOL[dtype],
+          what='avgpool16')
+    small = rnd(n, c, 5, 5, seed=9)
+    buf = Fn.act_empty(n, c, h, w, DEV, dtype=dtype)
+    Fn.bilinear_fwd(act16(small, dtype), buf)
+    close(buf, F.interpolate(q(small, dtype), size=(h, w), mode='bilinear', align_corners=False),
+          tol=TOL[dtype], what='bilinear16')
+    sr = q(small, dtype).requires_grad_(True)
+    F.interpolate(sr, size=(h, w), mode='bilinear', align_corners=False).backward(q(x, dtype))
+    close(Fn.bilinear_bwd(act16(x, dtype), (5, 5)), sr.grad, tol=TOL[dtype], what='bilinear16 bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_head_act_and_casts16(dtype):
+    from emsanet_amd import ops
+    Fn = _fn()
+    x = rnd(2, 8, 6, 7, seed=1)
+    xq = q(x, dtype).requires_grad_(True)
+    y = torch.cat([torch.sigmoid(xq[:, :1]), torch.tanh(xq[:, 1:3]), xq[:, 3:]], 1)
+    dy = rnd(*y.shape, seed=2)
+    y.backward(dy.double())
+    xg = act16(x, dtype).requires_grad_(True)
+    c, o, r = ops.HeadActFunction.apply(xg, 1, 2, (1, 2, 2))
+    assert c.dtype == torch.float32                       # model outputs are fp32
+    close(torch.cat([c, o, r], 1), y[:, :5], tol=2e-4, what='head act16')
+    torch.autograd.backward([c, o, r], [dy[:, :1].contiguous().to(DEV), dy[:, 1:3].contiguous().to(DEV),
+                                        dy[:, 3:5].contiguous().to(DEV)])
+    ref = xq.grad.clone()
+    ref[:, 5:] = 0
+    assert xg.grad.dtype == dtype
+    close(xg.grad, ref, tol=TOL[dtype], what='head act16 bwd')
+    # casts (side outputs / scene logits leave the engine as fp32)
+    t = act16(x, dtype).requires_grad_(True)
+    f = ops.to_float(t)
+    assert f.dtype == torch.float32 and torch.equal(f.cpu().double(), q(x, dtype))
+    f.backward(torch.ones_like(f))
+    assert t.grad.dtype == dtype and float(t.grad.float().min()) == 1.0
