@@ -66,6 +66,10 @@ def parse():
                     help='complete training step: all task losses on device (semantic / scene CE, '
                          'instance MSE / L1 / von Mises, multi-scale, reference weights) and '
                          'loss.backward() instead of fixed output cotangents')
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16', 'f16'),
+                    help='storage type of the activations: f32 = the reference arithmetic and the '
+                         'headline metric (BASELINE configs[1]); bf16 = configs[2] mixed precision '
+                         '(fp32 master weights, statistics, accumulation, outputs); f16: --eval only')
     ap.add_argument('--grad-dtype', default='f32', choices=('f32', 'bf16'),
                     help='dtype of the gradient all-reduce buckets on the wire (bf16: half the xGMI '
                          'bytes, SURVEY 8e)')
@@ -234,7 +238,8 @@ def run(args):
 
     L = _lib.lib()
     a = full_args(input_height=args.height, input_width=args.width,
-                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone)
+                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone,
+                  compute_dtype={'f32': 'float32', 'bf16': 'bfloat16', 'f16': 'float16'}[args.dtype])
     torch.manual_seed(0)
     model = EMSANet(a, nyuv2_config())
     deterministic_init_(model)
@@ -413,8 +418,11 @@ def run(args):
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         # EMSA_BF16_MFMA=1 is an opt-in mixed-precision mode (BASELINE config 3), never the headline
-        'dtype': 'bf16-mfma/f32-accumulate+storage' if os.environ.get('EMSA_BF16_MFMA') == '1'
-        else 'f32',
+        'dtype': {'f32': 'bf16-mfma/f32-accumulate+storage'
+                  if os.environ.get('EMSA_BF16_MFMA') == '1' else 'f32',
+                  'bf16': 'bf16 (activations + MFMA operands; fp32 accumulate, master weights, '
+                          'BatchNorm statistics, outputs)',
+                  'f16': 'f16 (activations + MFMA operands; fp32 accumulate, inference only)'}[args.dtype],
         'data': 'synthetic',
         'config': {'workload': f'BASELINE.json configs[1]: full EMSANet RGB-D ({args.backbone}-NBt1D x2, '
                                'SE-add fusion, PPM, semantic+instance+orientation+scene heads), '
