@@ -35,7 +35,10 @@ def grad_target(p):
     if owner._taken.get(p) == owner._epoch:
         return None
     owner._taken[p] = owner._epoch
-    return view
+    # a FRESH alias of the bucket view: autograd's AccumulateGrad only adopts ("steals") a gradient
+    # tensor nobody else references; handed the long-lived view object itself it clones it -- one
+    # memcpy per parameter per step (measured: 742 x 4 us) and a second copy back into the bucket
+    return view.detach()
 
 
 class GradientBuckets:

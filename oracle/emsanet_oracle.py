@@ -46,6 +46,84 @@ class Spec:
     ORIENTATION_L2_NORMALIZE = False   # [U] raw 2-ch biternion
     RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
                      'resnet101': (3, 4, 23, 3)}   # NBt1D has expansion 1 -> 64/128/256/512
+    # Storage emulation (NOT part of the reference, which computes in fp32): None = plain
+    # arithmetic in the module's dtype.  torch.bfloat16 / torch.float16: every tensor the 16-bit
+    # engine keeps in HBM is rounded to that type where the engine rounds it (conv / BN+act / SE /
+    # pooling / up-sampling outputs, conv weights; gradients of those tensors are rounded on the
+    # way back), everything else -- accumulation, BatchNorm statistics (taken BEFORE the conv
+    # output is rounded, like the engine's fused epilogue does), parameters, SE vectors, the model
+    # outputs -- stays in the module's dtype.  tests/test_model16_gpu.py runs the fp64 oracle in
+    # this mode so that the 16-bit engine can be checked at a tight tolerance: what is left is
+    # accumulation order and rounding-boundary flips, not 100 layers of compounding storage noise.
+    STORAGE = None
+
+
+class _Store(torch.autograd.Function):
+    """value AND gradient rounded to the storage type (a tensor the engine keeps in 16 bits)"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class _RoundSTE(torch.autograd.Function):
+    """16-bit copy of an fp32 master parameter: rounded value, gradient passed straight through
+    (the engine computes the weight gradient in fp32 from the 16-bit activations)"""
+
+    @staticmethod
+    def forward(ctx, w, dtype):
+        return w.to(dtype).to(w.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def store(x):
+    return x if Spec.STORAGE is None else _Store.apply(x, Spec.STORAGE)
+
+
+def conv_q(conv, x):
+    """conv with the engine's 16-bit operand copy of the weights (bias stays fp32)"""
+    if Spec.STORAGE is None:
+        return conv(x)
+    return F.conv2d(x, _RoundSTE.apply(conv.weight, Spec.STORAGE), conv.bias, conv.stride,
+                    conv.padding, conv.dilation, conv.groups)
+
+
+def _fused_eval(module):
+    """the engine's no-grad eval path folds BatchNorm into the conv epilogue: the conv output is
+    never stored on its own"""
+    return (not module.training) and (not torch.is_grad_enabled())
+
+
+def bn_q(bn, y, fused=False):
+    """BatchNorm of a conv output.  Storage emulation: the statistics come from the UNROUNDED
+    accumulators (conv epilogue), the normalisation reads the STORED (rounded) conv output --
+    unless the engine's fused eval path applies (no intermediate tensor)."""
+    if Spec.STORAGE is None or fused:
+        return bn(y)
+    yq = store(y)
+    if not (bn.training or bn.running_mean is None):
+        return bn(yq)
+    dims = (0, 2, 3)
+    mean = y.mean(dims)
+    var = y.var(dims, unbiased=False)
+    if bn.training and bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            n = y.numel() / y.shape[1]
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - mom).add_(mom * mean)
+            bn.running_var.mul_(1 - mom).add_(mom * var * (n / max(n - 1, 1)))
+            bn.num_batches_tracked += 1
+    inv = torch.rsqrt(var + bn.eps)
+    sh = (1, -1, 1, 1)
+    return (yq - mean.view(sh)) * (inv * bn.weight).view(sh) + bn.bias.view(sh)
 
 
 # --------------------------------------------------------------------------------------
@@ -102,6 +180,12 @@ class ConvNormAct(nn.Sequential):
         if act:
             self.add_module('act', nn.ReLU())
 
+    def forward(self, x):
+        y = bn_q(self.norm, conv_q(self.conv, x), _fused_eval(self))
+        if hasattr(self, 'act'):
+            y = self.act(y)
+        return store(y)
+
 
 class NonBottleneck1D(nn.Module):
     """conv3x1+b -> ReLU -> conv1x3+b -> BN -> ReLU -> conv3x1+b -> ReLU -> conv1x3+b -> BN
@@ -124,13 +208,15 @@ class NonBottleneck1D(nn.Module):
             self.downsample = None
 
     def forward(self, x):
-        out = F.relu(self.conv3x1_1(x))
-        out = F.relu(self.bn1(self.conv1x3_1(out)))
-        out = F.relu(self.conv3x1_2(out))
-        out = self.bn2(self.conv1x3_2(out))
+        fused = _fused_eval(self)
+        out = store(F.relu(conv_q(self.conv3x1_1, x)))
+        out = store(F.relu(bn_q(self.bn1, conv_q(self.conv1x3_1, out), fused)))
+        out = store(F.relu(conv_q(self.conv3x1_2, out)))
+        out = bn_q(self.bn2, conv_q(self.conv1x3_2, out), fused)
         out = self.dropout(out)
-        identity = x if self.downsample is None else self.downsample(x)
-        return F.relu(out + identity)
+        identity = x if self.downsample is None else \
+            store(bn_q(self.downsample[1], conv_q(self.downsample[0], x), fused))
+        return store(F.relu(out + identity))
 
 
 class ResNetNBt1D(nn.Module):
@@ -152,7 +238,8 @@ class ResNetNBt1D(nn.Module):
 
     def forward_stage(self, i, x):
         if i == 0:
-            return F.relu(self.bn1(self.conv1(x)))
+            # (the fp32 network input is converted to the storage type when the stem packs it)
+            return store(F.relu(bn_q(self.bn1, conv_q(self.conv1, store(x)), _fused_eval(self))))
         if i == 1:
             x = F.max_pool2d(x, 3, stride=2, padding=1)
         return getattr(self, f'layer{i}')(x)
@@ -177,7 +264,7 @@ class SEAddUniRGB(nn.Module):
         self.se_depth = SqueezeAndExcitation(c)
 
     def forward(self, rgb, depth):
-        return self.se_rgb(rgb) + self.se_depth(depth), depth
+        return store(self.se_rgb(rgb) + self.se_depth(depth)), depth
 
 
 class FusedEncoder(nn.Module):
@@ -230,9 +317,9 @@ class PyramidPoolingModule(nn.Module):
         h, w = x.shape[2:]
         outs, feats = [x], []
         for f in self.features:
-            y = f(x)
+            y = f[1](store(f[0](x)))
             feats.append(y)
-            outs.append(F.interpolate(y, (h, w), mode='bilinear', align_corners=False))
+            outs.append(store(F.interpolate(y, (h, w), mode='bilinear', align_corners=False)))
         return self.final_conv(torch.cat(outs, 1)), tuple(feats)
 
 
@@ -262,7 +349,7 @@ class SemanticSideHead(nn.Module):
                               padding=Spec.SIDE_OUTPUT_KERNEL // 2)
 
     def forward(self, x):
-        return self.conv(x)
+        return store(conv_q(self.conv, x))
 
 
 class InstanceSideHead(nn.Module):
@@ -275,7 +362,7 @@ class InstanceSideHead(nn.Module):
         self.task_convs = nn.ModuleList([nn.Conv2d(c, o, k, padding=k // 2) for o in outs])
 
     def forward(self, x):
-        return torch.cat([conv(x) for conv in self.task_convs], dim=1)
+        return store(torch.cat([conv_q(conv, x) for conv in self.task_convs], dim=1))
 
 
 class DecoderModule(nn.Module):
@@ -296,7 +383,7 @@ class DecoderModule(nn.Module):
         x = self.upsampling(x)
         if self.skip_fusion is not None:
             skip = self.skip_fusion(skip)
-        return x + skip, side
+        return store(x + skip), side        # (up-sampling + skip add: one kernel, one rounding)
 
 
 class DecoderBody(nn.Module):
@@ -327,7 +414,8 @@ class SemanticHead(nn.Module):
         self.upsampling = nn.Sequential(LearnedUpsampling(n_classes), LearnedUpsampling(n_classes))
 
     def forward(self, x):
-        return self.upsampling(self.conv(x))
+        # head conv and the first up-sampling are stored; the last one writes the fp32 logits
+        return self.upsampling[1](store(self.upsampling[0](store(conv_q(self.conv, x)))))
 
 
 class SemanticDecoder(DecoderBody):
@@ -364,8 +452,9 @@ class InstanceHead(nn.Module):
     def forward(self, x):
         x = self.shared_conv(x)
         parts = torch.split(x, self.n_per_task, dim=1)
-        x = torch.cat([conv(p) for conv, p in zip(self.task_convs, parts)], dim=1)
-        return self.upsampling(x)
+        x = store(torch.cat([conv_q(conv, p) for conv, p in zip(self.task_convs, parts)], dim=1))
+        # both up-samplings are stored; the head activations then produce the fp32 outputs
+        return store(self.upsampling[1](store(self.upsampling[0](x))))
 
 
 class InstanceDecoder(DecoderBody):
@@ -411,7 +500,11 @@ class SceneClassificationDecoder(nn.Module):
 
     def forward(self, x, skips, batch=None, do_postprocessing=False):
         feat = x[1][0]                      # GAP branch of the context module (B,256,1,1)
-        out = self.head(torch.flatten(feat, 1))
+        if Spec.STORAGE is None:
+            out = self.head(torch.flatten(feat, 1))
+        else:
+            out = store(F.linear(torch.flatten(feat, 1),
+                                 _RoundSTE.apply(self.head.weight, Spec.STORAGE), self.head.bias))
         if not do_postprocessing:
             return out, ()
         r = {'scene_output': out}
