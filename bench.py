@@ -34,6 +34,8 @@ import numpy as np    # noqa: E402
 import torch          # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured copy)
 FWD_GFLOP_PER_IMAGE = 119.672609792    # FlopCounterMode on the oracle at 480x640
 
 
@@ -365,6 +367,8 @@ def run(args):
             _lib.check(L.emsa_prof_read(cls, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)),
                        'emsa_prof_read')
             if n.value:
+                nbytes = ctypes.c_double()
+                _lib.check(L.emsa_prof_read_bytes(cls, ctypes.byref(nbytes)), 'emsa_prof_read_bytes')
                 seen = L.emsa_prof_seen(cls)
                 scale = seen / n.value            # sampled -> all launches of the class
                 kernels.append({'kernel': L.emsa_prof_name(cls).decode(), 'launches': seen,
@@ -373,6 +377,9 @@ def run(args):
                                 'avg_us': round(1e3 * ms.value / n.value, 2),
                                 'algo_gflop_per_launch': round(fl.value / n.value / 1e9, 4),
                                 'tflops': round(fl.value / ms.value / 1e9, 2)})
+                if nbytes.value > 0:
+                    kernels[-1]['algo_mb_per_launch'] = round(nbytes.value / n.value / 1e6, 2)
+                    kernels[-1]['algo_gbps'] = round(nbytes.value / ms.value / 1e6, 1)
                 if 'wino' in kernels[-1]['kernel']:
                     # Winograd F(2,3): 4 MFMA multiplies per 6 direct-convolution multiplies;
                     # 'tflops' is algorithmic (direct-conv FLOPs / time), this is what the
@@ -402,6 +409,14 @@ def run(args):
                     'launches': k['launches'], 'avg_us': k['avg_us'],
                     'algo_gflop_per_launch': k['algo_gflop_per_launch'],
                     'share_of_step': round(k['total_ms'] / (dt * 1e3), 4)}
+        if args.dtype != 'f32' and 'algo_gbps' in k:
+            # 16-bit operands: at 2.5 PFLOP/s the convolutions are bounded by bytes, not by the
+            # matrix pipe: achieved = algorithmic bytes per launch / average duration
+            roofline.update({'bound': 'hbm', 'achieved': k['algo_gbps'], 'peak': HBM_PEAK_GBPS,
+                             'unit': 'GB/s', 'frac': round(k['algo_gbps'] / HBM_PEAK_GBPS, 4),
+                             'algo_mb_per_launch': k['algo_mb_per_launch'],
+                             'mfma_tflops': k['tflops'],
+                             'mfma_frac_of_bf16_peak': round(k['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4)})
         if 'mfma_executed_tflops' in k:
             roofline['mfma_executed_tflops'] = k['mfma_executed_tflops']
             roofline['note'] = ('Winograd F(2,3) kernel: achieved = direct-convolution FLOPs / '
@@ -424,9 +439,9 @@ def run(args):
                           'BatchNorm statistics, outputs)',
                   'f16': 'f16 (activations + MFMA operands; fp32 accumulate, inference only)'}[args.dtype],
         'data': 'synthetic',
-        'config': {'workload': f'BASELINE.json configs[1]: full EMSANet RGB-D ({args.backbone}-NBt1D x2, '
+        'config': {'workload': f'BASELINE.json configs[{1 if args.dtype == "f32" else 2}]: full EMSANet RGB-D ({args.backbone}-NBt1D x2, '
                                'SE-add fusion, PPM, semantic+instance+orientation+scene heads), '
-                               f'{args.width}x{args.height}, bs={bs}/GPU, fp32, train mode '
+                               f'{args.width}x{args.height}, bs={bs}/GPU, {args.dtype}, train mode '
                                '(BN batch stats, Dropout2d), step = fwd + bwd (fixed output '
                                'cotangents) + grad all-reduce + SGD-nesterov update',
                    'global_batch': bs * world, 'parallelism': f'dp{world}',

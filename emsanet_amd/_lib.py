@@ -150,6 +150,7 @@ SIGNATURES = {
     'emsa_prof_name': (c_char_p, [c_int32]),
     'emsa_prof_read': (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                POINTER(c_int32)]),
+    'emsa_prof_read_bytes': (c_int, [c_int32, POINTER(ctypes.c_double)]),
 }
 
 _ERR = {-1: 'EMSA_E_SHAPE (unsupported geometry)', -2: 'EMSA_E_ARG (bad argument)',

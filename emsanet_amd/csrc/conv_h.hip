@@ -427,7 +427,12 @@ int launch_h(const ConvHArgs& a, hipStream_t st) {
                        ((a.g.div_h > 1 || a.g.div_w > 1) ? (double)a.g.in_h * a.g.in_w
                                                          : (double)a.g.out_h * a.g.out_w) *
                        a.g.k_ch * a.g.n_ch * a.g.kh * a.g.kw;
-  const int ps = emsa_prof_begin(kProfClassConvH, flops, st);
+  // algorithmic bytes: every tensor of the launch once (input, output, weights, fused operands)
+  const double px_out = (double)a.M * a.g.n_ch * 2.0;
+  const double bytes = (double)a.g.n_img * a.g.in_h * a.g.in_w * a.g.k_ch * 2.0 + px_out +
+                       (double)a.g.kh * a.g.kw * a.g.n_ch * a.g.k_ch * 2.0 +
+                       (a.residual ? px_out : 0.0) + (a.mask_src ? px_out : 0.0);
+  const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
   hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T>), dim3(grid), dim3(256), lds, st, a);
   emsa_prof_end(ps, st);
   return emsa_launch_status();

@@ -34,7 +34,7 @@ namespace {
 struct ProfSlotImpl {
   hipEvent_t a, b;
   int cls;
-  double flops;
+  double flops, bytes;
 };
 std::vector<ProfSlotImpl> g_prof_pool;
 size_t g_prof_used = 0;
@@ -49,7 +49,7 @@ const char* const kProfNames[kProfClasses] = {
     "conv1d_wino_kernel", "conv_h_kernel (16-bit igemm)", "wgrad kernels on 16-bit activations"};
 }  // namespace
 
-int emsa_prof_begin(int cls, double flops, hipStream_t st) {
+int emsa_prof_begin(int cls, double flops, hipStream_t st, double bytes) {
   if (g_prof_every <= 0) return -1;
   struct ClearOverride {            // the override applies to exactly one launch, sampled or not
     ~ClearOverride() { g_prof_next_flops = 0.0; }
@@ -64,6 +64,7 @@ int emsa_prof_begin(int cls, double flops, hipStream_t st) {
   ProfSlotImpl* s = &g_prof_pool[id];
   s->cls = cls;
   s->flops = g_prof_next_flops > 0.0 ? g_prof_next_flops : flops;
+  s->bytes = bytes;
   (void)hipEventRecord(s->a, st);
   return id;
 }
@@ -73,7 +74,9 @@ void emsa_prof_end(int slot, hipStream_t st) {
 
 namespace {
 using ProfSlot = int;
-inline int prof_begin(int cls, double flops, hipStream_t st) { return emsa_prof_begin(cls, flops, st); }
+inline int prof_begin(int cls, double flops, hipStream_t st, double bytes = 0.0) {
+  return emsa_prof_begin(cls, flops, st, bytes);
+}
 inline void prof_end(int s, hipStream_t st) { emsa_prof_end(s, st); }
 
 // algorithmic (direct-convolution) FLOPs of one launch: 2 * pixels * k_ch * n_ch * taps, pixels
@@ -1609,7 +1612,10 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * 12288 : nullptr;
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
-    const int ps = prof_begin(kHalf ? kProfClassWgradH : 7, algo_flops(a.g), st);
+    // algorithmic bytes: x and dy read once, the fp32 gradient written once
+    const double wbytes = (double)g->n_img * g->in_h * g->in_w * g->k_ch * sizeof(T) +
+                          (double)a.M * g->n_ch * sizeof(T) + (double)taps * g->n_ch * g->k_ch * 4.0;
+    const int ps = prof_begin(kHalf ? kProfClassWgradH : 7, algo_flops(a.g), st, wbytes);
     static const bool bf16 = [] {
       const char* e = getenv("EMSA_BF16_MFMA");
       return e && e[0] == '1';
@@ -1685,6 +1691,16 @@ extern "C" int emsa_prof_reset(void) {
 extern "C" int emsa_prof_seen(int32_t cls) { return (cls >= 0 && cls < kProfClasses) ? g_prof_seen[cls] : 0; }
 extern "C" const char* emsa_prof_name(int32_t cls) {
   return (cls >= 0 && cls < kProfClasses) ? kProfNames[cls] : "";
+}
+// algorithmic HBM bytes summed over the SAMPLED launches of a class (0 when the class does not
+// track them): with emsa_prof_read's time this gives the achieved GB/s of an HBM-bound kernel
+extern "C" int emsa_prof_read_bytes(int32_t cls, double* total_bytes) {
+  if (!total_bytes) return EMSA_E_ARG;
+  double b = 0.0;
+  for (size_t i = 0; i < g_prof_used; ++i)
+    if (g_prof_pool[i].cls == cls) b += g_prof_pool[i].bytes;
+  *total_bytes = b;
+  return EMSA_OK;
 }
 // call after the stream has been synchronised; sums over the launches recorded since reset
 extern "C" int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops,

@@ -9,6 +9,7 @@ constexpr int kProfClassWino = 8;
 constexpr int kProfClassConvH = 9;     // 16-bit implicit GEMM (conv_h.hip)
 constexpr int kProfClassWgradH = 10;   // weight gradients on 16-bit activations
 
-// returns a slot id (or -1 when this launch is not sampled); `flops` = algorithmic FLOPs
-int emsa_prof_begin(int cls, double flops, hipStream_t st);
+// returns a slot id (or -1 when this launch is not sampled); `flops` = algorithmic FLOPs, `bytes` =
+// algorithmic HBM bytes (every tensor the launch reads or writes counted once; 0 = not tracked)
+int emsa_prof_begin(int cls, double flops, hipStream_t st, double bytes = 0.0);
 void emsa_prof_end(int slot, hipStream_t st);

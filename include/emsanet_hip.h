@@ -512,6 +512,8 @@ int emsa_prof_reset(void);
 int emsa_prof_seen(int32_t cls);       /* launches of the class since reset (sampled or not) */
 const char* emsa_prof_name(int32_t cls);
 int emsa_prof_read(int32_t cls, double* total_ms, double* total_flops, int32_t* launches);
+/* algorithmic HBM bytes of the sampled launches (tracked by the 16-bit kernel classes) */
+int emsa_prof_read_bytes(int32_t cls, double* total_bytes);
 
 #ifdef __cplusplus
 }
