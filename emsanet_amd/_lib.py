@@ -140,6 +140,7 @@ SIGNATURES = {
     'emsa_conv_stats_rows_t': (c_int, [c_int32, _GP]),
     'emsa_conv_igemm_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
                                   c_int32, _P]),
+    'emsa_conv_wgrad_ws_bytes_t': (c_int64, [c_int32, _GP]),
     'emsa_conv_wgrad_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P]),
     'emsa_pack_weight_t': (c_int, [c_int32, _P, _P, _P] + [c_int32] * 8 + [_P]),
     'emsa_stem_pack_weight_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, _P]),

@@ -1268,6 +1268,254 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the stride-1 3-tap convolutions from 16-bit activations (bf16 training path)
+// ------------------------------------------------------------------------------------------
+// dW_t[co][ci] = sum_p dy[p][co] x[p + t - 1][ci] on v_mfma_f32_32x32x16_bf16: the MFMA K index
+// is the PIXEL, so both operands must be K-contiguous per channel -- the transpose of the NHWC
+// rows they are loaded as.  Each loader thread owns 4 consecutive pixels x 4 channels of BOTH
+// tensors (four coalesced 8-byte loads each: 16 lanes cover one 128-byte pixel row), transposes the
+// 4x4 blocks in registers (8 v_perm_b32 each) and writes four 8-byte rows of the [channel][pixel]
+// LDS images.  One x image serves all three taps: the centre tap reads it with ds_read_b128, the
+// left / right taps are the same eight pixels shifted by one element -- rebuilt from the centre
+// registers and ONE extra dword with four v_alignbit_b32 each -- so LDS holds every element once
+// (the Winograd F(3,2) form stores four transformed copies of each and rounds them to bf16 once
+// more).  The pixel in front of the step and the one behind it share one halo dword per row.
+// Lines are enumerated with one virtual zero pixel behind every line (L = Lr + 1), so taps never
+// cross a line end and no masks exist.  64 pixels per K step: 12 MFMAs per wave between barriers.
+// Direct products of the stored bf16 values with fp32 accumulation: as exact as the fp32 kernel on
+// the same inputs.
+// Measured (bs=32 layer shapes, incl. the reduction pass): 42-48 us at EVERY channel count (the
+// Winograd bf16 kernel: 75-80): a launch moves ~157 MB through the CUs' vector memory path whatever
+// C is (HBM at C=64, L2 re-reads by the 64x64 tiles at C=512) with one K step (16 KB) in flight
+// per workgroup -- latency x occupancy bound at ~18 GB/s per CU.  A variant with 16-byte loads
+// (4 pixels x 8 channels per thread, waves 0-1 staging dy and waves 2-3 x) was SLOWER (51-57 us):
+// its eight-rows-apart LDS stores are 4-way bank conflicted whatever the row stride (rows are
+// 16-byte aligned), and the load width was never the limit.
+constexpr int kWH_PK = 64;          // pixels per K step
+constexpr int kWH_ROW = 72;         // LDS row (elements): 64 pixels + halo dword + pad = 144 B = 36
+                                    // banks -> conflict-free ds_read_b128 over 16 distinct rows
+template <typename T>
+__global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArgs p) {
+  constexpr int BCO = 64, BCI = 64;
+  constexpr uint32_t ES = sizeof(T);
+  typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  T* const dS = reinterpret_cast<T*>(smem);          // [64 co][kWH_ROW]: pixel k0 + e at e < 64
+  T* const xS = dS + BCO * kWH_ROW;                  // [64 ci][kWH_ROW]: same; elements 64 / 65 =
+                                                     // pixels k0 + 64 / k0 - 1 (the halo dword)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wco = wave & 1, wci = wave >> 1;
+#if EMSA_W1D_XCD
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+#else
+  const int wg = blockIdx.x;
+#endif
+  const int tile = wg % p.n_tiles, kr = (wg / p.n_tiles) % p.R;
+  const int ks = wg / (p.n_tiles * p.R);
+  const int dline = p.R == 3 ? kr - 1 : 0;         // x is read `dline` lines away (3x3 row tap)
+  const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(s_begin + p.steps_per_split, p.steps_total);
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
+  // loader unit: pixel group pg (4 pixels) x channel quad q.  A 16-lane group holds 4 quads x 4
+  // pixel groups: the ds_write_b64 of one group then hit 16 distinct bank pairs (rows 4q + c are
+  // 16 banks apart, pixel groups 2 banks), while every load instruction of the wave still covers
+  // whole 128-byte pixel rows (16 quads x 8 B).
+  const int q = (lane & 3) | ((lane >> 4) << 2);       // 0..15
+  const int pg = wave * 4 + ((lane >> 2) & 3);         // 0..15
+  const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
+  const bool dok = co0 + 4 * q < p.n_ch, xok = ci0 + 4 * q < p.k_ch;
+  const uint32_t dadd = dok ? (uint32_t)(co0 + 4 * q) * ES : 0u, dmask = dok ? 0u : kOOB;
+  const uint32_t xadd = xok ? (uint32_t)(ci0 + 4 * q) * ES : 0u, xmask = xok ? 0u : kOOB;
+
+  // byte offsets (or kOOB) of pixel k of the padded enumeration in dy (od) and in x (ox)
+  auto px_off = [&](int k, uint32_t& od, uint32_t& ox) {
+    const bool valid = k >= 0 && k < p.M;
+    const uint32_t ku = valid ? (uint32_t)k : 0u;
+    const uint32_t img = fast_div(ku, p.div_al);
+    const uint32_t line = fast_div(ku, p.div_l);                 // = img * A + a
+    const int b_ = (int)(ku - __umul24(line, (uint32_t)p.L));
+    const int a_ = (int)(line - __umul24(img, (uint32_t)p.A));
+    const int a2 = a_ + dline;
+    const bool in_line = valid && b_ < p.Lr;                     // the virtual pixel reads zero
+    od = in_line ? (__umul24(img, (uint32_t)p.dy_simg) + __umul24((uint32_t)a_, (uint32_t)p.dy_sa) +
+                    __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * ES : kOOB;
+    ox = (in_line && a2 >= 0 && a2 < p.A)
+        ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa) +
+           __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * ES : kOOB;
+  };
+
+  u32x2w rd[4], rx[4], rhalo;
+  float4 bsum = emsa_zero4();
+  auto load_regs = [&](int s) {
+    const int k0 = s * kWH_PK;
+    // lane l of every wave decomposes pixel k0 + l once; the loading threads fetch the offsets of
+    // their four pixels with wave shuffles
+    uint32_t off_d, off_x;
+    px_off(k0 + lane, off_d, off_x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int src = (4 * pg + j) * 4;
+      const uint32_t od = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_d);
+      const uint32_t ox = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_x);
+      rd[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)((od + dadd) | dmask), 0, 0);
+      rx[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((ox + xadd) | xmask), 0, 0);
+    }
+    if (tid < 32) {
+      // halo: x of pixel k0 - 1 (threads 0..15) and k0 + 64 (16..31), four channels each
+      uint32_t hd, hx;
+      px_off(tid < 16 ? k0 - 1 : k0 + kWH_PK, hd, hx);
+      const int hq = tid & 15;
+      const bool hok = ci0 + 4 * hq < p.k_ch;
+      rhalo = __builtin_amdgcn_raw_buffer_load_b64(
+          rs_in, (int)(hok ? hx + (uint32_t)(ci0 + 4 * hq) * ES : kOOB), 0, 0);
+    }
+  };
+  // 4 pixels x 4 channels (one u32x2 = 4 channels per pixel) -> per channel 4 pixels = 8 bytes
+  auto tr_store = [&](T* base, const u32x2w (&r)[4]) {
+    constexpr unsigned kLo = 0x05040100u, kHi = 0x07060302u;     // v_perm_b32 byte selectors
+    u32x2w c0, c1, c2, c3;
+    c0.x = __builtin_amdgcn_perm(r[1].x, r[0].x, kLo); c0.y = __builtin_amdgcn_perm(r[3].x, r[2].x, kLo);
+    c1.x = __builtin_amdgcn_perm(r[1].x, r[0].x, kHi); c1.y = __builtin_amdgcn_perm(r[3].x, r[2].x, kHi);
+    c2.x = __builtin_amdgcn_perm(r[1].y, r[0].y, kLo); c2.y = __builtin_amdgcn_perm(r[3].y, r[2].y, kLo);
+    c3.x = __builtin_amdgcn_perm(r[1].y, r[0].y, kHi); c3.y = __builtin_amdgcn_perm(r[3].y, r[2].y, kHi);
+    T* o = base + (4 * q) * kWH_ROW + 4 * pg;
+    *reinterpret_cast<u32x2w*>(o) = c0;
+    *reinterpret_cast<u32x2w*>(o + kWH_ROW) = c1;
+    *reinterpret_cast<u32x2w*>(o + 2 * kWH_ROW) = c2;
+    *reinterpret_cast<u32x2w*>(o + 3 * kWH_ROW) = c3;
+  };
+  auto store_lds = [&]() {
+    if (do_bias) {
+      // bias gradient = column sums of dy, summed where the prefetched registers are consumed
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = raw_f4(rd[j], (T*)nullptr);
+        bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+      }
+    }
+    tr_store(dS, rd);
+    tr_store(xS, rx);
+    if (tid < 32) {
+      // halo dword of a row: element 64 (low half) = pixel k0 + 64, element 65 (high) = pixel k0 - 1
+      unsigned short* xh = reinterpret_cast<unsigned short*>(xS) + (4 * (tid & 15)) * kWH_ROW +
+                           (tid < 16 ? kWH_PK + 1 : kWH_PK);
+      xh[0] = (unsigned short)(rhalo.x & 0xFFFFu);
+      xh[kWH_ROW] = (unsigned short)(rhalo.x >> 16);
+      xh[2 * kWH_ROW] = (unsigned short)(rhalo.y & 0xFFFFu);
+      xh[3 * kWH_ROW] = (unsigned short)(rhalo.y >> 16);
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (s_begin < s_end) {
+    load_regs(s_begin);
+    store_lds();
+  }
+  __syncthreads();
+
+  typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type E;
+  typedef E ev8 __attribute__((ext_vector_type(8)));
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool has_next = s + 1 < s_end;
+    if (has_next) load_regs(s + 1);
+    const T* drow = dS + (wco * 32 + l31) * kWH_ROW + 8 * lh;
+    const T* xrow0 = xS + (wci * 32 + l31) * kWH_ROW;
+    const T* xrow = xrow0 + 8 * lh;
+    const unsigned halo = *reinterpret_cast<const unsigned*>(xrow0 + kWH_PK);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k16 = 0; k16 < kWH_PK / 16; ++k16) {
+      const u32x4h a = *reinterpret_cast<const u32x4h*>(drow + 16 * k16);
+      const u32x4h c = *reinterpret_cast<const u32x4h*>(xrow + 16 * k16);
+      // the dwords in front of / behind the eight pixels; at the tile's ends the halo dword
+      // (alignbit uses the high half on the left, the low half on the right)
+      unsigned wl, wr;
+      if (k16 == 0) {
+        const unsigned w_in = *reinterpret_cast<const unsigned*>(xrow0 + 6);     // lh = 1: elements 6, 7
+        wl = lh ? w_in : halo;
+      } else {
+        wl = *reinterpret_cast<const unsigned*>(xrow + 16 * k16 - 2);
+      }
+      if (k16 == kWH_PK / 16 - 1) {
+        const unsigned w_in = *reinterpret_cast<const unsigned*>(xrow0 + kWH_PK - 8);   // lh = 0: 56, 57
+        wr = lh ? halo : w_in;
+      } else {
+        wr = *reinterpret_cast<const unsigned*>(xrow + 16 * k16 + 8);
+      }
+      u32x4h lft, rgt;
+      lft.x = __builtin_amdgcn_alignbit(c.x, wl, 16);  lft.y = __builtin_amdgcn_alignbit(c.y, c.x, 16);
+      lft.z = __builtin_amdgcn_alignbit(c.z, c.y, 16); lft.w = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+      rgt.x = __builtin_amdgcn_alignbit(c.y, c.x, 16); rgt.y = __builtin_amdgcn_alignbit(c.z, c.y, 16);
+      rgt.z = __builtin_amdgcn_alignbit(c.w, c.z, 16); rgt.w = __builtin_amdgcn_alignbit(wr, c.w, 16);
+      const ev8 av = __builtin_bit_cast(ev8, a);
+      if constexpr (std::is_same<T, emsa_f16>::value) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, lft), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, c), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, rgt), acc[2], 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, lft), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, c), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, rgt), acc[2], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (has_next) store_lds();
+    __syncthreads();
+  }
+
+  if (p.ws != nullptr) {
+    // deterministic split-K: this workgroup's partial tile [3][BCO][BCI] goes to the workspace
+    float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (3 * BCO * BCI);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        wt[(t * BCO + wco * 32 + row) * BCI + wci * 32 + l31] = acc[t][r];
+      }
+  } else {
+    const int ci = ci0 + wci * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = co0 + wco * 32 + row;
+        if (co < p.n_ch && ci < p.k_ch)
+          unsafeAtomicAdd(p.dw + ((size_t)(kr * 3 + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
+      }
+  }
+  if (do_bias) {
+    float* red = smem;   // [16 pixel groups][BCO]
+    __syncthreads();     // (the K loop's LDS reads are done; red overlays dS)
+    red[pg * BCO + 4 * q + 0] = bsum.x;
+    red[pg * BCO + 4 * q + 1] = bsum.y;
+    red[pg * BCO + 4 * q + 2] = bsum.z;
+    red[pg * BCO + 4 * q + 3] = bsum.w;
+    __syncthreads();
+    if (tid < BCO) {
+      float a = 0.f;
+      for (int r = 0; r < 16; ++r) a += red[r * BCO + tid];
+      if (p.ws_bias != nullptr)
+        p.ws_bias[((size_t)ks * p.n_co_tiles + co_t) * BCO + tid] = a;
+      else if (co0 + tid < p.n_ch)
+        unsafeAtomicAdd(p.dbias + co0 + tid, a);
+    }
+  }
+}
+
 // second pass of the deterministic split-K: dw[co][ci][t] (OIHW of a 3-tap 1-D conv) =
 // sum over splits of ws[split][tile][t][co_l][ci_l]; dbias[co] = sum of ws_bias[split][co].
 // workgroup = one (tile, t, co_l) row of 64 ci (16 float4 columns) x 16 split groups; the
@@ -1501,7 +1749,8 @@ struct Wgrad1dPlan {
   int ksplit;
   bool wino;
 };
-bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, size_t esize = sizeof(float)) {
+bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, size_t esize = sizeof(float),
+                  bool direct16 = false) {
   // a 3x3 conv = three row taps, each a 3-tap 1-D weight gradient along W on x shifted by a line
   const bool sq = g->kh == 3 && g->kw == 3 && g->off_w == -1 && g->off_h == -1;
   const bool along_w = (g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0) || sq;
@@ -1537,8 +1786,9 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, siz
     const char* e = getenv("EMSA_WGRAD_WINO");
     return !(e && e[0] == '0');
   }();
-  pl.wino = wino_on;
-  w.L = (pl.wino && (w.Lr & 1)) ? w.Lr + 1 : w.Lr;
+  pl.wino = wino_on && !direct16;
+  // direct16 (conv_wgrad1d_h_kernel): every line gets a virtual zero pixel behind it
+  w.L = (direct16 || (pl.wino && (w.Lr & 1))) ? w.Lr + 1 : w.Lr;
   w.M = g->n_img * A * w.L;
   w.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * esize);
   w.dout_bytes = (uint32_t)((size_t)g->n_img * H * W * g->ld_out * esize);
@@ -1547,16 +1797,19 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, siz
   w.n_co_tiles = (g->n_ch + 63) / 64;
   w.n_ci_tiles = (g->k_ch + 63) / 64;
   w.n_tiles = w.n_co_tiles * w.n_ci_tiles;
-  w.steps_total = (w.M + 31) / 32;
+  const int pk = direct16 ? kWH_PK : 32;
+  w.steps_total = (w.M + pk - 1) / pk;
   // split-K: one round of resident workgroups for the Winograd variant (3 per CU), two rounds
   // of 3 for the direct one (4 per CU) -- measured optima (EMSA_W1D_BLOCKS: tuning only)
   static const int forced_blocks = [] {
     const char* e = getenv("EMSA_W1D_BLOCKS");
     return e ? atoi(e) : 0;
   }();
-  const int target_blocks = forced_blocks > 0 ? forced_blocks : (pl.wino ? 768 : 1536);
+  // (direct16: 768 / 1024 / 1536 / 2048 workgroups measured 46 / 49 / 55 / 63 us at C=64: more
+  //  splits = more partial-tile traffic for the reduction pass)
+  const int target_blocks = forced_blocks > 0 ? forced_blocks : (pl.wino || direct16 ? 768 : 1536);
   int ksplit = target_blocks / (w.n_tiles * w.R);
-  const int max_split = (w.steps_total + 7) / 8;
+  const int max_split = (w.steps_total + (direct16 ? 3 : 7)) / (direct16 ? 4 : 8);   // >= 256 pixels
   if (ksplit > max_split) ksplit = max_split;
   if (ksplit < 1) ksplit = 1;
   w.steps_per_split = (w.steps_total + ksplit - 1) / ksplit;
@@ -1571,12 +1824,35 @@ bool dout_is_aligned(const EmsaConvGeom* g, const float* dout) {
 
 // bytes of workspace for the deterministic two-pass weight gradient of `g` (0: not available for
 // this geometry -> emsa_conv_wgrad accumulates with atomics into the packed layout)
-extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
+namespace {
+// the 16-bit activations' weight gradient: direct bf16 kernel (default) or, EMSA_WGRAD16=wino, the
+// Winograd F(3,2) kernel with bf16 loads (A/B)
+bool wgrad16_direct() {
+  static const bool v = [] {
+    const char* e = getenv("EMSA_WGRAD16");
+    return !(e && e[0] == 'w');
+  }();
+  return v;
+}
+// geometry admits the direct 16-bit kernel (8-byte accesses: 4 channels; dout_is_aligned checks dy)
+bool direct16_geom(const EmsaConvGeom* g) { return wgrad16_direct() && !(g->k_ch & 3); }
+int64_t wgrad_ws_bytes(const EmsaConvGeom* g, size_t esize) {
   if (!geom_ok(g)) return 0;
   Wgrad1dPlan pl;
-  if (!plan_wgrad1d(g, dout_is_aligned(g, nullptr), pl)) return 0;
+  const bool half = esize != sizeof(float);
+  const bool d16 = half && direct16_geom(g);
+  if (!plan_wgrad1d(g, dout_is_aligned(g, nullptr), pl, esize, d16)) return 0;
+  if (half && !d16 && !pl.wino) return 0;
   return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * pl.w.R * 12288 +
                                (int64_t)pl.w.n_co_tiles * 64) * (int64_t)sizeof(float);
+}
+}  // namespace
+extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
+  return wgrad_ws_bytes(g, sizeof(float));
+}
+// workspace of emsa_conv_wgrad_t for activations of `dtype` (the split-K plan depends on it)
+extern "C" int64_t emsa_conv_wgrad_ws_bytes_t(int32_t dtype, const EmsaConvGeom* g) {
+  return wgrad_ws_bytes(g, dtype == EMSA_DT_F32 ? sizeof(float) : 2);
 }
 
 namespace {
@@ -1603,7 +1879,10 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
   hipStream_t st = (hipStream_t)stream;
   const int taps = g->kh * g->kw;
   Wgrad1dPlan pl;
-  const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl, sizeof(T)) && (!kHalf || pl.wino);
+  const bool direct16 = kHalf && direct16_geom(g);
+  if (direct16 && ((((uintptr_t)in) | ((uintptr_t)dout)) & 7)) return EMSA_E_SHAPE;
+  const bool one_d = plan_wgrad1d(g, a.dout_aligned != 0, pl, sizeof(T), direct16) &&
+                     (!kHalf || direct16 || pl.wino);
   if (ws != nullptr && !one_d) return EMSA_E_SHAPE;   // ws_bytes(g) was 0
   if (one_d) {
     Wgrad1dArgs& w = pl.w;
@@ -1621,8 +1900,12 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
       return e && e[0] == '1';
     }();
     if constexpr (kHalf) {
-      // 16-bit activations: operands are bf16 already; E / D are formed in fp32 and rounded to bf16
-      // as they enter LDS, one v_mfma_f32_32x32x16_bf16 per Winograd component and K step
+      if (direct16) {
+        hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T>), dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
+                           (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);
+      } else
+      // EMSA_WGRAD16=wino: E / D are formed in fp32 and rounded to bf16 as they enter LDS, one
+      // v_mfma_f32_32x32x16_bf16 per Winograd component and K step
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true, T>),
                          dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
                          (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);

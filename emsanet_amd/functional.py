@@ -361,7 +361,7 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db
     taps = spec.kh * spec.kw
     nw = taps * spec.cout * spec.cin
     nb = spec.cout if want_bias else 0
-    ws_bytes = L.emsa_conv_wgrad_ws_bytes(g) if (like is not None and two_pass) else 0
+    ws_bytes = call_t('emsa_conv_wgrad_ws_bytes', dt(x), g) if (like is not None and two_pass) else 0
     if ws_bytes > 0:
         ws = _empty((ws_bytes // 4,), x.device)
         if dw_out is not None and (db_out is not None or not want_bias):

@@ -423,7 +423,8 @@ int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int6
  *   are fp32.  k_ch, n_ch, ld_* must be multiples of 8 (16-byte accesses).  EMSA_DT_F32 forwards
  *   to emsa_conv_igemm.  emsa_conv_stats_rows_t: statistics rows of that launch.
  * emsa_conv_wgrad_t: weight (+bias) gradient from `dtype` activations (bf16) into fp32 gradients;
- *   same workspace contract as emsa_conv_wgrad (emsa_conv_wgrad_ws_bytes).
+ *   same workspace contract as emsa_conv_wgrad, sized by emsa_conv_wgrad_ws_bytes_t (the
+ *   split-K plan of the 16-bit kernel differs: 64-pixel K steps of the bf16 MFMA).
  * emsa_pack_weight_t / emsa_stem_pack_weight_t: fp32 OIHW parameter -> 16-bit packed operands.
  * ------------------------------------------------------------------------------------------ */
 int emsa_conv_stats_rows_t(int32_t dtype, const EmsaConvGeom* g);
@@ -431,6 +432,7 @@ int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in, cons
                       void* out, const float* bias, float* stats, const float* scale,
                       const float* shift, const void* residual, int32_t ld_res,
                       const void* mask_src, int32_t ld_mask, int32_t act, void* stream);
+int64_t emsa_conv_wgrad_ws_bytes_t(int32_t dtype, const EmsaConvGeom* g);
 int emsa_conv_wgrad_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* dout,
                       float* dw, float* dbias, float* ws, void* stream);
 int emsa_pack_weight_t(int32_t dtype, const float* w, void* wp_fwd, void* wp_dgrad, int32_t cout,

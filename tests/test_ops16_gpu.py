@@ -6,9 +6,7 @@ convolutions, 16-bit-rounded weights) the kernel reads, so what is left is the k
 fp32 accumulation (negligible) + ONE rounding of the result to the storage type.  Stated tolerance:
     bf16 storage: 2^-8 relative per element  -> 6e-3 of the tensor's max magnitude
     fp16 storage: 2^-11                      -> 1e-3
-    fp32 results computed from 16-bit inputs (statistics, weight gradients, SE vectors): 2e-4,
-    except the Winograd F(3,2) weight gradient, whose transformed operands (sums of two inputs) are
-    rounded to bf16 once more: 1e-2.
+    fp32 results computed from 16-bit inputs (statistics, weight gradients, SE vectors): 2e-4.
 """
 import pytest
 import torch
@@ -144,8 +142,8 @@ def test_conv16_wgrad(cfg):
         if packed:
             dw = Fn.unpack_wgrad(dw, like)
         torch.cuda.synchronize()
-        wino = Fn.wino_eligible(spec)       # Winograd F(3,2): operands rounded to bf16 once more
-        close(dw, wt.grad, tol=1e-2 if wino else 2e-4, what=f'wgrad16 (two_pass={two_pass})')
+        # direct products of the stored bf16 values, fp32 accumulation: fp32-kernel accuracy
+        close(dw, wt.grad, tol=2e-4, what=f'wgrad16 (two_pass={two_pass})')
         close(db, b.grad, tol=2e-4, what='dbias16')
 
 
