@@ -508,9 +508,10 @@ def bn_act(x, scale, shift, drop=None, residual=None, act=ACT_NONE, want_mask=Fa
     return (y, bits) if want_mask else y
 
 
-def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
+def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres, dg_out=None, db_out=None):
     """returns dx, dres (or None), dgamma, dbeta.  `y` = the activation output (ReLU mask y > 0)
-    or the int64 bit mask `bn_act(..., want_mask=True)` produced"""
+    or the int64 bit mask `bn_act(..., want_mask=True)` produced.  dg_out / db_out: destinations
+    of dgamma / dbeta (the parameters' flat gradient-bucket views)"""
     n, c, h, w = x.shape
     assert ld_of(x) == c and ld_of(dy) == c and dy.dtype == x.dtype
     L = _lib.lib()
@@ -524,11 +525,13 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres):
                  _p(drop), n, h * w, c, act, _p(partial), _stream()), 'emsa_bn_bwd_reduce')
     dx = act_empty(n, c, h, w, x.device, dtype=x.dtype)
     dres = act_empty(n, c, h, w, x.device, dtype=x.dtype) if want_dres else None
-    dgb = _empty((2, c), x.device)
+    if dg_out is None or db_out is None:
+        dgb = _empty((2, c), x.device)
+        dg_out, db_out = dgb[0], dgb[1]
     check(call_t('emsa_bn_bwd_apply', code, _p(dy), _p(y), _p(bits), _p(x), _p(gamma), _p(mean),
                  _p(invstd), _p(drop), _p(partial), rows, n, h * w, c, act, 1 if train else 0,
-                 _p(dx), _p(dres), _p(dgb[0]), _p(dgb[1]), _stream()), 'emsa_bn_bwd_apply')
-    return dx, dres, dgb[0], dgb[1]
+                 _p(dx), _p(dres), _p(dg_out), _p(db_out), _stream()), 'emsa_bn_bwd_apply')
+    return dx, dres, dg_out, db_out
 
 
 def dropout2d_mask(n, c, p, seed, layer_id, device):

@@ -283,6 +283,12 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
     return out, y, mean, invstd, mask
 
 
+def _bn_targets(brt):
+    """destinations of dgamma / dbeta inside the flat gradient buckets (or nothing)"""
+    tg, tb = grad_target(brt.bn.weight), grad_target(brt.bn.bias)
+    return {'dg_out': tg, 'db_out': tb} if tg is not None and tb is not None else {}
+
+
 def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None):
     """-> dx (or None), dw (OIHW), dbias (or None)"""
     conv = crt.conv
@@ -374,13 +380,13 @@ class NBt1DFunction(Function):
 
         # out = relu(bn2(y4)*drop + idn)
         dy4, dres, dg2, db2 = Fn.bn_bwd(dout, k2, y4, rt.bn2.bn.weight.detach(), m2, is2, drop,
-                                        ACT_RELU, t2, want_dres=True)
+                                        ACT_RELU, t2, want_dres=True, **_bn_targets(rt.bn2))
         # conv1x3_2 (input y3 = relu(.)): ReLU mask fused into the dgrad epilogue
         dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3, mask_bits=q3)
         # conv3x1_2 (input a2 = relu(bn1(y2)))
         da2, dw3, dbias3 = _conv_backward(a2, dz3, rt.c31_2, True)
         dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
-                                     ACT_RELU, t1, want_dres=False)
+                                     ACT_RELU, t1, want_dres=False, **_bn_targets(rt.bn1))
         dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1, mask_bits=q1)
         grads = []
         if rt.cds is None:
@@ -388,7 +394,8 @@ class NBt1DFunction(Function):
             dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dres)
         else:
             dyd, _, dgd, dbd = Fn.bn_bwd(dres, None, yd, rt.bnds.bn.weight.detach(), md, isd,
-                                         None, ACT_NONE, tds, want_dres=False)
+                                         None, ACT_NONE, tds, want_dres=False,
+                                         **_bn_targets(rt.bnds))
             dxd, dwd, _ = _conv_backward(x, dyd, rt.cds, need_dx)
             dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dxd)
         grads = [dw1, dbias1, dw2, dbias2, dg1, db1, dw3, dbias3, dw4, dbias4, dg2, db2]
@@ -438,7 +445,7 @@ class ConvBNActFunction(Function):
         ctx.saved = None
         dout = Fn.as_act(dout, dense=True)
         dy, _, dg, db = Fn.bn_bwd(dout, mask, y, ctx.brt.bn.weight.detach(), mean, invstd, None,
-                                  ctx.act, ctx.bn_train, want_dres=False)
+                                  ctx.act, ctx.bn_train, want_dres=False, **_bn_targets(ctx.brt))
         dx, dw, _ = _conv_backward(x, dy, ctx.crt, ctx.needs_input_grad[0])
         return dx, None, None, None, dw, dg, db
 
@@ -643,7 +650,7 @@ class StemFunction(Function):
         n, h, w = ctx.hw
         dout = Fn.as_act(dout, dense=True)
         dy, _, dg, db = Fn.bn_bwd(dout, mask, y, rt.brt.bn.weight.detach(), mean, invstd, None,
-                                  ACT_RELU, ctx.bn_train, want_dres=False)
+                                  ACT_RELU, ctx.bn_train, want_dres=False, **_bn_targets(rt.brt))
         res = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight,
                             out=grad_target(rt.conv.weight), want_bias=ctx.has_bias)
         dw, dbias = res if ctx.has_bias else (res, None)
