@@ -111,8 +111,12 @@ __device__ __forceinline__ uint32_t h_gather(const HGather& q, int img_off, int 
   return ok ? (uint32_t)(img_off + hn * q.row_stride + wn * q.px_stride) * 2u : kHOOB;
 }
 
-template <int BM, int BN, int WM, int WN, typename T>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 4 : 2) void conv_h_kernel(
+// PF = K steps of global loads in flight (register sets).  PF = 2 (a second register set, the loop
+// unrolled by two) was built to hide more load latency and measured 10-20 % slower on every layer
+// shape (106 / 166 / 253 VGPRs instead of 74 / 98 / 157); kept as an A/B switch (EMSA_CONVH_PF=2).
+template <int BM, int BN, int WM, int WN, typename T, int PF>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? (PF == 2 && BM * BN > 64 * 64 ? 3 : 4) : 2)
+void conv_h_kernel(
     const ConvHArgs p) {
   static_assert(WM * WN == 4, "4 waves");
   typedef typename Vec8<T>::type V8;
@@ -171,11 +175,11 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 4 : 2) void conv_h_ker
   const int steps = taps * p.kchunks;
   const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 2u;
   int tap_n = 0, kc_n = 0;
-  hu32x4 ra[AR], rb[BR];
+  hu32x4 rset[PF][AR + BR];
   // kHOOB for the lanes whose channels lie beyond k_ch in the last chunk of a tap
   const uint32_t last_oob = (p.kchunks - 1) * kHK + c8 < g.k_ch ? 0u : kHOOB;
 
-  auto load_regs = [&]() {
+  auto load_regs = [&](hu32x4 (&rr)[AR + BR]) {
     // (tap, channel chunk) are wave-uniform: the gathered pixel offsets change once per tap, the
     // channel advance travels in the scalar offset operand
     if (kc_n == 0) {
@@ -192,21 +196,21 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 4 : 2) void conv_h_ker
     // (no branch around the loads: a join behind them costs an s_waitcnt on the fresh data)
     const uint32_t pm = k0 + kHK > g.k_ch ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-    for (int j = 0; j < AR; ++j) ra[j] = h_ld16s(rs_in, a_off[j] | (last_oob & pm), sa);
+    for (int j = 0; j < AR; ++j) rr[j] = h_ld16s(rs_in, a_off[j] | (last_oob & pm), sa);
 #pragma unroll
-    for (int j = 0; j < BR; ++j) rb[j] = h_ld16s(rs_w, b_off[j] | (last_oob & pm), sb);
+    for (int j = 0; j < BR; ++j) rr[AR + j] = h_ld16s(rs_w, b_off[j] | (last_oob & pm), sb);
     if (++kc_n == p.kchunks) {
       kc_n = 0;
       ++tap_n;
     }
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](const hu32x4 (&rr)[AR + BR]) {
 #pragma unroll
     for (int j = 0; j < AR; ++j)
-      *reinterpret_cast<hu32x4*>(As + (rl + kRowsPerPass * j) * kHLD + c8) = ra[j];
+      *reinterpret_cast<hu32x4*>(As + (rl + kRowsPerPass * j) * kHLD + c8) = rr[j];
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<hu32x4*>(Bs + (rl + kRowsPerPass * j) * kHLD + c8) = rb[j];
+      *reinterpret_cast<hu32x4*>(Bs + (rl + kRowsPerPass * j) * kHLD + c8) = rr[AR + j];
   };
 
   f32x16 acc[TM][TN];
@@ -217,13 +221,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 4 : 2) void conv_h_ker
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_regs();
-  store_lds();
-  __syncthreads();
-
-  for (int s = 0; s < steps; ++s) {
-    const bool has_next = s + 1 < steps;
-    if (has_next) load_regs();
+  auto compute = [&]() {
     const T* a = As + (wm * TM * 32 + l31) * kHLD + lh * 8;
     const T* b = Bs + (wn * TN * 32 + l31) * kHLD + lh * 8;
     __builtin_amdgcn_s_setprio(1);
@@ -240,9 +238,41 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 4 : 2) void conv_h_ker
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
     }
     __builtin_amdgcn_s_setprio(0);
-    __syncthreads();                 // every wave is done reading the buffer
-    if (has_next) store_lds();
-    __syncthreads();
+  };
+
+  // step s: [issue the loads of step s + PF] -> MFMAs on the LDS tile of step s -> barrier ->
+  // LDS <- registers of step s + 1 (loaded PF - 1 iterations ago) -> barrier
+  load_regs(rset[0]);
+  if constexpr (PF == 2) {
+    if (steps > 1) load_regs(rset[1]);
+  }
+  store_lds(rset[0]);
+  __syncthreads();
+  if constexpr (PF == 1) {
+    for (int s = 0; s < steps; ++s) {
+      const bool has_next = s + 1 < steps;
+      if (has_next) load_regs(rset[0]);
+      compute();
+      __syncthreads();                 // every wave is done reading the buffer
+      if (has_next) store_lds(rset[0]);
+      __syncthreads();
+    }
+  } else {
+    // two register sets, unrolled by two so that each is addressed statically: at the top of
+    // iteration s set (s & 1) is free (its step s is in LDS) and set ((s + 1) & 1) is in flight
+    for (int s = 0; s < steps; s += 2) {
+      if (s + 2 < steps) load_regs(rset[0]);
+      compute();
+      __syncthreads();
+      if (s + 1 < steps) store_lds(rset[1]);
+      __syncthreads();
+      if (s + 1 >= steps) break;
+      if (s + 3 < steps) load_regs(rset[1]);
+      compute();
+      __syncthreads();
+      if (s + 2 < steps) store_lds(rset[0]);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -390,8 +420,12 @@ HTile pick_htile(long M, int n_ch) {
   const char* e = getenv("EMSA_CONVH_TILE");
   const int f = (e && *e) ? atoi(e) : -1;
   if (f >= 0 && f < HT_COUNT) return (HTile)f;
+  // measured per layer shape at bs=32 (tools/conv_bench16.py, us for 128x64 / 128x128 / 64x64):
+  // c64@/4 51 / 76 / 52, c128@/8 42 / 37 / 44, c256@/16 36 / 30 / 37, c512@/32 33 / 33 / 33,
+  // 3x3 256->128@/8 139 / 120 / 154 -- the differences are small: the loop is bound by the CU's
+  // load path (every tile is re-fetched through L1/L2), not by the tile's shape
+  if (n_ch >= 128 && M >= 128 * 256) return HT_128x128;
   if (M < 128 * 512) return HT_64x64;             // few pixels (low resolutions, batch 1): more tiles
-  if (n_ch >= 128) return HT_128x128;
   return HT_128x64;
 }
 
@@ -415,6 +449,16 @@ bool h_geom_ok(const EmsaConvGeom* g) {
   return true;
 }
 
+// EMSA_CONVH_PF=1|2: global-load prefetch depth (A/B; default 1)
+int convh_pf() {
+  static const int v = [] {
+    const char* e = getenv("EMSA_CONVH_PF");
+    const int x = e ? atoi(e) : 1;      // (two steps in flight measured 10-20 % SLOWER on every
+    return x == 2 ? 2 : 1;              //  layer shape: +32 VGPRs cost more occupancy than they hide)
+  }();
+  return v;
+}
+
 template <int BM, int BN, int WM, int WN, typename T>
 int launch_h(const ConvHArgs& a, hipStream_t st) {
   constexpr size_t lds_main = (size_t)(BM + BN) * kHLD * 2;
@@ -433,7 +477,10 @@ int launch_h(const ConvHArgs& a, hipStream_t st) {
                        (double)a.g.kh * a.g.kw * a.g.n_ch * a.g.k_ch * 2.0 +
                        (a.residual ? px_out : 0.0) + (a.mask_src ? px_out : 0.0);
   const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
-  hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T>), dim3(grid), dim3(256), lds, st, a);
+  if (convh_pf() == 2)
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 2>), dim3(grid), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1>), dim3(grid), dim3(256), lds, st, a);
   emsa_prof_end(ps, st);
   return emsa_launch_status();
 }
