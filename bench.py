@@ -76,7 +76,8 @@ def parse():
                     help='dtype of the gradient all-reduce buckets on the wire (bf16: half the xGMI '
                          'bytes, SURVEY 8e)')
     ap.add_argument('--graph', action='store_true',
-                    help='with --eval: replay the whole-model hipGraph (BASELINE config 5 shape)')
+                    help='replay the step from a hipGraph: with --eval the whole-model forward '
+                         '(BASELINE config 5 shape), otherwise the whole training step')
     return ap.parse_args()
 
 
@@ -276,6 +277,7 @@ def run(args):
     if args.eval and args.graph:
         from emsanet_amd.graph import GraphedInference
         graphed = GraphedInference(model, batch)
+    train_graph = None
 
     def step():
         nonlocal cots
@@ -285,6 +287,9 @@ def run(args):
                 return
             with torch.no_grad():
                 model(batch)
+            return
+        if train_graph is not None:
+            train_graph.replay()
             return
         buckets.reset()
         if crit is not None:
@@ -311,6 +316,24 @@ def run(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.graph and not args.eval:
+        # the whole training step (forward, backward, SGD) as ONE hipGraph replay; kernel timing by
+        # HIP events is not available inside a graph
+        from emsanet_amd.graph import GraphedTrainStep
+        if world > 1 or args.force_dist:
+            raise SystemExit("--graph captures the single-process training step")
+        flat0 = flatten_outputs(model(batch))
+        g = torch.Generator(device='cpu').manual_seed(4321)
+        cots = [(torch.randn(t.shape, generator=g) * 1e-3).to(dev).contiguous(
+            memory_format=torch.channels_last if t.dim() == 4 else torch.contiguous_format)
+            for t in flat0]
+        del flat0
+        args.no_kernel_timing = True
+        if crit is not None:
+            train_graph = GraphedTrainStep(model, batch, buckets, opt,
+                                           loss_fn=lambda out: crit(out, targets)[0])
+        else:
+            train_graph = GraphedTrainStep(model, batch, buckets, opt, cotangents=cots)
     for _ in range(args.warmup):
         step()
     buckets.reset_stats()
@@ -447,7 +470,7 @@ def run(args):
                    'global_batch': bs * world, 'parallelism': f'dp{world}',
                    'weights': 'random init (deterministic)',
                    'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval
-                   else ('train+losses' if args.losses else 'train')},
+                   else ('train+losses' if args.losses else 'train') + ('-hipgraph' if args.graph else '')},
         'roofline': roofline,
         'conv_kernels': kernels,
         'conv_mfma_time_share': round(conv_ms / (dt * 1e3), 4) if kernels else None,

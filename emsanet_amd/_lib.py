@@ -144,6 +144,9 @@ SIGNATURES = {
     'emsa_conv_wgrad_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P]),
     'emsa_pack_weight_t': (c_int, [c_int32, _P, _P, _P] + [c_int32] * 8 + [_P]),
     'emsa_stem_pack_weight_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, _P]),
+    'emsa_dropout2d_mask_dev': (c_int, [_P, c_int32, c_int32, c_float, _P, c_uint32, _P]),
+    'emsa_u32_add': (c_int, [_P, c_uint32, _P]),
+    'emsa_sgd_nesterov_dev': (c_int, [_P, _P, _P, c_int64, _P, _P]),
     'emsa_prof_enable': (c_int, [c_int32]),
     'emsa_prof_next_flops': (c_int, [ctypes.c_double]),
     'emsa_prof_reset': (c_int, []),

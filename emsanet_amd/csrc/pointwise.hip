@@ -439,10 +439,14 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   }
 }
 
+// state (optional): {base seed, training step} in DEVICE memory; the step's seed is
+// base + 0x632BE5AB * step like EMSANet._dropout_seed computes it on the host (a training step
+// captured in a hipGraph draws fresh masks at every replay)
 __global__ void dropout2d_mask_kernel(float* mask, int n, int c, float p, uint32_t seed,
-                                      uint32_t layer_id) {
+                                      uint32_t layer_id, const uint32_t* __restrict__ state) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * c) return;
+  if (state) seed = state[0] + 0x632BE5ABu * state[1];
   const uint32_t nn = i / c, cc = i % c;
   const uint32_t key = emsa_lowbias32(seed + layer_id * 0x9E3779B1u);
   const uint32_t h = emsa_lowbias32(key + nn * 0x85EBCA77u + cc * 0xC2B2AE3Du);
@@ -1115,6 +1119,10 @@ __global__ void head_act_bwd_kernel(const TO* __restrict__ dy, const TO* __restr
   }
 }
 
+__global__ void u32_add_kernel(uint32_t* p, uint32_t v) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p += v;
+}
+
 template <typename TS, typename TD>
 __global__ void copy_channels_kernel(const TS* __restrict__ x, int ld_x, TD* __restrict__ y,
                                      int ld_y, long pixels, int c) {
@@ -1153,9 +1161,16 @@ inline bool c4_ok(int c) { return c >= 4 && (c & 3) == 0 && c <= 1024; }
 //   d = g * grad_scale + wd * p;  buf = first ? d : mu * buf + d;  p -= lr * (d + mu * buf)
 // one pass: reads p, g, buf, writes p, buf (5 streams instead of the ~12 of a foreach SGD).
 // ------------------------------------------------------------------------------------------
+// hp (optional): the hyper-parameters {lr, momentum, weight_decay, grad_scale, first_step} in DEVICE
+// memory -- a training step captured in a hipGraph reads the schedule's current values at replay
+// time instead of the values baked into the launch
 __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g,
                                     float* __restrict__ m, long n4, long n, float lr, float mu,
-                                    float wd, float gs, int first) {
+                                    float wd, float gs, int first, const float* __restrict__ hp) {
+  if (hp) {
+    lr = hp[0]; mu = hp[1]; wd = hp[2]; gs = hp[3];
+    first = hp[4] != 0.f;
+  }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
        i += (long)gridDim.x * blockDim.x) {
     const float4 pv = emsa_ld4(p + i * 4), gv = emsa_ld4(g + i * 4);
@@ -1432,7 +1447,19 @@ extern "C" int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, u
                                    uint32_t layer_id, void* stream) {
   if (!mask) return EMSA_E_ARG;
   hipLaunchKernelGGL(dropout2d_mask_kernel, dim3((n * c + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, mask, n, c, p, seed, layer_id);
+                     (hipStream_t)stream, mask, n, c, p, seed, layer_id, (const uint32_t*)nullptr);
+  return emsa_launch_status();
+}
+extern "C" int emsa_dropout2d_mask_dev(float* mask, int32_t n, int32_t c, float p,
+                                       const uint32_t* state, uint32_t layer_id, void* stream) {
+  if (!mask || !state) return EMSA_E_ARG;
+  hipLaunchKernelGGL(dropout2d_mask_kernel, dim3((n * c + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, mask, n, c, p, 0u, layer_id, state);
+  return emsa_launch_status();
+}
+extern "C" int emsa_u32_add(uint32_t* counter, uint32_t value, void* stream) {
+  if (!counter) return EMSA_E_ARG;
+  hipLaunchKernelGGL(u32_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, value);
   return emsa_launch_status();
 }
 
@@ -1841,6 +1868,17 @@ extern "C" int emsa_sgd_nesterov(float* param, const float* grad, float* momentu
   const long n4 = (long)n / 4;
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0,
                      (hipStream_t)stream, param, grad, momentum_buf, n4, (long)n, lr, momentum,
-                     weight_decay, grad_scale, first_step ? 1 : 0);
+                     weight_decay, grad_scale, first_step ? 1 : 0, (const float*)nullptr);
+  return emsa_launch_status();
+}
+extern "C" int emsa_sgd_nesterov_dev(float* param, const float* grad, float* momentum_buf,
+                                     int64_t n, const float* hyper, void* stream) {
+  if (!param || !grad || !momentum_buf || !hyper) return EMSA_E_ARG;
+  if (n < 1) return EMSA_OK;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)momentum_buf)) & 15) return EMSA_E_SHAPE;
+  const long n4 = (long)n / 4;
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0,
+                     (hipStream_t)stream, param, grad, momentum_buf, n4, (long)n, 0.f, 0.f, 0.f,
+                     0.f, 0, hyper);
   return emsa_launch_status();
 }

@@ -535,9 +535,15 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, drop, act, train, want_dres, dg_out=No
 
 
 def dropout2d_mask(n, c, p, seed, layer_id, device):
+    """seed: int (host value) or an int32 device tensor {base seed, training step} -- the seed of the
+    step is then formed on the device (hipGraph-captured training steps)"""
     m = _empty((n, c), device)
-    check(_lib.lib().emsa_dropout2d_mask(_p(m), n, c, p, seed & 0xFFFFFFFF, layer_id, _stream()),
-          'emsa_dropout2d_mask')
+    if torch.is_tensor(seed):
+        check(_lib.lib().emsa_dropout2d_mask_dev(_p(m), n, c, p, _p(seed), layer_id, _stream()),
+              'emsa_dropout2d_mask_dev')
+    else:
+        check(_lib.lib().emsa_dropout2d_mask(_p(m), n, c, p, seed & 0xFFFFFFFF, layer_id,
+                                             _stream()), 'emsa_dropout2d_mask')
     return m
 
 

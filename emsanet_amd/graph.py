@@ -51,3 +51,90 @@ class GraphedInference:
 
     def outputs(self):
         return _flatten(self.static_out)
+
+
+class GraphedTrainStep:
+    """One whole training step -- forward, backward, fused SGD update -- captured in a hipGraph.
+
+    The eager step issues ~2,500 launches (kernels, zero-fills, gradient bookkeeping) and needs
+    35-40 ms of host time however small the batch is; at fp32 / bs=32 the GPU hides that, with
+    16-bit storage (58 ms of GPU work) or smaller batches it does not.  The replay needs one launch.
+
+    What makes the step replayable:
+      * static shapes: `example_batch` fixes them; inputs are copied into static tensors;
+      * Dropout2d masks: {seed, step} live in device memory (`EMSANet.use_device_dropout_state`),
+        the mask kernels form the step's seed on the device and a captured one-thread kernel bumps
+        the step counter -- every replay draws the masks the eager step would have drawn;
+      * learning rate / momentum: read by the update kernel from device memory
+        (`FusedSGD.use_device_hyperparameters`), `set_schedule()` between replays is honoured;
+      * gradients are (re)written in place: bucket views for the convolution / BatchNorm parameters,
+        graph-pool tensors for the rest; BatchNorm running statistics are updated by the captured
+        kernels, their step counters by `replay()` on the host.
+    `loss_fn(outputs) -> scalar` (or fixed cotangents, `cotangents=[...]` per flattened output).
+    Single process: the gradient all-reduce of the data-parallel path is not captured (RCCL
+    collectives issued from autograd hooks inside a capture are not supported here)."""
+
+    def __init__(self, model, example_batch, buckets, optimizer, loss_fn=None, cotangents=None,
+                 warmup=3):
+        if not model.training:
+            raise ValueError("GraphedTrainStep captures the train-mode step")
+        if buckets.active:
+            raise NotImplementedError("graph capture of the multi-rank step (collectives in hooks)")
+        if (loss_fn is None) == (cotangents is None):
+            raise ValueError("give either loss_fn or cotangents")
+        self.model, self.buckets, self.opt = model, buckets, optimizer
+        self.loss_fn, self.cots = loss_fn, cotangents
+        self.static_in = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
+        self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
+        model.use_device_dropout_state(True)
+        optimizer.use_device_hyperparameters(True)
+        from . import ops
+        self._bn_rts = [rt for rt in ops._BN_RTS if rt.bn.training]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):     # packs weights, sets kernel attributes, warms the pool
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pend = {id(rt): rt.pending_batches for rt in self._bn_rts}
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss, self.static_out = self._step()
+        # the capture RECORDED a step, it did not run one: take its host-side effects back (what
+        # ONE step adds to the host-side BatchNorm step counters is replayed by `replay()`)
+        self._bn_inc = [(rt, rt.pending_batches - pend[id(rt)]) for rt in self._bn_rts]
+        for rt, inc in self._bn_inc:
+            rt.pending_batches -= inc
+        model.dropout_step -= 1
+        model._seed_dev_host = (model.dropout_seed & 0xFFFFFFFF, model.dropout_step & 0xFFFFFFFF)
+        self.replays = 0
+
+    def _step(self):
+        self.buckets.reset()
+        out = self.model({**self.static_in, **self.extra})
+        flat = _flatten(out)
+        if self.loss_fn is not None:
+            loss = self.loss_fn(out)
+            loss.backward()
+        else:
+            loss = None
+            torch.autograd.backward(flat, self.cots)
+        self.buckets.finish()
+        self.opt.step()
+        return loss, out
+
+    def replay(self, batch=None):
+        """one training step on `batch` (same shapes as the example; None: the static inputs)"""
+        if batch is not None:
+            for k, v in self.static_in.items():
+                v.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        m = self.model
+        m.dropout_step += 1                      # (the device counter was bumped by the graph)
+        m._seed_dev_host = (m.dropout_seed & 0xFFFFFFFF, m.dropout_step & 0xFFFFFFFF)
+        for rt, inc in self._bn_inc:
+            rt.pending_batches += inc
+        self.opt.after_replay()
+        return self.static_loss, self.static_out

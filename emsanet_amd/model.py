@@ -106,6 +106,8 @@ class EMSANet(nn.Module):
         # Dropout2d bookkeeping (counter-based masks, one id per dropout layer)
         self.dropout_seed = 0
         self.dropout_step = 0
+        self._seed_dev = None        # device copy {seed, step} (see use_device_dropout_state)
+        self._seed_dev_host = None   # the host values the device copy corresponds to
         lid = 0
         for m in self.modules():
             if isinstance(m, Dropout2dHash):
@@ -148,7 +150,41 @@ class EMSANet(nn.Module):
         return self
 
     def _dropout_seed(self):
+        if self._seed_dev is not None:
+            return self._seed_dev
         return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF
+
+    def use_device_dropout_state(self, enable=True):
+        """keep {dropout_seed, dropout_step} in device memory and let the mask kernels form the
+        step's seed there (identical masks): a training step captured in a hipGraph then draws
+        fresh masks at every replay.  The host attributes stay the source of truth between steps
+        (`_sync_dropout_state` re-uploads them when they were changed by hand)."""
+        if not enable:
+            self._seed_dev = self._seed_dev_host = None
+            return self
+        dev = next(self.parameters()).device
+        self._seed_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        self._seed_dev_host = None
+        self._sync_dropout_state()
+        return self
+
+    def _sync_dropout_state(self):
+        if self._seed_dev is None:
+            return
+        now = (self.dropout_seed & 0xFFFFFFFF, self.dropout_step & 0xFFFFFFFF)
+        if now != self._seed_dev_host:
+            import numpy as np
+            host = torch.from_numpy(np.array(now, dtype=np.uint32).view(np.int32).copy())
+            self._seed_dev.copy_(host)
+            self._seed_dev_host = now
+
+    def _advance_dropout_step(self):
+        self.dropout_step += 1
+        if self._seed_dev is not None:
+            _lib.check(_lib.lib().emsa_u32_add(self._seed_dev[1:].data_ptr(), 1,
+                                               torch.cuda.current_stream().cuda_stream),
+                       'emsa_u32_add')
+            self._seed_dev_host = (self.dropout_seed & 0xFFFFFFFF, self.dropout_step & 0xFFFFFFFF)
 
     def forward(self, batch, do_postprocessing=False) -> Dict[str, Any]:
         """contract of /root/reference/emsanet/model.py:192-233: list of per-decoder
@@ -168,6 +204,8 @@ class EMSANet(nn.Module):
             raise _lib.EmsaError("float16 storage is an inference mode (no loss scaling); train "
                                  "in bfloat16 or float32")
         self._pack_plan.refresh(self.compute_dtype)
+        if self.training and not torch.cuda.is_current_stream_capturing():
+            self._sync_dropout_state()
 
         deep, skips = self.encoder(feeds)
         # the context module sees the fused rgb stream, or the only stream there is
@@ -177,7 +215,7 @@ class EMSANet(nn.Module):
         results = [dec((ctx, ctx_branches), skips, batch, do_postprocessing=do_postprocessing)
                    for dec in self.decoders.values()]
         if self.training:
-            self.dropout_step += 1
+            self._advance_dropout_step()
         if not do_postprocessing:
             return results
         merged = {}

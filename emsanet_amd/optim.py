@@ -53,6 +53,7 @@ class FusedSGD:
         self.buckets = buckets
         self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
         self._first = True
+        self._hyper = None           # device {lr, momentum, weight_decay, grad_scale, first_step}
         self.flat_params, self.flat_momentum = [], []
         with torch.no_grad():
             for flat_g, ps, views in buckets.buckets:
@@ -68,13 +69,41 @@ class FusedSGD:
 
     def set_schedule(self, lr, momentum):
         self.lr, self.momentum = float(lr), float(momentum)
+        self._upload_hyper()
+
+    def use_device_hyperparameters(self, enable=True):
+        """the update kernel reads {lr, momentum, weight_decay, grad_scale, first_step} from device
+        memory at run time instead of taking them as launch arguments: a training step captured in
+        a hipGraph follows the schedule (`set_schedule`) between replays"""
+        if enable:
+            self._hyper = torch.zeros(8, device=self.flat_params[0].device, dtype=torch.float32)
+            self._upload_hyper()
+        else:
+            self._hyper = None
+        return self
+
+    def _grad_scale(self):
+        b = self.buckets
+        return 1.0 / b.world if (b.active and not b.average and b.world > 1) else 1.0
+
+    def _upload_hyper(self):
+        if self._hyper is not None:
+            host = torch.tensor([self.lr, self.momentum, self.weight_decay, self._grad_scale(),
+                                 1.0 if self._first else 0.0, 0.0, 0.0, 0.0], dtype=torch.float32)
+            self._hyper.copy_(host)
+
+    def after_replay(self):
+        """bookkeeping after a hipGraph replay of a captured `step()`"""
+        if self._first:
+            self._first = False
+            self._upload_hyper()
 
     @torch.no_grad()
     def step(self):
         b = self.buckets
         # GradientBuckets(average=False) leaves the world SUM in the flat buffers: the 1/world
         # averaging is folded into the update kernel (no separate pass over the 254 MB)
-        scale = 1.0 / b.world if (b.active and not b.average and b.world > 1) else 1.0
+        scale = self._grad_scale()
         L = _lib.lib()
         for (flat_g, ps, views), fp, fm in zip(b.buckets, self.flat_params, self.flat_momentum):
             stray = [(v, p.grad) for v, p in zip(views, ps)
@@ -84,13 +113,22 @@ class FusedSGD:
                 flat_g.zero_()
             if stray:       # single-process mode: gradients were not gathered by the hooks
                 torch._foreach_copy_([v for v, _ in stray], [g for _, g in stray])
-            check(L.emsa_sgd_nesterov(Fn._p(fp), Fn._p(flat_g), Fn._p(fm), fp.numel(), self.lr,
-                                      self.momentum, self.weight_decay, scale,
-                                      1 if self._first else 0, Fn._stream()), 'emsa_sgd_nesterov')
+            if self._hyper is not None:
+                check(L.emsa_sgd_nesterov_dev(Fn._p(fp), Fn._p(flat_g), Fn._p(fm), fp.numel(),
+                                              Fn._p(self._hyper), Fn._stream()),
+                      'emsa_sgd_nesterov_dev')
+            else:
+                check(L.emsa_sgd_nesterov(Fn._p(fp), Fn._p(flat_g), Fn._p(fm), fp.numel(), self.lr,
+                                          self.momentum, self.weight_decay, scale,
+                                          1 if self._first else 0, Fn._stream()),
+                      'emsa_sgd_nesterov')
             # the kernel wrote the parameters through raw pointers: tell autograd (and with it the
             # engine's packed-weight caches, which key on `_version`) that they changed in place
             torch.autograd.graph.increment_version(ps)
-        self._first = False
+        if not torch.cuda.is_current_stream_capturing():
+            if self._first:
+                self._first = False
+                self._upload_hyper()
 
     def state_dict(self):
         return {'lr': self.lr, 'momentum': self.momentum, 'weight_decay': self.weight_decay,

@@ -234,6 +234,12 @@ int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t* mask_bits
 /* Dropout2d channel mask [n][c]: 0 or 1/(1-p); counter-based hash shared with the oracle */
 int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, uint32_t seed,
                         uint32_t layer_id, void* stream);
+/* the same with the seed in DEVICE memory: state = {base seed, training step}, seed of the step =
+ * base + 0x632BE5AB * step (what EMSANet._dropout_seed computes on the host); emsa_u32_add bumps the
+ * step counter on the stream.  A training step captured in a hipGraph draws fresh masks per replay. */
+int emsa_dropout2d_mask_dev(float* mask, int32_t n, int32_t c, float p, const uint32_t* state,
+                            uint32_t layer_id, void* stream);
+int emsa_u32_add(uint32_t* counter, uint32_t value, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling / squeeze-and-excitation fusion / upsampling
@@ -411,6 +417,10 @@ int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t total, float
 int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int64_t n, float lr,
                       float momentum, float weight_decay, float grad_scale, int32_t first_step,
                       void* stream);
+/* the same with {lr, momentum, weight_decay, grad_scale, first_step} read from DEVICE memory at run
+ * time (hipGraph-captured training step: the one-cycle schedule changes them between replays) */
+int emsa_sgd_nesterov_dev(float* param, const float* grad, float* momentum_buf, int64_t n,
+                          const float* hyper, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 16-bit convolution family (BASELINE configs[2] bf16 mixed-precision training, configs[4] 16-bit
