@@ -76,6 +76,23 @@ __device__ __forceinline__ void emsa_st1(emsa_f16* p, float v) { *p = (emsa_f16)
     default: return EMSA_E_ARG;                                         \
   }
 
+// Zero-fill by a KERNEL.  hipMemsetAsync is not used anywhere in this library: captured into a
+// hipGraph as a memset node it was found to be clobbered when other (eager) work that itself issues
+// memsets runs between two replays of the graph (ROCm 7.2: the gradients behind the pyramid-pooling
+// bilinear backward turned to garbage from the second replay on; kernels never showed this).
+static __global__ void emsa_zero_kernel(uint32_t* __restrict__ p, long n_words) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_words;
+       i += (long)gridDim.x * blockDim.x)
+    p[i] = 0u;
+}
+static inline void emsa_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const long words = (long)(bytes / 4);      // (every buffer zeroed here is a multiple of 4 bytes)
+  long blocks = (words + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(emsa_zero_kernel, dim3((int)blocks), dim3(256), 0, st, (uint32_t*)p, words);
+}
+
 // counter-based hash shared with oracle/emsanet_oracle.py (_lowbias32)
 __host__ __device__ __forceinline__ uint32_t emsa_lowbias32(uint32_t x) {
   x ^= x >> 16;

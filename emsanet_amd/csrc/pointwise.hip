@@ -1766,8 +1766,7 @@ template <typename T>
 static int bilinear_bwd_impl(const T* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
   if (!dy || !dx) return EMSA_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dx, 0, (size_t)n * ih * iw * c * sizeof(float), st) != hipSuccess)
-    return EMSA_E_LAUNCH;
+  emsa_zero_async(dx, (size_t)n * ih * iw * c * sizeof(float), st);
   const long total = (long)n * oh * ow * c;
   hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, dy, dx, n,
                      ih, iw, oh, ow, c, ld_dy);

@@ -286,7 +286,7 @@ extern "C" int emsa_instance_centers(const float* heat, int32_t ld, int32_t n, i
       top_k > kMaxCand)
     return EMSA_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws_count, 0, (size_t)n * sizeof(int), st) != hipSuccess) return EMSA_E_LAUNCH;
+  emsa_zero_async(ws_count, (size_t)n * sizeof(int), st);
   hipLaunchKernelGGL(center_nms_kernel, dim3(grid1d((long)n * h * w)), dim3(256), 0, st, heat, ld,
                      n, h, w, nms_kernel, threshold, fg, ws_count, ws_score, ws_pos);
   hipLaunchKernelGGL(center_topk_kernel, dim3(n), dim3(kMaxCand), 0, st, ws_count, ws_score, ws_pos,
@@ -345,8 +345,7 @@ extern "C" int emsa_panoptic_merge(const int64_t* semantic_idx, const int32_t* i
   hipStream_t st = (hipStream_t)stream;
   const int slots = top_k + 1;
   const long total = (long)n * hw;
-  if (hipMemsetAsync(ws_votes, 0, (size_t)n * slots * n_classes * sizeof(int32_t), st) != hipSuccess)
-    return EMSA_E_LAUNCH;
+  emsa_zero_async(ws_votes, (size_t)n * slots * n_classes * sizeof(int32_t), st);
   hipLaunchKernelGGL(panoptic_votes_kernel, dim3(grid1d(total)), dim3(256), 0, st, semantic_idx,
                      instance_ids, class_is_thing, (long)hw, total, n_classes, slots, ws_votes);
   hipLaunchKernelGGL(panoptic_class_kernel, dim3((n * slots + 255) / 256), dim3(256), 0, st, ws_votes,
