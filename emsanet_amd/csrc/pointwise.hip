@@ -5,6 +5,8 @@
 // (cdna_hip_programming.md Guideline 11/13).
 //
 // Reference modules these stand in for are cited per entry point in include/emsanet_hip.h.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -207,52 +209,103 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
   }
 }
 
+// ---- vector access per lane: 16 bytes = 4 fp32 or 8 16-bit channels ---------------------------
+// (the first 16-bit versions of the three BatchNorm passes moved 4 channels = 8 bytes per lane and
+//  ran at the SAME time as their fp32 twins on half the bytes: 35 vs 43, 35 vs 34, 23 vs 32 us)
+template <typename T> struct VecIO {
+  static constexpr int V = 8;
+  typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type E;
+  typedef E ev __attribute__((ext_vector_type(8)));
+  typedef float fv __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void load(const T* p, float (&v)[8]) {
+    const fv f = __builtin_convertvector(*reinterpret_cast<const ev*>(p), fv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f[k];
+  }
+  static __device__ __forceinline__ void store(T* p, const float (&v)[8]) {
+    fv f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = v[k];
+    *reinterpret_cast<ev*>(p) = __builtin_convertvector(f, ev);
+  }
+};
+template <> struct VecIO<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 f = emsa_ld4(p);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    emsa_st4(p, make_float4(v[0], v[1], v[2], v[3]));
+  }
+};
+template <int V>
+__device__ __forceinline__ void ldf(const float* p, float (&v)[V]) {       // V fp32 parameters
+#pragma unroll
+  for (int k = 0; k < V; k += 4) {
+    const float4 f = emsa_ld4(p + k);
+    v[k] = f.x; v[k + 1] = f.y; v[k + 2] = f.z; v[k + 3] = f.w;
+  }
+}
+
+// `cvn` = channel vectors per pixel (c / V), `totalv` = pixels * cvn.  mask_bits: (y > 0) as 1 bit
+// per element for the backward pass (which otherwise re-reads y only for this): the wave's 64
+// vector indices [i & ~63, +64) -> V words, one per component; lanes past the end are inactive and
+// contribute 0 bits
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ drop,
-                                  const T* __restrict__ residual, long hw, int c4n, long total4,
+                                  const T* __restrict__ residual, long hw, int cvn, long totalv,
                                   int act, uint64_t* __restrict__ mask_bits) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+  constexpr int V = VecIO<T>::V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalv;
        i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const long pix = i / c4n;
-    float4 v = emsa_ld4(x + i * 4);
-    const float4 sc = emsa_ld4(scale + c4 * 4), sh = emsa_ld4(shift + c4 * 4);
-    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
-    v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    const int cv = (int)(i % cvn);
+    const long pix = i / cvn;
+    float v[V], sc[V], sh[V];
+    VecIO<T>::load(x + i * V, v);
+    ldf<V>(scale + cv * V, sc);
+    ldf<V>(shift + cv * V, sh);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = v[k] * sc[k] + sh[k];
     if (drop) {
-      const float4 d = emsa_ld4(drop + (pix / hw) * (long)c4n * 4 + c4 * 4);
-      v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+      float d[V];
+      ldf<V>(drop + (pix / hw) * (long)cvn * V + cv * V, d);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] *= d[k];
     }
     if (residual) {
-      const float4 r = emsa_ld4(residual + i * 4);
-      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      float r[V];
+      VecIO<T>::load(residual + i * V, r);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] += r[k];
     }
     if (act == EMSA_ACT_RELU) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = fmaxf(v[k], 0.f);
     }
-    emsa_st4(y + i * 4, v);
+    VecIO<T>::store(y + i * V, v);
     if (mask_bits) {
-      // (y > 0) as 1 bit per element for the backward pass (which otherwise re-reads y only for
-      // this): the wave's 64 float4 indices [i & ~63, +64) -> 4 words, one per component; lanes
-      // past the end are inactive here and contribute 0 bits
-      const uint64_t b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f);
-      const uint64_t b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+      uint64_t b[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) b[k] = __ballot(v[k] > 0.f);
       if ((i & 63) == 0) {
-        uint64_t* m = mask_bits + (i >> 6) * 4;
-        m[0] = b0; m[1] = b1; m[2] = b2; m[3] = b3;
+        uint64_t* m = mask_bits + (i >> 6) * V;
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = b[k];
       }
     }
   }
 }
 
-// (y > 0) of float4 index i from the bit mask written by bn_act_fwd_kernel
-__device__ __forceinline__ void relu_mask4(const uint64_t* __restrict__ bits, long i, bool (&m)[4]) {
-  const uint64_t* w = bits + (i >> 6) * 4;
+// (y > 0) of vector index i from the bit mask written by bn_act_fwd_kernel
+template <int V>
+__device__ __forceinline__ void relu_maskv(const uint64_t* __restrict__ bits, long i, bool (&m)[V]) {
+  const uint64_t* w = bits + (i >> 6) * V;
   const int sh = (int)(i & 63);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) m[k] = (w[k] >> sh) & 1ull;
+  for (int k = 0; k < V; ++k) m[k] = (w[k] >> sh) & 1ull;
 }
 
 // generic "per-channel reduction of up to two float4 quantities over a pixel range":
@@ -288,51 +341,84 @@ __device__ __forceinline__ void column_reduce(long p0, long p1, int c4n, F f, fl
   }
 }
 
+// masked / dropped gradient of one vector and the BatchNorm input beside it (shared by the two
+// backward passes)
+template <typename T, int V>
+__device__ __forceinline__ void bn_bwd_load(const T* __restrict__ dy, const T* __restrict__ y,
+                                            const uint64_t* __restrict__ mask_bits,
+                                            const float* __restrict__ drop, long i, long pix,
+                                            long hw, int cvn, int cv, int act, float (&g)[V],
+                                            float (&gres)[V]) {
+  VecIO<T>::load(dy + i * V, g);
+  if (act == EMSA_ACT_RELU) {
+    if (mask_bits) {
+      bool m[V];
+      relu_maskv<V>(mask_bits, i, m);
+#pragma unroll
+      for (int k = 0; k < V; ++k) g[k] = m[k] ? g[k] : 0.f;
+    } else {
+      float yy[V];
+      VecIO<T>::load(y + i * V, yy);
+#pragma unroll
+      for (int k = 0; k < V; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) gres[k] = g[k];       // gradient of the residual operand
+  if (drop) {
+    float d[V];
+    ldf<V>(drop + ((pix / hw) * cvn + cv) * V, d);
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] *= d[k];
+  }
+}
+
+// block = (cvn channel vectors) x (256 / cvn row lanes) over a chunk of pixels -> partial sums
+// (sum g, sum g * xhat) per channel: partial = [2][rows_alloc][c], rows [0, gridDim.x) written here
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                      const uint64_t* __restrict__ mask_bits,
                                      const T* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ invstd,
-                                     const float* __restrict__ drop, long pixels, long hw, int c4n,
+                                     const float* __restrict__ drop, long pixels, long hw, int cvn,
                                      int act, int rows_alloc, float* __restrict__ partial) {
-  const int rows = gridDim.x;            // partial = [2][rows_alloc][c], rows [0, rows) written here
+  constexpr int V = VecIO<T>::V;
+  extern __shared__ __attribute__((aligned(16))) float cred[];   // [2][lanes][c]
+  const int rows = gridDim.x;
   const long chunk = (pixels + rows - 1) / rows;
   const long p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
-  float4 o1, o2;
-  bool leader;
-  int c4;
-  column_reduce(
-      p0, p1, c4n,
-      [&](long p, int cc, float4& t1, float4& t2) {
-        const long i = (p * c4n + cc) * 4;
-        float4 g = emsa_ld4(dy + i);
-        if (act == EMSA_ACT_RELU) {
-          if (mask_bits) {
-            bool m[4];
-            relu_mask4(mask_bits, p * c4n + cc, m);
-            g.x = m[0] ? g.x : 0.f; g.y = m[1] ? g.y : 0.f;
-            g.z = m[2] ? g.z : 0.f; g.w = m[3] ? g.w : 0.f;
-          } else {
-            const float4 yy = emsa_ld4(y + i);
-            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-          }
-        }
-        if (drop) {
-          const float4 d = emsa_ld4(drop + ((p / hw) * c4n + cc) * 4);
-          g.x *= d.x; g.y *= d.y; g.z *= d.z; g.w *= d.w;
-        }
-        const float4 xx = emsa_ld4(x + i);
-        const float4 mu = emsa_ld4(mean + cc * 4), is = emsa_ld4(invstd + cc * 4);
-        t1 = g;
-        t2.x = g.x * (xx.x - mu.x) * is.x; t2.y = g.y * (xx.y - mu.y) * is.y;
-        t2.z = g.z * (xx.z - mu.z) * is.z; t2.w = g.w * (xx.w - mu.w) * is.w;
-      },
-      o1, o2, leader, c4);
-  if (leader) {
-    const int c = c4n * 4;
-    emsa_st4(partial + ((long)0 * rows_alloc + blockIdx.x) * c + c4 * 4, o1);
-    emsa_st4(partial + ((long)1 * rows_alloc + blockIdx.x) * c + c4 * 4, o2);
+  const int lanes = kThreads / cvn, c = cvn * V;
+  const int cv = threadIdx.x % cvn, rl = threadIdx.x / cvn;
+  float a1[V], a2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) a1[k] = a2[k] = 0.f;
+  if (rl < lanes) {
+    float mu[V], is[V];
+    ldf<V>(mean + cv * V, mu);
+    ldf<V>(invstd + cv * V, is);
+    for (long p = p0 + rl; p < p1; p += lanes) {
+      const long i = p * cvn + cv;
+      float g[V], gres[V], xx[V];
+      bn_bwd_load<T, V>(dy, y, mask_bits, drop, i, p, hw, cvn, cv, act, g, gres);
+      VecIO<T>::load(x + i * V, xx);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        a1[k] += g[k];
+        a2[k] += g[k] * (xx[k] - mu[k]) * is[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      cred[(0 * lanes + rl) * c + cv * V + k] = a1[k];
+      cred[(1 * lanes + rl) * c + cv * V + k] = a2[k];
+    }
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < 2 * c; ch += blockDim.x) {
+    const int which = ch / c, cc = ch % c;
+    float a = 0.f;
+    for (int k = 0; k < lanes; ++k) a += cred[(which * lanes + k) * c + cc];
+    partial[((long)which * rows_alloc + blockIdx.x) * c + cc] = a;
   }
 }
 
@@ -377,19 +463,21 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     const float* __restrict__ drop,
                                     const float* __restrict__ partial, int rows,
                                     int rows_alloc, float* __restrict__ dbeta_out,
-                                    float* __restrict__ dgamma_out, long hw, int c4n,
-                                    long total4, float inv_count, int act, int train,
+                                    float* __restrict__ dgamma_out, long hw, int cvn,
+                                    long totalv, float inv_count, int act, int train,
                                     T* __restrict__ dx, T* __restrict__ dres) {
+  constexpr int V = VecIO<T>::V;
   // level 2 of the (sum dy, sum dy*xhat) reduction: merge the slice sums of bn_bwd_sum_kernel
   extern __shared__ __attribute__((aligned(16))) float sums[];   // [2][c]
+  const int c = cvn * V;
   float* const dbeta = sums;
-  float* const dgamma = sums + c4n * 4;
-  for (int ch = threadIdx.x; ch < c4n * 4; ch += blockDim.x) {
+  float* const dgamma = sums + c;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
     for (int sl = 0; sl < kBwdSlices; ++sl) {
-      a1 += (double)partial[((long)0 * rows_alloc + rows + sl) * (c4n * 4) + ch];
-      a2 += (double)partial[((long)1 * rows_alloc + rows + sl) * (c4n * 4) + ch];
+      a1 += (double)partial[((long)0 * rows_alloc + rows + sl) * c + ch];
+      a2 += (double)partial[((long)1 * rows_alloc + rows + sl) * c + ch];
     }
     dbeta[ch] = (float)a1;
     dgamma[ch] = (float)a2;
@@ -399,43 +487,29 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     }
   }
   __syncthreads();
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalv;
        i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const long pix = i / c4n;
-    float4 g = emsa_ld4(dy + i * 4);
-    if (act == EMSA_ACT_RELU) {
-      if (mask_bits) {
-        bool m[4];
-        relu_mask4(mask_bits, i, m);
-        g.x = m[0] ? g.x : 0.f; g.y = m[1] ? g.y : 0.f;
-        g.z = m[2] ? g.z : 0.f; g.w = m[3] ? g.w : 0.f;
-      } else {
-        const float4 yy = emsa_ld4(y + i * 4);
-        g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-        g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-      }
-    }
-    if (dres) emsa_st4(dres + i * 4, g);
-    if (drop) {
-      const float4 d = emsa_ld4(drop + (pix / hw) * (long)c4n * 4 + c4 * 4);
-      g.x *= d.x; g.y *= d.y; g.z *= d.z; g.w *= d.w;
-    }
-    const float4 ga = emsa_ld4(gamma + c4 * 4), is = emsa_ld4(invstd + c4 * 4);
-    float4 o;
+    const int cv = (int)(i % cvn);
+    const long pix = i / cvn;
+    float g[V], gres[V], o[V], ga[V], is[V];
+    bn_bwd_load<T, V>(dy, y, mask_bits, drop, i, pix, hw, cvn, cv, act, g, gres);
+    if (dres) VecIO<T>::store(dres + i * V, gres);
+    ldf<V>(gamma + cv * V, ga);
+    ldf<V>(invstd + cv * V, is);
     if (train) {
-      const float4 xx = emsa_ld4(x + i * 4);
-      const float4 mu = emsa_ld4(mean + c4 * 4);
-      const float4 db = emsa_ld4(dbeta + c4 * 4), dg = emsa_ld4(dgamma + c4 * 4);
-      o.x = ga.x * is.x * (g.x - db.x * inv_count - (xx.x - mu.x) * is.x * dg.x * inv_count);
-      o.y = ga.y * is.y * (g.y - db.y * inv_count - (xx.y - mu.y) * is.y * dg.y * inv_count);
-      o.z = ga.z * is.z * (g.z - db.z * inv_count - (xx.z - mu.z) * is.z * dg.z * inv_count);
-      o.w = ga.w * is.w * (g.w - db.w * inv_count - (xx.w - mu.w) * is.w * dg.w * inv_count);
+      float xx[V], mu[V], db[V], dg[V];
+      VecIO<T>::load(x + i * V, xx);
+      ldf<V>(mean + cv * V, mu);
+      ldf<V>(dbeta + cv * V, db);
+      ldf<V>(dgamma + cv * V, dg);
+#pragma unroll
+      for (int k = 0; k < V; ++k)
+        o[k] = ga[k] * is[k] * (g[k] - db[k] * inv_count - (xx[k] - mu[k]) * is[k] * dg[k] * inv_count);
     } else {
-      o.x = g.x * ga.x * is.x; o.y = g.y * ga.y * is.y;
-      o.z = g.z * ga.z * is.z; o.w = g.w * ga.w * is.w;
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] = g[k] * ga[k] * is[k];
     }
-    emsa_st4(dx + i * 4, o);
+    VecIO<T>::store(dx + i * V, o);
   }
 }
 
@@ -1342,18 +1416,23 @@ extern "C" int emsa_bn_fold(const float* gamma, const float* beta, const float* 
   return emsa_launch_status();
 }
 
+// 64-bit words of the (y > 0) bit mask of a tensor: V words per 64 channel vectors (V = 4 fp32 or 8
+// 16-bit channels per lane); the bound below covers both groupings
 extern "C" int64_t emsa_relu_mask_words(int64_t elements) {
-  return ((elements / 4 + 63) / 64) * 4;
+  return ((elements / 4 + 63) / 64) * 4 + 8;
 }
+// channel count admissible for the vectorised BatchNorm passes of storage type T
+template <typename T> static bool cv_ok(int c) { return c4_ok(c) && c % VecIO<T>::V == 0; }
 
 template <typename T>
 static int bn_act_fwd_impl(const T* x, T* y, const float* scale, const float* shift, const float* drop, const T* residual, int32_t n_img, int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits, void* stream) {
   if (!x || !y || !scale || !shift) return EMSA_E_ARG;
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
-  const long total4 = (long)n_img * hw * (c / 4);
-  hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(grid_for(total4)), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, y, scale, shift, drop, residual, (long)hw, c / 4,
-                     total4, act, mask_bits);
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
+  constexpr int V = VecIO<T>::V;
+  const long totalv = (long)n_img * hw * (c / V);
+  hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(grid_for(totalv)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, scale, shift, drop, residual, (long)hw, c / V,
+                     totalv, act, mask_bits);
   return emsa_launch_status();
 }
 extern "C" int emsa_bn_act_fwd(const float* x, float* y, const float* scale, const float* shift, const float* drop, const float* residual, int32_t n_img, int64_t hw, int32_t c, int32_t act, uint64_t* mask_bits, void* stream) {
@@ -1387,13 +1466,13 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* save_mean, const float* save_invstd, const float* drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream) {
   if (!dy || !x || !save_mean || !save_invstd || !partial) return EMSA_E_ARG;
   if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const long pixels = (long)n_img * hw;
   const int rows = bn_bwd_rows_for(pixels, c);
-  const int c4n = c / 4, lanes = kThreads / c4n;
+  const int cvn = c / VecIO<T>::V, lanes = kThreads / cvn;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
-                     dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, c4n, act,
+                     dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, cvn, act,
                      rows + kBwdSlices, partial);
   return emsa_launch_status();
 }
@@ -1414,20 +1493,21 @@ static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits,
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
     return EMSA_E_ARG;
   if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const long pixels = (long)n_img * hw;
   const int rows = bn_bwd_rows_for(pixels, c);
   if (rows_alloc != rows + kBwdSlices) return EMSA_E_ARG;
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32, kBwdSlices), dim3(256), 0, st, partial,
                      rows, rows_alloc, c);
-  const long total4 = pixels * (c / 4);
+  constexpr int V = VecIO<T>::V;
+  const long totalv = pixels * (c / V);
   // four workgroups per CU (the other streaming kernels: eight): measured -0.3 ms per step
-  int ap_grid = grid_for(total4);
+  int ap_grid = grid_for(totalv);
   if (ap_grid > 256 * 4) ap_grid = 256 * 4;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ap_grid), dim3(kThreads),
                      (size_t)2 * c * sizeof(float), st, dy, y, mask_bits, x, gamma, save_mean,
-                     save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / 4, total4,
+                     save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / V, totalv,
                      1.0f / (float)pixels, act, train, dx, dres);
   return emsa_launch_status();
 }
