@@ -108,10 +108,12 @@ class FusedSGD:
         for (flat_g, ps, views), fp, fm in zip(b.buckets, self.flat_params, self.flat_momentum):
             stray = [(v, p.grad) for v, p in zip(views, ps)
                      if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
-            missing = any(p.grad is None for p in ps)
+            # a parameter without a gradient this step contributes zeros -- only ITS slice is
+            # cleared: the backward kernels have written the other gradients straight into the bucket
+            missing = [v for v, p in zip(views, ps) if p.grad is None]
             if missing:
-                flat_g.zero_()
-            if stray:       # single-process mode: gradients were not gathered by the hooks
+                torch._foreach_zero_(missing)
+            if stray:       # gradients that were not written in place (or gathered by the hooks)
                 torch._foreach_copy_([v for v, _ in stray], [g for _, g in stray])
             if self._hyper is not None:
                 check(L.emsa_sgd_nesterov_dev(Fn._p(fp), Fn._p(flat_g), Fn._p(fm), fp.numel(),
