@@ -411,20 +411,26 @@ def run(args):
     kernels.sort(key=lambda k: -k['total_ms'])
     roofline = None
     traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-    except Exception:
-        pmc = None
+    pmc, pmc_file = None, None
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):      # newest measurement first
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            pmc_file = 'profiles/' + name
+            break
+        except Exception:
+            continue
     if kernels:
         k = kernels[0]
-        if pmc and (args.height, args.width, bs) == (480, 640, 32) and not args.eval:
+        if pmc and (args.height, args.width, bs) == (480, 640, 32) and not args.eval \
+                and args.dtype == 'f32':
             name = k['kernel'].replace(' ', '')
             ent = pmc['kernels'].get(name) or next(
                 (v for kk, v in pmc['kernels'].items() if kk.startswith(name + '<')), None)
             if ent:
                 traffic = ent['hbm_bytes_per_launch']
-                traffic_src = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / ' \
-                              'WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)'
+                traffic_src = f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                              f"command at commit {pmc.get('commit', 'of round 1')}, FETCH x2 gfx950 " \
+                              "correction; the PMC passes cannot run inside the timed bench)"
         roofline = {'bound': 'mfma', 'kernel': k['kernel'], 'achieved': k['tflops'],
                     'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(k['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,

@@ -1,7 +1,7 @@
 """gpurun_out/pmc_traffic/raw.json (tools/pmc_traffic.sh) -> profiles/<name>.json: HBM bytes per
 launch of every conv kernel class.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 128-B requests as 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section) -- checked against
-the 1 GiB calibration copies of the same pass.   usage: python tools/pmc_traffic_json.py raw.json out.json"""
+the 1 GiB calibration copies of the same pass.   usage: python tools/pmc_traffic_json.py raw.json out.json [commit]"""
 import json
 import sys
 
@@ -20,7 +20,8 @@ def main():
             if best is None or avg > best[1]:
                 best = (k, avg, v['launches'])
         calib[name] = best
-    out = {'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- '
+    commit = sys.argv[3] if len(sys.argv) > 3 else 'unknown'
+    out = {'commit': commit, 'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- '
                       'python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing '
                       '(after 4 calibration copies of 1 GiB)',
            'calibration': {
