@@ -204,7 +204,8 @@ class EMSANet(nn.Module):
             raise _lib.EmsaError("float16 storage is an inference mode (no loss scaling); train "
                                  "in bfloat16 or float32")
         self._pack_plan.refresh(self.compute_dtype)
-        if self.training and not torch.cuda.is_current_stream_capturing():
+        if self.training and self._seed_dev is not None and \
+                not torch.cuda.is_current_stream_capturing():
             self._sync_dropout_state()
 
         deep, skips = self.encoder(feeds)

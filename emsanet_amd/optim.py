@@ -127,10 +127,9 @@ class FusedSGD:
             # the kernel wrote the parameters through raw pointers: tell autograd (and with it the
             # engine's packed-weight caches, which key on `_version`) that they changed in place
             torch.autograd.graph.increment_version(ps)
-        if not torch.cuda.is_current_stream_capturing():
-            if self._first:
-                self._first = False
-                self._upload_hyper()
+        if self._first and (self._hyper is None or not torch.cuda.is_current_stream_capturing()):
+            self._first = False
+            self._upload_hyper()
 
     def state_dict(self):
         return {'lr': self.lr, 'momentum': self.momentum, 'weight_decay': self.weight_decay,
