@@ -12,7 +12,8 @@ a.normal_()
 for _ in range(4):
     b.copy_(a)
 torch.cuda.synchronize()
-sys.argv = ['bench.py', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-kernel-timing']
+sys.argv = ['bench.py', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-kernel-timing'] \
+    + os.environ.get('EMSA_PMC_BENCH_ARGS', '').split()
 exec(open(os.path.join(os.environ['GRAFT_REPO_ROOT'], 'bench.py')).read())
 PY
 for c in FETCH_SIZE WRITE_SIZE; do
