@@ -75,6 +75,10 @@ def parse():
     ap.add_argument('--grad-dtype', default='f32', choices=('f32', 'bf16'),
                     help='dtype of the gradient all-reduce buckets on the wire (bf16: half the xGMI '
                          'bytes, SURVEY 8e)')
+    ap.add_argument('--h2d', action='store_true',
+                    help='also time the same steps with every batch staged from pinned host memory '
+                         '(raw uint8/uint16 frames, overlapped copy, on-device normalisation); '
+                         'reported as h2d_staged beside the HBM-resident value')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step from a hipGraph: with --eval the whole-model forward '
                          '(BASELINE config 5 shape), otherwise the whole training step')
@@ -279,28 +283,30 @@ def run(args):
         graphed = GraphedInference(model, batch)
     train_graph = None
 
-    def step():
+    def step(fresh=None):
+        # `fresh`: a batch that was just staged from host memory (--h2d); default: the HBM-resident one
         nonlocal cots
+        b = batch if fresh is None else fresh
         if args.eval:
             if graphed is not None:
-                graphed(batch)
+                graphed(b)
                 return
             with torch.no_grad():
-                model(batch)
+                model(b)
             return
         if train_graph is not None:
-            train_graph.replay()
+            train_graph.replay(fresh)
             return
         buckets.reset()
         if crit is not None:
             # --losses: the complete training step (all task losses on device, weighted like the
             # reference's training command) instead of fixed output cotangents
-            total, _ = crit(model(batch), targets)
+            total, _ = crit(model(b), targets)
             total.backward()
             buckets.finish()
             opt.step()
             return
-        flat = flatten_outputs(model(batch))
+        flat = flatten_outputs(model(b))
         if cots is None:
             g = torch.Generator(device='cpu').manual_seed(4321)
             cots = [(torch.randn(t.shape, generator=g) * 1e-3).to(dev).contiguous(
@@ -350,6 +356,31 @@ def run(args):
     dt = time.perf_counter() - t0
     L.emsa_prof_enable(0)
     Fn.PROF_REAL_FLOPS = False
+    staged = None
+    if args.h2d:
+        # the same K steps once more with every batch coming from pinned HOST memory as raw uint8 /
+        # uint16 frames: copied on a separate stream while the previous step runs, normalised on
+        # the device (emsanet_amd/staging.py).  Reported beside `value`, never as `value`.
+        import itertools
+        from emsanet_amd.staging import BatchStager, pinned_raw_batch
+        raw = [pinned_raw_batch(bs, args.height, args.width, seed=77 + i) for i in range(3)]
+        stager = BatchStager(itertools.cycle(raw), dev, depth_stats=(2841.94, 1417.26))
+        feed = iter(stager)
+        for _ in range(2):
+            step(next(feed))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(next(feed))
+        barrier()
+        dt_h = time.perf_counter() - t1
+        per = sum(v.numel() * v.element_size() for v in raw[0].values())
+        staged = {'value': round(bs * world * args.steps / dt_h, 2), 'unit': 'images/s',
+                  'ms_per_step': round(1e3 * dt_h / args.steps, 2),
+                  'host_bytes_per_step': per,
+                  'input': 'raw uint8 RGB + uint16 depth frames in pinned host memory, H2D on a copy '
+                           'stream overlapped with the previous step, NormalizeRGB/NormalizeDepth + '
+                           'HWC->CHW as device kernels'}
     comm = None
     if dist.is_initialized():
         # evidence that the ranks really ran and exchanged: every rank reports (rank, device index,
@@ -503,6 +534,8 @@ def run(args):
         if step_gflop else None,
         'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         'comm': comm,
+        'input': 'resident in HBM before the timed region',
+        'h2d_staged': staged,
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args)
