@@ -86,6 +86,8 @@ SIGNATURES = {
     'emsa_up2x_dw3x3_fwd': (c_int, [_P] * 5 + [c_int32] * 4 + [_P]),
     'emsa_up2x_dw3x3_bwd_data': (c_int, [_P] * 3 + [c_int32] * 4 + [_P]),
     'emsa_up2x_dw3x3_bwd_weight': (c_int, [_P] * 4 + [c_int32] * 4 + [_P]),
+    'emsa_up2x_dw3x3_bwd': (c_int, [_P] * 6 + [c_int32] * 4 + [_P]),
+    'emsa_up2x_dw3x3_bwd_supported': (c_int, [c_int32, c_int32]),
     'emsa_adaptive_avgpool_fwd': (c_int, [_P, _P] + [c_int32] * 5 + [_P]),
     'emsa_adaptive_avgpool_bwd': (c_int, [_P, _P] + [c_int32] * 6 + [_P]),
     'emsa_bilinear_fwd': (c_int, [_P, _P] + [c_int32] * 7 + [_P]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     'emsa_up2x_dw3x3_fwd_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_up2x_dw3x3_bwd_data_t': (c_int, [c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_up2x_dw3x3_bwd_weight_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_up2x_dw3x3_bwd_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_adaptive_avgpool_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_adaptive_avgpool_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_bilinear_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),

@@ -1033,6 +1033,176 @@ __global__ void up2x_dw_bwd_weight_kernel(const TO* __restrict__ dy, const T* __
   }
 }
 
+// dx, dw and db in ONE pass over dy (the backward of the learned up-sampling reads a tensor four
+// times the size of everything else it touches; the two kernels above each stream it, and each
+// thread of them re-reads its 4x4 / 3x3 neighbourhood through the vector L1 at 16 loads per 16
+// bytes of result: 2.0-2.4 TB/s).  Here a workgroup stages a tile -- kUpTH x TW input pixels, i.e.
+// the (2 kUpTH + 2) x (2 TW + 2) patch of dy and the (kUpTH + 2) x (TW + 2) patch of x, CC channels
+// deep -- in LDS with full-line loads (every element leaves global memory once per tile) and
+// all neighbourhood re-reads are ds_read_b128.  A workgroup is bound to ONE channel chunk and walks
+// its share of the spatial tiles, so the ten weight / bias gradient accumulators stay in registers
+// over the whole launch and are reduced once at the end.
+//   one thread = (input pixel of the tile, 4 channels): rows p = 0..3 of the 4x4 neighbourhood are
+//   consumed as they are read (dx += dy * collapsed taps; rows 1, 2 x columns 1, 2 are the pixel's
+//   own 2x2 output quad and feed the 9 taps against the 3x3 x neighbourhood).
+constexpr int kUpTH = 4;
+//   CC and TW are template parameters: with run-time strides the ~45 LDS addresses of a thread are
+//   loop invariants that the compiler keeps in registers across the tile loop (on top of the 40
+//   accumulators: spills); with compile-time strides they are immediates off one base register.
+template <typename T, typename TO, int CC, int TW>
+__global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
+    const TO* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ wdw,
+    T* __restrict__ dx, float* __restrict__ dwt, float* __restrict__ db, int n, int h, int w,
+    int C, int bpc) {
+  extern __shared__ __attribute__((aligned(16))) float upsm[];
+  const int tid = threadIdx.x;
+  constexpr int tpp = CC >> 2;                // threads per input pixel
+  constexpr int npx = kUpTH * TW;
+  constexpr int DW = 2 * TW + 2, XW = TW + 2;   // patch widths in pixels
+  float* dyt = upsm;                          // [2 kUpTH + 2][DW][CC]
+  float* xt = dyt + (2 * kUpTH + 2) * DW * CC;   // [kUpTH + 2][XW][CC]
+  float* wc = xt + (kUpTH + 2) * XW * CC;     // [16][CC] collapsed taps of the data gradient
+  const int chunk = blockIdx.x / bpc, bic = blockIdx.x % bpc;
+  const int c0 = chunk * CC;
+  const int cw = min(CC, C - c0);             // live channels of this chunk
+  for (int j = tid; j < 16 * CC; j += kThreads) {
+    const int c = j % CC, pq = j / CC, pp = pq >> 2, qq = pq & 3;
+    float a = 0.f;
+    if (c < cw)
+      for (int kh = 0; kh < 3; ++kh) {
+        if (kh != 2 - pp && kh != 3 - pp) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          if (kw != 2 - qq && kw != 3 - qq) continue;
+          a += wdw[(c0 + c) * 9 + kh * 3 + kw];
+        }
+      }
+    wc[j] = a;
+  }
+  const bool active = tid < npx * tpp;
+  const int c4 = tid % tpp, pl = tid / tpp, lw = pl % TW, lh = pl / TW;
+  const bool cok = c4 * 4 < cw;
+  float4 acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = emsa_zero4();
+  const int tiles_w = (w + TW - 1) / TW, tiles_h = (h + kUpTH - 1) / kUpTH;
+  const long ntiles = (long)n * tiles_h * tiles_w;
+  const int OH = 2 * h, OW = 2 * w;
+  constexpr int V = VecIO<TO>::V, VX = VecIO<T>::V;
+  constexpr int uv = CC / V, uvx = CC / VX;
+  for (long t = bic; t < ntiles; t += bpc) {
+    const int tw_i = (int)(t % tiles_w);
+    const long r = t / tiles_w;
+    const int th_i = (int)(r % tiles_h), img = (int)(r / tiles_h);
+    const int h0 = th_i * kUpTH, w0 = tw_i * TW;
+    __syncthreads();                          // the previous tile has been consumed (and wc is set)
+    for (int u = tid; u < (2 * kUpTH + 2) * DW * uv; u += kThreads) {
+      const int cv = u % uv, px = u / uv, col = px % DW, row = px / DW;
+      const int oh = 2 * h0 - 1 + row, ow = 2 * w0 - 1 + col;
+      float v[V];
+      if (oh >= 0 && oh < OH && ow >= 0 && ow < OW && cv * V < cw) {
+        VecIO<TO>::load(dy + (((long)img * OH + oh) * OW + ow) * C + c0 + cv * V, v);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < V; k += 4)
+        emsa_st4(dyt + px * CC + cv * V + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+    }
+    for (int u = tid; u < (kUpTH + 2) * XW * uvx; u += kThreads) {
+      const int cv = u % uvx, px = u / uvx, col = px % XW, row = px / XW;
+      const int hh = h0 - 1 + row, ww = w0 - 1 + col;
+      float v[VX];
+      if (hh >= 0 && hh < h && ww >= 0 && ww < w && cv * VX < cw) {
+        VecIO<T>::load(x + (((long)img * h + hh) * w + ww) * C + c0 + cv * VX, v);
+      } else {
+#pragma unroll
+        for (int k = 0; k < VX; ++k) v[k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < VX; k += 4)
+        emsa_st4(xt + px * CC + cv * VX + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
+    }
+    __syncthreads();
+    if (active) {
+      // data gradient: the 4x4 dy neighbourhood against the collapsed taps, streamed
+      float4 d = emsa_zero4();
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 g = emsa_ld4(dyt + ((2 * lh + p) * DW + 2 * lw + q) * CC + c4 * 4);
+          const float4 ws = emsa_ld4(wc + (p * 4 + q) * CC + c4 * 4);
+          d.x += g.x * ws.x; d.y += g.y * ws.y; d.z += g.z * ws.z; d.w += g.w * ws.w;
+        }
+        // (without these the scheduler hoists all 45 LDS reads of the tile to the front and the
+        //  40 accumulator registers spill)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int ih = h0 + lh, iw = w0 + lw;
+      if (dx != nullptr && cok && ih < h && iw < w)
+        emsa_st4(dx + (((long)img * h + ih) * w + iw) * C + c0 + c4 * 4, d);
+      // weight gradient: the pixel's own 2x2 output quad stays in registers, the 3x3 x
+      // neighbourhood is streamed (entry (r, s) meets the taps with ((a+kh+1)>>1, (b+kw+1)>>1) ==
+      // (r, s); all conditions fold at compile time)
+      float4 g[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+          g[a][b2] = emsa_ld4(dyt + ((2 * lh + 1 + a) * DW + 2 * lw + 1 + b2) * CC + c4 * 4);
+          acc[9].x += g[a][b2].x; acc[9].y += g[a][b2].y;
+          acc[9].z += g[a][b2].z; acc[9].w += g[a][b2].w;
+        }
+#pragma unroll
+      for (int r2 = 0; r2 < 3; ++r2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+          const float4 v = emsa_ld4(xt + ((lh + r2) * XW + lw + s2) * CC + c4 * 4);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              if (((a + kh + 1) >> 1) != r2) continue;
+#pragma unroll
+              for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                  if (((b2 + kw + 1) >> 1) != s2) continue;
+                  float4& tt = acc[kh * 3 + kw];
+                  const float4 gg = g[a][b2];
+                  tt.x += gg.x * v.x; tt.y += gg.y * v.y; tt.z += gg.z * v.z; tt.w += gg.w * v.w;
+                }
+            }
+        }
+      }
+    }
+  }
+  // the accumulators of the npx pixel lanes -> one sum per (tap, channel), five taps per round so
+  // that the scratch fits the tile area
+  float* wred = upsm;                         // [npx][5][CC]
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (active)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) emsa_st4(wred + ((pl * 5 + t) * CC) + c4 * 4, acc[half * 5 + t]);
+    __syncthreads();
+    for (int o = tid; o < 5 * CC; o += kThreads) {
+      const int t = o / CC, ch = o % CC;
+      if (ch >= cw) continue;
+      float a = 0.f;
+      for (int k = 0; k < npx; ++k) a += wred[(k * 5 + t) * CC + ch];
+      const int tap = half * 5 + t;
+      if (tap < 9)
+        unsafeAtomicAdd(dwt + (c0 + ch) * 9 + tap, a);
+      else
+        unsafeAtomicAdd(db + c0 + ch, a);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // pyramid pooling
 // ------------------------------------------------------------------------------------------
@@ -1781,6 +1951,68 @@ extern "C" int emsa_up2x_dw3x3_bwd_weight_t(int32_t dtype, int32_t out_f32, cons
     case EMSA_DT_F32: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<float, float>((const TO_*)dy, (const float*)x, dw, db, n, h, w, c, stream); } else { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<float, float>((const TO_*)dy, (const float*)x, dw, db, n, h, w, c, stream); } }
     case EMSA_DT_BF16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<emsa_bf16, float>((const TO_*)dy, (const emsa_bf16*)x, dw, db, n, h, w, c, stream); } else { using TO_ = emsa_bf16; return up2x_dw3x3_bwd_weight_impl<emsa_bf16, emsa_bf16>((const TO_*)dy, (const emsa_bf16*)x, dw, db, n, h, w, c, stream); } }
     case EMSA_DT_F16: { if (out_f32) { using TO_ = float; return up2x_dw3x3_bwd_weight_impl<emsa_f16, float>((const TO_*)dy, (const emsa_f16*)x, dw, db, n, h, w, c, stream); } else { using TO_ = emsa_f16; return up2x_dw3x3_bwd_weight_impl<emsa_f16, emsa_f16>((const TO_*)dy, (const emsa_f16*)x, dw, db, n, h, w, c, stream); } }
+    default: return EMSA_E_ARG;
+  }
+}
+
+// fused backward (dx optional): geometry of the LDS tiles, see up2x_dw_bwd_fused_kernel.
+// Channel chunk / tile width pairs that are instantiated: whole pixels for c <= 64, 64-channel
+// chunks above; TW = 256 threads / (CC/4 threads per pixel) / kUpTH rows, capped at 16.
+static bool up2x_fused_geom(int c, int vmax, int* CC, int* TW) {
+  if (c % vmax) return false;
+  if (c == 8 || c == 16) { *CC = c; *TW = 16; return true; }
+  if (c == 32) { *CC = 32; *TW = 8; return true; }
+  if (c == 40) { *CC = 40; *TW = 6; return true; }
+  if (c >= 64 && c % 64 == 0) { *CC = 64; *TW = 4; return true; }
+  return false;
+}
+extern "C" int emsa_up2x_dw3x3_bwd_supported(int32_t c, int32_t esize) {
+  int CC, TW;
+  return up2x_fused_geom(c, esize == 4 ? 4 : 8, &CC, &TW) ? 1 : 0;
+}
+template <typename T, typename TO, int CC, int TW>
+static int up2x_dw3x3_bwd_launch(const TO* dy, const T* x, const float* wdw, T* dx, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  constexpr int npx = kUpTH * TW;
+  constexpr int tiles = (2 * kUpTH + 2) * (2 * TW + 2) * CC + (kUpTH + 2) * (TW + 2) * CC + 16 * CC;
+  constexpr int red = npx * 5 * CC;
+  constexpr size_t lds = sizeof(float) * (size_t)(tiles > red ? tiles : red);
+  const int nchunks = (c + CC - 1) / CC;
+  const long ntiles = (long)n * ((h + kUpTH - 1) / kUpTH) * ((w + TW - 1) / TW);
+  long bpc = 1024 / nchunks;
+  if (bpc > ntiles) bpc = ntiles;
+  if (bpc < 1) bpc = 1;
+  hipLaunchKernelGGL((up2x_dw_bwd_fused_kernel<T, TO, CC, TW>), dim3((unsigned)(bpc * nchunks)),
+                     dim3(kThreads), lds, (hipStream_t)stream, dy, x, wdw, dx, dw, db, n, h, w, c,
+                     (int)bpc);
+  return emsa_launch_status();
+}
+template <typename T, typename TO>
+static int up2x_dw3x3_bwd_impl(const TO* dy, const T* x, const float* wdw, T* dx, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  if (!dy || !x || !wdw || !dw || !db) return EMSA_E_ARG;
+  if (!c4_ok(c) || n < 1 || h < 1 || w < 1) return EMSA_E_SHAPE;
+  constexpr int vmax = VecIO<T>::V > VecIO<TO>::V ? VecIO<T>::V : VecIO<TO>::V;
+  int CC, TW;
+  if (!up2x_fused_geom(c, vmax, &CC, &TW)) return EMSA_E_SHAPE;
+  switch (CC) {
+    case 8: return up2x_dw3x3_bwd_launch<T, TO, 8, 16>(dy, x, wdw, dx, dw, db, n, h, w, c, stream);
+    case 16: return up2x_dw3x3_bwd_launch<T, TO, 16, 16>(dy, x, wdw, dx, dw, db, n, h, w, c, stream);
+    case 32: return up2x_dw3x3_bwd_launch<T, TO, 32, 8>(dy, x, wdw, dx, dw, db, n, h, w, c, stream);
+    case 40: return up2x_dw3x3_bwd_launch<T, TO, 40, 6>(dy, x, wdw, dx, dw, db, n, h, w, c, stream);
+    default: return up2x_dw3x3_bwd_launch<T, TO, 64, 4>(dy, x, wdw, dx, dw, db, n, h, w, c, stream);
+  }
+}
+extern "C" int emsa_up2x_dw3x3_bwd(const float* dy, const float* x, const float* wdw, float* dx, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  return up2x_dw3x3_bwd_impl<float, float>(dy, x, wdw, dx, dw, db, n, h, w, c, stream);
+}
+extern "C" int emsa_up2x_dw3x3_bwd_t(int32_t dtype, int32_t out_f32, const void* dy, const void* x, const float* wdw, void* dx, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: return up2x_dw3x3_bwd_impl<float, float>((const float*)dy, (const float*)x, wdw, (float*)dx, dw, db, n, h, w, c, stream);
+    case EMSA_DT_BF16:
+      if (out_f32) return up2x_dw3x3_bwd_impl<emsa_bf16, float>((const float*)dy, (const emsa_bf16*)x, wdw, (emsa_bf16*)dx, dw, db, n, h, w, c, stream);
+      return up2x_dw3x3_bwd_impl<emsa_bf16, emsa_bf16>((const emsa_bf16*)dy, (const emsa_bf16*)x, wdw, (emsa_bf16*)dx, dw, db, n, h, w, c, stream);
+    case EMSA_DT_F16:
+      if (out_f32) return up2x_dw3x3_bwd_impl<emsa_f16, float>((const float*)dy, (const emsa_f16*)x, wdw, (emsa_f16*)dx, dw, db, n, h, w, c, stream);
+      return up2x_dw3x3_bwd_impl<emsa_f16, emsa_f16>((const emsa_f16*)dy, (const emsa_f16*)x, wdw, (emsa_f16*)dx, dw, db, n, h, w, c, stream);
     default: return EMSA_E_ARG;
   }
 }

@@ -653,19 +653,27 @@ def up2x_dw_fwd(x, wdw, bias, skip=None, out_f32=False):
     return y
 
 
+# EMSA_UP2X_FUSED=0: the two separate passes (data / weight gradient) for A/B measurements
+UP2X_FUSED_BWD = os.environ.get('EMSA_UP2X_FUSED', '1') != '0'
+
+
 def up2x_dw_bwd(dy, x, wdw, need_dx=True):
     n, c, h, w = x.shape
     assert ld_of(dy) == c
     out_f32 = dy.dtype == torch.float32
     if not out_f32 and dy.dtype != x.dtype:
         raise _lib.EmsaError(f"up-sampling gradient {dy.dtype} for {x.dtype} features")
-    dx = None
-    if need_dx:
-        dx = act_empty(n, c, h, w, x.device, dtype=x.dtype)
-        check(_two('emsa_up2x_dw3x3_bwd_data', x, out_f32, _p(dy), _p(wdw), _p(dx), n, h, w, c,
-                   _stream()), 'emsa_up2x_dw3x3_bwd_data')
+    dx = act_empty(n, c, h, w, x.device, dtype=x.dtype) if need_dx else None
     dwb = torch.zeros(c * 10, device=x.device, dtype=torch.float32)
     dw, db = dwb[:c * 9], dwb[c * 9:]
+    if UP2X_FUSED_BWD and _lib.lib().emsa_up2x_dw3x3_bwd_supported(c, x.element_size()):
+        # one LDS-tiled pass over dy for dx, dw and db
+        check(_two('emsa_up2x_dw3x3_bwd', x, out_f32, _p(dy), _p(x), _p(wdw), _p(dx), _p(dw), _p(db),
+                   n, h, w, c, _stream()), 'emsa_up2x_dw3x3_bwd')
+        return dx, dw, db
+    if need_dx:
+        check(_two('emsa_up2x_dw3x3_bwd_data', x, out_f32, _p(dy), _p(wdw), _p(dx), n, h, w, c,
+                   _stream()), 'emsa_up2x_dw3x3_bwd_data')
     check(_two('emsa_up2x_dw3x3_bwd_weight', x, out_f32, _p(dy), _p(x), _p(dw), _p(db), n, h, w, c,
                _stream()), 'emsa_up2x_dw3x3_bwd_weight')
     return dx, dw, db

@@ -286,6 +286,12 @@ int emsa_up2x_dw3x3_bwd_data(const float* dy, const float* wdw, float* dx, int32
 /* dw [c][9] and db [c] accumulated with atomics: zero them first */
 int emsa_up2x_dw3x3_bwd_weight(const float* dy, const float* x, float* dw, float* db, int32_t n,
                                int32_t h, int32_t w, int32_t c, void* stream);
+/* The same backward in ONE pass over dy (LDS-tiled; dx may be NULL): the path the engine takes
+ * when emsa_up2x_dw3x3_bwd_supported(c, element size of the features) says so -- c in {8, 16, 32,
+ * 40} or a multiple of 64.  dw / db are accumulated with atomics: zero them first. */
+int emsa_up2x_dw3x3_bwd(const float* dy, const float* x, const float* wdw, float* dx, float* dw,
+                        float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_up2x_dw3x3_bwd_supported(int32_t c, int32_t esize);
 
 /* pyramid pooling ('ppm', emsanet/args.py:243-256): adaptive average pool to bins x bins and
  * bilinear (align_corners=False) upsampling back, written into a channel slice (ld_y)        */
@@ -486,6 +492,9 @@ int emsa_up2x_dw3x3_bwd_data_t(int32_t dtype, int32_t out_f32, const void* dy, c
     void* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int emsa_up2x_dw3x3_bwd_weight_t(int32_t dtype, int32_t out_f32, const void* dy, const void* x,
     float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
+int emsa_up2x_dw3x3_bwd_t(int32_t dtype, int32_t out_f32, const void* dy, const void* x, const
+    float* wdw, void* dx, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void*
+    stream);
 int emsa_adaptive_avgpool_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t h,
     int32_t w, int32_t c, int32_t bins, void* stream);
 int emsa_adaptive_avgpool_bwd_t(int32_t dtype, const void* dy, void* dx, int32_t n, int32_t h,

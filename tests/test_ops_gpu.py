@@ -460,6 +460,51 @@ def test_upsample_dw(c, cp):
     close(sg.grad, skip.grad, what='up dskip')
 
 
+@pytest.mark.parametrize('c', [8, 16, 32, 40, 64, 128])
+@pytest.mark.parametrize('shape', [(2, 5, 7), (1, 9, 33), (3, 4, 4)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_upsample_dw_backward_one_pass(c, shape, dtype, monkeypatch):
+    """the LDS-tiled single-pass backward (dx, dw, db from one read of dy) for every instantiated
+    (channel chunk, tile width) pair, tiles ragged in both directions: against the fp64 reference
+    and against the two separate passes; dy in the feature type and as fp32 (model boundary)"""
+    Fn = _fn()
+    n, h, w = shape
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, 1, 3, 3, seed=2, scale=0.3)
+    dy = rnd(n, c, 2 * h, 2 * w, seed=5)
+    if dtype != torch.float32:
+        x, dy16 = x.to(dtype).float(), dy.to(dtype).float()
+    else:
+        dy16 = dy
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    cases = [(dy16, to_act(dy16).to(dtype))]
+    if dtype != torch.float32:
+        cases.append((dy, to_act(dy)))               # fp32 cotangent of a 16-bit head
+    for dy_ref, dy_dev in cases:
+        xr = x.double().requires_grad_(True)
+        wr = wt.double().requires_grad_(True)
+        br = torch.zeros(c).double().requires_grad_(True)
+        y = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, br, padding=1, groups=c)
+        y.backward(dy_ref.double())
+        xd = to_act(x).to(dtype)
+        assert Fn._lib.lib().emsa_up2x_dw3x3_bwd_supported(c, xd.element_size()) == 1
+        monkeypatch.setattr(Fn, 'UP2X_FUSED_BWD', True)
+        dx, dw, db = Fn.up2x_dw_bwd(dy_dev, xd, wt.to(DEV).contiguous())
+        monkeypatch.setattr(Fn, 'UP2X_FUSED_BWD', False)
+        dx0, dw0, db0 = Fn.up2x_dw_bwd(dy_dev, xd, wt.to(DEV).contiguous())
+        assert dx.dtype == dtype
+        close(dx, xr.grad, tol=tol, what='one-pass dx')
+        close(dw.view(c, 1, 3, 3), wr.grad, tol=2e-4, what='one-pass dw')
+        close(db, br.grad, tol=2e-4, what='one-pass db')
+        close(dx, dx0.float().cpu(), tol=tol, what='one-pass dx vs separate passes')
+        close(dw, dw0.cpu(), tol=2e-4, what='one-pass dw vs separate passes')
+        # weight gradient only (dx not requested)
+        monkeypatch.setattr(Fn, 'UP2X_FUSED_BWD', True)
+        nodx, dw1, db1 = Fn.up2x_dw_bwd(dy_dev, xd, wt.to(DEV).contiguous(), need_dx=False)
+        assert nodx is None
+        close(dw1, dw.cpu(), tol=2e-4, what='one-pass dw without dx')
+
+
 def test_ppm_pieces():
     Fn = _fn()
     from emsanet_amd import ops
