@@ -565,37 +565,75 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
   }
 }
 
+// One thread = a 2x2 quad of INPUT pixels x V channels (16 bytes): the quad (2qh.., 2qw..) lies
+// under exactly the four windows (qh..qh+1, qw..qw+1), so four (dy, argmax) pairs are read for four
+// stores -- the pixel-per-thread form read 2.25 windows per pixel (4.5 loads per store) and moved
+// 2.4 TB/s.  Window (oh, ow) covers rows 2oh-1 .. 2oh+1: tap index kh = ih - 2oh + 1.
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ idx,
-                                   T* __restrict__ dx, int n, int h, int w, int c4n) {
-  const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;
-  const long total = (long)n * h * w * c4n;
+                                   T* __restrict__ dx, int n, int h, int w, int cvn) {
+  constexpr int V = VecIO<T>::V;
+  const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;      // also the number of quads per direction
+  const long total = (long)n * oh_n * ow_n * cvn;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long r = i / c4n;
-    const int iw = (int)(r % w); r /= w;
-    const int ih = (int)(r % h);
-    const int img = (int)(r / h);
-    float4 a = emsa_zero4();
-    // windows oh with oh*2-1 <= ih <= oh*2+1
-    for (int oh = (ih >> 1); oh <= ((ih + 1) >> 1); ++oh) {
-      if (oh < 0 || oh >= oh_n) continue;
-      const int kh = ih - (oh * 2 - 1);
-      for (int ow = (iw >> 1); ow <= ((iw + 1) >> 1); ++ow) {
-        if (ow < 0 || ow >= ow_n) continue;
-        const int kw = iw - (ow * 2 - 1);
-        const int t = kh * 3 + kw;
-        const long o = (((long)img * oh_n + oh) * ow_n + ow) * c4n + c4;
-        const char4 k = *reinterpret_cast<const char4*>(idx + o * 4);
-        const float4 g = emsa_ld4(dy + o * 4);
-        if (k.x == t) a.x += g.x;
-        if (k.y == t) a.y += g.y;
-        if (k.z == t) a.z += g.z;
-        if (k.w == t) a.w += g.w;
+    const int cv = (int)(i % cvn);
+    long r = i / cvn;
+    const int qw = (int)(r % ow_n); r /= ow_n;
+    const int qh = (int)(r % oh_n);
+    const int img = (int)(r / oh_n);
+    float acc[2][2][V];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[a][b2][k] = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int oh = qh + dh, ow = qw + dw;
+        if (oh >= oh_n || ow >= ow_n) continue;
+        const long o = ((((long)img * oh_n + oh) * ow_n + ow) * cvn + cv) * V;
+        float g[V];
+        VecIO<T>::load(dy + o, g);
+        int8_t kk[V];
+        if constexpr (V == 8) {
+          const uint2 raw = *reinterpret_cast<const uint2*>(idx + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            kk[k] = (int8_t)((raw.x >> (8 * k)) & 0xFF);
+            kk[4 + k] = (int8_t)((raw.y >> (8 * k)) & 0xFF);
+          }
+        } else {
+          const uint32_t raw = *reinterpret_cast<const uint32_t*>(idx + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) kk[k] = (int8_t)((raw >> (8 * k)) & 0xFF);
+        }
+        // quad pixel (a, b) = input (2qh + a, 2qw + b): kh = a - 2 dh + 1, kw = b - 2 dw + 1
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int kh = a - 2 * dh + 1;
+          if (kh < 0 || kh > 2) continue;
+#pragma unroll
+          for (int b2 = 0; b2 < 2; ++b2) {
+            const int kw = b2 - 2 * dw + 1;
+            if (kw < 0 || kw > 2) continue;
+            const int t = kh * 3 + kw;
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[a][b2][k] += (kk[k] == t) ? g[k] : 0.f;
+          }
+        }
       }
-    }
-    emsa_st4(dx + i * 4, a);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int ih = 2 * qh + a, iw = 2 * qw + b2;
+        if (ih < h && iw < w)
+          VecIO<T>::store(dx + ((((long)img * h + ih) * w + iw) * cvn + cv) * V, acc[a][b2]);
+      }
   }
 }
 
@@ -1736,10 +1774,11 @@ extern "C" int emsa_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, in
 template <typename T>
 static int maxpool3x3s2_bwd_impl(const T* dy, const int8_t* idx, T* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!dy || !dx || !idx) return EMSA_E_ARG;
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
-  const long total = (long)n * h * w * (c / 4);
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
+  constexpr int V = VecIO<T>::V;
+  const long total = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / V);
   hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dy, idx, dx, n, h, w, c / 4);
+                     (hipStream_t)stream, dy, idx, dx, n, h, w, c / V);
   return emsa_launch_status();
 }
 extern "C" int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {

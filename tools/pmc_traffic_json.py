@@ -3,6 +3,7 @@ launch of every conv kernel class.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx95
 128-B requests as 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section) -- checked against
 the 1 GiB calibration copies of the same pass.   usage: python tools/pmc_traffic_json.py raw.json out.json [commit]"""
 import json
+import os
 import sys
 
 
@@ -23,7 +24,7 @@ def main():
     commit = sys.argv[3] if len(sys.argv) > 3 else 'unknown'
     out = {'commit': commit, 'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- '
                       'python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing '
-                      '(after 4 calibration copies of 1 GiB)',
+                      + os.environ.get('EMSA_PMC_BENCH_ARGS', '') + ' (after 4 calibration copies of 1 GiB)',
            'calibration': {
                'copy_bytes': 1 << 30,
                'copy_kernel': calib['FETCH'][0][:80],
