@@ -75,8 +75,6 @@ def parse():
     ap.add_argument('--grad-dtype', default='f32', choices=('f32', 'bf16'),
                     help='dtype of the gradient all-reduce buckets on the wire (bf16: half the xGMI '
                          'bytes, SURVEY 8e)')
-    ap.add_argument('--wgrad-stream', action='store_true',
-                    help='weight gradients on a second HIP stream (emsanet_amd.parallel.WgradStream)')
     ap.add_argument('--h2d', action='store_true',
                     help='also time the same steps with every batch staged from pinned host memory '
                          '(raw uint8/uint16 frames, overlapped copy, on-device normalisation); '
@@ -246,9 +244,6 @@ def run(args):
     from emsanet_amd.parallel import GradientBuckets, broadcast_parameters
 
     L = _lib.lib()
-    if args.wgrad_stream:
-        from emsanet_amd import parallel as _par
-        _par.enable_wgrad_stream(True)
     a = full_args(input_height=args.height, input_width=args.width,
                   rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone,
                   compute_dtype={'f32': 'float32', 'bf16': 'bfloat16', 'f16': 'float16'}[args.dtype])

@@ -955,67 +955,10 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
   }
 }
 
-// Output-centric form: one thread = one OUTPUT pixel x 4 channels.  The kernel above writes, per
-// store instruction, every other output pixel (lanes run over INPUT pixels): with 40 channels a
-// pixel is 160 bytes, so each instruction leaves half-covered 64-byte sectors behind and the
-// 1.6 GB prediction map of the semantic head was written at 2.1-2.6 TB/s.  Here consecutive lanes
-// write consecutive output bytes (1 KiB per wave instruction); the price is 4 input loads per
-// output instead of 9 per 4, all of them L1/L2 hits on a tensor a quarter the size of the output.
-// An output row 2m+a reads up-sampled rows 2m+a-1 .. 2m+a+1 = input rows {m-1, m, m} (a = 0) or
-// {m, m, m+1} (a = 1): the 3x3 taps collapse onto a 2x2 input patch with per-parity weights
-// wq[parity a][parity b][2][2][c], summed once per workgroup into LDS.  Up-sampled rows outside the
-// image (zero padding) are exactly the input rows -1 / h, loaded as zeros.
-template <typename T, typename TO>
-__global__ void up2x_dw_fwd_out_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
-                                       const float* __restrict__ bias, const T* __restrict__ skip,
-                                       TO* __restrict__ y, int n, int h, int w, int c4n) {
-  extern __shared__ __attribute__((aligned(16))) float wq[];      // [2][2][2][2][C]
-  const int C = c4n * 4;
-  for (int j = threadIdx.x; j < 16 * C; j += blockDim.x) {
-    const int c = j % C, e = j / C;                   // e = ((a*2 + b)*2 + r)*2 + s
-    const int s2 = e & 1, r2 = (e >> 1) & 1, b = (e >> 2) & 1, a = e >> 3;
-    float acc = 0.f;
-    for (int kh = 0; kh < 3; ++kh) {
-      if ((((a + kh + 1) >> 1) - a) != r2) continue;   // input row offset of tap kh: m - 1 + ...
-      for (int kw = 0; kw < 3; ++kw) {
-        if ((((b + kw + 1) >> 1) - b) != s2) continue;
-        acc += wdw[c * 9 + kh * 3 + kw];
-      }
-    }
-    wq[e * C + c] = acc;
-  }
-  __syncthreads();
-  const int OH = 2 * h, OW = 2 * w;
-  const long total = (long)n * OH * OW * c4n;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long r = i / c4n;
-    const int ow = (int)(r % OW); r /= OW;
-    const int oh = (int)(r % OH);
-    const int img = (int)(r / OH);
-    const int a = oh & 1, b = ow & 1;
-    const int r0 = (oh >> 1) - 1 + a, s0 = (ow >> 1) - 1 + b;     // top-left of the 2x2 patch
-    float4 acc = bias ? emsa_ld4(bias + c4 * 4) : emsa_zero4();
-    const float* wp = wq + ((a * 2 + b) * 4) * C + c4 * 4;
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const int hh = r0 + rr, ww = s0 + ss;
-        if (hh < 0 || hh >= h || ww < 0 || ww >= w) continue;
-        const float4 v = emsa_ld4(x + ((((long)img * h + hh) * w + ww) * c4n + c4) * 4);
-        const float4 k = emsa_ld4(wp + (rr * 2 + ss) * C);
-        acc.x += v.x * k.x; acc.y += v.y * k.y; acc.z += v.z * k.z; acc.w += v.w * k.w;
-      }
-    if (skip) {
-      const float4 sk = emsa_ld4(skip + i * 4);
-      acc.x += sk.x; acc.y += sk.y; acc.z += sk.z; acc.w += sk.w;
-    }
-    emsa_st4(y + i * 4, acc);
-  }
-}
-
+// (An output-centric form -- one thread per OUTPUT pixel, consecutive lanes writing consecutive
+//  bytes, per-parity collapsed 2x2 taps -- was built to get rid of the half-covered sectors this
+//  kernel's stores leave behind at 40 channels; measured it is 0.2-0.4 % SLOWER per training step
+//  in both storage types: 16 L1 loads per four outputs instead of 9 cost what the stores gained.)
 // dx(ih,iw) = sum over the 4x4 output neighbourhood (2ih-1 .. 2ih+2) of dy * (collapsed taps):
 // output (oh,ow) touches input row ih through taps kh with ((oh+kh-1)>>1) == ih.
 template <typename T, typename TO>
@@ -1986,19 +1929,9 @@ static int up2x_dw3x3_fwd_impl(const T* x, const float* wdw, const float* bias, 
   if (!x || !wdw || !y) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * 4 * h * w * (c / 4);
-  // EMSA_UP2X_FWD=quad: the input-centric kernel (one thread per 2x2 output quad) for A/B runs
-  static const bool quad = [] {
-    const char* e = getenv("EMSA_UP2X_FWD");
-    return e && e[0] == 'q';
-  }();
-  if (quad)
-    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
-                       (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y,
-                       n, h, w, c / 4);
-  else
-    hipLaunchKernelGGL((up2x_dw_fwd_out_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
-                       (size_t)16 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y,
-                       n, h, w, c / 4);
+  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
+                     (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
+                     h, w, c / 4);
   return emsa_launch_status();
 }
 extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias, const float* skip, float* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {

@@ -19,7 +19,7 @@ from . import _lib
 from . import functional as Fn
 from ._lib import check
 from .functional import ACT_NONE, ACT_RELU
-from .parallel import grad_target, wgrad_stream
+from .parallel import grad_target
 
 # debug: set to a list to record (tag, tensor clone) for every backward's inputs and outputs
 TRACE = None
@@ -296,25 +296,12 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=
     # GradientBuckets manages the parameters (no gather copy later)
     tw = grad_target(conv.weight)
     tb = grad_target(conv.bias) if conv.bias is not None else None
-    side = wgrad_stream()
-    if side is not None and tw is not None and (conv.bias is None or tb is not None):
-        # off the critical path: the weight gradient runs on the side stream while this stream goes
-        # on with the data gradient and the next BatchNorm backward (parallel.WgradStream)
-        with torch.cuda.stream(side.begin()):
-            dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight,
-                                           dw_out=tw, db_out=tb)
-            if packed:
-                dw = Fn.unpack_wgrad(dw, conv.weight, out=tw)
-            elif dw.data_ptr() == tw.data_ptr():
-                dw = tw
-        side.end(x, dy, dw, db)
-    else:
-        dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight,
-                                       dw_out=tw, db_out=tb)
-        if packed:
-            dw = Fn.unpack_wgrad(dw, conv.weight, out=tw)
-        elif tw is not None and dw.data_ptr() == tw.data_ptr():
-            dw = tw
+    dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight,
+                                   dw_out=tw, db_out=tb)
+    if packed:
+        dw = Fn.unpack_wgrad(dw, conv.weight, out=tw)
+    elif tw is not None and dw.data_ptr() == tw.data_ptr():
+        dw = tw
     dx = None
     if need_dx:
         dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual,

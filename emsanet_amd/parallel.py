@@ -19,8 +19,6 @@ waits and averages (or leaves the sum for `FusedSGD`, which folds 1/world into i
 `comm_dtype=torch.bfloat16` exchanges the buckets as bf16 (half the xGMI bytes).
 With a single process nothing is copied or reduced at all.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -41,85 +39,6 @@ def grad_target(p):
     # tensor nobody else references; handed the long-lived view object itself it clones it -- one
     # memcpy per parameter per step (measured: 742 x 4 us) and a second copy back into the bucket
     return view.detach()
-
-
-class WgradStream:
-    """Weight gradients on a second HIP stream (`EMSA_WGRAD_STREAM=1`).
-
-    In the backward pass only the data gradients and the BatchNorm backward passes are on the
-    critical path; the weight gradient of a conv depends on nothing but that conv's input and
-    output gradient and nobody needs it before the bucket all-reduce / the optimizer.  Issued on a
-    side stream, the matrix-bound weight-gradient kernels can share the CUs with the
-    bandwidth-bound BatchNorm passes (and, in 16-bit storage, two latency-bound kernels can keep
-    twice the bytes in flight).  Only gradients that are written in place into a flat bucket
-    (`grad_target`) take this path: autograd then adopts the tensor without launching a kernel on
-    the main stream.
-
-    Lifetime of the operands: the side stream may lag the main stream by at most `depth`
-    convolutions -- the main stream waits for the event of the conv `depth` launches back and only
-    then drops its references to that conv's operands (so the caching allocator cannot hand their
-    memory to a main-stream kernel while the side stream still reads them; graph-capture safe,
-    unlike `Tensor.record_stream`).  `drain()` joins completely: called before a bucket is
-    all-reduced, at the end of every backward pass (autograd engine callback) and by `finish()`."""
-
-    def __init__(self, depth=6):
-        self.depth = depth
-        self.stream = None
-        self.pending = []            # [(event recorded on the side stream, operand references)]
-        self._callback_queued = False
-
-    def begin(self):
-        """-> the side stream, ordered behind everything enqueued on the current stream so far"""
-        if self.stream is None:
-            self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        if not self._callback_queued:
-            # join at the end of this backward pass, whoever reads the gradients next
-            from torch.autograd import Variable
-            try:
-                Variable._execution_engine.queue_callback(self._end_of_backward)
-                self._callback_queued = True
-            except RuntimeError:
-                pass                 # not inside a backward pass (direct call in a test)
-        return self.stream
-
-    def end(self, *operands):
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        self.pending.append((ev, operands))
-        while len(self.pending) > self.depth:
-            old, _ = self.pending.pop(0)
-            torch.cuda.current_stream().wait_event(old)
-
-    def drain(self):
-        if self.pending:
-            torch.cuda.current_stream().wait_event(self.pending[-1][0])
-            self.pending = []
-
-    def _end_of_backward(self):
-        self._callback_queued = False
-        self.drain()
-
-
-WGRAD_STREAM = WgradStream() if os.environ.get('EMSA_WGRAD_STREAM') == '1' else None
-
-
-def wgrad_stream():
-    """the process-wide side stream for weight gradients, or None (default: disabled)"""
-    return WGRAD_STREAM
-
-
-def enable_wgrad_stream(on=True, depth=6):
-    global WGRAD_STREAM
-    if WGRAD_STREAM is not None:
-        WGRAD_STREAM.drain()
-    WGRAD_STREAM = WgradStream(depth) if on else None
-    return WGRAD_STREAM
-
-
-def _drain_wgrad_stream():
-    if WGRAD_STREAM is not None:
-        WGRAD_STREAM.drain()
 
 
 class GradientBuckets:
@@ -197,7 +116,6 @@ class GradientBuckets:
         self._epoch += 1
 
     def _launch(self, bi):
-        _drain_wgrad_stream()             # gradients written on the side stream are complete
         flat, ps, views = self.buckets[bi]
         have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
         if len(have) != len(ps):
@@ -240,7 +158,6 @@ class GradientBuckets:
     def finish(self):
         """call after backward: wait for the collectives; gradients become the world average
         (`average=True`) or stay the world SUM (`average=False`: FusedSGD folds 1/world in)"""
-        _drain_wgrad_stream()
         if self.active:
             for bi in range(len(self.buckets)):
                 if not self._launched[bi]:      # some parameter received no gradient this step
