@@ -1080,109 +1080,144 @@ __global__ void up2x_dw_bwd_weight_kernel(const TO* __restrict__ dy, const T* __
 // thread of them re-reads its 4x4 / 3x3 neighbourhood through the vector L1 at 16 loads per 16
 // bytes of result: 2.0-2.4 TB/s).  Here a workgroup stages a tile -- kUpTH x TW input pixels, i.e.
 // the (2 kUpTH + 2) x (2 TW + 2) patch of dy and the (kUpTH + 2) x (TW + 2) patch of x, CC channels
-// deep -- in LDS with full-line loads (every element leaves global memory once per tile) and
-// all neighbourhood re-reads are ds_read_b128.  A workgroup is bound to ONE channel chunk and walks
-// its share of the spatial tiles, so the ten weight / bias gradient accumulators stay in registers
-// over the whole launch and are reduced once at the end.
-//   one thread = (input pixel of the tile, 4 channels): rows p = 0..3 of the 4x4 neighbourhood are
-//   consumed as they are read (dx += dy * collapsed taps; rows 1, 2 x columns 1, 2 are the pixel's
-//   own 2x2 output quad and feed the 9 taps against the 3x3 x neighbourhood).
+// deep -- in LDS (every element leaves global memory once per tile) and all neighbourhood
+// re-reads are LDS reads.  A workgroup is bound to ONE channel chunk and walks its share of the
+// spatial tiles, so the ten weight / bias gradient accumulators stay in registers over the whole
+// launch and are reduced once at the end.
+//   * Staging is LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no staging
+//     registers) into TWO tile buffers: the next tile's loads are in flight while this one is
+//     consumed, one barrier per tile.  The first version staged through registers: with the 40
+//     accumulators that made ~200 VGPRs = 2 workgroups per CU and no overlap inside a workgroup
+//     (1.2 ms for the 1.6 GB gradient of the semantic map, barely better than the two-pass form).
+//     The tiles are kept in their storage type; pixels outside the image are fetched from a
+//     16-byte zero page (a flat DMA has no out-of-range-reads-zero).
+//   * one thread = (input pixel of the tile, 4 channels): the 4x4 dy neighbourhood is streamed
+//     against the collapsed taps for dx; the pixel's own 2x2 output quad stays in registers and
+//     meets the streamed 3x3 x neighbourhood for the 9 taps.
+//   * CC and TW are template parameters: with run-time strides the ~45 LDS addresses of a thread
+//     are loop invariants the compiler keeps in registers across the tile loop.
 constexpr int kUpTH = 4;
-//   CC and TW are template parameters: with run-time strides the ~45 LDS addresses of a thread are
-//   loop invariants that the compiler keeps in registers across the tile loop (on top of the 40
-//   accumulators: spills); with compile-time strides they are immediates off one base register.
+__device__ const uint4 kUpZeroPage = {0u, 0u, 0u, 0u};
+
+template <typename E>
+__device__ __forceinline__ float4 up_lds4(const E* p) {       // 4 consecutive channels from LDS
+  if constexpr (std::is_same<E, float>::value) {
+    return *reinterpret_cast<const float4*>(p);
+  } else {
+    return emsa_ld4(p);
+  }
+}
+__device__ __forceinline__ void up_dma16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)src,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 template <typename T, typename TO, int CC, int TW>
 __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
     const TO* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ wdw,
     T* __restrict__ dx, float* __restrict__ dwt, float* __restrict__ db, int n, int h, int w,
     int C, int bpc) {
-  extern __shared__ __attribute__((aligned(16))) float upsm[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char upsm[];
   const int tid = threadIdx.x;
   constexpr int tpp = CC >> 2;                // threads per input pixel
   constexpr int npx = kUpTH * TW;
-  constexpr int DW = 2 * TW + 2, XW = TW + 2;   // patch widths in pixels
-  float* dyt = upsm;                          // [2 kUpTH + 2][DW][CC]
-  float* xt = dyt + (2 * kUpTH + 2) * DW * CC;   // [kUpTH + 2][XW][CC]
-  float* wc = xt + (kUpTH + 2) * XW * CC;     // [16][CC] collapsed taps of the data gradient
+  constexpr int DH = 2 * kUpTH + 2, DW = 2 * TW + 2, XH = kUpTH + 2, XW = TW + 2;
+  constexpr int kDyBytes = DH * DW * CC * (int)sizeof(TO);
+  constexpr int kXBytes = XH * XW * CC * (int)sizeof(T);
+  constexpr int kStage = kDyBytes + kXBytes;  // one tile buffer (multiple of 16)
+  constexpr int dy_upp = CC * (int)sizeof(TO) / 16, x_upp = CC * (int)sizeof(T) / 16;   // 16-B units per pixel
+  constexpr int dy_units = DH * DW * dy_upp, x_units = XH * XW * x_upp;
+  float* wc = reinterpret_cast<float*>(upsm + 2 * kStage);     // [16][CC] collapsed taps (data gradient)
   const int chunk = blockIdx.x / bpc, bic = blockIdx.x % bpc;
-  const int c0 = chunk * CC;
-  const int cw = min(CC, C - c0);             // live channels of this chunk
+  const int c0 = chunk * CC;                  // (C is CC or a multiple of it: every chunk is full)
   for (int j = tid; j < 16 * CC; j += kThreads) {
     const int c = j % CC, pq = j / CC, pp = pq >> 2, qq = pq & 3;
     float a = 0.f;
-    if (c < cw)
-      for (int kh = 0; kh < 3; ++kh) {
-        if (kh != 2 - pp && kh != 3 - pp) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-          if (kw != 2 - qq && kw != 3 - qq) continue;
-          a += wdw[(c0 + c) * 9 + kh * 3 + kw];
-        }
+    for (int kh = 0; kh < 3; ++kh) {
+      if (kh != 2 - pp && kh != 3 - pp) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kw != 2 - qq && kw != 3 - qq) continue;
+        a += wdw[(c0 + c) * 9 + kh * 3 + kw];
       }
+    }
     wc[j] = a;
   }
   const bool active = tid < npx * tpp;
   const int c4 = tid % tpp, pl = tid / tpp, lw = pl % TW, lh = pl / TW;
-  const bool cok = c4 * 4 < cw;
   float4 acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = emsa_zero4();
   const int tiles_w = (w + TW - 1) / TW, tiles_h = (h + kUpTH - 1) / kUpTH;
   const long ntiles = (long)n * tiles_h * tiles_w;
   const int OH = 2 * h, OW = 2 * w;
-  constexpr int V = VecIO<TO>::V, VX = VecIO<T>::V;
-  constexpr int uv = CC / V, uvx = CC / VX;
-  for (long t = bic; t < ntiles; t += bpc) {
+  const int wave_u0 = tid & ~63;              // first unit of this wave within a 256-unit round
+
+  // issue the DMA of tile t into buffer `buf`: unit u = (pixel of the patch, 16-byte piece)
+  auto issue = [&](long t, int buf) {
     const int tw_i = (int)(t % tiles_w);
     const long r = t / tiles_w;
     const int th_i = (int)(r % tiles_h), img = (int)(r / tiles_h);
     const int h0 = th_i * kUpTH, w0 = tw_i * TW;
-    __syncthreads();                          // the previous tile has been consumed (and wc is set)
-    for (int u = tid; u < (2 * kUpTH + 2) * DW * uv; u += kThreads) {
-      const int cv = u % uv, px = u / uv, col = px % DW, row = px / DW;
-      const int oh = 2 * h0 - 1 + row, ow = 2 * w0 - 1 + col;
-      float v[V];
-      if (oh >= 0 && oh < OH && ow >= 0 && ow < OW && cv * V < cw) {
-        VecIO<TO>::load(dy + (((long)img * OH + oh) * OW + ow) * C + c0 + cv * V, v);
-      } else {
+    unsigned char* sdy = upsm + buf * kStage;
+    unsigned char* sx = sdy + kDyBytes;
 #pragma unroll
-        for (int k = 0; k < V; ++k) v[k] = 0.f;
+    for (int u0 = 0; u0 < dy_units; u0 += kThreads) {
+      const int u = u0 + tid;
+      if (u < dy_units) {
+        const int cu = u % dy_upp, px = u / dy_upp, col = px % DW, row = px / DW;
+        const int oh = 2 * h0 - 1 + row, ow = 2 * w0 - 1 + col;
+        const bool in = oh >= 0 && oh < OH && ow >= 0 && ow < OW;
+        const void* src = in ? (const void*)(reinterpret_cast<const unsigned char*>(
+                                                 dy + (((long)img * OH + oh) * OW + ow) * C + c0) +
+                                             cu * 16)
+                             : (const void*)&kUpZeroPage;
+        up_dma16(src, sdy + (u0 + wave_u0) * 16);
       }
-#pragma unroll
-      for (int k = 0; k < V; k += 4)
-        emsa_st4(dyt + px * CC + cv * V + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
     }
-    for (int u = tid; u < (kUpTH + 2) * XW * uvx; u += kThreads) {
-      const int cv = u % uvx, px = u / uvx, col = px % XW, row = px / XW;
-      const int hh = h0 - 1 + row, ww = w0 - 1 + col;
-      float v[VX];
-      if (hh >= 0 && hh < h && ww >= 0 && ww < w && cv * VX < cw) {
-        VecIO<T>::load(x + (((long)img * h + hh) * w + ww) * C + c0 + cv * VX, v);
-      } else {
 #pragma unroll
-        for (int k = 0; k < VX; ++k) v[k] = 0.f;
+    for (int u0 = 0; u0 < x_units; u0 += kThreads) {
+      const int u = u0 + tid;
+      if (u < x_units) {
+        const int cu = u % x_upp, px = u / x_upp, col = px % XW, row = px / XW;
+        const int hh = h0 - 1 + row, ww = w0 - 1 + col;
+        const bool in = hh >= 0 && hh < h && ww >= 0 && ww < w;
+        const void* src = in ? (const void*)(reinterpret_cast<const unsigned char*>(
+                                                 x + (((long)img * h + hh) * w + ww) * C + c0) +
+                                             cu * 16)
+                             : (const void*)&kUpZeroPage;
+        up_dma16(src, sx + (u0 + wave_u0) * 16);
       }
-#pragma unroll
-      for (int k = 0; k < VX; k += 4)
-        emsa_st4(xt + px * CC + cv * VX + k, make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]));
     }
+  };
+
+  if (bic < ntiles) issue(bic, 0);
+  int buf = 0;
+  for (long t = bic; t < ntiles; t += bpc, buf ^= 1) {
+    // this wave's pieces of tile t have landed; after the barrier everybody's have, and everybody
+    // is done reading the other buffer (tile t - bpc) -> refill it while tile t is consumed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (t + bpc < ntiles) issue(t + bpc, buf ^ 1);
+    const int tw_i = (int)(t % tiles_w);
+    const long r = t / tiles_w;
+    const int th_i = (int)(r % tiles_h), img = (int)(r / tiles_h);
+    const int h0 = th_i * kUpTH, w0 = tw_i * TW;
+    const TO* dyt = reinterpret_cast<const TO*>(upsm + buf * kStage);
+    const T* xt = reinterpret_cast<const T*>(upsm + buf * kStage + kDyBytes);
     if (active) {
       // data gradient: the 4x4 dy neighbourhood against the collapsed taps, streamed
       float4 d = emsa_zero4();
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 g = emsa_ld4(dyt + ((2 * lh + p) * DW + 2 * lw + q) * CC + c4 * 4);
-          const float4 ws = emsa_ld4(wc + (p * 4 + q) * CC + c4 * 4);
+          const float4 g = up_lds4(dyt + ((2 * lh + p) * DW + 2 * lw + q) * CC + c4 * 4);
+          const float4 ws = *reinterpret_cast<const float4*>(wc + (p * 4 + q) * CC + c4 * 4);
           d.x += g.x * ws.x; d.y += g.y * ws.y; d.z += g.z * ws.z; d.w += g.w * ws.w;
         }
-        // (without these the scheduler hoists all 45 LDS reads of the tile to the front and the
-        //  40 accumulator registers spill)
-        __builtin_amdgcn_sched_barrier(0);
-      }
       const int ih = h0 + lh, iw = w0 + lw;
-      if (dx != nullptr && cok && ih < h && iw < w)
+      if (dx != nullptr && ih < h && iw < w)
         emsa_st4(dx + (((long)img * h + ih) * w + iw) * C + c0 + c4 * 4, d);
       // weight gradient: the pixel's own 2x2 output quad stays in registers, the 3x3 x
       // neighbourhood is streamed (entry (r, s) meets the taps with ((a+kh+1)>>1, (b+kw+1)>>1) ==
@@ -1192,16 +1227,15 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) {
-          g[a][b2] = emsa_ld4(dyt + ((2 * lh + 1 + a) * DW + 2 * lw + 1 + b2) * CC + c4 * 4);
+          g[a][b2] = up_lds4(dyt + ((2 * lh + 1 + a) * DW + 2 * lw + 1 + b2) * CC + c4 * 4);
           acc[9].x += g[a][b2].x; acc[9].y += g[a][b2].y;
           acc[9].z += g[a][b2].z; acc[9].w += g[a][b2].w;
         }
 #pragma unroll
-      for (int r2 = 0; r2 < 3; ++r2) {
-        __builtin_amdgcn_sched_barrier(0);
+      for (int r2 = 0; r2 < 3; ++r2)
 #pragma unroll
         for (int s2 = 0; s2 < 3; ++s2) {
-          const float4 v = emsa_ld4(xt + ((lh + r2) * XW + lw + s2) * CC + c4 * 4);
+          const float4 v = up_lds4(xt + ((lh + r2) * XW + lw + s2) * CC + c4 * 4);
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1218,22 +1252,21 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
                 }
             }
         }
-      }
     }
   }
   // the accumulators of the npx pixel lanes -> one sum per (tap, channel), five taps per round so
   // that the scratch fits the tile area
-  float* wred = upsm;                         // [npx][5][CC]
+  float* wred = reinterpret_cast<float*>(upsm);          // [npx][5][CC]
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
     if (active)
 #pragma unroll
-      for (int t = 0; t < 5; ++t) emsa_st4(wred + ((pl * 5 + t) * CC) + c4 * 4, acc[half * 5 + t]);
+      for (int t = 0; t < 5; ++t)
+        *reinterpret_cast<float4*>(wred + ((pl * 5 + t) * CC) + c4 * 4) = acc[half * 5 + t];
     __syncthreads();
     for (int o = tid; o < 5 * CC; o += kThreads) {
       const int t = o / CC, ch = o % CC;
-      if (ch >= cw) continue;
       float a = 0.f;
       for (int k = 0; k < npx; ++k) a += wred[(k * 5 + t) * CC + ch];
       const int tap = half * 5 + t;
@@ -2016,9 +2049,17 @@ extern "C" int emsa_up2x_dw3x3_bwd_supported(int32_t c, int32_t esize) {
 template <typename T, typename TO, int CC, int TW>
 static int up2x_dw3x3_bwd_launch(const TO* dy, const T* x, const float* wdw, T* dx, float* dw, float* db, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   constexpr int npx = kUpTH * TW;
-  constexpr int tiles = (2 * kUpTH + 2) * (2 * TW + 2) * CC + (kUpTH + 2) * (TW + 2) * CC + 16 * CC;
-  constexpr int red = npx * 5 * CC;
-  constexpr size_t lds = sizeof(float) * (size_t)(tiles > red ? tiles : red);
+  constexpr int stage = (2 * kUpTH + 2) * (2 * TW + 2) * CC * (int)sizeof(TO) +
+                        (kUpTH + 2) * (TW + 2) * CC * (int)sizeof(T);
+  constexpr int tiles = 2 * stage + 16 * CC * (int)sizeof(float);
+  constexpr int red = npx * 5 * CC * (int)sizeof(float);
+  constexpr size_t lds = (size_t)(tiles > red ? tiles : red);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_fused_kernel<T, TO, CC, TW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
   const int nchunks = (c + CC - 1) / CC;
   const long ntiles = (long)n * ((h + kUpTH - 1) / kUpTH) * ((w + TW - 1) / TW);
   long bpc = 1024 / nchunks;
