@@ -47,6 +47,12 @@ SIGNATURES = {
     'emsa_conv1d_wino_supported': (c_int, [_GP]),
     'emsa_conv1d_wino_stats_rows': (c_int, [_GP]),
     'emsa_conv_relu_bits_words': (c_int64, [c_int64, c_int32]),
+    'emsa_conv1d_wino_bnb': (c_int, [_GP, _P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P,
+                                     c_int32, _P]),
+    'emsa_conv_igemm_bnb_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P, _P,
+                                      _P, c_int32, _P]),
+    'emsa_bn_bwd_apply_rows_t': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64,
+                                         c_int32, c_int32, _P, _P, _P, _P]),
     'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P,
                                  _P, _P]),
     'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),

@@ -76,6 +76,14 @@ struct ConvHArgs {
   const float* shift;
   const void* residual;
   const void* mask_src;
+  // BatchNorm-backward sums fused into a data gradient (emsa_conv_igemm_bnb_t): mask_src = t (the
+  // BatchNorm input), scale / shift = the BatchNorm's affine form (used for the ReLU mask of
+  // a = relu(bn(t)) only, NOT applied to the result); the stored result is g = dz * (a > 0) and
+  // bnb_out receives per pixel tile  sum g  and  sum g * (t - mean) * invstd
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  float* bnb_out;                   // [2][bnb_rows_alloc][n_ch]
+  int bnb_rows_alloc;
   int ld_res, ld_mask, act;
   int M, tiles_m, tiles_n, kchunks;
   uint32_t in_bytes, w_bytes;
@@ -114,8 +122,10 @@ __device__ __forceinline__ uint32_t h_gather(const HGather& q, int img_off, int 
 // PF = K steps of global loads in flight (register sets).  PF = 2 (a second register set, the loop
 // unrolled by two) was built to hide more load latency and measured 10-20 % slower on every layer
 // shape (106 / 166 / 253 VGPRs instead of 74 / 98 / 157); kept as an A/B switch (EMSA_CONVH_PF=2).
-template <int BM, int BN, int WM, int WN, typename T, int PF>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? (PF == 2 && BM * BN > 64 * 64 ? 3 : 4) : 2)
+// BNB: the epilogue with the fused BatchNorm-backward sums (ConvHArgs::bnb_out) as its own
+// instantiation (its accumulators and channel vectors spilled in the common kernel).
+template <int BM, int BN, int WM, int WN, typename T, int PF, bool BNB = false>
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? ((PF == 2 || BNB) && BM * BN > 64 * 64 ? 3 : 4) : 2)
 void conv_h_kernel(
     const ConvHArgs p) {
   static_assert(WM * WN == 4, "4 waves");
@@ -359,9 +369,17 @@ void conv_h_kernel(
   const int n = n0 + col8 * 8;
   const bool nok = n < g.n_ch;
   float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sc1 = sc0, sh0 = emsa_zero4(), sh1 = sh0;
-  if (p.scale && nok) {
+  constexpr bool bnb = BNB;
+  if (p.scale && nok && !bnb) {
     sc0 = emsa_ld4(p.scale + n); sc1 = emsa_ld4(p.scale + n + 4);
     sh0 = emsa_ld4(p.shift + n); sh1 = emsa_ld4(p.shift + n + 4);
+  }
+  hf32x8 bsc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, b0 = bsc, b1 = bsc;
+  if (bnb && nok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bsc[e] = p.scale[n + e]; bsh[e] = p.shift[n + e]; bmu[e] = p.bnb_mean[n + e];
+    }
   }
   const T* const res = reinterpret_cast<const T*>(p.residual);
   const T* const msk = reinterpret_cast<const T*>(p.mask_src);
@@ -395,7 +413,17 @@ void conv_h_kernel(
           const V8 rr = *reinterpret_cast<const V8*>(res + (size_t)m * p.ld_res + n);
           v += __builtin_convertvector(rr, hf32x8);
         }
-        if (msk) {
+        if constexpr (bnb) {
+          // msk = t: a = t * scale + shift as bn_act_fwd forms it; g = dz * (a > 0)
+          const hf32x8 tt =
+              __builtin_convertvector(*reinterpret_cast<const V8*>(msk + (size_t)m * p.ld_mask + n), hf32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = (tt[e] * bsc[e] + bsh[e]) > 0.f ? v[e] : 0.f;
+            b0[e] += v[e];
+            b1[e] += v[e] * (tt[e] - bmu[e]);
+          }
+        } else if (msk) {
           const hf32x8 mm =
               __builtin_convertvector(*reinterpret_cast<const V8*>(msk + (size_t)m * p.ld_mask + n), hf32x8);
 #pragma unroll
@@ -406,6 +434,30 @@ void conv_h_kernel(
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *reinterpret_cast<V8*>(outp + (size_t)m * g.ld_out + n) = __builtin_convertvector(v, V8);
+      }
+    }
+  }
+  if constexpr (bnb) {
+    // the RPP row lanes' sums -> one value per (pixel tile, channel), fixed order (no atomics)
+    __syncthreads();
+    float* red0 = smem;                            // [RPP][BN]
+    float* red1 = smem + RPP * BN;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red0[row0 * BN + col8 * 8 + e] = nok ? b0[e] : 0.f;
+      red1[row0 * BN + col8 * 8 + e] = nok ? b1[e] : 0.f;
+    }
+    __syncthreads();
+    for (int col = tid; col < BN; col += NT) {
+      const int nn = n0 + col;
+      if (nn < g.n_ch) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int r = 0; r < RPP; ++r) {
+          a0 += red0[r * BN + col];
+          a1 += red1[r * BN + col];
+        }
+        p.bnb_out[((size_t)0 * p.bnb_rows_alloc + mt) * g.n_ch + nn] = a0;
+        p.bnb_out[((size_t)1 * p.bnb_rows_alloc + mt) * g.n_ch + nn] = a1 * p.bnb_invstd[nn];
       }
     }
   }
@@ -477,7 +529,9 @@ int launch_h(const ConvHArgs& a, hipStream_t st) {
                        (double)a.g.kh * a.g.kw * a.g.n_ch * a.g.k_ch * 2.0 +
                        (a.residual ? px_out : 0.0) + (a.mask_src ? px_out : 0.0);
   const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
-  if (convh_pf() == 2)
+  if (a.bnb_out)
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1, true>), dim3(grid), dim3(256), lds, st, a);
+  else if (convh_pf() == 2)
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 2>), dim3(grid), dim3(256), lds, st, a);
   else
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1>), dim3(grid), dim3(256), lds, st, a);
@@ -504,15 +558,12 @@ extern "C" int emsa_conv_stats_rows_t(int32_t dtype, const EmsaConvGeom* g) {
   return (int)((M + ht_bm(t) - 1) / ht_bm(t));
 }
 
-extern "C" int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
-                                 const void* w, void* out, const float* bias, float* stats,
-                                 const float* scale, const float* shift, const void* residual,
-                                 int32_t ld_res, const void* mask_src, int32_t ld_mask,
-                                 int32_t act, void* stream) {
-  if (dtype == EMSA_DT_F32)
-    return emsa_conv_igemm(g, (const float*)in, (const float*)w, (float*)out, bias, stats, scale,
-                           shift, (const float*)residual, ld_res, (const float*)mask_src, ld_mask,
-                           act, stream);
+static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                             const void* w, void* out, const float* bias, float* stats,
+                             const float* scale, const float* shift, const void* residual,
+                             int32_t ld_res, const void* mask_src, int32_t ld_mask,
+                             int32_t act, const float* bnb_mean, const float* bnb_invstd,
+                             float* bnb_out, int32_t bnb_rows_alloc, void* stream) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
   if (!h_geom_ok(g)) return EMSA_E_SHAPE;
   if (!in || !w || !out) return EMSA_E_ARG;
@@ -527,10 +578,15 @@ extern "C" int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const voi
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats;
   a.scale = scale; a.shift = shift; a.residual = residual; a.mask_src = mask_src;
   a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
+  a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out;
+  a.bnb_rows_alloc = bnb_rows_alloc;
   const long M = (long)g->n_img * g->out_h * g->out_w;
   a.M = (int)M;
   const HTile t = pick_htile(M, g->n_ch);
   a.tiles_m = (int)((M + ht_bm(t) - 1) / ht_bm(t));
+  if (bnb_out && (!mask_src || !scale || !bnb_mean || !bnb_invstd || stats ||
+                  act != EMSA_ACT_NONE || bnb_rows_alloc < a.tiles_m))
+    return EMSA_E_ARG;
   a.tiles_n = (g->n_ch + ht_bn(t) - 1) / ht_bn(t);
   a.kchunks = (g->k_ch + kHK - 1) / kHK;
   a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * 2);
@@ -540,4 +596,34 @@ extern "C" int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const voi
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EMSA_DT_BF16) return conv_h_dispatch<emsa_bf16>(a, t, st);
   return conv_h_dispatch<emsa_f16>(a, t, st);
+}
+
+extern "C" int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                 const void* w, void* out, const float* bias, float* stats,
+                                 const float* scale, const float* shift, const void* residual,
+                                 int32_t ld_res, const void* mask_src, int32_t ld_mask,
+                                 int32_t act, void* stream) {
+  if (dtype == EMSA_DT_F32)
+    return emsa_conv_igemm(g, (const float*)in, (const float*)w, (float*)out, bias, stats, scale,
+                           shift, (const float*)residual, ld_res, (const float*)mask_src, ld_mask,
+                           act, stream);
+  return conv_igemm_h_impl(dtype, g, in, w, out, bias, stats, scale, shift, residual, ld_res,
+                           mask_src, ld_mask, act, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// 16-bit data gradient with the BatchNorm-backward sums of the layer in front fused into the
+// epilogue (ConvHArgs::bnb_out; the fp32 twin is emsa_conv1d_wino_bnb): stores
+// g = dz * (t * bn_scale + bn_shift > 0) and partial[0/1][tile][c] for the
+// emsa_conv_stats_rows_t(dtype, g) pixel tiles; `partial` = float[2][rows_alloc][c],
+// rows_alloc >= tiles + 16 (emsa_bn_bwd_apply_rows_t merges the rows).
+extern "C" int emsa_conv_igemm_bnb_t(int32_t dtype, const EmsaConvGeom* g, const void* dy,
+                                     const void* w, void* out, const void* residual,
+                                     int32_t ld_res, const void* t, int32_t ld_t,
+                                     const float* bn_scale, const float* bn_shift,
+                                     const float* bn_mean, const float* bn_invstd, float* partial,
+                                     int32_t rows_alloc, void* stream) {
+  if (!partial || !t) return EMSA_E_ARG;
+  return conv_igemm_h_impl(dtype, g, dy, w, out, nullptr, nullptr, bn_scale, bn_shift, residual,
+                           ld_res, t, ld_t, EMSA_ACT_NONE, bn_mean, bn_invstd, partial, rows_alloc,
+                           stream);
 }

@@ -62,6 +62,15 @@ struct WinoArgs {
   const uint64_t* mask_bits;        // alternative to mask_src: 1 bit per element, see relu_bits
   uint64_t* relu_bits;              // out: (result > 0), one word per (pixel, 64-channel tile):
                                     // bit = component*16 + float4 column
+  // BatchNorm-backward sums fused into a data gradient (emsa_conv1d_wino_bnb): the result dz is the
+  // gradient w.r.t. a = relu(bn(t)); the epilogue applies the ReLU mask recomputed from t
+  // (mask_src = t, scale/shift = the BatchNorm's affine form, NOT applied to the result), stores
+  // g = dz * (a > 0) and emits per tile  sum g  and  sum g * (t - mean) * invstd  -- the rows
+  // bn_bwd_reduce would produce, without its pass over dz and t.
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  float* bnb_out;                   // [2][bnb_rows_alloc][n_ch], rows [0, tiles_m) written
+  int bnb_rows_alloc;
   int ld_out, ld_res, ld_mask, act;
   int L, PL, A, MP;                 // line length, pairs per line, lines per image, total pairs
   int k_ch, n_ch;                   // k_ch = R * c_in (GEMM K), n_ch output channels
@@ -90,8 +99,11 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
 #define EMSA_WINO_PRIO 2   // 0 = no s_setprio, 1 = raised around the MFMA cluster, 2 = also: the next step's loads
                           // issue at the highest priority (measured +1..2 %)
 #endif
-template <int kWN, bool BF16 = false>   // kWN: output channels per workgroup, 64 (2 MFMA tiles per wave) or 32
-__global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(const WinoArgs p) {
+// BNB: the epilogue with the fused BatchNorm-backward sums (WinoArgs::bnb_out) is its own
+// instantiation with one wave per SIMD less: compiled into the common kernel it cost that one 13-15
+// spilled registers at 5 waves per SIMD.
+template <int kWN, bool BF16 = false, bool BNB = false>   // kWN: output channels per workgroup, 64 (2 MFMA tiles per wave) or 32
+__global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_wino_kernel(const WinoArgs p) {
   constexpr int NT = kWN / 32;                    // accumulator tiles per wave
   constexpr int NC4 = kWN / 4;                    // float4 columns of a tile row
   constexpr int RG = 256 / NC4;                   // pixel rows covered by one pass of the block
@@ -421,11 +433,18 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
 
   {
     wf32x2 sclo = {1.f, 1.f}, schi = {1.f, 1.f}, shlo = {0.f, 0.f}, shhi = {0.f, 0.f};
-    const bool affine = p.scale != nullptr;        // uniform
-    if (affine && nok) {
+    constexpr bool bnb = BNB;
+    const bool affine = p.scale != nullptr && !bnb;
+    if (p.scale != nullptr && nok) {
       const float4 sc = emsa_ld4(p.scale + n), sh = emsa_ld4(p.shift + n);
       sclo = wf32x2{sc.x, sc.y}; schi = wf32x2{sc.z, sc.w};
       shlo = wf32x2{sh.x, sh.y}; shhi = wf32x2{sh.z, sh.w};
+    }
+    wf32x2 mulo = {0.f, 0.f}, muhi = {0.f, 0.f};
+    wf32x2 b0lo = {0.f, 0.f}, b0hi = {0.f, 0.f}, b1lo = {0.f, 0.f}, b1hi = {0.f, 0.f};
+    if (bnb && nok) {
+      const float4 mu = emsa_ld4(p.bnb_mean + n);
+      mulo = wf32x2{mu.x, mu.y}; muhi = wf32x2{mu.z, mu.w};
     }
 #pragma unroll
     for (int k = 0; k < PXI; ++k) {
@@ -440,7 +459,19 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
         vhi += wf32x2{rres[k].z, rres[k].w};
       }
       float4 v = make_float4(vlo.x, vlo.y, vhi.x, vhi.y);
-      if (p.mask_src) {
+      if constexpr (bnb) {
+        // rmsk holds t (the BatchNorm input): a = t * scale + shift exactly as bn_act_fwd forms it
+        const float4 tt = rmsk[k];
+        const wf32x2 alo = __builtin_elementwise_fma(wf32x2{tt.x, tt.y}, sclo, shlo);
+        const wf32x2 ahi = __builtin_elementwise_fma(wf32x2{tt.z, tt.w}, schi, shhi);
+        const float lv = live ? 1.f : 0.f;
+        v.x = alo.x > 0.f ? v.x * lv : 0.f; v.y = alo.y > 0.f ? v.y * lv : 0.f;
+        v.z = ahi.x > 0.f ? v.z * lv : 0.f; v.w = ahi.y > 0.f ? v.w * lv : 0.f;
+        const wf32x2 glo = {v.x, v.y}, ghi = {v.z, v.w};
+        b0lo += glo; b0hi += ghi;
+        b1lo = __builtin_elementwise_fma(glo, wf32x2{tt.x, tt.y} - mulo, b1lo);
+        b1hi = __builtin_elementwise_fma(ghi, wf32x2{tt.z, tt.w} - muhi, b1hi);
+      } else if (p.mask_src) {
         const float4 mm = rmsk[k];
         v.x = mm.x > 0.f ? v.x : 0.f; v.y = mm.y > 0.f ? v.y : 0.f;
         v.z = mm.z > 0.f ? v.z : 0.f; v.w = mm.w > 0.f ? v.w : 0.f;
@@ -474,6 +505,26 @@ __global__ __launch_bounds__(256, kWN == 64 ? 5 : 6) void conv1d_wino_kernel(con
                 ((b0 >> sh16) & 0xFFFFull) | (((b1 >> sh16) & 0xFFFFull) << 16) |
                 (((b2 >> sh16) & 0xFFFFull) << 32) | (((b3 >> sh16) & 0xFFFFull) << 48);
         }
+      }
+    }
+    if constexpr (bnb) {
+      // the RG row groups' sums -> one value per (tile, channel), fixed order (no atomics)
+      __syncthreads();                             // every wave is done with `stage`
+      float* red0 = smem;                          // [RG][kWN]
+      float* red1 = smem + RG * kWN;
+      emsa_st4(red0 + rgi * kWN + col4 * 4, make_float4(b0lo.x, b0lo.y, b0hi.x, b0hi.y));
+      emsa_st4(red1 + rgi * kWN + col4 * 4, make_float4(b1lo.x, b1lo.y, b1hi.x, b1hi.y));
+      __syncthreads();
+      if (tid < kWN && n0 + tid < p.n_ch) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < RG; ++g2) {
+          a0 += red0[g2 * kWN + tid];
+          a1 += red1[g2 * kWN + tid];
+        }
+        p.bnb_out[((size_t)0 * p.bnb_rows_alloc + mt) * p.n_ch + n0 + tid] = a0;
+        p.bnb_out[((size_t)1 * p.bnb_rows_alloc + mt) * p.n_ch + n0 + tid] =
+            a1 * p.bnb_invstd[n0 + tid];
       }
     }
   }
@@ -688,11 +739,13 @@ extern "C" int emsa_conv1d_wino_stats_rows(const EmsaConvGeom* g) {
   return (int)((mp + kPairs - 1) / kPairs);
 }
 
-extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, float* out,
-                                const float* bias, float* stats, const float* scale,
-                                const float* shift, const float* residual, int32_t ld_res,
-                                const float* mask_src, int32_t ld_mask, int32_t act,
-                                const uint64_t* mask_bits, uint64_t* relu_bits, void* stream) {
+static int conv1d_wino_impl(const EmsaConvGeom* g, const float* in, const float* u, float* out,
+                            const float* bias, float* stats, const float* scale,
+                            const float* shift, const float* residual, int32_t ld_res,
+                            const float* mask_src, int32_t ld_mask, int32_t act,
+                            const uint64_t* mask_bits, uint64_t* relu_bits,
+                            const float* bnb_mean, const float* bnb_invstd, float* bnb_out,
+                            int32_t bnb_rows_alloc, void* stream) {
   if (!emsa_conv1d_wino_supported(g)) return EMSA_E_SHAPE;
   if (!in || !u || !out) return EMSA_E_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
@@ -705,6 +758,8 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   a.in = in; a.u = u; a.out = out; a.bias = bias; a.stats = stats; a.scale = scale;
   a.shift = shift; a.residual = residual; a.mask_src = mask_src;
   a.mask_bits = mask_bits; a.relu_bits = relu_bits;
+  a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out;
+  a.bnb_rows_alloc = bnb_rows_alloc;
   a.ld_out = g->ld_out; a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
   const bool aw = g->kw == 3;
   const int H = g->out_h, W = g->out_w;
@@ -731,6 +786,13 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
   if (mask_bits && mask_src) return EMSA_E_ARG;
   a.tiles_m = (a.MP + kPairs - 1) / kPairs;
   a.tiles_n = (g->n_ch + wn - 1) / wn;
+  if (bnb_out) {
+    // fused BatchNorm-backward sums: t through the mask_src operand, the affine form through
+    // scale / shift; room for the tile rows plus the slice sums of emsa_bn_bwd_apply_rows
+    if (!mask_src || !scale || !bnb_mean || !bnb_invstd || mask_bits || relu_bits || stats ||
+        act != EMSA_ACT_NONE || !al16(bnb_mean) || bnb_rows_alloc < a.tiles_m)
+      return EMSA_E_ARG;
+  }
   {
     // the epilogue addresses out / residual / mask with 32-bit byte offsets below 2 GiB
     const long px = (long)g->n_img * H * W, lim = 1L << 29;
@@ -756,7 +818,11 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
     const char* e = getenv("EMSA_BF16_MFMA");
     return e && e[0] == '1';
   }();
-  if (wn == 64 && bf16)
+  if (bnb_out) {
+    if (wn != 64) return EMSA_E_SHAPE;
+    hipLaunchKernelGGL((conv1d_wino_kernel<64, false, true>), dim3(a.tiles_m * a.tiles_n),
+                       dim3(256), lds, (hipStream_t)stream, a);
+  } else if (wn == 64 && bf16)
     hipLaunchKernelGGL((conv1d_wino_kernel<64, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds,
                        (hipStream_t)stream, a);
   else if (wn == 64)
@@ -767,4 +833,30 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
                        lds, (hipStream_t)stream, a);
   emsa_prof_end(ps, (hipStream_t)stream);
   return emsa_launch_status();
+}
+
+extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, float* out,
+                                const float* bias, float* stats, const float* scale,
+                                const float* shift, const float* residual, int32_t ld_res,
+                                const float* mask_src, int32_t ld_mask, int32_t act,
+                                const uint64_t* mask_bits, uint64_t* relu_bits, void* stream) {
+  return conv1d_wino_impl(g, in, u, out, bias, stats, scale, shift, residual, ld_res, mask_src,
+                          ld_mask, act, mask_bits, relu_bits, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Data gradient with the BatchNorm-backward sums of the layer in front fused into the epilogue
+// (see WinoArgs::bnb_out): dz -> g = dz * (t * bn_scale + bn_shift > 0) stored to `out`, and
+// partial[0][tile][c] = sum g, partial[1][tile][c] = sum g * (t - mean) * invstd for the
+// emsa_conv1d_wino_stats_rows(g) tiles; `partial` = float[2][rows_alloc][c] with rows_alloc >=
+// tiles + 16 (emsa_bn_bwd_apply_rows merges the rows).
+extern "C" int emsa_conv1d_wino_bnb(const EmsaConvGeom* g, const float* dy, const float* u,
+                                    float* out, const float* residual, int32_t ld_res,
+                                    const float* t, int32_t ld_t, const float* bn_scale,
+                                    const float* bn_shift, const float* bn_mean,
+                                    const float* bn_invstd, float* partial, int32_t rows_alloc,
+                                    void* stream) {
+  if (!partial || !t) return EMSA_E_ARG;
+  return conv1d_wino_impl(g, dy, u, out, nullptr, nullptr, bn_scale, bn_shift, residual, ld_res, t,
+                          ld_t, EMSA_ACT_NONE, nullptr, nullptr, bn_mean, bn_invstd, partial,
+                          rows_alloc, stream);
 }

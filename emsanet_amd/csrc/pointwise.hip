@@ -1734,15 +1734,17 @@ extern "C" int emsa_bn_bwd_reduce_t(int32_t dtype, const void* dy, const void* y
 }
 
 template <typename T>
-static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, T* dx, T* dres, float* dgamma, float* dbeta, void* stream) {
+static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, T* dx, T* dres, float* dgamma, float* dbeta, void* stream, int32_t rows_given = -1) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
     return EMSA_E_ARG;
   if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const long pixels = (long)n_img * hw;
-  const int rows = bn_bwd_rows_for(pixels, c);
-  if (rows_alloc != rows + kBwdSlices) return EMSA_E_ARG;
+  // rows_given: the partial sums come from a convolution epilogue (one row per pixel tile of that
+  // launch) instead of emsa_bn_bwd_reduce
+  const int rows = rows_given >= 0 ? rows_given : bn_bwd_rows_for(pixels, c);
+  if (rows < 1 || rows_alloc != rows + kBwdSlices) return EMSA_E_ARG;
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32, kBwdSlices), dim3(256), 0, st, partial,
                      rows, rows_alloc, c);
   constexpr int V = VecIO<T>::V;
@@ -1764,6 +1766,18 @@ extern "C" int emsa_bn_bwd_apply_t(int32_t dtype, const void* dy, const void* y,
     case EMSA_DT_F32: { return bn_bwd_apply_impl<float>((const float*)dy, (const float*)y, mask_bits, (const float*)x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, (float*)dx, (float*)dres, dgamma, dbeta, stream); }
     case EMSA_DT_BF16: { return bn_bwd_apply_impl<emsa_bf16>((const emsa_bf16*)dy, (const emsa_bf16*)y, mask_bits, (const emsa_bf16*)x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, (emsa_bf16*)dx, (emsa_bf16*)dres, dgamma, dbeta, stream); }
     case EMSA_DT_F16: { return bn_bwd_apply_impl<emsa_f16>((const emsa_f16*)dy, (const emsa_f16*)y, mask_bits, (const emsa_f16*)x, gamma, save_mean, save_invstd, drop, partial, rows_alloc, n_img, hw, c, act, train, (emsa_f16*)dx, (emsa_f16*)dres, dgamma, dbeta, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+// BatchNorm backward from per-tile sums a data-gradient epilogue already produced
+// (emsa_conv1d_wino_bnb / emsa_conv_igemm_bnb_t): g = the masked gradient that kernel stored,
+// partial = float[2][rows + 16][c] with rows [0, rows) = (sum g, sum g * xhat) per tile.  Merges
+// the rows and applies  dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)); dgamma, dbeta.
+extern "C" int emsa_bn_bwd_apply_rows_t(int32_t dtype, const void* g, const void* x, const float* gamma, const float* save_mean, const float* save_invstd, float* partial, int32_t rows, int32_t n_img, int64_t hw, int32_t c, int32_t train, void* dx, float* dgamma, float* dbeta, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: return bn_bwd_apply_impl<float>((const float*)g, nullptr, nullptr, (const float*)x, gamma, save_mean, save_invstd, nullptr, partial, rows + kBwdSlices, n_img, hw, c, EMSA_ACT_NONE, train, (float*)dx, (float*)nullptr, dgamma, dbeta, stream, rows);
+    case EMSA_DT_BF16: return bn_bwd_apply_impl<emsa_bf16>((const emsa_bf16*)g, nullptr, nullptr, (const emsa_bf16*)x, gamma, save_mean, save_invstd, nullptr, partial, rows + kBwdSlices, n_img, hw, c, EMSA_ACT_NONE, train, (emsa_bf16*)dx, (emsa_bf16*)nullptr, dgamma, dbeta, stream, rows);
+    case EMSA_DT_F16: return bn_bwd_apply_impl<emsa_f16>((const emsa_f16*)g, nullptr, nullptr, (const emsa_f16*)x, gamma, save_mean, save_invstd, nullptr, partial, rows + kBwdSlices, n_img, hw, c, EMSA_ACT_NONE, train, (emsa_f16*)dx, (emsa_f16*)nullptr, dgamma, dbeta, stream, rows);
     default: return EMSA_E_ARG;
   }
 }

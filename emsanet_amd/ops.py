@@ -105,6 +105,24 @@ class ConvRT:
             return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, mask_bits=mask_bits, **kw)
         return Fn.conv_dgrad(dy, self.packed_dgrad(), self.spec, in_hw, **kw)
 
+    def dgrad_bnb(self, dy, in_hw, t, affine, mean, invstd, residual=None):
+        """data gradient + the backward reduction of the BatchNorm in front of this conv
+        (Fn.conv_dgrad_bnb), or None when this conv's kernel has no such epilogue (fp32 without
+        the Winograd form)"""
+        if affine is None or not Fn.bn_fused_reduce(dy.dtype):
+            return None
+        scale, shift = affine
+        if dy.dtype != torch.float32:
+            return Fn.conv_dgrad_bnb(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw, t, scale,
+                                     shift, mean, invstd, residual=residual)
+        if not self.wino:
+            return None
+        u, ud = self._wino_weights()
+        if ud is None:
+            ud = Fn.pack_wino(self.conv.weight.detach(), fwd=False, dgrad=True)[1]
+        return Fn.conv_dgrad_bnb(dy, None, self.spec, in_hw, t, scale, shift, mean, invstd,
+                                 residual=residual, wino_u=ud)
+
     def packed(self, dtype=torch.float32):
         w = self.conv.weight
         key = (w._version, w.data_ptr())
@@ -280,6 +298,10 @@ def _conv_bn_forward(x, crt, brt, act, drop=None, residual=None):
         y, stats, count = crt.forward(x, bias=bias), None, 0
     scale, shift, mean, invstd = brt.forward_stats(stats, count)
     out, mask = Fn.bn_act(y, scale, shift, drop, residual, act, want_mask=True)
+    # (the affine form travels with the statistics: a data gradient with the fused BatchNorm
+    #  reduction recomputes the ReLU mask from it)
+    if brt.batch_stats():                # (`mean` is this call's own tensor, not the running buffer)
+        mean._emsa_affine = (scale, shift)
     return out, y, mean, invstd, mask
 
 
@@ -289,8 +311,10 @@ def _bn_targets(brt):
     return {'dg_out': tg, 'db_out': tb} if tg is not None and tb is not None else {}
 
 
-def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None):
-    """-> dx (or None), dw (OIHW), dbias (or None)"""
+def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None, bnb=None):
+    """-> dx (or None), dw (OIHW), dbias (or None); with bnb = (t, (scale, shift), mean, invstd) of
+    the BatchNorm+ReLU in front of the conv: -> dx, dw, dbias, (partial, rows) or None -- dx then
+    already carries that ReLU's mask (ConvRT.dgrad_bnb)"""
     conv = crt.conv
     # the gradients go straight into their flat all-reduce / optimizer bucket views when
     # GradientBuckets manages the parameters (no gather copy later)
@@ -303,6 +327,12 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=
     elif tw is not None and dw.data_ptr() == tw.data_ptr():
         dw = tw
     dx = None
+    if bnb is not None:
+        t, affine, mean, invstd = bnb
+        r = crt.dgrad_bnb(dy, x.shape[2:], t, affine, mean, invstd, residual=residual)
+        if r is not None:
+            return r[0], dw, db, (r[1], r[2])
+        return crt.dgrad(dy, x.shape[2:], residual=residual), dw, db, None
     if need_dx:
         dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual,
                        mask_bits=mask_bits)
@@ -384,9 +414,16 @@ class NBt1DFunction(Function):
         # conv1x3_2 (input y3 = relu(.)): ReLU mask fused into the dgrad epilogue
         dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3, mask_bits=q3)
         # conv3x1_2 (input a2 = relu(bn1(y2)))
-        da2, dw3, dbias3 = _conv_backward(a2, dz3, rt.c31_2, True)
-        dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
-                                     ACT_RELU, t1, want_dres=False, **_bn_targets(rt.bn1))
+        # the data gradient's epilogue applies bn1's ReLU mask and emits bn1's backward sums (one
+        # pass over da2 and y2 less); falls back to the separate reduction pass
+        da2, dw3, dbias3, fused = _conv_backward(a2, dz3, rt.c31_2, True,
+                                                 bnb=(y2, getattr(m1, '_emsa_affine', None), m1, is1))
+        if fused is not None:
+            dy2, dg1, db1 = Fn.bn_bwd_from_rows(da2, y2, rt.bn1.bn.weight.detach(), m1, is1,
+                                                fused[0], fused[1], t1, **_bn_targets(rt.bn1))
+        else:
+            dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
+                                         ACT_RELU, t1, want_dres=False, **_bn_targets(rt.bn1))
         dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1, mask_bits=q1)
         grads = []
         if rt.cds is None:

@@ -134,6 +134,18 @@ int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const float* u, flo
                      const float* residual, int32_t ld_res, const float* mask_src,
                      int32_t ld_mask, int32_t act, const uint64_t* mask_bits,
                      uint64_t* relu_bits, void* stream);
+/* Data gradient of the conv BEHIND a BatchNorm+ReLU with that BatchNorm's backward reduction fused
+ * into the epilogue (the NBt1D block's conv3x1_2 -> bn1: one pass over dz and t less per block).
+ * dz = conv_transpose(dy) is the gradient w.r.t. a = relu(t * bn_scale + bn_shift); the kernel
+ * stores g = dz * (a > 0) (+ residual before the mask) to `out` and writes, per pixel tile,
+ *   partial[0][tile][c] = sum g,   partial[1][tile][c] = sum g * (t - bn_mean) * bn_invstd
+ * i.e. the rows emsa_bn_bwd_reduce would produce.  partial = float[2][rows_alloc][n_ch] with
+ * rows_alloc = emsa_conv1d_wino_stats_rows(g) + 16; emsa_bn_bwd_apply_rows_t turns (g, partial)
+ * into the BatchNorm's dx, dgamma, dbeta.  16-bit twin: emsa_conv_igemm_bnb_t.                     */
+int emsa_conv1d_wino_bnb(const EmsaConvGeom* g, const float* dy, const float* u, float* out,
+                         const float* residual, int32_t ld_res, const float* t, int32_t ld_t,
+                         const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                         const float* bn_invstd, float* partial, int32_t rows_alloc, void* stream);
 /* u (forward weights [4][cout][rows*cin]) and/or u_dgrad (data-gradient weights
  * [4][cin][rows*cout]) from the OIHW taps in one launch; either output may be NULL              */
 int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout, int32_t cin,
@@ -448,6 +460,19 @@ int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in, cons
                       void* out, const float* bias, float* stats, const float* scale,
                       const float* shift, const void* residual, int32_t ld_res,
                       const void* mask_src, int32_t ld_mask, int32_t act, void* stream);
+/* 16-bit twin of emsa_conv1d_wino_bnb (tiles: emsa_conv_stats_rows_t(dtype, g)) and the BatchNorm
+ * backward that consumes its output: g = the masked gradient stored by the conv, partial =
+ * float[2][rows + 16][c] with rows [0, rows) filled; dtype EMSA_DT_F32 pairs with the Winograd
+ * entry point above.                                                                             */
+int emsa_conv_igemm_bnb_t(int32_t dtype, const EmsaConvGeom* g, const void* dy, const void* w,
+                          void* out, const void* residual, int32_t ld_res, const void* t,
+                          int32_t ld_t, const float* bn_scale, const float* bn_shift,
+                          const float* bn_mean, const float* bn_invstd, float* partial,
+                          int32_t rows_alloc, void* stream);
+int emsa_bn_bwd_apply_rows_t(int32_t dtype, const void* g, const void* x, const float* gamma,
+                             const float* save_mean, const float* save_invstd, float* partial,
+                             int32_t rows, int32_t n_img, int64_t hw, int32_t c, int32_t train,
+                             void* dx, float* dgamma, float* dbeta, void* stream);
 int64_t emsa_conv_wgrad_ws_bytes_t(int32_t dtype, const EmsaConvGeom* g);
 int emsa_conv_wgrad_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* dout,
                       float* dw, float* dbias, float* ws, void* stream);

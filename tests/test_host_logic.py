@@ -180,14 +180,35 @@ def test_dry_run_orchestration(fake_lib, train, monkeypatch):
     c = fake_lib.calls
     # 2 encoders x 16 + 2 decoders x 9 NBt1D blocks, 4 MFMA convs each (+3 downsample per encoder)
     assert c['emsa_conv_wgrad'] >= 50 * 4
-    assert c['emsa_conv_igemm'] + c['emsa_conv1d_wino'] > c['emsa_conv_wgrad']
+    assert c['emsa_conv_igemm'] + c['emsa_conv1d_wino'] + c['emsa_conv1d_wino_bnb'] > c['emsa_conv_wgrad']
     # every stride-1 3x1/1x3 conv runs on the Winograd kernel, forward and data gradient
-    assert c['emsa_conv1d_wino'] >= 2 * (50 * 4 - 2 * 3 * 2) - 2
+    # (fp32: bn1's backward reduction is its own pass; the fused form: test_dry_run_fused_bn_reduction)
+    assert c['emsa_conv1d_wino_bnb'] == 0
+    assert c['emsa_conv1d_wino'] + c['emsa_conv1d_wino_bnb'] >= 2 * (50 * 4 - 2 * 3 * 2) - 2
     assert c['emsa_se_mlp_fwd'] == 10 and c['emsa_maxpool3x3s2_fwd'] == 2
     assert c['emsa_up2x_dw3x3_fwd'] == 2 * 3 + 2 * 2
     # merged dict variant (do_postprocessing=True), /root/reference/emsanet/model.py:230-231
     d = model(batch, do_postprocessing=True)
     assert isinstance(d, dict) and 'semantic_output' in d and 'instance_centers' in d
+
+
+def test_dry_run_fused_bn_reduction(fake_lib, monkeypatch):
+    """with the fused form forced on, the data gradient of every NBt1D block's conv3x1_2 carries
+    bn1's backward reduction and bn1's backward is the apply-from-rows entry point"""
+    import emsanet_amd.model as M
+    from emsanet_amd import full_args, functional as Fn
+    from oracle.emsanet_oracle import synthetic_batch
+    monkeypatch.setattr(Fn, '_BN_FUSE_ENV', '1')
+    model = _model(full_args(input_height=64, input_width=96)).train()
+    monkeypatch.setattr(M.EMSANet, 'forward', _bypass_device_check(model))
+    outs = model(synthetic_batch(2, 64, 96))
+    flat = [t for o, sides in outs for t in (list(o) if isinstance(o, tuple) else [o])]
+    flat += [t for _, sides in outs for s in sides for t in (list(s) if isinstance(s, tuple) else [s])]
+    torch.autograd.backward(flat, [torch.zeros_like(t) for t in flat])
+    c = fake_lib.calls
+    assert c['emsa_conv1d_wino_bnb'] == 50
+    assert c['emsa_bn_bwd_apply_rows_t'] == 50
+    assert all(p.grad is not None for p in model.parameters())
 
 
 def test_dry_run_fast_eval_uses_folded_kernels(fake_lib, monkeypatch):

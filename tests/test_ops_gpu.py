@@ -636,3 +636,71 @@ print("BF16_OK %.2e" % worst)
     r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True,
                        text=True, timeout=300)
     assert 'BF16_OK' in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kernel', [(3, 1), (1, 3)])
+@pytest.mark.parametrize('c,shape', [(64, (2, 9, 11)), (128, (3, 8, 20)), (72, (1, 5, 7))])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_dgrad_with_fused_bn_backward_sums(dtype, kernel, c, shape, with_res):
+    """conv3x1_2 -> bn1 of the NBt1D backward: the data gradient whose epilogue applies the
+    BatchNorm's ReLU mask and emits its backward reduction (emsa_conv1d_wino_bnb /
+    emsa_conv_igemm_bnb_t) + emsa_bn_bwd_apply_rows_t == fp64 autograd of
+    conv(relu(batch_norm(t))), and == the separate passes (dgrad, bn_bwd_reduce, bn_bwd_apply)"""
+    Fn = _fn()
+    n, h, w = shape
+    pad = (1, 0) if kernel == (3, 1) else (0, 1)
+    spec = Fn.ConvSpec(c, c, kernel, 1, pad)
+    lo = dtype != torch.float32
+    q = (lambda t: t.to(dtype).float()) if lo else (lambda t: t)
+    t = q(rnd(n, c, h, w, seed=1))
+    wt = q(rnd(c, c, *kernel, seed=2, scale=0.1))
+    dy = q(rnd(n, c, h, w, seed=3))
+    res = q(rnd(n, c, h, w, seed=4)) if with_res else None
+    gamma = rnd(c, seed=5) * 0.2 + 1
+    beta = rnd(c, seed=6) * 0.3
+    eps = 1e-3
+    # fp64 reference: a = relu(bn(t)) (batch statistics), z = conv(a) (+ a second consumer whose
+    # gradient arrives as the residual operand)
+    tr = t.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(tr, None, None, gr, br, training=True, eps=eps))
+    z = F.conv2d(a, wt.double(), padding=pad)
+    loss = (z * dy.double()).sum()
+    if with_res:
+        loss = loss + (a * res.double()).sum()
+    loss.backward()
+    # engine: statistics of t the way bn_finalize produces them
+    g, b = gamma.to(DEV), beta.to(DEV)
+    xs = t.permute(0, 2, 3, 1).reshape(-1, c)
+    stats = torch.stack([xs.sum(0, keepdim=True), ((xs - xs.mean(0)) ** 2).sum(0, keepdim=True),
+                         torch.full((1, c), float(xs.shape[0]))]).to(DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    scale, shift, mean, invstd = Fn.bn_finalize(stats, xs.shape[0], g, b, eps, 0.1, rm, rv)
+    ta = to_act(t).to(dtype)
+    dya = to_act(dy).to(dtype)
+    resa = to_act(res).to(dtype) if with_res else None
+    if lo:
+        wpd = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=False, dgrad=True)[1]
+        gm, partial, rows = Fn.conv_dgrad_bnb(dya, wpd, spec, (h, w), ta, scale, shift, mean, invstd,
+                                              residual=resa)
+    else:
+        ud = Fn.pack_wino(wt.to(DEV), fwd=False, dgrad=True)[1]
+        gm, partial, rows = Fn.conv_dgrad_bnb(dya, None, spec, (h, w), ta, scale, shift, mean, invstd,
+                                              residual=resa, wino_u=ud)
+    dx, dg, db = Fn.bn_bwd_from_rows(gm, ta, g, mean, invstd, partial, rows, True)
+    tol = 2e-2 if lo else 2e-4
+    close(dx, tr.grad, tol=tol, what='fused dx')
+    close(dg, gr.grad, tol=1e-2 if lo else 2e-4, what='fused dgamma')
+    close(db, br.grad, tol=1e-2 if lo else 2e-4, what='fused dbeta')
+    # the separate passes on the same inputs
+    a_dev, bits = Fn.bn_act(ta, scale, shift, None, None, Fn.ACT_RELU, want_mask=True)
+    if lo:
+        da = Fn.conv_dgrad(dya, wpd, spec, (h, w), residual=resa)
+    else:
+        da = Fn.conv_dgrad(dya, None, spec, (h, w), residual=resa, wino_u=ud)
+    dx0, _, dg0, db0 = Fn.bn_bwd(da, bits, ta, g, mean, invstd, None, Fn.ACT_RELU, True,
+                                 want_dres=False)
+    close(dx, dx0.float().cpu(), tol=tol, what='fused vs separate dx')
+    close(dg, dg0.cpu(), tol=1e-2 if lo else 2e-4, what='fused vs separate dgamma')
+    close(db, db0.cpu(), tol=1e-2 if lo else 2e-4, what='fused vs separate dbeta')
