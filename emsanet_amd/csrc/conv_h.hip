@@ -157,7 +157,14 @@ void conv_h_kernel(
   // ---- loader state ---------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rs_in = h_rsrc(p.in, p.in_bytes);
   const __amdgpu_buffer_rsrc_t rs_w = h_rsrc(p.w, p.w_bytes);
-  const int rl = tid / kHRowLanes, c8 = (tid % kHRowLanes) * 8;
+  // PF == 0 (LDS-DMA staging): the LDS tiles are unpadded [row][64 channels] images written
+  // linearly by the DMA (wave base + lane x 16 B), so the bank-conflict swizzle sits on the SOURCE
+  // side: the lane that writes physical 16-byte chunk c' of row r fetches logical chunk
+  // c' ^ (r & 7), and the MFMA operand reads apply the same XOR.  r & 7 == lane >> 3 for every row
+  // a lane serves (rows advance by 32 per pass, waves by 8), so the logical chunk is a per-lane
+  // constant.
+  const int rl = tid / kHRowLanes;
+  const int c8 = PF == 0 ? (((lane & 7) ^ (lane >> 3)) * 8) : (tid % kHRowLanes) * 8;
   int a_bh[AR], a_bw[AR], a_img[AR];
   uint32_t a_off[AR], b_off[BR];
 #pragma unroll
@@ -185,7 +192,7 @@ void conv_h_kernel(
   const int steps = taps * p.kchunks;
   const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 2u;
   int tap_n = 0, kc_n = 0;
-  hu32x4 rset[PF][AR + BR];
+  hu32x4 rset[PF > 0 ? PF : 1][AR + BR];
   // kHOOB for the lanes whose channels lie beyond k_ch in the last chunk of a tap
   const uint32_t last_oob = (p.kchunks - 1) * kHK + c8 < g.k_ch ? 0u : kHOOB;
 
@@ -223,6 +230,40 @@ void conv_h_kernel(
       *reinterpret_cast<hu32x4*>(Bs + (rl + kRowsPerPass * j) * kHLD + c8) = rr[AR + j];
   };
 
+  // PF == 0: the step's A and B tiles go straight from global memory into LDS buffer `buf`
+  // (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass); out-of-range offsets
+  // (zero padding, tails) deliver zeros like the register path
+  constexpr int kStageElems = (BM + BN) * kHK;     // elements per LDS buffer, rows of 128 bytes
+  auto issue_dma = [&](int buf) {
+    if (kc_n == 0) {
+      const int kh = tap_n / g.kw, kw = tap_n - kh * g.kw;
+#pragma unroll
+      for (int j = 0; j < AR; ++j) {
+        const uint32_t o = h_gather(q, a_img[j], a_bh[j], a_bw[j], kh, kw);
+        a_off[j] = (o & kHOOB) ? kHOOB : o + (uint32_t)c8 * 2u;
+      }
+    }
+    const int k0 = kc_n * kHK;
+    const uint32_t sa = (uint32_t)k0 * 2u, sb = (uint32_t)tap_n * w_tap_bytes + (uint32_t)k0 * 2u;
+    const uint32_t pm = k0 + kHK > g.k_ch ? 0xFFFFFFFFu : 0u;
+    T* const a_dst = As + buf * kStageElems + (wave * 8) * kHK;     // wave-uniform
+    T* const b_dst = a_dst + BM * kHK;
+#pragma unroll
+    for (int j = 0; j < AR; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_in, (__attribute__((address_space(3))) void*)(a_dst + kRowsPerPass * j * kHK), 16,
+          (int)(a_off[j] | (last_oob & pm)), (int)sa, 0, 0);
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_w, (__attribute__((address_space(3))) void*)(b_dst + kRowsPerPass * j * kHK), 16,
+          (int)(b_off[j] | (last_oob & pm)), (int)sb, 0, 0);
+    if (++kc_n == p.kchunks) {
+      kc_n = 0;
+      ++tap_n;
+    }
+  };
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -231,6 +272,28 @@ void conv_h_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // operands of buffer `buf` (PF == 0): row stride 64 elements, logical chunk ks * 2 + lh sits at
+  // physical chunk (ks * 2 + lh) ^ (row & 7), row & 7 == l31 & 7
+  auto compute_dma = [&](int buf) {
+    const T* a = As + buf * kStageElems + (wm * TM * 32 + l31) * kHK;
+    const T* b = As + buf * kStageElems + BM * kHK + (wn * TN * 32 + l31) * kHK;
+    const int sw = l31 & 7;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < kHK / 16; ++ks) {
+      const int ch = ((ks * 2 + lh) ^ sw) * 8;
+      V8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const V8*>(a + i * 32 * kHK + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const V8*>(b + j * 32 * kHK + ch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
   auto compute = [&]() {
     const T* a = As + (wm * TM * 32 + l31) * kHLD + lh * 8;
     const T* b = Bs + (wn * TN * 32 + l31) * kHLD + lh * 8;
@@ -252,13 +315,28 @@ void conv_h_kernel(
 
   // step s: [issue the loads of step s + PF] -> MFMAs on the LDS tile of step s -> barrier ->
   // LDS <- registers of step s + 1 (loaded PF - 1 iterations ago) -> barrier
+  if constexpr (PF == 0) {
+    // two LDS buffers: step s + 1 is in flight (DMA) while step s is multiplied; ONE barrier per
+    // step: behind it every wave's pieces of step s have landed (each wave waited for its own) and
+    // every wave is done reading the other buffer (step s - 1)
+    issue_dma(0);
+    for (int s = 0; s < steps; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 1 < steps) issue_dma((s + 1) & 1);
+      compute_dma(s & 1);
+    }
+    __syncthreads();                   // the epilogue reuses the buffers
+  } else {
   load_regs(rset[0]);
   if constexpr (PF == 2) {
     if (steps > 1) load_regs(rset[1]);
   }
   store_lds(rset[0]);
   __syncthreads();
-  if constexpr (PF == 1) {
+  }
+  if constexpr (PF == 0) {
+  } else if constexpr (PF == 1) {
     for (int s = 0; s < steps; ++s) {
       const bool has_next = s + 1 < steps;
       if (has_next) load_regs(rset[0]);
@@ -501,19 +579,23 @@ bool h_geom_ok(const EmsaConvGeom* g) {
   return true;
 }
 
-// EMSA_CONVH_PF=1|2: global-load prefetch depth (A/B; default 1)
-int convh_pf() {
-  static const int v = [] {
-    const char* e = getenv("EMSA_CONVH_PF");
-    const int x = e ? atoi(e) : 1;      // (two steps in flight measured 10-20 % SLOWER on every
-    return x == 2 ? 2 : 1;              //  layer shape: +32 VGPRs cost more occupancy than they hide)
-  }();
-  return v;
+// EMSA_CONVH_PF=0|1|2: how the next K step reaches LDS.  0 (default): LDS-DMA into the second of
+// two LDS buffers, one barrier per step, no staging registers -- measured 2-11 % faster than 1 on
+// the 3-tap / 3x3 shapes (c256@/16 38.3 -> 35.4 us, 3x3 256->128 136 -> 121 us), equal at C = 64,
+// 1-4 % slower on the 1x1 convs (one K step per tap: nothing to overlap), +1.8 % on the bf16
+// training step.  1: one register set + one padded LDS buffer (two barriers per step).  2: two
+// register sets (10-20 % SLOWER than 1 on every shape: +32 VGPRs cost more occupancy than they hide).
+int convh_pf() {              // (read per launch like EMSA_CONVH_TILE: the tests switch it)
+  const char* e = getenv("EMSA_CONVH_PF");
+  const int x = (e && *e) ? atoi(e) : 0;
+  return (x == 1 || x == 2) ? x : 0;
 }
 
 template <int BM, int BN, int WM, int WN, typename T>
 int launch_h(const ConvHArgs& a, hipStream_t st) {
-  constexpr size_t lds_main = (size_t)(BM + BN) * kHLD * 2;
+  constexpr size_t lds_reg = (size_t)(BM + BN) * kHLD * 2;        // one padded buffer (PF >= 1)
+  constexpr size_t lds_dma = (size_t)2 * (BM + BN) * kHK * 2;     // two linear buffers (PF == 0)
+  constexpr size_t lds_main = lds_reg > lds_dma ? lds_reg : lds_dma;
   constexpr size_t lds_epi = (size_t)(BM / WM) * (BN + 4) * sizeof(float);
   constexpr size_t lds_stat = (size_t)(WM + 1) * BN * sizeof(float);
   constexpr size_t lds0 = lds_main > lds_epi ? lds_main : lds_epi;
@@ -531,6 +613,8 @@ int launch_h(const ConvHArgs& a, hipStream_t st) {
   const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
   if (a.bnb_out)
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1, true>), dim3(grid), dim3(256), lds, st, a);
+  else if (convh_pf() == 0)
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0>), dim3(grid), dim3(256), lds, st, a);
   else if (convh_pf() == 2)
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 2>), dim3(grid), dim3(256), lds, st, a);
   else

@@ -61,12 +61,15 @@ CONVS = [
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('tile', [-1, 0, 1, 2])
+@pytest.mark.parametrize('tile,staging', [(-1, 0), (0, 0), (1, 0), (2, 0), (-1, 1), (1, 1), (2, 2)])
 @pytest.mark.parametrize('cfg', CONVS)
-def test_conv16_fwd(cfg, tile, dtype, monkeypatch):
+def test_conv16_fwd(cfg, tile, staging, dtype, monkeypatch):
+    """staging: how the K steps reach LDS -- 0 = LDS-DMA into two buffers (default), 1 = register
+    prefetch + one padded buffer, 2 = two register sets (EMSA_CONVH_PF)"""
     Fn = _fn()
     if tile >= 0:
         monkeypatch.setenv('EMSA_CONVH_TILE', str(tile))
+    monkeypatch.setenv('EMSA_CONVH_PF', str(staging))
     cin, cout, k, s, p, n, h, w = cfg
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, *k, seed=2, scale=0.1)
@@ -97,12 +100,13 @@ def test_conv16_fwd(cfg, tile, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('tile', [-1, 1])
+@pytest.mark.parametrize('tile,staging', [(-1, 0), (1, 0), (-1, 1)])
 @pytest.mark.parametrize('cfg', CONVS)
-def test_conv16_dgrad(cfg, tile, dtype, monkeypatch):
+def test_conv16_dgrad(cfg, tile, staging, dtype, monkeypatch):
     Fn = _fn()
     if tile >= 0:
         monkeypatch.setenv('EMSA_CONVH_TILE', str(tile))
+    monkeypatch.setenv('EMSA_CONVH_PF', str(staging))
     cin, cout, k, s, p, n, h, w = cfg
     x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
     wt = rnd(cout, cin, *k, seed=2, scale=0.1)
