@@ -7,9 +7,40 @@ import os
 import sys
 
 
+def readable(name):
+    """rocprofv3 leaves kernels whose template arguments contain __bf16 / _Float16 mangled (or
+    demangles them into nonsense like 'bool _Accum'): name<ints..., type> from the Itanium string"""
+    import re
+    m = re.match(r'_ZN12_GLOBAL__N_1(\d+)', name)
+    if m:
+        n = int(m.group(1))
+        base = name[m.end():m.end() + n]
+        rest = name[m.end() + n:]
+        args = []
+        for tok in re.finditer(r'Li(\d+)E|Lb([01])E|DF16b|DF16_|f', rest.split('EEv')[0]):
+            t = tok.group(0)
+            args.append(tok.group(1) if t.startswith('Li') else
+                        ('true' if tok.group(2) == '1' else 'false') if t.startswith('Lb') else
+                        {'DF16b': 'bf16', 'DF16_': 'f16', 'f': 'float'}[t])
+        return base + ('<' + ','.join(args) + '>' if args else '')
+    if 'bool _Accum' in name:          # broken demangling of a __bf16 argument: keep the base name
+        return name.split('<')[0] + '<bf16 instance:' + str(__import__('zlib').crc32(name.encode()) % 1000) + '>'
+    return name
+
+
+def merge(d):
+    out = {}
+    for k, v in d.items():
+        r = readable(k.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0])
+        e = out.setdefault(r, {'sum': 0.0, 'launches': 0})
+        e['sum'] += v['sum']
+        e['launches'] += v['launches']
+    return out
+
+
 def main():
     raw = json.load(open(sys.argv[1]))
-    fetch, write = raw['FETCH_SIZE'], raw['WRITE_SIZE']
+    fetch, write = merge(raw['FETCH_SIZE']), merge(raw['WRITE_SIZE'])
     # calibration: the elementwise copies of exactly 1 GiB
     calib = {}
     for name, d in (('FETCH', fetch), ('WRITE', write)):
