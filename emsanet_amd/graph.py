@@ -30,20 +30,36 @@ class GraphedInference:
             raise ValueError("GraphedInference captures the eval-mode forward")
         self.model = model
         self.do_postprocessing = do_postprocessing
+        self.warmup = warmup
         self.static_in = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
+        self.captures = 0
+        self._capture()
+
+    def _weights_key(self):
+        # the packed / Winograd-transformed weights are built by the warm-up runs and the graph
+        # holds pointers to them: a parameter that changed afterwards (optimizer step,
+        # load_state_dict) makes the capture stale
+        return tuple((p._version, p.data_ptr()) for p in self.model.parameters())
+
+    def _capture(self):
+        model = self.model
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):       # packs weights, sets kernel attributes, warms the pool
-                model({**self.static_in, **self.extra}, do_postprocessing=do_postprocessing)
+            for _ in range(self.warmup):  # packs weights, sets kernel attributes, warms the pool
+                model({**self.static_in, **self.extra}, do_postprocessing=self.do_postprocessing)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = model({**self.static_in, **self.extra},
-                                    do_postprocessing=do_postprocessing)
+                                    do_postprocessing=self.do_postprocessing)
+        self._key = self._weights_key()
+        self.captures += 1
 
     def __call__(self, batch):
+        if self._weights_key() != self._key:
+            self._capture()               # weights changed since the capture: re-pack, re-capture
         for k, v in self.static_in.items():
             v.copy_(batch[k], non_blocking=True)
         self.graph.replay()

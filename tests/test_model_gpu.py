@@ -311,6 +311,19 @@ def test_hipgraph_inference_matches_eager():
     for a, b in zip(o2, e2):
         assert torch.equal(a, b)
     assert not torch.equal(o1[0], o2[0])
+    # weights changed after the capture (a fine-tuning step, load_state_dict): the graph holds
+    # pointers to the packed weights of its warm-up runs -> it notices and re-captures
+    assert g.captures == 1
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)
+        e3 = [t.clone() for t in _flatten(model(b1))]
+    o3 = [t.clone() for t in _flatten(g(b1))]
+    torch.cuda.synchronize()
+    assert g.captures == 2
+    for a, b in zip(o3, e3):
+        assert torch.equal(a, b)
+    assert not torch.equal(o3[0], o1[0])
 
 
 def test_missing_gpu_input_fails_loudly():
