@@ -550,12 +550,16 @@ HTile pick_htile(long M, int n_ch) {
   const char* e = getenv("EMSA_CONVH_TILE");
   const int f = (e && *e) ? atoi(e) : -1;
   if (f >= 0 && f < HT_COUNT) return (HTile)f;
-  // measured per layer shape at bs=32 (tools/conv_bench16.py, us for 128x64 / 128x128 / 64x64):
-  // c64@/4 51 / 76 / 52, c128@/8 42 / 37 / 44, c256@/16 36 / 30 / 37, c512@/32 33 / 33 / 33,
-  // 3x3 256->128@/8 139 / 120 / 154 -- the differences are small: the loop is bound by the CU's
-  // load path (every tile is re-fetched through L1/L2), not by the tile's shape
-  if (n_ch >= 128 && M >= 128 * 256) return HT_128x128;
-  if (M < 128 * 512) return HT_64x64;             // few pixels (low resolutions, batch 1): more tiles
+  // measured per layer shape at bs=32 with LDS-DMA staging (tools/conv_bench16.py, forward, us for
+  // 128x64 / 128x128 / 64x64): c64@/4 57 / 88 / 60, c128@/8 44 / 40 / 46, c256@/16 33 / 35 / 38,
+  // c512@/32 32 / 31 / 38, 3x3 512->512@/32 72 / 71 / 92, 3x3 256->128@/8 136 / 122 / 154,
+  // 3x3 128->40@/4 142 / 232 / 170, 1x1 c256@/16 19 / 21 / 21 (data gradients alike): 128x64
+  // unless there are >= 128 output channels AND >= ~100 K pixels (128x128: half the operand bytes
+  // per FLOP, still >= 600 workgroups); 64x64 only when 128x64 would leave CUs without a tile
+  // (batch-1 inference, tiny maps)
+  const long wgs = ((M + 127) / 128) * ((n_ch + 63) / 64);
+  if (wgs < 256) return HT_64x64;
+  if (n_ch >= 128 && M >= 100000) return HT_128x128;
   return HT_128x64;
 }
 
