@@ -556,7 +556,8 @@ HTile pick_htile(long M, int n_ch) {
   // 3x3 128->40@/4 142 / 232 / 170, 1x1 c256@/16 19 / 21 / 21 (data gradients alike): 128x64
   // unless there are >= 128 output channels AND >= ~100 K pixels (128x128: half the operand bytes
   // per FLOP, still >= 600 workgroups); 64x64 only when 128x64 would leave CUs without a tile
-  // (batch-1 inference, tiny maps)
+  // (batch-1 inference, tiny maps).  In the bf16 training step, same box: 604.6 / 602.2 images/s
+  // with this rule vs 582.0 / 585.5 with the one tuned for register staging.
   const long wgs = ((M + 127) / 128) * ((n_ch + 63) / 64);
   if (wgs < 256) return HT_64x64;
   if (n_ch >= 128 && M >= 100000) return HT_128x128;
