@@ -28,9 +28,13 @@
 
 namespace {
 
-constexpr int kHK = 64;               // channels per K step
-constexpr int kHLD = kHK + 8;         // padded LDS row (elements): 144 B
-constexpr int kHRowLanes = kHK / 8;   // lanes (16 B each) per staged row
+// Channels per K step: a template parameter HK of the kernel, 64 (a 128-byte line per pixel row) or
+// 32.  With 32 a workgroup's LDS buffers are half the size (more workgroups per CU) and a step is
+// half the work between barriers: measured faster where the whole K dimension is <= 6 steps of 64
+// (the 64- and 128-channel 1-D convs, the 1x1 convs: c64@/4 57 -> 52 us, 1x1 c128 27 -> 24 us) and
+// slower on the long-K shapes (3x3 128->40 147 -> 176 us, c512@/32 31 -> 34 us); +2.3 % on the
+// bf16 training step with the per-launch choice below (same box, 623.5 vs 609.2 images/s).
+constexpr int kHKMax = 64;
 
 typedef unsigned int hu32x4 __attribute__((ext_vector_type(4)));
 typedef float hf32x8 __attribute__((ext_vector_type(8)));
@@ -124,11 +128,15 @@ __device__ __forceinline__ uint32_t h_gather(const HGather& q, int img_off, int 
 // shape (106 / 166 / 253 VGPRs instead of 74 / 98 / 157); kept as an A/B switch (EMSA_CONVH_PF=2).
 // BNB: the epilogue with the fused BatchNorm-backward sums (ConvHArgs::bnb_out) as its own
 // instantiation (its accumulators and channel vectors spilled in the common kernel).
-template <int BM, int BN, int WM, int WN, typename T, int PF, bool BNB = false>
+template <int BM, int BN, int WM, int WN, typename T, int PF, bool BNB = false, int HK = 64>
 __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? ((PF == 2 || BNB) && BM * BN > 64 * 64 ? 3 : 4) : 2)
 void conv_h_kernel(
     const ConvHArgs p) {
   static_assert(WM * WN == 4, "4 waves");
+  static_assert(HK == 64 || HK == 32, "K step");
+  constexpr int kHK = HK;               // channels per K step
+  constexpr int kHLD = kHK + 8;         // padded LDS row of the register-staged variants (elements)
+  constexpr int kHRowLanes = kHK / 8;   // lanes (16 B each) per staged row
   typedef typename Vec8<T>::type V8;
   constexpr int NT = 256;
   constexpr int kRowsPerPass = NT / kHRowLanes;                   // 32
@@ -164,7 +172,11 @@ void conv_h_kernel(
   // a lane serves (rows advance by 32 per pass, waves by 8), so the logical chunk is a per-lane
   // constant.
   const int rl = tid / kHRowLanes;
-  const int c8 = PF == 0 ? (((lane & 7) ^ (lane >> 3)) * 8) : (tid % kHRowLanes) * 8;
+  // (32-channel steps: four chunks per 64-byte row, swizzle term (row >> 2) & 3 -- rows r..r+3 fill
+  //  one 256-byte bank row with the same chunk index, the next four rows take the next one)
+  const int dma_row = lane / kHRowLanes;           // row within this wave's DMA instruction
+  const int dma_swz = kHRowLanes == 8 ? (dma_row & 7) : ((dma_row >> 2) & 3);
+  const int c8 = PF == 0 ? (((lane % kHRowLanes) ^ dma_swz) * 8) : (tid % kHRowLanes) * 8;
   int a_bh[AR], a_bw[AR], a_img[AR];
   uint32_t a_off[AR], b_off[BR];
 #pragma unroll
@@ -246,7 +258,7 @@ void conv_h_kernel(
     const int k0 = kc_n * kHK;
     const uint32_t sa = (uint32_t)k0 * 2u, sb = (uint32_t)tap_n * w_tap_bytes + (uint32_t)k0 * 2u;
     const uint32_t pm = k0 + kHK > g.k_ch ? 0xFFFFFFFFu : 0u;
-    T* const a_dst = As + buf * kStageElems + (wave * 8) * kHK;     // wave-uniform
+    T* const a_dst = As + buf * kStageElems + (wave * (64 / kHRowLanes)) * kHK;     // wave-uniform
     T* const b_dst = a_dst + BM * kHK;
 #pragma unroll
     for (int j = 0; j < AR; ++j)
@@ -277,7 +289,7 @@ void conv_h_kernel(
   auto compute_dma = [&](int buf) {
     const T* a = As + buf * kStageElems + (wm * TM * 32 + l31) * kHK;
     const T* b = As + buf * kStageElems + BM * kHK + (wn * TN * 32 + l31) * kHK;
-    const int sw = l31 & 7;
+    const int sw = kHRowLanes == 8 ? (l31 & 7) : ((l31 >> 2) & 3);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < kHK / 16; ++ks) {
@@ -596,8 +608,25 @@ int convh_pf() {              // (read per launch like EMSA_CONVH_TILE: the test
   return (x == 1 || x == 2) ? x : 0;
 }
 
-template <int BM, int BN, int WM, int WN, typename T>
-int launch_h(const ConvHArgs& a, hipStream_t st) {
+// K steps of 64 channels over all taps up to which the 32-channel step is used (LDS-DMA variant)
+constexpr int kShortK = 6;
+
+// EMSA_CONVH_SHORTK=0: 64-channel K steps for every launch (A/B)
+bool convh_short_k() {
+  const char* e = getenv("EMSA_CONVH_SHORTK");
+  return !(e && e[0] == '0');
+}
+
+template <int BM, int BN, int WM, int WN, typename T, int HK = 64>
+int launch_h(const ConvHArgs& a_in, hipStream_t st) {
+  if constexpr (HK == 64) {
+    const int steps64 = a_in.g.kh * a_in.g.kw * ((a_in.g.k_ch + 63) / 64);
+    if (!a_in.bnb_out && convh_pf() == 0 && steps64 <= kShortK && convh_short_k())
+      return launch_h<BM, BN, WM, WN, T, 32>(a_in, st);
+  }
+  ConvHArgs a = a_in;
+  a.kchunks = (a.g.k_ch + HK - 1) / HK;
+  constexpr int kHK = HK, kHLD = HK + 8;
   constexpr size_t lds_reg = (size_t)(BM + BN) * kHLD * 2;        // one padded buffer (PF >= 1)
   constexpr size_t lds_dma = (size_t)2 * (BM + BN) * kHK * 2;     // two linear buffers (PF == 0)
   constexpr size_t lds_main = lds_reg > lds_dma ? lds_reg : lds_dma;
@@ -616,7 +645,10 @@ int launch_h(const ConvHArgs& a, hipStream_t st) {
                        (double)a.g.kh * a.g.kw * a.g.n_ch * a.g.k_ch * 2.0 +
                        (a.residual ? px_out : 0.0) + (a.mask_src ? px_out : 0.0);
   const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
-  if (a.bnb_out)
+  if constexpr (HK == 32) {
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, 32>), dim3(grid), dim3(256), lds,
+                       st, a);
+  } else if (a.bnb_out)
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1, true>), dim3(grid), dim3(256), lds, st, a);
   else if (convh_pf() == 0)
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0>), dim3(grid), dim3(256), lds, st, a);
@@ -677,7 +709,7 @@ static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* i
                   act != EMSA_ACT_NONE || bnb_rows_alloc < a.tiles_m))
     return EMSA_E_ARG;
   a.tiles_n = (g->n_ch + ht_bn(t) - 1) / ht_bn(t);
-  a.kchunks = (g->k_ch + kHK - 1) / kHK;
+  a.kchunks = (g->k_ch + kHKMax - 1) / kHKMax;      // (launch_h sets it for its K step)
   a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * 2);
   a.w_bytes = (uint32_t)((size_t)g->kh * g->kw * g->n_ch * g->k_ch * 2);
   a.div_ohw = h_make_fastdiv((uint32_t)(g->out_h * g->out_w));

@@ -99,6 +99,29 @@ def test_conv16_fwd(cfg, tile, staging, dtype, monkeypatch):
     close(y2, ref2, tol=TOL[dtype], what='conv16 epilogue')
 
 
+@pytest.mark.parametrize('cfg', [CONVS[0], CONVS[-2], CONVS[-1]])
+def test_conv16_k_step_choice(cfg, monkeypatch):
+    """short-K convs (<= 6 steps of 64 channels over all taps) run with 32-channel K steps under
+    LDS-DMA staging: same accumulation order, so the result equals the 64-channel-step kernel's
+    bit for bit (EMSA_CONVH_SHORTK=0)"""
+    Fn = _fn()
+    dtype = torch.bfloat16
+    cin, cout, k, s_, p_, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    b = rnd(cout, seed=3)
+    spec = Fn.ConvSpec(cin, cout, k, s_, p_)
+    wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
+    monkeypatch.setenv('EMSA_CONVH_PF', '0')
+    y32, st32 = Fn.conv_fwd(act16(x, dtype), wp, spec, bias=b.to(DEV), want_stats=True)
+    monkeypatch.setenv('EMSA_CONVH_SHORTK', '0')
+    y64, st64 = Fn.conv_fwd(act16(x, dtype), wp, spec, bias=b.to(DEV), want_stats=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y32, y64) and torch.equal(st32, st64)
+    ref = F.conv2d(q(x, dtype), q(wt, dtype), b.double(), stride=s_, padding=p_)
+    close(y32, ref, tol=TOL[dtype], what='conv16 (k-step choice)')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('tile,staging', [(-1, 0), (1, 0), (-1, 1)])
 @pytest.mark.parametrize('cfg', CONVS)
