@@ -32,6 +32,9 @@ class EmsaConvGeom(Structure):
         ('mul_w', c_int32), ('off_w', c_int32), ('step_w', c_int32), ('div_w', c_int32),
         ('in_img_stride', c_int64), ('in_row_stride', c_int64),
         ('in_px_stride', c_int32), ('ld_out', c_int32),
+        # optional output pixel map (0 = dense), see include/emsanet_hip.h
+        ('out_pix_img', c_int32), ('out_pix_row', c_int32), ('out_pix_px', c_int32),
+        ('out_pix_off', c_int32),
     ]
 
 

@@ -90,6 +90,7 @@ struct ConvHArgs {
   int bnb_rows_alloc;
   int ld_res, ld_mask, act;
   int M, tiles_m, tiles_n, kchunks;
+  int mapped;                       // output pixel map in use (EmsaConvGeom::out_pix_*)
   uint32_t in_bytes, w_bytes;
   HFastDiv div_ohw, div_ow;
 };
@@ -492,8 +493,17 @@ void conv_h_kernel(
     if (nok) {
 #pragma unroll 2
       for (int row = row0; row < HR; row += RPP) {
-        const int m = m0 + h * HR + row;
-        if (m >= p.M) break;
+        const int mrow = m0 + h * HR + row;
+        if (mrow >= p.M) break;
+        // pixel of the produced tensor: the row index, or through the output map (a phase of a
+        // strided data gradient writes every s-th row / column)
+        int m = mrow;
+        if (p.mapped) {
+          const int img = (int)h_fast_div((uint32_t)mrow, p.div_ohw);
+          const int rem = mrow - img * (int)p.div_ohw.d;
+          const int oh = (int)h_fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
+          m = img * g.out_pix_img + oh * g.out_pix_row + ow * g.out_pix_px + g.out_pix_off;
+        }
         const float4 v0 = emsa_ld4(stage + row * SLD + col8 * 8);
         const float4 v1 = emsa_ld4(stage + row * SLD + col8 * 8 + 4);
         hf32x8 v = {v0.x * sc0.x + sh0.x, v0.y * sc0.y + sh0.y, v0.z * sc0.z + sh0.z,
@@ -701,6 +711,8 @@ static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* i
   a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
   a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out;
   a.bnb_rows_alloc = bnb_rows_alloc;
+  a.mapped = (g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off) ? 1 : 0;
+  if (a.mapped && (stats || bnb_out)) return EMSA_E_ARG;    // (per-tile sums count one launch's rows)
   const long M = (long)g->n_img * g->out_h * g->out_w;
   a.M = (int)M;
   const HTile t = pick_htile(M, g->n_ch);

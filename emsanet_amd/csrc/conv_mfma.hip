@@ -143,6 +143,7 @@ struct ConvArgs {
   int M, tiles_m, tiles_n, kchunks;
   uint32_t in_bytes, w_bytes;
   int vec_epilogue;          // float4 epilogue legal (n_ch, ld's, pointers 16-B aligned)
+  int mapped;                // output pixel map in use (EmsaConvGeom::out_pix_*)
   FastDiv div_ohw, div_ow;
 };
 
@@ -483,8 +484,17 @@ conv_igemm_kernel(const ConvArgs p) {
       }
 #pragma unroll 4
       for (int row = row0; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= p.M) break;
+        const int mrow = m0 + row;
+        if (mrow >= p.M) break;
+        // pixel of the produced tensor: row index itself, or through the output map (one phase
+        // of a strided data gradient writes every s-th row / column)
+        int m = mrow;
+        if (p.mapped) {
+          const int img = (int)fast_div((uint32_t)mrow, p.div_ohw);
+          const int rem = mrow - img * (int)p.div_ohw.d;
+          const int oh = (int)fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
+          m = img * g.out_pix_img + oh * g.out_pix_row + ow * g.out_pix_px + g.out_pix_off;
+        }
         float4 v = emsa_ld4(stage + row * SLD + col4 * 4);
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
         v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -520,8 +530,15 @@ conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int m = m0 + row;
-          if (m < p.M && nok) {
+          const int mrow = m0 + row;
+          if (mrow < p.M && nok) {
+            int m = mrow;
+            if (p.mapped) {
+              const int img = (int)fast_div((uint32_t)mrow, p.div_ohw);
+              const int rem = mrow - img * (int)p.div_ohw.d;
+              const int oh = (int)fast_div((uint32_t)rem, p.div_ow), ow = rem - oh * g.out_w;
+              m = img * g.out_pix_img + oh * g.out_pix_row + ow * g.out_pix_px + g.out_pix_off;
+            }
             float v = (acc[i][j][r] + bvv[j]) * sc + sh;
             if (p.residual) v += p.residual[(size_t)m * p.ld_res + n];
             if (p.mask_src) v = p.mask_src[(size_t)m * p.ld_mask + n] > 0.f ? v : 0.f;
@@ -1633,6 +1650,9 @@ ConvTile pick_tile(long M, int n_ch) {
   return TILE_64x64;
 }
 
+bool geom_mapped(const EmsaConvGeom* g) {
+  return g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off;
+}
 bool geom_ok(const EmsaConvGeom* g) {
   if (!g) return false;
   if (g->k_ch <= 0 || g->n_ch <= 0 || (g->k_ch & 3) || (g->in_px_stride & 3)) return false;
@@ -1717,6 +1737,8 @@ extern "C" int emsa_conv_igemm(const EmsaConvGeom* g, const float* in, const flo
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats;
   a.scale = scale; a.shift = shift; a.residual = residual; a.mask_src = mask_src;
   a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
+  a.mapped = geom_mapped(g) ? 1 : 0;
+  if (a.mapped && stats) return EMSA_E_ARG;          // (statistics count the rows of one launch)
   const long M = (long)g->n_img * g->out_h * g->out_w;
   a.M = (int)M;
   const ConvTile t = pick_tile(M, g->n_ch);
@@ -1863,7 +1885,7 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
   // (the argument structs carry byte addresses; the kernels read them through typed loaders)
   const float* in = reinterpret_cast<const float*>(in_t);
   const float* dout = reinterpret_cast<const float*>(dout_t);
-  if (!geom_ok(g)) return EMSA_E_SHAPE;
+  if (!geom_ok(g) || geom_mapped(g)) return EMSA_E_SHAPE;
   if (!in || !dout || !dw) return EMSA_E_ARG;
   if (g->div_h != 1 || g->div_w != 1) return EMSA_E_SHAPE;
   WgradArgs a;

@@ -712,6 +712,7 @@ extern "C" int emsa_pack_wino_packed(const float* w_packed, float* u, int32_t n_
 
 // 1 if `g` (forward or data-gradient geometry of a conv) is a stride-1 3-tap 1-D "same" conv
 extern "C" int emsa_conv1d_wino_supported(const EmsaConvGeom* g) {
+  if (g && (g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off)) return 0;
   if (!g) return 0;
   // forward geometry: off = -1, step = +1; data gradient: off = +1, step = -1
   auto tap3 = [](int off, int step) { return (off == -1 || off == 1) && step == -off; };

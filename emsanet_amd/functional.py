@@ -307,6 +307,76 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
     return (res, bits) if want_relu_bits else res
 
 
+# Strided data gradients by output phase (one dense stride-1 launch per parity class instead of ONE
+# launch that visits every tap for every output pixel, half of them structurally zero at stride 2).
+# Measured per training step: fp32 +1.2 % (the matrix-bound implicit GEMM does half the MACs: 12
+# launches of ~230 us -> 24 of ~60); bf16 +-0 (latency-bound launches: two cost what one did).
+# Default: fp32 only; EMSA_DGRAD_PHASES=0 / 1 forces it off / on for every storage type.
+_DGRAD_PHASES_ENV = os.environ.get('EMSA_DGRAD_PHASES')
+DGRAD_PHASES = None          # tests: True / False overrides the default rule
+
+
+def dgrad_phases(dtype):
+    if DGRAD_PHASES is not None:
+        return DGRAD_PHASES
+    if _DGRAD_PHASES_ENV is not None:
+        return _DGRAD_PHASES_ENV != '0'
+    return dtype == torch.float32
+
+
+def _dgrad_phases(spec, h, w):
+    """phase decomposition of a strided data gradient: output pixels (s_h*j + p_h, s_w*i + p_w) only
+    meet the taps kh = kh0 + s_h*t with kh0 = (p_h + pad_h) % s_h -- a DENSE stride-1 convolution of
+    dy with those taps.  -> [(p_h, p_w, khs, kws, off_h, off_w, rows, cols)]"""
+    def axis(size, k, s_, pad):
+        res = []
+        for ph in range(s_):
+            k0 = (ph + pad) % s_
+            taps = list(range(k0, k, s_))
+            n_out = (size - ph + s_ - 1) // s_ if size > ph else 0
+            res.append((ph, taps, (ph + pad - k0) // s_, n_out))
+        return res
+    return [(ph, pw, khs, kws, oh_, ow_, nh, nw)
+            for ph, khs, oh_, nh in axis(h, spec.kh, spec.sh, spec.ph)
+            for pw, kws, ow_, nw in axis(w, spec.kw, spec.sw, spec.pw)]
+
+
+def _conv_dgrad_phased(dy, wpd, spec, in_hw, mask_src, residual, out):
+    n = dy.shape[0]
+    h, w = in_hw
+    phases = _dgrad_phases(spec, h, w)
+    empty = [p_ for p_ in phases if not p_[2] or not p_[3]]
+    if empty and (mask_src is not None or residual is not None):
+        return None                       # (a phase without taps still owes the fused epilogue)
+    if out is None:
+        out = act_empty(n, spec.cin, h, w, dy.device, dtype=dy.dtype)
+    if empty:
+        out.zero_()
+    L = _lib.lib()
+    oh, ow = dy.shape[2], dy.shape[3]
+    ld_dy, ld_dx = ld_of(dy), ld_of(out)
+    lr = ld_of(residual) if residual is not None else 0
+    lm = ld_of(mask_src) if mask_src is not None else 0
+    taps = spec.kh * spec.kw
+    wv = wpd.view(taps, spec.cin * spec.cout)
+    for ph, pw, khs, kws, off_h, off_w, rows, cols in phases:
+        if not khs or not kws or rows == 0 or cols == 0:
+            continue
+        idx = [kh * spec.kw + kw for kh in khs for kw in kws]
+        if idx == list(range(idx[0], idx[0] + len(idx))):
+            wp = wv[idx[0]:idx[0] + len(idx)]                     # contiguous taps: a view
+        else:
+            wp = torch.cat([wv[i:i + 1] for i in idx])       # (no host table: graph-capture safe)
+        g = EmsaConvGeom(n, oh, ow, rows, cols, spec.cout, spec.cin, len(khs), len(kws),
+                         1, off_h, -1, 1, 1, off_w, -1, 1,
+                         oh * ow * ld_dy, ow * ld_dy, ld_dy, ld_dx,
+                         h * w, spec.sh * w, spec.sw, ph * w + pw)
+        check(call_t('emsa_conv_igemm', dt(dy), g, _p(dy), _p(wp), _p(out), None, None, None, None,
+                     _p(residual), lr, _p(mask_src), lm, ACT_NONE, _stream()),
+              'emsa_conv_igemm(dgrad phase)')
+    return out
+
+
 def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, wino_u=None,
                mask_bits=None):
     """dx = conv_transpose(dy); optional fused `* (mask_src > 0)` -- or the same mask as bits
@@ -321,6 +391,11 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
     lr = ld_of(residual) if residual is not None else 0
     if code != 0:
         wino_u = None
+    if wino_u is None and (spec.sh > 1 or spec.sw > 1) and dgrad_phases(dy.dtype) \
+            and wpd is not None and wpd.dtype == dy.dtype:
+        r = _conv_dgrad_phased(dy, wpd, spec, in_hw, mask_src, residual, out)
+        if r is not None:
+            return r
     if wino_u is not None:
         if mask_bits is not None:
             mask_src = None

@@ -76,6 +76,14 @@ typedef struct EmsaConvGeom {
   int64_t in_img_stride, in_row_stride;   /* elements */
   int32_t in_px_stride;                   /* elements */
   int32_t ld_out;                         /* pixel stride of the produced tensor */
+  /* Optional output pixel map (all four 0 = dense: row m is pixel m of the produced tensor).
+   * Otherwise GEMM row (img, oh, ow) is stored at pixel
+   *     img*out_pix_img + oh*out_pix_row + ow*out_pix_px + out_pix_off
+   * of the produced tensor (and read there from `residual` / `mask_src`): a launch that produces
+   * every s-th row / column of a larger tensor -- one PHASE of a strided data gradient, which is a
+   * dense stride-1 convolution over the taps of its parity (emsa_conv_igemm and emsa_conv_igemm_t;
+   * the Winograd and weight-gradient entry points return EMSA_E_SHAPE for a mapped geometry). */
+  int32_t out_pix_img, out_pix_row, out_pix_px, out_pix_off;
 } EmsaConvGeom;
 
 /* out[m][n] = epilogue( sum_{tap,c} in[gather(m,tap)][c] * w[tap][n][c] )

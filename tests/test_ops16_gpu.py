@@ -43,6 +43,8 @@ CONVS = [
     (64, 128, (3, 1), (2, 1), (1, 0), 2, 12, 20),
     (128, 128, (1, 3), (1, 2), (0, 1), 2, 6, 20),
     (64, 128, (1, 1), (2, 2), (0, 0), 2, 12, 20),
+    (64, 128, (3, 1), (2, 1), (1, 0), 2, 15, 20),      # odd height: data-gradient phases of unequal length
+    (16, 32, (3, 3), (2, 2), (1, 1), 1, 9, 11),        # four phases with 4 / 2 / 2 / 1 taps
     (256, 128, (3, 3), (1, 1), (1, 1), 2, 8, 10),
     (128, 40, (3, 3), (1, 1), (1, 1), 2, 8, 10),
     (96, 8, (3, 3), (1, 1), (1, 1), 2, 8, 10),
@@ -130,6 +132,9 @@ def test_conv16_dgrad(cfg, tile, staging, dtype, monkeypatch):
     if tile >= 0:
         monkeypatch.setenv('EMSA_CONVH_TILE', str(tile))
     monkeypatch.setenv('EMSA_CONVH_PF', str(staging))
+    # strided convs: one launch over all taps (the 16-bit default) and, with the default tile and
+    # staging, one launch per output phase through the output pixel map
+    monkeypatch.setattr(Fn, 'DGRAD_PHASES', tile == -1 and staging == 0)
     cin, cout, k, s, p, n, h, w = cfg
     x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
     wt = rnd(cout, cin, *k, seed=2, scale=0.1)

@@ -96,6 +96,53 @@ def test_conv_dgrad(cfg, tile, monkeypatch):
     close(dx3, x.grad + res, what='dgrad residual')
 
 
+STRIDED = [
+    # cin, cout, kernel, stride, padding, n, h, w: odd sizes (phases of unequal length), 2-D strides,
+    # a 3x3 stride-2 kernel (four phases with 4 / 2 / 2 / 1 taps), stride 3
+    (64, 128, (3, 1), (2, 1), (1, 0), 2, 15, 20),
+    (64, 64, (1, 3), (1, 2), (0, 1), 1, 7, 13),
+    (64, 128, (1, 1), (2, 2), (0, 0), 2, 15, 9),
+    (16, 32, (3, 3), (2, 2), (1, 1), 2, 9, 11),
+    (8, 8, (3, 3), (2, 2), (1, 1), 1, 4, 4),
+    (16, 16, (1, 3), (1, 3), (0, 1), 1, 3, 11),
+    (64, 128, (3, 1), (2, 1), (1, 0), 4, 60, 80),
+]
+
+
+@pytest.mark.parametrize('cfg', STRIDED)
+def test_conv_dgrad_strided_phases(cfg, monkeypatch):
+    """strided data gradient as one dense stride-1 launch per output phase (emsa_conv_igemm with
+    the output pixel map) == fp64 autograd == the single launch over all taps, incl. the fused
+    mask / residual epilogue (a phase without taps -- 1x1 stride 2 -- falls back to that one when
+    an epilogue operand is given)"""
+    Fn = _fn()
+    cin, cout, k, s, p, n, h, w = cfg
+    x = rnd(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1)
+    y = F.conv2d(x, wt.double(), None, stride=s, padding=p)
+    dy = rnd(*y.shape, seed=7)
+    y.backward(dy.double())
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    wpd = Fn.pack_weight(wt.to(DEV), 'dgrad')
+    mask = rnd(n, cin, h, w, seed=8)
+    res = rnd(n, cin, h, w, seed=9)
+    outs = {}
+    for phases in (True, False):
+        monkeypatch.setattr(Fn, 'DGRAD_PHASES', phases)
+        outs[phases] = (Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w)),
+                        Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w), mask_src=to_act(mask)),
+                        Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w), residual=to_act(res)),
+                        Fn.conv_dgrad(to_act(dy), wpd, spec, (h, w), mask_src=to_act(mask),
+                                      residual=to_act(res)))
+    torch.cuda.synchronize()
+    for phases in (True, False):
+        d0, d1, d2, d3 = outs[phases]
+        close(d0, x.grad, what=f'dgrad (phases={phases})')
+        close(d1, x.grad * (mask > 0), what=f'dgrad mask (phases={phases})')
+        close(d2, x.grad + res, what=f'dgrad residual (phases={phases})')
+        close(d3, (x.grad + res) * (mask > 0), what=f'dgrad residual+mask (phases={phases})')
+
+
 WINO = [
     # cin, cout, kernel, n, h, w   (stride 1, "same" padding)
     (64, 64, (3, 3), 2, 12, 20),         # 3x3: Winograd along W, kernel rows in the GEMM K
