@@ -69,6 +69,9 @@ SIGNATURES = {
     'emsa_pack_weight_pair': (c_int, [_P, _P, _P] + [c_int32] * 4 + [_P]),
     'emsa_stem_pack_input': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_stem_pack_weight': (c_int, [_P, _P, c_int32, c_int32, _P]),
+    'emsa_stem_pack_input_rows_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, _P]),
+    'emsa_stem_pack_weight_rows_t': (c_int, [c_int32, _P, _P, c_int32, _P]),
+    'emsa_stem_unpack_wgrad_rows': (c_int, [_P, _P, c_int32, _P]),
     'emsa_stem_unpack_wgrad': (c_int, [_P, _P, c_int32, c_int32, _P]),
     'emsa_bn_finalize': (c_int, [_P, c_int32, c_int32, c_int64, _P, _P, c_float, c_float,
                                  _P, _P, _P, _P, _P, _P, _P, _P]),

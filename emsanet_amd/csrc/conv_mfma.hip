@@ -1949,6 +1949,7 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     return emsa_launch_status();
   }
   if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2, T>(a, st);
+  if (taps == 2 && g->k_ch <= 32) return launch_wgrad<64, 32, 2, 2, 1, 2, T>(a, st);   // one-channel stem
   if (taps == 1) {
     // (a 128x128 tile was measured slower for the 1x1 convs: 96 / 82 us vs 66 / 63 us at 128 /
     //  256 channels -- four times the split-K partial-tile volume per workgroup)

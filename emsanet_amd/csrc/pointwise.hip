@@ -99,6 +99,51 @@ __global__ void stem_pack_input_kernel(const float* __restrict__ x, T* __restric
   }
 }
 
+// One-channel stem (the depth encoder): the four "channel" slots of a packed pixel hold four
+// consecutive ROWS of the single input plane instead of one channel and three zeros,
+//   y[n][r'][col][r] = x[n][0][r' - 3 + r][col - 3]        (r' in [0, h + 4), zero outside),
+// so that one 32-float K chunk covers 8 kw positions x 4 kh rows: the 7x7 kernel is TWO super-taps
+// (kh = 0..3 and 4..6) instead of seven row taps -- 2/7 of the matrix work for the same result.
+template <typename T>
+__global__ void stem_pack_input_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int n,
+                                            int h, int w) {
+  const int wp = w + 8, hp = h + 4;
+  const long total = (long)n * hp * wp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % wp);
+    const long r = i / wp;
+    const int row = (int)(r % hp), img = (int)(r / hp);
+    const int sw = col - 3;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (sw >= 0 && sw < w) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sr = row - 3 + k;
+        if (sr >= 0 && sr < h) v[k] = x[((long)img * h + sr) * w + sw];
+      }
+    }
+    emsa_st4(y + i * 4, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+// weights of the one-channel stem: OIHW [cout][1][7][7] <-> [2 (super-tap)][cout][32 = 8(kw) x 4(r)],
+// kh = 4 * tap + r
+template <typename T>
+__global__ void stem_pack_weight_rows_kernel(const float* __restrict__ w, T* __restrict__ wp,
+                                             int cout, int unpack) {
+  const int total = 2 * cout * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i % 32, co = (i / 32) % cout, t = i / (32 * cout);
+    const int kw = k / 4, kh = 4 * t + (k % 4);
+    const bool real = kw < 7 && kh < 7;
+    if (!unpack) {
+      emsa_st1(wp + i, real ? w[(co * 7 + kh) * 7 + kw] : 0.f);
+    } else if (real) {
+      emsa_st1(wp + (co * 7 + kh) * 7 + kw, w[i]);
+    }
+  }
+}
+
 // stem weights: OIHW [cout][cin][7][7] <-> [7(kh)][cout][32 = 8(kw) x 4(c)]
 template <typename T>
 __global__ void stem_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wp,
@@ -1625,6 +1670,36 @@ extern "C" int emsa_stem_unpack_wgrad(const float* dwp, float* dw, int32_t cout,
   if (cin < 1 || cin > 4) return EMSA_E_SHAPE;
   hipLaunchKernelGGL(stem_pack_weight_kernel<float>, dim3(grid_for(7L * cout * 32)), dim3(kThreads),
                      0, (hipStream_t)stream, dwp, dw, cout, cin, 1);
+  return emsa_launch_status();
+}
+
+// one-channel stem in the rows-as-channels layout (see stem_pack_input_rows_kernel): packed image
+// [n][h + 4][w + 8][4], packed weights [2][cout][32]
+extern "C" int emsa_stem_pack_input_rows_t(int32_t dtype, const float* x, void* xp, int32_t n,
+                                           int32_t h, int32_t w, void* stream) {
+  if (!x || !xp) return EMSA_E_ARG;
+  const long total = (long)n * (h + 4) * (w + 8);
+  EMSA_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((stem_pack_input_rows_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
+                       (hipStream_t)stream, x, (T*)xp, n, h, w);
+    return emsa_launch_status();
+  });
+  return EMSA_E_ARG;
+}
+extern "C" int emsa_stem_pack_weight_rows_t(int32_t dtype, const float* w, void* wp, int32_t cout,
+                                            void* stream) {
+  if (!w || !wp) return EMSA_E_ARG;
+  EMSA_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL(stem_pack_weight_rows_kernel<T>, dim3(grid_for(2L * cout * 32)),
+                       dim3(kThreads), 0, (hipStream_t)stream, w, (T*)wp, cout, 0);
+    return emsa_launch_status();
+  });
+  return EMSA_E_ARG;
+}
+extern "C" int emsa_stem_unpack_wgrad_rows(const float* dwp, float* dw, int32_t cout, void* stream) {
+  if (!dwp || !dw) return EMSA_E_ARG;
+  hipLaunchKernelGGL(stem_pack_weight_rows_kernel<float>, dim3(grid_for(2L * cout * 32)),
+                     dim3(kThreads), 0, (hipStream_t)stream, dwp, dw, cout, 1);
   return emsa_launch_status();
 }
 

@@ -527,11 +527,20 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db
 # ---------------------------------------------------------------------------------------------
 # stem (7x7 s2 p3 on NCHW input)
 # ---------------------------------------------------------------------------------------------
+# EMSA_STEM_ROWS=0: the one-channel (depth) stem in the generic NHWC4 layout (seven row taps of 32,
+# 28 of them zeros) instead of rows-as-channels (two super-taps) -- A/B switch
+STEM_ROWS = os.environ.get('EMSA_STEM_ROWS', '1') != '0'
+
+
 class StemSpec:
-    """7x7/2 conv expressed as a 7x1 conv over the zero-padded NHWC4 image (k_ch = 32)."""
+    """7x7/2 conv expressed as a 7x1 conv over the zero-padded NHWC4 image (k_ch = 32); with ONE
+    input channel (`rows`): as a 2x1 conv over the rows-as-channels image (emsa_stem_*_rows*),
+    2/7 of the matrix work"""
 
     def __init__(self, cin, cout=64):
         self.cin, self.cout = cin, cout
+        self.rows = cin == 1 and STEM_ROWS
+        self.taps = 2 if self.rows else 7
         self._geoms = {}
 
     def out_hw(self, h, w):
@@ -543,9 +552,15 @@ class StemSpec:
         if g is None:
             oh, ow = self.out_hw(h, w)
             wp = w + 8
-            g = EmsaConvGeom(n, h, wp, oh, ow, 32, self.cout, 7, 1,
-                             2, -3, 1, 1, 2, 0, 1, 1,
-                             h * wp * 4, wp * 4, 4, ld_out)
+            if self.rows:
+                hp = h + 4
+                g = EmsaConvGeom(n, hp, wp, oh, ow, 32, self.cout, 2, 1,
+                                 2, 0, 4, 1, 2, 0, 1, 1,
+                                 hp * wp * 4, wp * 4, 4, ld_out)
+            else:
+                g = EmsaConvGeom(n, h, wp, oh, ow, 32, self.cout, 7, 1,
+                                 2, -3, 1, 1, 2, 0, 1, 1,
+                                 h * wp * 4, wp * 4, 4, ld_out)
             self._geoms[key] = g
         return g
 
@@ -553,6 +568,11 @@ class StemSpec:
 def stem_pack_input(x_nchw, dtype=torch.float32):
     x = x_nchw.contiguous()
     n, c, h, w = x.shape
+    if c == 1 and STEM_ROWS:
+        xp = _empty((n, h + 4, w + 8, 4), x.device, dtype)
+        check(_lib.lib().emsa_stem_pack_input_rows_t(DT[dtype], _p(x), _p(xp), n, h, w, _stream()),
+              'emsa_stem_pack_input_rows_t')
+        return xp
     xp = _empty((n, h, w + 8, 4), x.device, dtype)
     check(call_t('emsa_stem_pack_input', DT[dtype], _p(x), _p(xp), n, c, h, w, _stream()),
           'emsa_stem_pack_input')
@@ -561,6 +581,11 @@ def stem_pack_input(x_nchw, dtype=torch.float32):
 
 def stem_pack_weight(w, dtype=torch.float32):
     cout, cin = w.shape[:2]
+    if cin == 1 and STEM_ROWS:
+        wp = _empty(2 * cout * 32, w.device, dtype)
+        check(_lib.lib().emsa_stem_pack_weight_rows_t(DT[dtype], _p(w), _p(wp), cout, _stream()),
+              'emsa_stem_pack_weight_rows_t')
+        return wp
     wp = _empty(7 * cout * 32, w.device, dtype)
     check(call_t('emsa_stem_pack_weight', DT[dtype], _p(w), _p(wp), cout, cin, _stream()),
           'emsa_stem_pack_weight')
@@ -596,17 +621,21 @@ def stem_fwd_folded(xp, wpk, spec, n, h, w, scale, shift, bias=None):
 def stem_wgrad(xp, dy, spec, n, h, w, like, out=None, want_bias=False):
     """-> dw (OIHW), or (dw, dbias) with want_bias"""
     g = spec.geom(n, h, w, ld_of(dy))
-    buf = torch.zeros(7 * spec.cout * 32 + (spec.cout if want_bias else 0), device=dy.device,
-                      dtype=torch.float32)
-    dwp = buf[:7 * spec.cout * 32]
-    db = buf[7 * spec.cout * 32:] if want_bias else None
+    nw = spec.taps * spec.cout * 32
+    buf = torch.zeros(nw + (spec.cout if want_bias else 0), device=dy.device, dtype=torch.float32)
+    dwp = buf[:nw]
+    db = buf[nw:] if want_bias else None
     oh, ow = spec.out_hw(h, w)
     prof_flops(2.0 * n * oh * ow * spec.cout * 49 * spec.cin)
     check(call_t('emsa_conv_wgrad', dt(dy), g, _p(xp), _p(dy), _p(dwp), _p(db), None, _stream()),
           'emsa_conv_wgrad(stem)')
     dw = out if out is not None else _empty(tuple(like.shape), like.device)
-    check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
-          'emsa_stem_unpack_wgrad')
+    if spec.rows:
+        check(_lib.lib().emsa_stem_unpack_wgrad_rows(_p(dwp), _p(dw), spec.cout, _stream()),
+              'emsa_stem_unpack_wgrad_rows')
+    else:
+        check(_lib.lib().emsa_stem_unpack_wgrad(_p(dwp), _p(dw), spec.cout, spec.cin, _stream()),
+              'emsa_stem_unpack_wgrad')
     return (dw, db) if want_bias else dw
 
 

@@ -207,6 +207,16 @@ int emsa_stem_pack_weight(const float* w_oihw, float* w_packed, int32_t cout, in
                           void* stream);
 int emsa_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, int32_t cout, int32_t cin,
                            void* stream);
+/* One-channel stem (depth encoder) in the rows-as-channels layout: the four slots of a packed
+ * pixel hold four consecutive ROWS of the input plane, xp [n][h+4][w+8][4] with
+ * xp[n][r'][col][r] = x[n][0][r'-3+r][col-3]; the 7x7 kernel becomes two super-taps (kh = 4*tap + r),
+ * packed weights [2][cout][32 = 8 kw x 4 r].  Geometry for emsa_conv_igemm(_t) / emsa_conv_wgrad(_t):
+ * in (h+4) x (w+8), k_ch 32, kh 2, kw 1, mul_h 2, off_h 0, step_h 4, mul_w 2, off_w 0: 2/7 of the
+ * matrix work of the generic stem for the same result. */
+int emsa_stem_pack_input_rows_t(int32_t dtype, const float* x, void* xp, int32_t n, int32_t h,
+                                int32_t w, void* stream);
+int emsa_stem_pack_weight_rows_t(int32_t dtype, const float* w, void* wp, int32_t cout, void* stream);
+int emsa_stem_unpack_wgrad_rows(const float* dwp, float* dw, int32_t cout, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (+ReLU, +Dropout2d, +residual add)  -- nn.BatchNorm2d / activation / nn.Dropout2d /

@@ -328,10 +328,14 @@ def test_conv_wgrad_split_k_large():
     assert torch.equal(dw2, dw3), 'two-pass weight gradient is not bit-reproducible'
 
 
-@pytest.mark.parametrize('cin', [3, 1])
-def test_stem(cin):
+@pytest.mark.parametrize('shape', [(2, 32, 48), (1, 22, 26)])
+@pytest.mark.parametrize('cin,rows', [(3, True), (1, True), (1, False)])
+def test_stem(cin, rows, shape, monkeypatch):
+    """rows: the one-channel stem in the rows-as-channels layout (two super-taps) vs the generic
+    NHWC4 layout (seven row taps)"""
     Fn = _fn()
-    n, h, w = 2, 32, 48
+    monkeypatch.setattr(Fn, 'STEM_ROWS', rows)
+    n, h, w = shape
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(64, cin, 7, 7, seed=2, scale=0.1).double().requires_grad_(True)
     y = F.conv2d(x.double(), wt, None, stride=2, padding=3)
