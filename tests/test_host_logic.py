@@ -356,3 +356,39 @@ def test_spec_switches_change_the_structure_like_the_oracle(monkeypatch):
         if name == 'SKIP_FUSION_1X1':
             assert 'decoders.semantic_decoder.decoder_modules.0.skip_fusion.conv.weight' in sm
         monkeypatch.undo()
+
+
+@pytest.mark.parametrize('cfg', [
+    (3, 4, (3, 1), (2, 1), (1, 0), 2, 15, 6), (3, 4, (1, 3), (1, 2), (0, 1), 1, 7, 13),
+    (3, 4, (1, 1), (2, 2), (0, 0), 1, 5, 9), (2, 3, (3, 3), (2, 2), (1, 1), 1, 9, 11),
+    (2, 2, (1, 3), (1, 3), (0, 1), 1, 3, 11), (2, 2, (3, 3), (2, 2), (1, 1), 1, 4, 4),
+    (2, 2, (3, 1), (1, 1), (1, 0), 1, 5, 4)])
+def test_strided_dgrad_phase_plan(cfg):
+    """host logic of the phase-decomposed strided data gradient (functional._dgrad_phases): every
+    output pixel belongs to exactly one phase, and evaluating each phase as the dense stride-1
+    convolution of dy it describes (tap subset, row / column offsets) reproduces autograd's dx"""
+    import torch.nn.functional as F
+    from emsanet_amd import functional as Fn
+    cin, cout, k, s, p, n, h, w = cfg
+    torch.manual_seed(0)
+    x = torch.randn(n, cin, h, w, dtype=torch.double, requires_grad=True)
+    wt = torch.randn(cout, cin, *k, dtype=torch.double)
+    y = F.conv2d(x, wt, None, stride=s, padding=p)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    spec = Fn.ConvSpec(cin, cout, k, s, p)
+    oh, ow = y.shape[2:]
+    dx = torch.full((n, cin, h, w), float('nan'), dtype=torch.double)
+    for ph, pw, khs, kws, off_h, off_w, rows, cols in Fn._dgrad_phases(spec, h, w):
+        for j in range(rows):
+            for i in range(cols):
+                acc = torch.zeros(n, cin, dtype=torch.double)
+                for th, kh in enumerate(khs):
+                    for tw, kw in enumerate(kws):
+                        r, c = j + off_h - th, i + off_w - tw
+                        if 0 <= r < oh and 0 <= c < ow:
+                            acc += dy[:, :, r, c] @ wt[:, :, kh, kw]
+                assert torch.isnan(dx[:, :, s[0] * j + ph, s[1] * i + pw]).all()      # written once
+                dx[:, :, s[0] * j + ph, s[1] * i + pw] = acc
+    assert not torch.isnan(dx).any()                                                   # covered
+    assert float((dx - x.grad).abs().max()) < 1e-12
