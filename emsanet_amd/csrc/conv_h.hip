@@ -10,12 +10,13 @@
 //   * at 2.5 PFLOP/s the 64/128-channel layers are HBM-bound (arithmetic intensity 96 / 192 FLOP/B
 //     against a ridge of ~400) and the 256/512-channel ones LDS/issue-bound, never MFMA-bound, so
 //     the kernel is built around bytes: activations, weights and LDS tiles are 16-bit, one K step
-//     is 64 channels (a 128-byte line per pixel row and 16-byte accesses per lane everywhere),
-//     Winograd is NOT used (it saves matrix instructions, which are free here, and costs
-//     transforms + precision);
-//   * one MFMA consumes 8 consecutive k per lane = one ds_read_b128, so no K permutation trick is
-//     needed; LDS rows are padded to 144 bytes (36 banks) -> the 16-lane groups of ds_read_b128
-//     cover all 64 banks, staging writes are 8 lanes x 16 B per row;
+//     is 64 channels (a 128-byte line per pixel row; 32 for short-K launches, see HK below) and
+//     every access is 16 bytes per lane, Winograd is NOT used (it saves matrix instructions, which
+//     are free here, and costs transforms + precision);
+//   * K steps reach LDS by LDS-DMA (buffer_load ... lds) into two unpadded buffers with the bank
+//     swizzle on the source side (PF == 0, default), or through registers into one padded buffer
+//     (PF >= 1: rows of 144 bytes = 36 banks); either way one MFMA consumes 8 consecutive k per
+//     lane = one conflict-free ds_read_b128, so no K permutation trick is needed;
 //   * wave tile 64x32 / 64x64 (2x1 / 2x2 MFMA tiles): per 16-deep k sub-step 3-4 ds_read_b128 feed
 //     2-4 MFMAs of 32 cycles, which keeps the LDS pipe below the matrix pipe's issue time;
 //   * the epilogue converts to the storage type and stores 16 bytes (8 channels) per lane; the
