@@ -690,26 +690,45 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __res
 // run-to-run noise there flips ReLU masks downstream)
 template <typename T>
 __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                   float* __restrict__ ws, long hw, int c4n, int splits) {
+                                   float* __restrict__ ws, long hw, int cvn, int splits) {
+  // 16 bytes per lane in every storage type (8 channels of bf16 / fp16, 4 of fp32): block =
+  // (cvn channel vectors) x (256 / cvn row lanes) over this split's pixels
+  constexpr int V = VecIO<T>::V;
+  extern __shared__ __attribute__((aligned(16))) float cred[];   // [lanes][c]
   const int img = blockIdx.x / splits, sp = blockIdx.x % splits;
   const long chunk = (hw + splits - 1) / splits;
   const long p0 = img * hw + sp * chunk, p1 = min(img * hw + (sp + 1) * chunk, (img + 1) * hw);
-  float4 o1, o2;
-  bool leader;
-  int c4;
-  column_reduce(
-      p0, p1, c4n,
-      [&](long p, int cc, float4& t1, float4& t2) {
-        const long i = (p * c4n + cc) * 4;
-        t1 = emsa_ld4(a + i);
-        if (b) {
-          const float4 bb = emsa_ld4(b + i);
-          t1.x *= bb.x; t1.y *= bb.y; t1.z *= bb.z; t1.w *= bb.w;
-        }
-        t2 = emsa_zero4();
-      },
-      o1, o2, leader, c4);
-  if (leader) emsa_st4(ws + ((long)blockIdx.x * c4n + c4) * 4, o1);
+  const int lanes = kThreads / cvn, c = cvn * V;
+  const int cv = threadIdx.x % cvn, rl = threadIdx.x / cvn;
+  if (rl < lanes) {
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (long p = p0 + rl; p < p1; p += lanes) {
+      const long i = (p * cvn + cv) * V;
+      float va[V];
+      VecIO<T>::load(a + i, va);
+      if (b) {
+        float vb[V];
+        VecIO<T>::load(b + i, vb);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += va[k] * vb[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += va[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) cred[rl * c + cv * V + k] = acc[k];
+  }
+  __syncthreads();
+  // (kThreads, not blockDim.x: with blockDim.x here the hipGraph-captured training step read a
+  //  different value at replay than the eager launch does -- bisected with single-kernel builds)
+  for (int ch = threadIdx.x; ch < c; ch += kThreads) {
+    float t = 0.f;
+    for (int k = 0; k < lanes; ++k) t += cred[k * c + ch];
+    ws[(long)blockIdx.x * c + ch] = t;
+  }
 }
 
 __global__ void channel_dot_finish_kernel(const float* __restrict__ ws, float* __restrict__ out,
@@ -889,18 +908,25 @@ __global__ void se_mlp_bwd_kernel(const float* __restrict__ gap, const float* __
 template <typename T>
 __global__ void se_scale_add_fwd_kernel(const T* __restrict__ a, const float* __restrict__ sa,
                                         const T* __restrict__ b, const float* __restrict__ sb,
-                                        T* __restrict__ out, long hw, int c4n, long total4) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+                                        T* __restrict__ out, long hw, int cvn, long totalv) {
+  constexpr int V = VecIO<T>::V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalv;
        i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const long img = (i / c4n) / hw;
-    const float4 va = emsa_ld4(a + i * 4), ka = emsa_ld4(sa + (img * c4n + c4) * 4);
-    float4 o = make_float4(va.x * ka.x, va.y * ka.y, va.z * ka.z, va.w * ka.w);
+    const int cv = (int)(i % cvn);
+    const long img = (i / cvn) / hw;
+    float va[V], ka[V], o[V];
+    VecIO<T>::load(a + i * V, va);
+    ldf<V>(sa + (img * cvn + cv) * V, ka);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = va[k] * ka[k];
     if (b) {
-      const float4 vb = emsa_ld4(b + i * 4), kb = emsa_ld4(sb + (img * c4n + c4) * 4);
-      o.x += vb.x * kb.x; o.y += vb.y * kb.y; o.z += vb.z * kb.z; o.w += vb.w * kb.w;
+      float vb[V], kb[V];
+      VecIO<T>::load(b + i * V, vb);
+      ldf<V>(sb + (img * cvn + cv) * V, kb);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] += vb[k] * kb[k];
     }
-    emsa_st4(out + i * 4, o);
+    VecIO<T>::store(out + i * V, o);
   }
 }
 
@@ -909,20 +935,25 @@ __global__ void se_scale_bwd_apply_kernel(const T* __restrict__ dout,
                                           const float* __restrict__ s,
                                           const float* __restrict__ dgap,
                                           const T* __restrict__ extra, T* __restrict__ dx,
-                                          long hw, int c4n, long total4, float inv_hw) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4;
+                                          long hw, int cvn, long totalv, float inv_hw) {
+  constexpr int V = VecIO<T>::V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalv;
        i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    const long img = (i / c4n) / hw;
-    const float4 g = emsa_ld4(dout + i * 4), k = emsa_ld4(s + (img * c4n + c4) * 4);
-    const float4 dg = emsa_ld4(dgap + (img * c4n + c4) * 4);
-    float4 o = make_float4(g.x * k.x + dg.x * inv_hw, g.y * k.y + dg.y * inv_hw,
-                           g.z * k.z + dg.z * inv_hw, g.w * k.w + dg.w * inv_hw);
+    const int cv = (int)(i % cvn);
+    const long img = (i / cvn) / hw;
+    float g[V], k_[V], dg[V], o[V];
+    VecIO<T>::load(dout + i * V, g);
+    ldf<V>(s + (img * cvn + cv) * V, k_);
+    ldf<V>(dgap + (img * cvn + cv) * V, dg);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = g[k] * k_[k] + dg[k] * inv_hw;
     if (extra) {
-      const float4 e = emsa_ld4(extra + i * 4);
-      o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+      float e[V];
+      VecIO<T>::load(extra + i * V, e);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] += e[k];
     }
-    emsa_st4(dx + i * 4, o);
+    VecIO<T>::store(dx + i * V, o);
   }
 }
 
@@ -1929,12 +1960,12 @@ static int channel_splits(long hw) {
 template <typename T>
 static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, long hw,
                        int c, float scale, hipStream_t st) {
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const int splits = channel_splits(hw);
-  const int c4n = c / 4, lanes = kThreads / c4n;
-  const size_t lds = (size_t)2 * lanes * c * sizeof(float);
+  const int cvn = c / VecIO<T>::V, lanes = kThreads / cvn;
+  const size_t lds = (size_t)lanes * c * sizeof(float);
   hipLaunchKernelGGL((channel_dot_kernel<T>), dim3(n * splits), dim3(kThreads), lds, st, a, b, ws,
-                     hw, c4n, splits);
+                     hw, cvn, splits);
   hipLaunchKernelGGL(channel_dot_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, ws,
                      out, n, c, splits, scale);
   return emsa_launch_status();
@@ -2007,10 +2038,10 @@ extern "C" int emsa_se_mlp_bwd(const float* gap, const float* w1, const float* w
 template <typename T>
 static int se_scale_add_fwd_impl(const T* a, const float* sa, const T* b, const float* sb, T* out, int32_t n, int64_t hw, int32_t c, void* stream) {
   if (!a || !sa || !out || ((b == nullptr) != (sb == nullptr))) return EMSA_E_ARG;
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
-  const long total4 = (long)n * hw * (c / 4);
-  hipLaunchKernelGGL((se_scale_add_fwd_kernel<T>), dim3(grid_for(total4)), dim3(kThreads), 0,
-                     (hipStream_t)stream, a, sa, b, sb, out, (long)hw, c / 4, total4);
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
+  const long totalv = (long)n * hw * (c / VecIO<T>::V);
+  hipLaunchKernelGGL((se_scale_add_fwd_kernel<T>), dim3(grid_for(totalv)), dim3(kThreads), 0,
+                     (hipStream_t)stream, a, sa, b, sb, out, (long)hw, c / VecIO<T>::V, totalv);
   return emsa_launch_status();
 }
 extern "C" int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b, const float* sb, float* out, int32_t n, int64_t hw, int32_t c, void* stream) {
@@ -2027,11 +2058,11 @@ extern "C" int emsa_se_scale_add_fwd_t(int32_t dtype, const void* a, const float
 template <typename T>
 static int se_scale_bwd_apply_impl(const T* dout, const float* s, const float* dgap, const T* dx_extra, T* dx, int32_t n, int64_t hw, int32_t c, void* stream) {
   if (!dout || !s || !dgap || !dx) return EMSA_E_ARG;
-  if (!c4_ok(c)) return EMSA_E_SHAPE;
-  const long total4 = (long)n * hw * (c / 4);
-  hipLaunchKernelGGL((se_scale_bwd_apply_kernel<T>), dim3(grid_for(total4)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dout, s, dgap, dx_extra, dx, (long)hw, c / 4, total4,
-                     1.0f / (float)hw);
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
+  const long totalv = (long)n * hw * (c / VecIO<T>::V);
+  hipLaunchKernelGGL((se_scale_bwd_apply_kernel<T>), dim3(grid_for(totalv)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dout, s, dgap, dx_extra, dx, (long)hw, c / VecIO<T>::V,
+                     totalv, 1.0f / (float)hw);
   return emsa_launch_status();
 }
 extern "C" int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap, const float* dx_extra, float* dx, int32_t n, int64_t hw, int32_t c, void* stream) {
