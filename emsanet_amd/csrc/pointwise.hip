@@ -724,7 +724,11 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict_
   __syncthreads();
   // (kThreads, not blockDim.x: with blockDim.x here the hipGraph-captured training step read a
   //  different value at replay than the eager launch does -- bisected with single-kernel builds)
+#ifdef EMSA_PROBE_BLOCKDIM            // tools/jobs/r03a.sh: the round-2 form, for the root-cause probe
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+#else
   for (int ch = threadIdx.x; ch < c; ch += kThreads) {
+#endif
     float t = 0.f;
     for (int k = 0; k < lanes; ++k) t += cred[k * c + ch];
     ws[(long)blockIdx.x * c + ch] = t;
@@ -1962,7 +1966,11 @@ static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, lon
                        int c, float scale, hipStream_t st) {
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const int splits = channel_splits(hw);
-  const int cvn = c / VecIO<T>::V, lanes = kThreads / cvn;
+  const int cvn = c / VecIO<T>::V;
+  // one thread column per channel vector: wider tensors (> 1024 fp32 / 2048 16-bit channels) would
+  // leave `lanes` = 0 and every sum silently zero -- refuse them
+  if (cvn > kThreads) return EMSA_E_SHAPE;
+  const int lanes = kThreads / cvn;
   const size_t lds = (size_t)lanes * c * sizeof(float);
   hipLaunchKernelGGL((channel_dot_kernel<T>), dim3(n * splits), dim3(kThreads), lds, st, a, b, ws,
                      hw, cvn, splits);

@@ -69,6 +69,38 @@ class GraphedInference:
         return _flatten(self.static_out)
 
 
+class _TrainStateSnapshot:
+    """everything a training step changes besides gradients: parameters + momentum (the flat
+    buffers of FusedSGD), BatchNorm running statistics and step counters, Dropout2d step,
+    first-step flag"""
+
+    def __init__(self, model, optimizer, bns):
+        self.model, self.opt, self.bns = model, optimizer, bns
+        self.params = [p.clone() for p in optimizer.flat_params]
+        self.momentum = [m.clone() for m in optimizer.flat_momentum]
+        self.buffers = [(b, b.clone()) for b in model.buffers()]
+        self.pending = [m._emsa_pending for m in bns]
+        self.first = optimizer._first
+        self.dropout_step = model.dropout_step
+
+    @torch.no_grad()
+    def restore(self):
+        for dst, src in zip(self.opt.flat_params, self.params):
+            dst.copy_(src)
+        for dst, src in zip(self.opt.flat_momentum, self.momentum):
+            dst.copy_(src)
+        for (_, ps, _) in self.opt.buckets.buckets:     # raw copies into the flat storage
+            torch.autograd.graph.increment_version(ps)
+        for b, src in self.buffers:
+            b.copy_(src)
+        for m, n in zip(self.bns, self.pending):
+            m._emsa_pending = n
+        self.opt._first = self.first
+        self.opt._upload_hyper()
+        self.model.dropout_step = self.dropout_step
+        self.model._sync_dropout_state()
+
+
 class GraphedTrainStep:
     """One whole training step -- forward, backward, fused SGD update -- captured in a hipGraph.
 
@@ -91,11 +123,19 @@ class GraphedTrainStep:
     collectives issued from autograd hooks inside a capture are not supported here)."""
 
     def __init__(self, model, example_batch, buckets, optimizer, loss_fn=None, cotangents=None,
-                 warmup=3):
+                 warmup=3, keep_warmup_updates=False):
+        """The constructor has to RUN `warmup` real steps on `example_batch` before it can record one
+        (they pack the weights, set kernel attributes and size the graph's memory pool).  By default
+        their effects are taken back: parameters, momentum buffers, BatchNorm running statistics and
+        step counters, the Dropout2d step and the optimizer's first-step flag are snapshotted before
+        and restored after the warm-up, so that building the graph does not train the model on one
+        batch behind the user's back.  `keep_warmup_updates=True` keeps them (the
+        warm-up then counts as `warmup` ordinary training steps at the optimizer's current lr)."""
         if not model.training:
             raise ValueError("GraphedTrainStep captures the train-mode step")
         if buckets.active:
-            raise NotImplementedError("graph capture of the multi-rank step (collectives in hooks)")
+            raise NotImplementedError("graph capture of the multi-rank step (collectives in hooks); "
+                                      "see SegmentedGraphedTrainStep")
         if (loss_fn is None) == (cotangents is None):
             raise ValueError("give either loss_fn or cotangents")
         self.model, self.buckets, self.opt = model, buckets, optimizer
@@ -104,8 +144,9 @@ class GraphedTrainStep:
         self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
         model.use_device_dropout_state(True)
         optimizer.use_device_hyperparameters(True)
-        from . import ops
-        self._bn_rts = [rt for rt in ops._BN_RTS if rt.bn.training]
+        self._bns = [m for m in model.modules()
+                     if hasattr(m, '_emsa_pending') and m.training]
+        snap = None if keep_warmup_updates else _TrainStateSnapshot(model, optimizer, self._bns)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -113,17 +154,23 @@ class GraphedTrainStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        pend = {id(rt): rt.pending_batches for rt in self._bn_rts}
+        if snap is not None:
+            snap.restore()
+            torch.cuda.synchronize()
+        pend = {id(m): m._emsa_pending for m in self._bns}
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss, self.static_out = self._step()
         # the capture RECORDED a step, it did not run one: take its host-side effects back (what
         # ONE step adds to the host-side BatchNorm step counters is replayed by `replay()`)
-        self._bn_inc = [(rt, rt.pending_batches - pend[id(rt)]) for rt in self._bn_rts]
-        for rt, inc in self._bn_inc:
-            rt.pending_batches -= inc
+        self._bn_inc = [(m, m._emsa_pending - pend[id(m)]) for m in self._bns]
+        for m, inc in self._bn_inc:
+            m._emsa_pending -= inc
         model.dropout_step -= 1
         model._seed_dev_host = (model.dropout_seed & 0xFFFFFFFF, model.dropout_step & 0xFFFFFFFF)
+        if snap is not None:
+            optimizer._first = snap.first          # (step() inside a capture leaves it alone)
+            optimizer._upload_hyper()
         self.replays = 0
 
     def _step(self):
@@ -150,7 +197,7 @@ class GraphedTrainStep:
         m = self.model
         m.dropout_step += 1                      # (the device counter was bumped by the graph)
         m._seed_dev_host = (m.dropout_seed & 0xFFFFFFFF, m.dropout_step & 0xFFFFFFFF)
-        for rt, inc in self._bn_inc:
-            rt.pending_batches += inc
-        self.opt.after_replay()
+        for bn, inc in self._bn_inc:
+            bn._emsa_pending += inc
+        self.opt.after_replay()     # version counters of the parameters, first-step flag
         return self.static_loss, self.static_out

@@ -130,9 +130,9 @@ class EMSANet(nn.Module):
         # BASELINE configs[2] mixed-precision training, 'bfloat16' / 'float16' = configs[4] inference
         self.compute_dtype = torch.float32
         self.set_compute_dtype(getattr(args, 'compute_dtype', 'float32'))
-        # BatchNorm step counters are kept on the host and written to the buffers when a
-        # state_dict is taken (no per-layer counter kernel in the training step)
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: ops.flush_bn_counters())
+        # BatchNorm step counters are kept on the host (on each BatchNorm module) and written to
+        # the buffers when a state_dict is taken -- of the model or of any sub-module -- by the
+        # per-module hooks of ops.BNRT (no per-layer counter kernel in the training step)
 
     def set_compute_dtype(self, dtype):
         """activations (and the packed conv operands) are stored as `dtype`; parameters, BatchNorm

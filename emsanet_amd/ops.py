@@ -9,7 +9,6 @@ per conv+BN+act, per SE fusion, per learned upsampling ...  Every Function only 
 into libemsanet_hip.so (emsanet_amd/functional.py); autograd is used for graph bookkeeping only.
 """
 import os
-import weakref
 
 import torch
 from torch.autograd import Function
@@ -234,16 +233,31 @@ class PackPlan:
         self._key = key
 
 
-_BN_RTS = weakref.WeakSet()
+# BatchNorm step counters (`num_batches_tracked`): nn.BatchNorm2d.forward is never called, so the
+# engine counts training steps on the host -- ON THE MODULE (`bn._emsa_pending`), not in a global
+# registry: a deep copy of the model (EMA twin) carries its own counts and hooks, and a
+# sub-module's `state_dict()` flushes exactly like the whole model's.  The hooks are
+# module-level functions (no closure over a runtime object), so `copy.deepcopy` keeps them valid.
+def _bn_flush_hook(module, prefix=None, keep_vars=None):
+    n = getattr(module, '_emsa_pending', 0)
+    if n and module.num_batches_tracked is not None:
+        module.num_batches_tracked += n
+    module._emsa_pending = 0
 
 
-def flush_bn_counters():
-    """add the host-side training-step counts to the `num_batches_tracked` buffers (called from
-    the model's state_dict pre-hook)"""
-    for rt in list(_BN_RTS):
-        if rt.pending_batches and rt.bn.num_batches_tracked is not None:
-            rt.bn.num_batches_tracked += rt.pending_batches
-        rt.pending_batches = 0
+def _bn_load_hook(module, state_dict, prefix, *unused):
+    # counts gathered before a checkpoint is loaded belong to the state that is being replaced
+    module._emsa_pending = 0
+
+
+def flush_bn_counters(root):
+    """add the host-side training-step counts of every BatchNorm below `root` to the
+    `num_batches_tracked` buffers.  (`state_dict()` of the model or of any sub-module does this
+    through the per-module pre-hook; a direct read of `bn.num_batches_tracked` during training
+    needs this call first.)"""
+    for m in root.modules():
+        if hasattr(m, '_emsa_pending'):
+            _bn_flush_hook(m)
 
 
 class BNRT:
@@ -251,8 +265,18 @@ class BNRT:
 
     def __init__(self, bn):
         self.bn = bn
-        self.pending_batches = 0
-        _BN_RTS.add(self)
+        if not hasattr(bn, '_emsa_pending'):
+            bn._emsa_pending = 0
+            bn.register_state_dict_pre_hook(_bn_flush_hook)
+            bn.register_load_state_dict_pre_hook(_bn_load_hook)
+
+    @property
+    def pending_batches(self):
+        return self.bn._emsa_pending
+
+    @pending_batches.setter
+    def pending_batches(self, value):
+        self.bn._emsa_pending = value
 
     def batch_stats(self):
         # torch semantics: batch statistics in training mode or when no running stats exist

@@ -51,7 +51,8 @@ class FusedSGD:
 
     def __init__(self, buckets, lr=0.01, momentum=0.9, weight_decay=1e-4):
         self.buckets = buckets
-        self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
+        self.lr, self.momentum = float(lr), float(momentum)
+        self._weight_decay = float(weight_decay)
         self._first = True
         self._hyper = None           # device {lr, momentum, weight_decay, grad_scale, first_step}
         self.flat_params, self.flat_momentum = [], []
@@ -66,6 +67,15 @@ class FusedSGD:
                     p.data = fp[off:off + n].view(p.shape)     # the Parameter becomes a view
                 self.flat_params.append(fp)
                 self.flat_momentum.append(torch.zeros_like(fp))
+
+    @property
+    def weight_decay(self):
+        return self._weight_decay
+
+    @weight_decay.setter
+    def weight_decay(self, value):
+        self._weight_decay = float(value)
+        self._upload_hyper()           # the device-side copy follows (hipGraph-captured steps)
 
     def set_schedule(self, lr, momentum):
         self.lr, self.momentum = float(lr), float(momentum)
@@ -93,7 +103,13 @@ class FusedSGD:
             self._hyper.copy_(host)
 
     def after_replay(self):
-        """bookkeeping after a hipGraph replay of a captured `step()`"""
+        """bookkeeping after a hipGraph replay of a captured `step()`: the replay moved every
+        parameter through raw pointers, and the version bump of the captured `step()` ran only
+        once, on the host, at capture time -- every packed-weight cache of the engine (PackPlan,
+        ConvRT, MultiConvRT, StemRT, GraphedInference) keys on `_version`, so an eval forward
+        after a replay would otherwise run on the weights of an earlier step"""
+        for _, ps, _ in self.buckets.buckets:
+            torch.autograd.graph.increment_version(ps)
         if self._first:
             self._first = False
             self._upload_hyper()
@@ -136,7 +152,11 @@ class FusedSGD:
                 'first': self._first, 'momentum_buffers': [m.clone() for m in self.flat_momentum]}
 
     def load_state_dict(self, sd):
-        self.lr, self.momentum, self.weight_decay = sd['lr'], sd['momentum'], sd['weight_decay']
-        self._first = sd['first']
+        self.lr, self.momentum = float(sd['lr']), float(sd['momentum'])
+        self._weight_decay = float(sd['weight_decay'])
+        self._first = bool(sd['first'])
         for m, src in zip(self.flat_momentum, sd['momentum_buffers']):
             m.copy_(src)
+        # a resumed run must not take its next (captured) step with the stale device-side
+        # {lr, momentum, weight decay, first-step flag}
+        self._upload_hyper()

@@ -657,15 +657,17 @@ def test_hipgraph_train_step_matches_eager():
         o.step()
         return float(loss.detach())
 
-    # the constructor runs 3 eager warm-up steps on batches[0] and RECORDS (does not run) one more;
-    # the eager twin does the same three steps
+    # the constructor runs 3 eager warm-up steps on batches[0], takes their effects back
+    # (parameters, momentum, BatchNorm statistics / counters, Dropout2d step: ADVICE r2) and
+    # RECORDS (does not run) one step: the eager twin starts from the same initial state
     m2, b2, o2 = build()
     m3, b3, o3 = build()
-    for _ in range(3):
-        eager_step(m3, b3, o3, batches[0])
+    sd0 = {k: v.clone() for k, v in m2.state_dict().items()}
     g = GraphedTrainStep(m2, batches[0], b2, o2, loss_fn=loss_of, warmup=3)
     torch.cuda.synchronize()
-    assert m2.dropout_step == m3.dropout_step == 3
+    assert m2.dropout_step == m3.dropout_step == 0
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd0[k]), f"building the graph changed {k}"
     for batch in batches[1:]:
         l2, _ = g.replay(batch)
         l3 = eager_step(m3, b3, o3, batch)
@@ -678,9 +680,9 @@ def test_hipgraph_train_step_matches_eager():
     sd2, sd3 = m2.state_dict(), m3.state_dict()
     for k in sd2:
         assert torch.equal(sd2[k], sd3[k]), k            # parameters untouched, statistics equal
-    assert m2.dropout_step == m3.dropout_step == 6
+    assert m2.dropout_step == m3.dropout_step == 3
     k = next(k for k in sd2 if k.endswith('num_batches_tracked'))
-    assert int(sd2[k]) == int(sd3[k]) == 6
+    assert int(sd2[k]) == int(sd3[k]) == 3
     # replaying the same batch twice: new Dropout2d masks, different loss (as in eager mode)
     la = float(g.replay(batches[1])[0])
     lb = float(g.replay(batches[1])[0])
@@ -702,3 +704,73 @@ def test_hipgraph_train_step_matches_eager():
         assert float((p2 - p3).abs().max()) <= 1e-3 * upd + 2.5e-7 * float(p3.abs().max()) + 1e-9, k
     assert moved > 0.0
 
+
+
+def test_hipgraph_train_replay_then_eval_sees_new_weights():
+    """a replay moves the parameters through raw pointers; every packed-weight
+    cache of the engine keys on `_version`, which the captured `FusedSGD.step()` bumped only once,
+    at capture time.  Flow of INTEGRATION.md: replay per batch, validate in between -- each eval
+    forward (eager AND through GraphedInference) must see the weights of the LAST replay.  Checked
+    against an eager twin at lr > 0: replay, eval, replay, eval."""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.graph import GraphedInference, GraphedTrainStep
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.optim import FusedSGD
+    from emsanet_amd.parallel import GradientBuckets
+    from oracle.emsanet_oracle import synthetic_batch
+    args = full_args(input_height=96, input_width=128, dropout_p=0.0)
+
+    def build():
+        torch.manual_seed(0)
+        m = EMSANet(args, nyuv2_config()).to(DEV).train()
+        b = GradientBuckets([p for p in m.parameters() if p.requires_grad])
+        o = FusedSGD(b, lr=0.01, momentum=0.9, weight_decay=0.0)
+        return m, b, o
+    batches = [{k: v.to(DEV) for k, v in synthetic_batch(4, 96, 128, seed=s).items()}
+               for s in (1, 2, 3)]
+    val = {k: v.to(DEV) for k, v in synthetic_batch(2, 96, 128, seed=9).items()}
+
+    def loss_of(out):
+        return sum((t * t).mean() for t in _flatten(out))
+
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad():
+            out = [t.clone() for t in _flatten(m(val))]
+        m.train()
+        return out
+
+    m2, b2, o2 = build()
+    m3, b3, o3 = build()
+    g = GraphedTrainStep(m2, batches[0], b2, o2, loss_fn=loss_of)
+    m2.eval()
+    gi = GraphedInference(m2, val)
+    m2.train()
+    evals2, evals3, graphed2 = [], [], []
+    for batch in batches:
+        g.replay(batch)
+        b3.reset()
+        loss_of(m3(batch)).backward()
+        b3.finish()
+        o3.step()
+        evals2.append(evaluate(m2))
+        m2.eval()
+        graphed2.append([t.clone() for t in _flatten(gi(val))])
+        m2.train()
+        evals3.append(evaluate(m3))
+    torch.cuda.synchronize()
+    assert gi.captures == len(batches) + 1            # re-captured after every update
+    def dist(xs, ys):
+        num = sum(float((x.double() - y.double()).pow(2).sum()) for x, y in zip(xs, ys))
+        den = sum(float(y.double().pow(2).sum()) for y in ys)
+        return (num / den) ** 0.5
+
+    for step, (e2, e3, q2) in enumerate(zip(evals2, evals3, graphed2)):
+        for a, c in zip(e2, q2):
+            assert torch.equal(a, c), f"step {step}: GraphedInference replayed stale weights"
+        if step:
+            # self-calibrating: the graphed model's eval must sit on the eager twin's CURRENT step,
+            # far from the twin's previous one (the two runs differ by atomics jitter only; a stale
+            # pack would reproduce the previous step's outputs)
+            d_cur, d_prev = dist(e2, e3), dist(e2, evals3[step - 1])
+            assert d_prev > 0.0 and d_cur <= 0.25 * d_prev, (step, d_cur, d_prev)
