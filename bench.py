@@ -484,9 +484,31 @@ def run(args):
                              'mfma_frac_of_bf16_peak': round(k['tflops'] / MFMA_BF16_PEAK_TFLOPS, 4)})
         if 'mfma_executed_tflops' in k:
             roofline['mfma_executed_tflops'] = k['mfma_executed_tflops']
+            roofline['frac_mfma_executed'] = round(k['mfma_executed_tflops'] / MFMA_F32_PEAK_TFLOPS, 4)
             roofline['note'] = ('Winograd F(2,3) kernel: achieved = direct-convolution FLOPs / '
                                 'time (SURVEY 8d algorithmic figure); the MFMA pipe executes 2/3 '
-                                'of them')
+                                'of them (frac_mfma_executed)')
+    # the 1-D NBt1D kernel and the dense 3x3 kernel reported apart (same kernels,
+    # separate launch classes), forward / data gradient and weight gradient, each with the
+    # direct-convolution fraction and the fraction the matrix pipe really executed
+    by_class = None
+    if kernels and args.dtype == 'f32':
+        labels = {'conv1d_wino_kernel (1-D': 'nbt1d_1d_fwd_dgrad',
+                  'conv1d_wino_kernel (dense': 'dense3x3_fwd_dgrad',
+                  'conv_wgrad1d_wino_kernel<64,64> (1-D': 'nbt1d_1d_wgrad',
+                  'conv_wgrad1d_wino_kernel<64,64> (dense': 'dense3x3_wgrad'}
+        by_class = {}
+        for kk in kernels:
+            for frag, label in labels.items():
+                if frag in kk['kernel']:
+                    ex = kk.get('mfma_executed_tflops', kk['tflops'])
+                    by_class[label] = {
+                        'kernel': kk['kernel'], 'launches': kk['launches'], 'avg_us': kk['avg_us'],
+                        'share_of_step': round(kk['total_ms'] / (dt * 1e3), 4),
+                        'achieved': kk['tflops'], 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(kk['tflops'] / MFMA_F32_PEAK_TFLOPS, 4),
+                        'mfma_executed_tflops': ex,
+                        'frac_mfma_executed': round(ex / MFMA_F32_PEAK_TFLOPS, 4)}
     conv_ms = sum(k['total_ms'] for k in kernels)
     conv_fl = sum(k['total_ms'] * k['tflops'] for k in kernels)     # ms * TFLOP/s = GFLOP
     step_gflop = (1 if args.eval else 3) * FWD_GFLOP_PER_IMAGE * bs \
@@ -527,6 +549,7 @@ def run(args):
                    'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval
                    else ('train+losses' if args.losses else 'train') + ('-hipgraph' if args.graph else '')},
         'roofline': roofline,
+        'roofline_by_class': by_class,
         'conv_kernels': kernels,
         'conv_mfma_time_share': round(conv_ms / (dt * 1e3), 4) if kernels else None,
         'conv_mfma_tflops_overall': round(conv_fl / conv_ms, 2) if conv_ms else None,

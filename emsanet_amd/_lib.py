@@ -58,6 +58,12 @@ SIGNATURES = {
                                          c_int32, c_int32, _P, _P, _P, _P]),
     'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P,
                                  _P, _P]),
+    'emsa_graph_count_nodes': (c_int, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    'emsa_graph_replace_memsets': (c_int, [_P, POINTER(c_int32)]),
+    'emsa_to_nhwc_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,
+                               c_int64, c_int64, _P]),
+    'emsa_conv1d_wino_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P]),
+    'emsa_conv_wgrad_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P]),
     'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
     'emsa_pack_batch': (c_int, [_P, c_int32, c_int32, _P]),
     'emsa_pack_wino_packed': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),

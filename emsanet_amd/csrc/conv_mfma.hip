@@ -45,8 +45,10 @@ const char* const kProfNames[kProfClasses] = {
     "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,4,2>",
     "conv_igemm_kernel<64,64,2,2>",   "conv_igemm_kernel<128,32,4,1>",
     "conv_wgrad_kernel<64,32,7,2,1,2>", "conv_wgrad_kernel<128,128,1,2,2,1> (unused)",
-    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_wino_kernel<64,64>",
-    "conv1d_wino_kernel", "conv_h_kernel (16-bit igemm)", "wgrad kernels on 16-bit activations"};
+    "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_wino_kernel<64,64> (1-D convs)",
+    "conv1d_wino_kernel (1-D 3x1/1x3 convs)", "conv_h_kernel (16-bit igemm)",
+    "wgrad kernels on 16-bit activations", "conv1d_wino_kernel (dense 3x3 convs, row-Winograd)",
+    "conv_wgrad1d_wino_kernel<64,64> (dense 3x3 convs)"};
 }  // namespace
 
 int emsa_prof_begin(int cls, double flops, hipStream_t st, double bytes) {
@@ -833,6 +835,11 @@ struct Wgrad1dArgs {
   float* ws_bias;
   uint32_t in_bytes, dout_bytes;
   FastDiv div_al, div_l;
+  // XBN (emsa_conv_wgrad_inbn): the x operand is a = relu(in * in_scale[c] + in_shift[c]) formed
+  // in the loader -- the weight gradient of a conv whose forward ran with the BatchNorm + ReLU of
+  // its input folded into ITS loader (emsa_conv1d_wino_inbn); `in` is the BatchNorm's input
+  const float* in_scale;
+  const float* in_shift;
 };
 
 // (tried: A operand by ds_read_b64 over even/odd channel tiles, waves splitting K -- halves the LDS
@@ -1062,9 +1069,13 @@ __global__ __launch_bounds__(256, EMSA_W1D_WPE) void conv_wgrad1d_kernel(
 // and one v_mfma_f32_32x32x16_bf16 per component covers the step's 16 pixel pairs; accumulation,
 // the transforms and everything in HBM stay fp32.
 typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
-template <int BCO, int BCI, bool BF16 = false, typename T = float>
-__global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
+#ifndef EMSA_W1DW_XBN_WPE
+#define EMSA_W1DW_XBN_WPE 3   // XBN needs ~10 registers more than the 128 of four waves per SIMD
+#endif
+template <int BCO, int BCI, bool BF16 = false, typename T = float, bool XBN = false>
+__global__ __launch_bounds__(256, XBN ? EMSA_W1DW_XBN_WPE : EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(const Wgrad1dArgs p) {
   static_assert(BCO == 64 && BCI == 64, "wave layout below is for a 64x64 (co x ci) tile");
+  static_assert(!XBN || (!BF16 && sizeof(T) == 4), "the folded input BatchNorm is an fp32 form");
   constexpr uint32_t ES = sizeof(T);            // bytes per activation element
   constexpr int PK = 32, NP = PK / 2, XROWS = PK + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1105,6 +1116,17 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
 
   typename Raw4<T>::type re_raw[2], rx_raw[4];
   float4 bsum = emsa_zero4();
+  // XBN: bit r set = x row d_r of the prefetched step is a real pixel (out-of-range rows -- line
+  // ends, image border, the virtual pixel of an odd line -- are ZERO after the BatchNorm + ReLU too)
+  uint32_t x_real = 0;
+  float* const xbnS = smem + NP * 4 * (BCO + BCI);   // XBN: [2: scale, shift][BCI]
+  if constexpr (XBN) {
+    if (tid < 2 * BCI) {
+      const int ch = ci0 + (tid & (BCI - 1));
+      const float* src = tid < BCI ? p.in_scale : p.in_shift;
+      xbnS[tid] = ch < p.k_ch ? src[ch] : 0.f;
+    }
+  }
   auto load_regs = [&](int s) {
     // lane l of every wave decomposes pixel k0 + l - 1 (l < 34) once; the loading threads fetch
     // their rows' byte offsets with wave shuffles
@@ -1140,6 +1162,8 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
     rx_raw[1] = buf_ld4raw<T>(rs_in, (o_d1 + xadd) | xmask);
     rx_raw[2] = buf_ld4raw<T>(rs_in, (o_d2 + xadd) | xmask);
     rx_raw[3] = buf_ld4raw<T>(rs_in, (o_d3 + xadd) | xmask);
+    if constexpr (XBN)
+      x_real = (~o_d0 >> 31) | ((~o_d1 >> 31) << 1) | ((~o_d2 >> 31) << 2) | ((~o_d3 >> 31) << 3);
   };
   auto add4 = [](const float4& a, const float4& b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
@@ -1149,8 +1173,22 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
   };
   auto store_lds = [&]() {
     const float4 re[2] = {raw_f4(re_raw[0], (T*)nullptr), raw_f4(re_raw[1], (T*)nullptr)};
-    const float4 rx[4] = {raw_f4(rx_raw[0], (T*)nullptr), raw_f4(rx_raw[1], (T*)nullptr),
-                          raw_f4(rx_raw[2], (T*)nullptr), raw_f4(rx_raw[3], (T*)nullptr)};
+    float4 rx[4] = {raw_f4(rx_raw[0], (T*)nullptr), raw_f4(rx_raw[1], (T*)nullptr),
+                    raw_f4(rx_raw[2], (T*)nullptr), raw_f4(rx_raw[3], (T*)nullptr)};
+    if constexpr (XBN) {
+      // a = relu(x * scale + shift) exactly as the forward loader formed it (one FMA, then
+      // v_med3(v, 0, cap): max(v, 0) for cap = +inf, 0 for an out-of-range row)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const float4 sc = emsa_ld4(xbnS + col4), sh = emsa_ld4(xbnS + BCI + col4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float cap = (x_real >> r) & 1u ? __builtin_inff() : 0.f;
+        const f2 lo = __builtin_elementwise_fma(f2{rx[r].x, rx[r].y}, f2{sc.x, sc.y}, f2{sh.x, sh.y});
+        const f2 hi = __builtin_elementwise_fma(f2{rx[r].z, rx[r].w}, f2{sc.z, sc.w}, f2{sh.z, sh.w});
+        rx[r] = make_float4(__builtin_amdgcn_fmed3f(lo.x, 0.f, cap), __builtin_amdgcn_fmed3f(lo.y, 0.f, cap),
+                            __builtin_amdgcn_fmed3f(hi.x, 0.f, cap), __builtin_amdgcn_fmed3f(hi.y, 0.f, cap));
+      }
+    }
     float* e = eS + pr * 4 * BCO + col4;
     float* d = dS + pr * 4 * BCI + col4;
     const float4 es = add4(re[0], re[1]);
@@ -1189,6 +1227,7 @@ __global__ __launch_bounds__(256, EMSA_W1DW_WPE) void conv_wgrad1d_wino_kernel(c
 
   if (s_begin < s_end) {
     load_regs(s_begin);
+    if constexpr (XBN) __syncthreads();            // the affine table is in LDS
     store_lds();
   }
   __syncthreads();
@@ -1880,7 +1919,8 @@ extern "C" int64_t emsa_conv_wgrad_ws_bytes_t(int32_t dtype, const EmsaConvGeom*
 namespace {
 template <typename T>
 int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float* dw, float* dbias,
-                    float* ws, void* stream) {
+                    float* ws, void* stream, const float* in_scale = nullptr,
+                    const float* in_shift = nullptr) {
   constexpr bool kHalf = sizeof(T) != 4;
   // (the argument structs carry byte addresses; the kernels read them through typed loaders)
   const float* in = reinterpret_cast<const float*>(in_t);
@@ -1910,13 +1950,16 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     Wgrad1dArgs& w = pl.w;
     w.in = in; w.dout = dout; w.dw = dw; w.dbias = dbias;
     w.ws = ws;
+    w.in_scale = in_scale; w.in_shift = in_shift;
+    if (in_scale && (kHalf || !pl.wino || w.R != 1)) return EMSA_E_SHAPE;
     w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * 12288 : nullptr;
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     // algorithmic bytes: x and dy read once, the fp32 gradient written once
     const double wbytes = (double)g->n_img * g->in_h * g->in_w * g->k_ch * sizeof(T) +
                           (double)a.M * g->n_ch * sizeof(T) + (double)taps * g->n_ch * g->k_ch * 4.0;
-    const int ps = prof_begin(kHalf ? kProfClassWgradH : 7, algo_flops(a.g), st, wbytes);
+    const int ps = prof_begin(kHalf ? kProfClassWgradH : (w.R == 3 ? kProfClassWgrad3x3 : 7),
+                              algo_flops(a.g), st, wbytes);
     static const bool bf16 = [] {
       const char* e = getenv("EMSA_BF16_MFMA");
       return e && e[0] == '1';
@@ -1935,7 +1978,12 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true>),
                          dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
                          (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
-    else if (pl.wino)
+    else if (pl.wino && in_scale) {
+      if constexpr (!kHalf)
+        hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, false, float, true>),
+                           dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
+                           (size_t)(16 * 4 * (BCO + BCI) + 2 * BCI) * sizeof(float), st, w);
+    } else if (pl.wino)
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
     else
@@ -1948,6 +1996,7 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     prof_end(ps, st);
     return emsa_launch_status();
   }
+  if (in_scale) return EMSA_E_SHAPE;             // only the 1-D Winograd form folds the input's BN
   if (taps == 7 && g->k_ch <= 32) return launch_wgrad<64, 32, 7, 2, 1, 2, T>(a, st);
   if (taps == 2 && g->k_ch <= 32) return launch_wgrad<64, 32, 2, 2, 1, 2, T>(a, st);   // one-channel stem
   if (taps == 1) {
@@ -1962,6 +2011,16 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
 extern "C" int emsa_conv_wgrad(const EmsaConvGeom* g, const float* in, const float* dout,
                                float* dw, float* dbias, float* ws, void* stream) {
   return conv_wgrad_impl<float>(g, in, dout, dw, dbias, ws, stream);
+}
+
+// Weight gradient of a conv whose input is a = relu(in * in_scale[c] + in_shift[c]) (the forward
+// ran as emsa_conv1d_wino_inbn): the x operand is formed in the loader, `in` is the BatchNorm's
+// input.  Stride-1 3-tap 1-D convs with an even or odd line (the Winograd F(3,2) form) only.
+extern "C" int emsa_conv_wgrad_inbn(const EmsaConvGeom* g, const float* in, const float* dout,
+                                    float* dw, float* dbias, float* ws, const float* in_scale,
+                                    const float* in_shift, void* stream) {
+  if (!in_scale || !in_shift) return EMSA_E_ARG;
+  return conv_wgrad_impl<float>(g, in, dout, dw, dbias, ws, stream, in_scale, in_shift);
 }
 
 // weight (+bias) gradient from activations in storage type `dtype` (training: EMSA_DT_BF16); the

@@ -71,6 +71,12 @@ struct WinoArgs {
   const float* bnb_invstd;
   float* bnb_out;                   // [2][bnb_rows_alloc][n_ch], rows [0, tiles_m) written
   int bnb_rows_alloc;
+  // BatchNorm + ReLU of the INPUT folded into the loader (emsa_conv1d_wino_inbn): the kernel
+  // convolves a = relu(in * in_scale[c] + in_shift[c]) without a ever existing in memory -- the
+  // NBt1D block's bn1 normalise+ReLU pass (one read + one write of the tensor) disappears into
+  // conv3x1_2 (reference block: /root/reference/emsanet/model.py:47-58).  Padding stays zero.
+  const float* in_scale;
+  const float* in_shift;
   int ld_out, ld_res, ld_mask, act;
   int L, PL, A, MP;                 // line length, pairs per line, lines per image, total pairs
   int k_ch, n_ch;                   // k_ch = R * c_in (GEMM K), n_ch output channels
@@ -102,7 +108,10 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
 // BNB: the epilogue with the fused BatchNorm-backward sums (WinoArgs::bnb_out) is its own
 // instantiation with one wave per SIMD less: compiled into the common kernel it cost that one 13-15
 // spilled registers at 5 waves per SIMD.
-template <int kWN, bool BF16 = false, bool BNB = false>   // kWN: output channels per workgroup, 64 (2 MFMA tiles per wave) or 32
+// INBN: the input's BatchNorm + ReLU applied where the K step enters LDS (WinoArgs::in_scale); 1-D
+// convs only (R = 1).  Costs 12 vector instructions per K step and thread (2 packed FMAs + 4
+// v_med3 per float4: max(v, 0) and the zero-padding mask in one instruction, cap = +inf / 0).
+template <int kWN, bool BF16 = false, bool BNB = false, bool INBN = false>   // kWN: output channels per workgroup, 64 (2 MFMA tiles per wave) or 32
 __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_wino_kernel(const WinoArgs p) {
   constexpr int NT = kWN / 32;                    // accumulator tiles per wave
   constexpr int NC4 = kWN / 4;                    // float4 columns of a tile row
@@ -112,6 +121,7 @@ __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_win
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;                          // [4 rows][32 pairs][kWLD]
   float* const Bs = smem + 4 * kPairs * kWLD;      // [4 comps][kWN n][kWLD]
+  float* const Ts = Bs + 4 * kWN * kWLD;           // INBN: [2: scale, shift][ksteps_c * kWK]
 
   // wave = component j; uniform -> kept in an SGPR (so are the row choice and sign below)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,7 +198,26 @@ __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_win
 #pragma unroll
     for (int j = 0; j < BLD; ++j) rb[j] = wbuf_ld4s(rs_u, b_voff[j] | (last_oob & pm), sb);
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](int s) {                     // s: the K step the registers hold
+    if constexpr (INBN) {
+      // a = relu(x * scale + shift); v_med3(v, 0, cap): max(v, 0) for cap = +inf, 0 for cap = 0
+      const int kt = p.ksteps_c * kWK;
+      const float4 sc = emsa_ld4(Ts + s * kWK + c4), sh = emsa_ld4(Ts + kt + s * kWK + c4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // cap: +inf for a real pixel row, 0 for a padding row (top bit of the row's load offset;
+        // R = 1: a_voff is fixed for the tile) -- rebuilt here rather than held in a register
+        const float cap = __uint_as_float(0x7F800000u & ~(uint32_t)((int32_t)a_voff[j] >> 31));
+        const wf32x2 lo = __builtin_elementwise_fma(wf32x2{ra[j].x, ra[j].y}, wf32x2{sc.x, sc.y},
+                                                    wf32x2{sh.x, sh.y});
+        const wf32x2 hi = __builtin_elementwise_fma(wf32x2{ra[j].z, ra[j].w}, wf32x2{sc.z, sc.w},
+                                                    wf32x2{sh.z, sh.w});
+        ra[j] = make_float4(__builtin_amdgcn_fmed3f(lo.x, 0.f, cap),
+                            __builtin_amdgcn_fmed3f(lo.y, 0.f, cap),
+                            __builtin_amdgcn_fmed3f(hi.x, 0.f, cap),
+                            __builtin_amdgcn_fmed3f(hi.y, 0.f, cap));
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) emsa_st4(As + wswz((tid >> 2) + 64 * j, c4), ra[j]);
 #pragma unroll
@@ -207,7 +236,17 @@ __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_win
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  store_lds();
+  if constexpr (INBN) {
+    // the affine table of all input channels (zeros beyond c_in: those K entries meet zero
+    // weights and must stay finite); R = 1, so the rows' validity is fixed for the tile
+    const int kt = p.ksteps_c * kWK;
+    for (int i = tid; i < kt; i += 256) {
+      Ts[i] = i < p.c_in ? p.in_scale[i] : 0.f;
+      Ts[kt + i] = i < p.c_in ? p.in_shift[i] : 0.f;
+    }
+    __syncthreads();
+  }
+  store_lds(0);
   __syncthreads();
   for (int s = 0; s < p.ksteps; ++s) {
     const bool has_next = s + 1 < p.ksteps;
@@ -273,7 +312,7 @@ __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_win
     __builtin_amdgcn_s_setprio(0);
 #endif
     __syncthreads();
-    if (has_next) store_lds();
+    if (has_next) store_lds(s + 1);
     __syncthreads();
   }
 
@@ -746,8 +785,10 @@ static int conv1d_wino_impl(const EmsaConvGeom* g, const float* in, const float*
                             const float* mask_src, int32_t ld_mask, int32_t act,
                             const uint64_t* mask_bits, uint64_t* relu_bits,
                             const float* bnb_mean, const float* bnb_invstd, float* bnb_out,
-                            int32_t bnb_rows_alloc, void* stream) {
+                            int32_t bnb_rows_alloc, const float* in_scale, const float* in_shift,
+                            void* stream) {
   if (!emsa_conv1d_wino_supported(g)) return EMSA_E_SHAPE;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return EMSA_E_ARG;
   if (!in || !u || !out) return EMSA_E_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
@@ -761,6 +802,7 @@ static int conv1d_wino_impl(const EmsaConvGeom* g, const float* in, const float*
   a.mask_bits = mask_bits; a.relu_bits = relu_bits;
   a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out;
   a.bnb_rows_alloc = bnb_rows_alloc;
+  a.in_scale = in_scale; a.in_shift = in_shift;
   a.ld_out = g->ld_out; a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
   const bool aw = g->kw == 3;
   const int H = g->out_h, W = g->out_w;
@@ -807,19 +849,25 @@ static int conv1d_wino_impl(const EmsaConvGeom* g, const float* in, const float*
   a.u_bytes = (uint32_t)((size_t)4 * g->n_ch * a.k_ch * sizeof(float));
   magic((uint32_t)a.PL, a.mul_pl, a.sh_pl);
   magic((uint32_t)a.A, a.mul_a, a.sh_a);
-  const size_t lds_main = (size_t)(4 * kPairs + 4 * wn) * kWLD * sizeof(float);
+  if (in_scale && (a.R != 1 || bnb_out || wn != 64)) return EMSA_E_SHAPE;   // 1-D forward convs only
+  const size_t lds_main = (size_t)(4 * kPairs + 4 * wn) * kWLD * sizeof(float) +
+                          (in_scale ? (size_t)2 * a.ksteps_c * kWK * sizeof(float) : 0);
   const size_t lds_epi = (size_t)4 * (kPairs / 2) * (wn + 4) * sizeof(float);
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   // algorithmic = direct-convolution FLOPs (3 taps); the kernel executes 4/6 of them on the MFMA
   const double flops = 2.0 * g->n_img * H * W * (double)g->k_ch * g->n_ch * 3.0 * a.R;
-  const int ps = emsa_prof_begin(kProfClassWino, flops, (hipStream_t)stream);
+  const int ps = emsa_prof_begin(a.R == 3 ? kProfClassWino3x3 : kProfClassWino, flops,
+                                 (hipStream_t)stream);
   // one workgroup per tile: a persistent grid with cross-tile prefetch measured SLOWER on MI355X
   // (static tile partition quantises to whole rounds: c256 /16 124 us vs 103 us)
   static const bool bf16 = [] {
     const char* e = getenv("EMSA_BF16_MFMA");
     return e && e[0] == '1';
   }();
-  if (bnb_out) {
+  if (in_scale) {
+    hipLaunchKernelGGL((conv1d_wino_kernel<64, false, false, true>),
+                       dim3(a.tiles_m * a.tiles_n), dim3(256), lds, (hipStream_t)stream, a);
+  } else if (bnb_out) {
     if (wn != 64) return EMSA_E_SHAPE;
     hipLaunchKernelGGL((conv1d_wino_kernel<64, false, true>), dim3(a.tiles_m * a.tiles_n),
                        dim3(256), lds, (hipStream_t)stream, a);
@@ -842,7 +890,21 @@ extern "C" int emsa_conv1d_wino(const EmsaConvGeom* g, const float* in, const fl
                                 const float* mask_src, int32_t ld_mask, int32_t act,
                                 const uint64_t* mask_bits, uint64_t* relu_bits, void* stream) {
   return conv1d_wino_impl(g, in, u, out, bias, stats, scale, shift, residual, ld_res, mask_src,
-                          ld_mask, act, mask_bits, relu_bits, nullptr, nullptr, nullptr, 0, stream);
+                          ld_mask, act, mask_bits, relu_bits, nullptr, nullptr, nullptr, 0, nullptr,
+                          nullptr, stream);
+}
+
+// Forward 1-D conv of a = relu(in * in_scale[c] + in_shift[c]) (per INPUT channel, c_in floats
+// each) with the affine map + ReLU applied in the loader: `in` is the BatchNorm's INPUT, the
+// normalised tensor is never written (see WinoArgs::in_scale).  Zero padding pads `a`, not `in`.
+extern "C" int emsa_conv1d_wino_inbn(const EmsaConvGeom* g, const float* in, const float* u,
+                                     float* out, const float* bias, float* stats,
+                                     const float* in_scale, const float* in_shift, int32_t act,
+                                     uint64_t* relu_bits, void* stream) {
+  if (!in_scale || !in_shift) return EMSA_E_ARG;
+  return conv1d_wino_impl(g, in, u, out, bias, stats, nullptr, nullptr, nullptr, 0, nullptr, 0, act,
+                          nullptr, relu_bits, nullptr, nullptr, nullptr, 0, in_scale, in_shift,
+                          stream);
 }
 
 // Data gradient with the BatchNorm-backward sums of the layer in front fused into the epilogue
@@ -859,5 +921,5 @@ extern "C" int emsa_conv1d_wino_bnb(const EmsaConvGeom* g, const float* dy, cons
   if (!partial || !t) return EMSA_E_ARG;
   return conv1d_wino_impl(g, dy, u, out, nullptr, nullptr, bn_scale, bn_shift, residual, ld_res, t,
                           ld_t, EMSA_ACT_NONE, nullptr, nullptr, bn_mean, bn_invstd, partial,
-                          rows_alloc, stream);
+                          rows_alloc, nullptr, nullptr, stream);
 }

@@ -1534,6 +1534,58 @@ __global__ void copy_channels_kernel(const TS* __restrict__ x, int ld_x, TD* __r
   }
 }
 
+// ---- module boundary: any layout of a logical (N, C, H, W) tensor -> dense NHWC -----------------
+// The reference's task helpers / tests hand the engine contiguous NCHW tensors (decoder inputs of
+// /root/reference/emsanet/tests/test_interface_decoders.py:73-88, cotangents of the NCHW losses).
+// Plane-contiguous sources (stride_w = 1, stride_h = W, stride_c = H*W: contiguous NCHW, any image
+// stride) go through a 64 (pixels) x 64 (channels) LDS tile: 256-byte reads along the plane, full
+// channel rows written; every other layout (expanded scalars, sliced / permuted views) takes the
+// element-wise gather form.  One pass either way -- no torch permute().contiguous().
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_tile_kernel(const T* __restrict__ x,
+                                                                T* __restrict__ y, int c, long hw,
+                                                                long s_n, int tiles_c,
+                                                                long tiles_hw) {
+  __shared__ T tile[64][65];
+  const long b = blockIdx.x;
+  const int tc = (int)(b % tiles_c);
+  const long thw = (b / tiles_c) % tiles_hw;
+  const long img = b / ((long)tiles_c * tiles_hw);
+  const int c0 = tc * 64;
+  const long p0 = thw * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const T* src = x + img * s_n;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int ch = c0 + ty + 4 * k;
+    const long px = p0 + tx;
+    if (ch < c && px < hw) tile[ty + 4 * k][tx] = src[(long)ch * hw + px];
+  }
+  __syncthreads();
+  T* dst = y + img * hw * c;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const long px = p0 + ty + 4 * k;
+    const int ch = c0 + tx;
+    if (ch < c && px < hw) dst[px * c + ch] = tile[tx][ty + 4 * k];
+  }
+}
+
+template <typename T>
+__global__ void strided_to_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int c, int h,
+                                       int w, long total, long s_n, long s_c, long s_h, long s_w) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int ww = (int)(r % w);
+    r /= w;
+    const int hh = (int)(r % h);
+    const long img = r / h;
+    y[i] = x[img * s_n + ch * s_c + hh * s_h + ww * s_w];
+  }
+}
+
 __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
                             float alpha) {
   const long n4 = n / 4;
@@ -2375,6 +2427,35 @@ extern "C" int emsa_cast_channels(int32_t src_dtype, const void* x, int32_t ld_x
   });
   return EMSA_E_ARG;
 }
+// dense NHWC copy of a logical (n, c, h, w) tensor with ELEMENT strides (s_n, s_c, s_h, s_w) in the
+// storage type `dtype` (see nchw_to_nhwc_tile_kernel); strides may be 0 (expanded tensors)
+extern "C" int emsa_to_nhwc_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t c,
+                              int32_t h, int32_t w, int64_t s_n, int64_t s_c, int64_t s_h,
+                              int64_t s_w, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  if (n < 1 || c < 1 || h < 1 || w < 1 || s_n < 0 || s_c < 0 || s_h < 0 || s_w < 0)
+    return EMSA_E_SHAPE;
+  const long hw = (long)h * w, total = (long)n * hw * c;
+  const bool planes = (s_w == 1 || w == 1) && (s_h == w || h == 1) && (s_c == hw || c == 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (planes) {
+    const int tiles_c = (c + 63) / 64;
+    const long tiles_hw = (hw + 63) / 64;
+    const long blocks = (long)n * tiles_c * tiles_hw;
+    if (blocks >= (1L << 31)) return EMSA_E_SHAPE;
+    EMSA_DISPATCH_DTYPE(dtype, T,
+                        hipLaunchKernelGGL((nchw_to_nhwc_tile_kernel<T>), dim3((unsigned)blocks),
+                                           dim3(256), 0, st, (const T*)x, (T*)y, c, hw, (long)s_n,
+                                           tiles_c, tiles_hw));
+  } else {
+    EMSA_DISPATCH_DTYPE(dtype, T,
+                        hipLaunchKernelGGL((strided_to_nhwc_kernel<T>), dim3(grid_for(total)),
+                                           dim3(kThreads), 0, st, (const T*)x, (T*)y, c, h, w, total,
+                                           (long)s_n, (long)s_c, (long)s_h, (long)s_w));
+  }
+  return emsa_launch_status();
+}
+
 extern "C" int emsa_axpy(const float* x, float* y, int64_t n, float alpha, void* stream) {
   if (!x || !y) return EMSA_E_ARG;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)n / 4 + 1)), dim3(kThreads), 0,

@@ -84,8 +84,9 @@ class DecoderModule(nn.Module):
 
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
-                 fusion_downsamplings, side_head_factory):
+                 fusion_downsamplings, side_head_factory, fusion='add-rgb'):
         super().__init__()
+        self.fusion = fusion
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
             mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc))
@@ -100,7 +101,16 @@ class DecoderBody(nn.Module):
         sides = []
         for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
                             self.fusion_downsamplings):
-            x, s = m(x, skips[str(ds)]['rgb'], h)
+            sk = skips[str(ds)]
+            if self.fusion == 'add-rgb':
+                skip = sk['rgb']
+            else:
+                # 'add' (single-modality models, /root/reference/emsanet/tests/
+                # test_interface_model.py:32): the only encoder stream there is
+                if len(sk) != 1:
+                    raise NotImplementedError("encoder-decoder fusion 'add' with two modalities")
+                skip = next(iter(sk.values()))
+            x, s = m(x, skip, h)
             sides.append(s)
         return x, tuple(sides)
 
@@ -299,7 +309,7 @@ def get_decoders(
     if 'semantic' in args.tasks:
         if args.semantic_decoder.lower() != 'emsanet':
             raise NotImplementedError(f"semantic decoder '{args.semantic_decoder}'")
-        if args.semantic_encoder_decoder_fusion != 'add-rgb':
+        if args.semantic_encoder_decoder_fusion not in ('add-rgb', 'add'):
             raise NotImplementedError(args.semantic_encoder_decoder_fusion)
         decoders['semantic_decoder'] = SemanticDecoder(
             n_classes=semantic_n_classes, n_channels_in=n_channels_in,
@@ -307,11 +317,12 @@ def get_decoders(
             n_blocks=args.semantic_decoder_n_blocks,
             dropout_p=args.semantic_decoder_block_dropout_p,
             fusion_n_channels=tuple(fusion_n_channels),
-            fusion_downsamplings=fusion_downsamplings)
+            fusion_downsamplings=fusion_downsamplings,
+            fusion=args.semantic_encoder_decoder_fusion)
     if 'instance' in args.tasks:
         if args.instance_decoder.lower() != 'emsanet':
             raise NotImplementedError(f"instance decoder '{args.instance_decoder}'")
-        if args.instance_encoder_decoder_fusion != 'add-rgb':
+        if args.instance_encoder_decoder_fusion not in ('add-rgb', 'add'):
             raise NotImplementedError(args.instance_encoder_decoder_fusion)
         decoders['instance_decoder'] = InstanceDecoder(
             with_orientation='orientation' in args.tasks,
@@ -322,7 +333,8 @@ def get_decoders(
             n_blocks=args.instance_decoder_n_blocks,
             dropout_p=args.instance_decoder_block_dropout_p,
             fusion_n_channels=tuple(fusion_n_channels),
-            fusion_downsamplings=fusion_downsamplings)
+            fusion_downsamplings=fusion_downsamplings,
+            fusion=args.instance_encoder_decoder_fusion)
         # post-processing parameters as in /root/reference/emsanet/decoder.py:95-104
         decoders['instance_decoder'].postprocessing = InstancePostprocessing(
             heatmap_threshold=args.instance_center_heatmap_threshold,

@@ -79,7 +79,10 @@ def ld_of(t):
 
 
 def to_nhwc(t):
-    """Boundary helper: accept any layout of a logical NCHW tensor, return dense NHWC memory."""
+    """Boundary helper: accept any layout of a logical NCHW tensor, return dense NHWC memory.
+    A foreign layout (the reference's contiguous NCHW decoder inputs and loss cotangents, expanded
+    scalars, sliced views) costs ONE pass of `emsa_to_nhwc_t` -- never a torch
+    permute().contiguous()."""
     if t.dtype not in DT:
         t = t.float()
     n, c, h, w = t.shape
@@ -88,7 +91,14 @@ def to_nhwc(t):
             return t
     except _lib.EmsaError:
         pass
-    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    if not t.is_cuda:
+        # host-side dry runs (tests with a stand-in library): layout bookkeeping only
+        return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    out = act_empty(n, c, h, w, t.device, dtype=t.dtype)
+    sn, sc, sh, sw = t.stride()
+    check(_lib.lib().emsa_to_nhwc_t(DT[t.dtype], _p(t), _p(out), n, c, h, w, sn, sc, sh, sw,
+                                    _stream()), 'emsa_to_nhwc_t')
+    return out
 
 
 def as_act(t, dense=False):
@@ -264,11 +274,13 @@ def pack_wino_packed(wp, n_ch, k_ch, rows, flip):
 
 
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
-             act=ACT_NONE, out=None, wino_u=None, want_relu_bits=False):
+             act=ACT_NONE, out=None, wino_u=None, want_relu_bits=False, in_affine=None):
     """wp = packed [tap][cout][cin] weights in the dtype of `x` (MFMA implicit GEMM) -- or, fp32
     only, wino_u = Winograd weights of an eligible conv (emsa_conv1d_wino).  want_relu_bits
     (Winograd kernel with act = ReLU): additionally returns (out > 0) as a bit mask for
-    `conv_dgrad(mask_bits=...)`, else None."""
+    `conv_dgrad(mask_bits=...)`, else None.  in_affine = (scale, shift) per INPUT channel: the
+    conv runs on relu(x * scale + shift) formed in its loader (emsa_conv1d_wino_inbn: the
+    BatchNorm + ReLU in front of a 1-D Winograd conv without a pass of its own)."""
     n, c, h, w = x.shape
     oh, ow = spec.out_hw(h, w)
     code = dt(x)
@@ -289,10 +301,19 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
         stats = _empty((3, rows, spec.cout), x.device)
     lr = ld_of(residual) if residual is not None else 0
     bits = None
+    if in_affine is not None and (wino_u is None or scale is not None or residual is not None):
+        raise _lib.EmsaError("in_affine: only the fp32 1-D Winograd forward folds its input's "
+                             "BatchNorm (no output affine / residual)")
     if wino_u is not None:
         if want_relu_bits and act == ACT_RELU:
             bits = torch.empty(L.emsa_conv_relu_bits_words(n * oh * ow, spec.cout),
                                device=x.device, dtype=torch.int64)
+        if in_affine is not None:
+            check(L.emsa_conv1d_wino_inbn(g, _p(x), _p(wino_u), _p(out), _p(bias), _p(stats),
+                                          _p(in_affine[0]), _p(in_affine[1]), act, _p(bits),
+                                          _stream()), 'emsa_conv1d_wino_inbn')
+            res = (out, stats) if want_stats else out
+            return (res, bits) if want_relu_bits else res
         check(L.emsa_conv1d_wino(g, _p(x), _p(wino_u), _p(out), _p(bias), _p(stats), _p(scale),
                                  _p(shift), _p(residual), lr, None, 0, act, None, _p(bits),
                                  _stream()), 'emsa_conv1d_wino')
@@ -427,6 +448,22 @@ def bn_fused_reduce(dtype):
     return dtype != torch.float32
 
 
+# The NBt1D block's bn1 without a forward pass of its own (fp32 training): conv3x1_2 and its weight
+# gradient form relu(bn1(y2)) in their loaders, the data gradient's epilogue recomputes the ReLU
+# decisions and emits the backward sums (conv_dgrad_bnb).  EMSA_BN1_FOLD=0 restores the separate
+# normalise + ReLU pass.  tests: BN1_FOLD = True / False overrides.
+_BN1_FOLD_ENV = os.environ.get('EMSA_BN1_FOLD')
+BN1_FOLD = None
+
+
+def bn1_fold(dtype):
+    if BN1_FOLD is not None:
+        return BN1_FOLD and dtype == torch.float32
+    if _BN1_FOLD_ENV is not None:
+        return _BN1_FOLD_ENV != '0' and dtype == torch.float32
+    return dtype == torch.float32
+
+
 def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invstd, residual=None,
                    wino_u=None):
     """data gradient of the conv behind a BatchNorm+ReLU with that BatchNorm's backward reduction
@@ -486,13 +523,16 @@ def deterministic_wgrad():
     return os.environ.get('EMSA_DETERMINISTIC', '1') != '0'
 
 
-def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db_out=None):
+def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db_out=None,
+               in_affine=None):
     """weight (+bias) gradient.  returns (dw, dbias or None, packed):
     packed=False: dw is already in the parameter layout [cout][cin][kh][kw] (deterministic
     two-pass kernel of the 1-D convs, needs `like` = the weight for the shape); `dw_out` /
     `db_out` (contiguous, parameter-shaped, 16-byte aligned: the flat gradient-bucket views)
     receive the result directly;
-    packed=True: dw is the flat packed [tap][cout][cin] accumulator (-> unpack_wgrad)."""
+    packed=True: dw is the flat packed [tap][cout][cin] accumulator (-> unpack_wgrad).
+    in_affine = (scale, shift): the conv's input was relu(x * scale + shift) formed in the forward
+    loader (conv_fwd(in_affine=...)); the weight gradient forms it again (emsa_conv_wgrad_inbn)."""
     if two_pass is None:
         two_pass = deterministic_wgrad()
     n, c, h, w = x.shape
@@ -517,8 +557,14 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db
         db = buf[nw:] if want_bias else None
     if x.dtype != dy.dtype:
         raise _lib.EmsaError(f"weight gradient of {x.dtype} activations with a {dy.dtype} gradient")
-    check(call_t('emsa_conv_wgrad', dt(x), g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _stream()),
-          'emsa_conv_wgrad')
+    if in_affine is not None:
+        if dt(x) != 0:
+            raise _lib.EmsaError("in_affine: fp32 only")
+        check(L.emsa_conv_wgrad_inbn(g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _p(in_affine[0]),
+                                     _p(in_affine[1]), _stream()), 'emsa_conv_wgrad_inbn')
+    else:
+        check(call_t('emsa_conv_wgrad', dt(x), g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _stream()),
+              'emsa_conv_wgrad')
     if ws is not None:
         return dw.view(like.shape), db, False
     return dw, db, True

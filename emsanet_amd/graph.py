@@ -9,7 +9,11 @@ replay it: bs=1 is launch-bound when run eagerly (host ~10 ms per forward), the 
 GPU-bound.  Kernels are captured through torch's stream capture (they are plain launches on
 `torch.cuda.current_stream()`), activations live in the graph's private memory pool.
 """
+import ctypes
+
 import torch
+
+from . import _lib
 
 
 def _flatten(out):
@@ -20,6 +24,34 @@ def _flatten(out):
     if isinstance(out, (list, tuple)):
         return [t for v in out for t in _flatten(v)]
     return []
+
+
+def _new_graph():
+    """a CUDAGraph whose raw hipGraph_t survives the capture (torch >= 2.8: keep_graph) so that it
+    can be repaired before it is instantiated"""
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True), True
+    except TypeError:                                  # older torch: no access to the raw graph
+        return torch.cuda.CUDAGraph(), False
+
+
+def _repair_and_instantiate(graph, kept):
+    """replace the capture's memset nodes by fill-kernel nodes (emsa_graph_replace_memsets: captured
+    memsets -- torch's zero-fills of reduction semaphores / scratch -- corrupt replays when eager
+    memsets run between them, ROCm 7.2) and instantiate.  -> {'nodes', 'memset_nodes', 'replaced'}"""
+    info = {'nodes': None, 'memset_nodes': None, 'replaced': 0}
+    if not kept:
+        return info
+    raw = graph.raw_cuda_graph()
+    raw = int(raw) if not hasattr(raw, 'value') else int(raw.value)
+    L = _lib.lib()
+    n, ms, kn, rep = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(L.emsa_graph_count_nodes(raw, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(kn)),
+               'emsa_graph_count_nodes')
+    _lib.check(L.emsa_graph_replace_memsets(raw, ctypes.byref(rep)), 'emsa_graph_replace_memsets')
+    graph.instantiate()
+    info.update(nodes=n.value, memset_nodes=ms.value, replaced=rep.value)
+    return info
 
 
 class GraphedInference:
@@ -50,10 +82,11 @@ class GraphedInference:
             for _ in range(self.warmup):  # packs weights, sets kernel attributes, warms the pool
                 model({**self.static_in, **self.extra}, do_postprocessing=self.do_postprocessing)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph, kept = _new_graph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = model({**self.static_in, **self.extra},
                                     do_postprocessing=self.do_postprocessing)
+        self.graph_info = _repair_and_instantiate(self.graph, kept)
         self._key = self._weights_key()
         self.captures += 1
 
@@ -158,9 +191,11 @@ class GraphedTrainStep:
             snap.restore()
             torch.cuda.synchronize()
         pend = {id(m): m._emsa_pending for m in self._bns}
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph, kept = _new_graph()
         with torch.cuda.graph(self.graph):
             self.static_loss, self.static_out = self._step()
+        # memset nodes (a user loss written with torch reductions brings them in) -> kernel nodes
+        self.graph_info = _repair_and_instantiate(self.graph, kept)
         # the capture RECORDED a step, it did not run one: take its host-side effects back (what
         # ONE step adds to the host-side BatchNorm step counters is replayed by `replay()`)
         self._bn_inc = [(m, m._emsa_pending - pend[id(m)]) for m in self._bns]

@@ -92,6 +92,11 @@ class ConvRT:
             return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
         return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
 
+    def folds_input_bn(self, dtype):
+        """this conv can take the BatchNorm + ReLU in front of it into its loader (fp32 1-D
+        Winograd form, forward and weight gradient; Fn.bn1_fold is the switch)"""
+        return self.wino and Fn.wino_rows(self.spec) == 1 and Fn.bn1_fold(dtype)
+
     def dgrad(self, dy, in_hw, mask_bits=None, **kw):
         """mask_bits: the ReLU mask of the producing layer as bits (conv_fwd(want_relu_bits));
         used by the Winograd kernel, otherwise the float `mask_src` applies"""
@@ -104,11 +109,12 @@ class ConvRT:
             return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud, mask_bits=mask_bits, **kw)
         return Fn.conv_dgrad(dy, self.packed_dgrad(), self.spec, in_hw, **kw)
 
-    def dgrad_bnb(self, dy, in_hw, t, affine, mean, invstd, residual=None):
+    def dgrad_bnb(self, dy, in_hw, t, affine, mean, invstd, residual=None, force=False):
         """data gradient + the backward reduction of the BatchNorm in front of this conv
         (Fn.conv_dgrad_bnb), or None when this conv's kernel has no such epilogue (fp32 without
-        the Winograd form)"""
-        if affine is None or not Fn.bn_fused_reduce(dy.dtype):
+        the Winograd form).  force: the caller has no other way (the forward folded the BatchNorm
+        into this conv's loader: no ReLU bit mask exists)"""
+        if affine is None or not (force or Fn.bn_fused_reduce(dy.dtype)):
             return None
         scale, shift = affine
         if dy.dtype != torch.float32:
@@ -335,17 +341,19 @@ def _bn_targets(brt):
     return {'dg_out': tg, 'db_out': tb} if tg is not None and tb is not None else {}
 
 
-def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None, bnb=None):
+def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None, bnb=None,
+                   in_affine=None):
     """-> dx (or None), dw (OIHW), dbias (or None); with bnb = (t, (scale, shift), mean, invstd) of
     the BatchNorm+ReLU in front of the conv: -> dx, dw, dbias, (partial, rows) or None -- dx then
-    already carries that ReLU's mask (ConvRT.dgrad_bnb)"""
+    already carries that ReLU's mask (ConvRT.dgrad_bnb).  in_affine: the forward folded that
+    BatchNorm + ReLU into the conv's loader (x = the BatchNorm's INPUT)"""
     conv = crt.conv
     # the gradients go straight into their flat all-reduce / optimizer bucket views when
     # GradientBuckets manages the parameters (no gather copy later)
     tw = grad_target(conv.weight)
     tb = grad_target(conv.bias) if conv.bias is not None else None
     dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight,
-                                   dw_out=tw, db_out=tb)
+                                   dw_out=tw, db_out=tb, in_affine=in_affine)
     if packed:
         dw = Fn.unpack_wgrad(dw, conv.weight, out=tw)
     elif tw is not None and dw.data_ptr() == tw.data_ptr():
@@ -353,9 +361,12 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=
     dx = None
     if bnb is not None:
         t, affine, mean, invstd = bnb
-        r = crt.dgrad_bnb(dy, x.shape[2:], t, affine, mean, invstd, residual=residual)
+        r = crt.dgrad_bnb(dy, x.shape[2:], t, affine, mean, invstd, residual=residual,
+                          force=in_affine is not None)
         if r is not None:
             return r[0], dw, db, (r[1], r[2])
+        if in_affine is not None:
+            raise _lib.EmsaError("folded BatchNorm: the data gradient has no fused reduction here")
         return crt.dgrad(dy, x.shape[2:], residual=residual), dw, db, None
     if need_dx:
         dx = crt.dgrad(dy, x.shape[2:], mask_src=mask_src, residual=residual,
@@ -400,8 +411,20 @@ class NBt1DFunction(Function):
         # y1, y3 = relu(conv): their ReLU masks go to the backward pass as bits (q1, q3; None when
         # the layer does not run on the Winograd kernel)
         y1, q1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU, want_relu_bits=True)
-        a2, y2, m1, is1, k1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
-        y3, q3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU, want_relu_bits=True)
+        fold = rt.bn1.batch_stats() and rt.c31_2.folds_input_bn(x.dtype)
+        if fold:
+            # bn1's normalise + ReLU happens in the loaders of conv3x1_2 (here) and of its weight
+            # gradient; a2 = relu(bn1(y2)) is never written, no ReLU bit mask either (the data
+            # gradient recomputes the decisions from y2)
+            y2, stats = rt.c13_1.forward(y1, bias=b(rt.c13_1), want_stats=True)
+            scale, shift, m1, is1 = rt.bn1.forward_stats(stats, y2.shape[0] * y2.shape[2] * y2.shape[3])
+            m1._emsa_affine = (scale, shift)
+            a2 = k1 = None
+            y3, q3 = rt.c31_2.forward(y2, bias=b(rt.c31_2), act=ACT_RELU, want_relu_bits=True,
+                                      in_affine=(scale, shift))
+        else:
+            a2, y2, m1, is1, k1 = _conv_bn_forward(y1, rt.c13_1, rt.bn1, ACT_RELU)
+            y3, q3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU, want_relu_bits=True)
         if rt.cds is not None:
             idn, yd, md, isd, _ = _conv_bn_forward(x, rt.cds, rt.bnds, ACT_NONE)
         else:
@@ -409,7 +432,8 @@ class NBt1DFunction(Function):
         out, y4, m2, is2, k2 = _conv_bn_forward(y3, rt.c13_2, rt.bn2, ACT_RELU, drop=drop,
                                                 residual=idn)
         if MASK_TRACE is not None:
-            for tag, t in (('nbt.y1', y1), ('nbt.a2', a2), ('nbt.y3', y3), ('nbt.out', out)):
+            a2t = a2 if a2 is not None else Fn.bn_act(y2, scale, shift, None, None, ACT_RELU)
+            for tag, t in (('nbt.y1', y1), ('nbt.a2', a2t), ('nbt.y3', y3), ('nbt.out', out)):
                 _trace_mask(tag, t)
         ctx.rt, ctx.drop = rt, drop
         ctx.save_for_backward(x)
@@ -440,8 +464,13 @@ class NBt1DFunction(Function):
         # conv3x1_2 (input a2 = relu(bn1(y2)))
         # the data gradient's epilogue applies bn1's ReLU mask and emits bn1's backward sums (one
         # pass over da2 and y2 less); falls back to the separate reduction pass
-        da2, dw3, dbias3, fused = _conv_backward(a2, dz3, rt.c31_2, True,
-                                                 bnb=(y2, getattr(m1, '_emsa_affine', None), m1, is1))
+        aff1 = getattr(m1, '_emsa_affine', None)
+        if a2 is None:                    # folded forward: the conv's input is relu(bn1(y2))
+            da2, dw3, dbias3, fused = _conv_backward(y2, dz3, rt.c31_2, True,
+                                                     bnb=(y2, aff1, m1, is1), in_affine=aff1)
+        else:
+            da2, dw3, dbias3, fused = _conv_backward(a2, dz3, rt.c31_2, True,
+                                                     bnb=(y2, aff1, m1, is1))
         if fused is not None:
             dy2, dg1, db1 = Fn.bn_bwd_from_rows(da2, y2, rt.bn1.bn.weight.detach(), m1, is1,
                                                 fused[0], fused[1], t1, **_bn_targets(rt.bn1))

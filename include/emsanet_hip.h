@@ -154,6 +154,20 @@ int emsa_conv1d_wino_bnb(const EmsaConvGeom* g, const float* dy, const float* u,
                          const float* residual, int32_t ld_res, const float* t, int32_t ld_t,
                          const float* bn_scale, const float* bn_shift, const float* bn_mean,
                          const float* bn_invstd, float* partial, int32_t rows_alloc, void* stream);
+/* The NBt1D block's bn1 folded into its consumers (/root/reference/emsanet/model.py:47-58: conv1x3_1
+ * -> BatchNorm -> ReLU -> conv3x1_2): the forward conv and its weight gradient read the BatchNorm's
+ * INPUT `in` and form a = relu(in * in_scale[c] + in_shift[c]) (c = input channel, k_ch floats each;
+ * the affine form emsa_bn_finalize produces) where the K step enters LDS, with zero padding applied
+ * to `a`.  The normalised tensor is never written: one read + one write of the activation less per
+ * block forward; emsa_conv1d_wino_bnb recomputes the same ReLU decisions for the backward pass.
+ * 1-D stride-1 3-tap convs only (EMSA_E_SHAPE otherwise); other arguments as emsa_conv1d_wino /
+ * emsa_conv_wgrad.                                                                                */
+int emsa_conv1d_wino_inbn(const EmsaConvGeom* g, const float* in, const float* u, float* out,
+                          const float* bias, float* stats, const float* in_scale,
+                          const float* in_shift, int32_t act, uint64_t* relu_bits, void* stream);
+int emsa_conv_wgrad_inbn(const EmsaConvGeom* g, const float* in, const float* dout, float* dw,
+                         float* dbias, float* ws, const float* in_scale, const float* in_shift,
+                         void* stream);
 /* u (forward weights [4][cout][rows*cin]) and/or u_dgrad (data-gradient weights
  * [4][cin][rows*cout]) from the OIHW taps in one launch; either output may be NULL              */
 int emsa_pack_wino(const float* w_oihw, float* u, float* u_dgrad, int32_t cout, int32_t cin,
@@ -559,6 +573,25 @@ int emsa_se_scale_bwd_reduce_t(int32_t dtype, const void* dout, const void* x, f
     ws, int32_t n, int64_t hw, int32_t c, void* stream);
 int emsa_cast_channels(int32_t src_dtype, const void* x, int32_t ld_x, int32_t dst_dtype, void*
     y, int32_t ld_y, int64_t pixels, int32_t c, void* stream);
+/* Module boundary (callers own ordinary PyTorch tensors): dense NHWC copy y[n][h][w][c]
+ * of a logical (n, c, h, w) tensor given by its ELEMENT strides -- contiguous NCHW as the reference's
+ * decoder tests build their inputs (/root/reference/emsanet/tests/test_interface_decoders.py:73-88)
+ * and as NCHW losses return their cotangents, or any other view (strides may be 0: expanded
+ * scalars).  Plane-contiguous sources take an LDS-tiled transpose, the rest an element-wise gather;
+ * one pass, storage type `dtype` on both sides.                                                    */
+int emsa_to_nhwc_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t c, int32_t h,
+                   int32_t w, int64_t s_n, int64_t s_c, int64_t s_h, int64_t s_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hipGraph surgery (emsanet_amd.graph: whole-step capture; new capability, the reference has no
+ * graph path -- its low-latency route is ONNX -> TensorRT, inference_time_whole_model.py:350-453).
+ * `graph` is a hipGraph_t obtained by stream capture and NOT yet instantiated.
+ * emsa_graph_replace_memsets rewrites every memset node (torch's zero-fills of reduction scratch
+ * and gradient buffers) as a fill KERNEL node with the same edges: captured memset nodes were
+ * found to corrupt replays when eager memsets run in between (ROCm 7.2).
+ * ------------------------------------------------------------------------------------------ */
+int emsa_graph_count_nodes(void* graph, int32_t* n_nodes, int32_t* n_memset, int32_t* n_kernel);
+int emsa_graph_replace_memsets(void* graph, int32_t* replaced);
 
 /* ------------------------------------------------------------------------------------------
  * Per-launch timing of the MFMA conv kernels (bench.py roofline): when enabled, every n-th

@@ -179,12 +179,17 @@ def test_dry_run_orchestration(fake_lib, train, monkeypatch):
         assert p.grad is not None and p.grad.shape == p.shape, k
     c = fake_lib.calls
     # 2 encoders x 16 + 2 decoders x 9 NBt1D blocks, 4 MFMA convs each (+3 downsample per encoder)
-    assert c['emsa_conv_wgrad'] >= 50 * 4
-    assert c['emsa_conv_igemm'] + c['emsa_conv1d_wino'] + c['emsa_conv1d_wino_bnb'] > c['emsa_conv_wgrad']
-    # every stride-1 3x1/1x3 conv runs on the Winograd kernel, forward and data gradient
-    # (fp32: bn1's backward reduction is its own pass; the fused form: test_dry_run_fused_bn_reduction)
-    assert c['emsa_conv1d_wino_bnb'] == 0
-    assert c['emsa_conv1d_wino'] + c['emsa_conv1d_wino_bnb'] >= 2 * (50 * 4 - 2 * 3 * 2) - 2
+    assert c['emsa_conv_wgrad'] + c['emsa_conv_wgrad_inbn'] >= 50 * 4
+    wino = c['emsa_conv1d_wino'] + c['emsa_conv1d_wino_bnb'] + c['emsa_conv1d_wino_inbn']
+    assert c['emsa_conv_igemm'] + wino > c['emsa_conv_wgrad'] + c['emsa_conv_wgrad_inbn']
+    # every stride-1 3x1/1x3 conv runs on the Winograd kernel, forward and data gradient.  fp32
+    # training (batch statistics): bn1 of every NBt1D block lives in the loaders of conv3x1_2
+    # (forward + weight gradient) and in the epilogue of its data gradient -- no separate
+    # normalise pass, no separate reduction pass; with frozen statistics nothing is folded
+    folded = 50 if train else 0
+    assert c['emsa_conv1d_wino_inbn'] == folded and c['emsa_conv_wgrad_inbn'] == folded
+    assert c['emsa_conv1d_wino_bnb'] == folded and c['emsa_bn_bwd_apply_rows_t'] == folded
+    assert wino >= 2 * (50 * 4 - 2 * 3 * 2) - 2
     assert c['emsa_se_mlp_fwd'] == 10 and c['emsa_maxpool3x3s2_fwd'] == 2
     assert c['emsa_up2x_dw3x3_fwd'] == 2 * 3 + 2 * 2
     # merged dict variant (do_postprocessing=True), /root/reference/emsanet/model.py:230-231
@@ -199,6 +204,7 @@ def test_dry_run_fused_bn_reduction(fake_lib, monkeypatch):
     from emsanet_amd import full_args, functional as Fn
     from oracle.emsanet_oracle import synthetic_batch
     monkeypatch.setattr(Fn, '_BN_FUSE_ENV', '1')
+    monkeypatch.setattr(Fn, 'BN1_FOLD', False)       # (the folded forward implies the fused form)
     model = _model(full_args(input_height=64, input_width=96)).train()
     monkeypatch.setattr(M.EMSANet, 'forward', _bypass_device_check(model))
     outs = model(synthetic_batch(2, 64, 96))
@@ -208,6 +214,7 @@ def test_dry_run_fused_bn_reduction(fake_lib, monkeypatch):
     c = fake_lib.calls
     assert c['emsa_conv1d_wino_bnb'] == 50
     assert c['emsa_bn_bwd_apply_rows_t'] == 50
+    assert c['emsa_conv1d_wino_inbn'] == 0 and c['emsa_conv_wgrad_inbn'] == 0
     assert all(p.grad is not None for p in model.parameters())
 
 

@@ -78,10 +78,16 @@ def _argmax_check(gpu_logits, ref64, what):
 
 @pytest.mark.parametrize('cin,cout,stride,p', [(64, 64, 1, 0.0), (64, 64, 1, 0.2),
                                               (64, 128, 2, 0.1), (128, 128, 1, 0.5)])
-@pytest.mark.parametrize('mode', ['train', 'eval_grad', 'eval_fast'])
-def test_nbt1d_block(cin, cout, stride, p, mode):
+@pytest.mark.parametrize('mode', ['train', 'train_unfolded', 'eval_grad', 'eval_fast'])
+def test_nbt1d_block(cin, cout, stride, p, mode, monkeypatch):
+    """'train' runs bn1 folded into the loaders of conv3x1_2 and of its weight gradient (the fp32
+    default), 'train_unfolded' with the separate normalise + ReLU pass"""
+    from emsanet_amd import functional as Fn
     from emsanet_amd.nn import NonBottleneck1D
     from oracle import emsanet_oracle as O
+    monkeypatch.setattr(Fn, 'BN1_FOLD', mode != 'train_unfolded')
+    if mode == 'train_unfolded':
+        mode = 'train'
     torch.manual_seed(0)
     ref = O.NonBottleneck1D(cin, cout, stride, p)
     for m in ref.modules():

@@ -755,3 +755,67 @@ def test_dgrad_with_fused_bn_backward_sums(dtype, kernel, c, shape, with_res):
     close(dx, dx0.float().cpu(), tol=tol, what='fused vs separate dx')
     close(dg, dg0.cpu(), tol=1e-2 if lo else 2e-4, what='fused vs separate dgamma')
     close(db, db0.cpu(), tol=1e-2 if lo else 2e-4, what='fused vs separate dbeta')
+
+
+WINO_1D = [c for c in WINO if c[2] != (3, 3)]
+
+
+@pytest.mark.parametrize('cfg', WINO_1D)
+def test_conv1d_winograd_folded_input_bn(cfg):
+    """the BatchNorm + ReLU in front of a 1-D conv formed in the conv's loader
+    (emsa_conv1d_wino_inbn) and again in the loader of its weight gradient (emsa_conv_wgrad_inbn):
+    == conv(relu(x * scale + shift)) with ZERO padding of the normalised tensor (a padding row
+    must not turn into relu(shift)), odd line lengths, channel tails, statistics, ReLU bits."""
+    Fn = _fn()
+    cin, cout, k, n, h, w = cfg
+    p = (k[0] // 2, k[1] // 2)
+    x = rnd(n, cin, h, w, seed=1)
+    sc = rnd(cin, seed=11).abs() + 0.5
+    sh = rnd(cin, seed=12) + 0.3            # mostly positive shifts: padding would show
+    wt = rnd(cout, cin, *k, seed=2, scale=0.1).double().requires_grad_(True)
+    b = rnd(cout, seed=3).double().requires_grad_(True)
+    # the kernels form a with ONE fused multiply-add in fp32; the reference takes the same values
+    a = F.relu(torch.addcmul(sh[None, :, None, None], x, sc[None, :, None, None])).double()
+    ref = F.conv2d(a, wt, b, padding=p)
+    spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
+    u = Fn.pack_wino(wt.detach().float().to(DEV))[0]
+    aff = (sc.to(DEV), sh.to(DEV))
+    (y, stats), bits = Fn.conv_fwd(to_act(x), None, spec, bias=b.detach().float().to(DEV),
+                                   want_stats=True, act=Fn.ACT_RELU, wino_u=u,
+                                   want_relu_bits=True, in_affine=aff)
+    torch.cuda.synchronize()
+    close(y, F.relu(ref), tol=2e-4, what='folded-bn conv')
+    # the same launch without the fold on the materialised tensor: bit-identical epilogue products
+    (y0, stats0), bits0 = Fn.conv_fwd(to_act(a.float()), None, spec,
+                                      bias=b.detach().float().to(DEV), want_stats=True,
+                                      act=Fn.ACT_RELU, wino_u=u, want_relu_bits=True)
+    close(y, y0.double(), tol=2e-5, what='folded vs materialised')
+    close(stats[0].sum(0), stats0[0].sum(0).double(), tol=2e-4, what='stats sums')
+    assert bits is not None and bits.shape == bits0.shape
+    # weight gradient with the same fold
+    dy = rnd(*ref.shape, seed=7)
+    ref.backward(dy.double())
+    like = wt.detach().float().to(DEV)
+    dw, db, packed = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True,
+                                   in_affine=aff)
+    torch.cuda.synchronize()
+    assert not packed
+    close(dw, wt.grad, tol=2e-4, what='folded-bn wgrad')
+    close(db, b.grad, tol=2e-4, what='folded-bn bgrad')
+    dw2, _, _ = Fn.conv_wgrad(to_act(x), to_act(dy), spec, True, like=like, two_pass=True,
+                              in_affine=aff)
+    assert torch.equal(dw, dw2)                               # deterministic two-pass form
+
+
+def test_folded_input_bn_rejects_unsupported():
+    """3x3 / strided convs have no folded loader: EMSA_E_SHAPE, never a silent plain conv"""
+    Fn = _fn()
+    from emsanet_amd._lib import EmsaError
+    x = to_act(rnd(1, 64, 8, 8, seed=1))
+    wt = rnd(64, 64, 3, 3, seed=2, scale=0.1).to(DEV)
+    spec = Fn.ConvSpec(64, 64, (3, 3), (1, 1), (1, 1))
+    aff = (torch.ones(64, device=DEV), torch.zeros(64, device=DEV))
+    with pytest.raises(EmsaError):
+        Fn.conv_fwd(x, None, spec, wino_u=Fn.pack_wino(wt)[0], in_affine=aff)
+    with pytest.raises(EmsaError):
+        Fn.conv_wgrad(x, x, spec, False, like=wt, two_pass=True, in_affine=aff)

@@ -93,6 +93,31 @@ def main():
             us = timeit(lambda i: Fn.conv_dgrad(DY[i % nb], None, spec, (h, w),
                                                 mask_src=X[i % nb], out=DX[i % nb], wino_u=ud))
             row += f" dgrad {us:7.1f}us {flops / us / 1e6:6.1f} |"
+        if what in ('inbn', 'all') and Fn.wino_eligible(spec) and Fn.wino_rows(spec) == 1:
+            # the NBt1D block's bn1 folded into the loaders (forward, weight gradient) and into the
+            # data gradient's epilogue, next to the unfolded launches they replace
+            u, ud = Fn.pack_wino(wt, fwd=True, dgrad=True)
+            aff = (torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV))
+            mean, istd = torch.randn(cin, device=DEV), torch.rand(cin, device=DEV) + 0.5
+            us0 = timeit(lambda i: Fn.conv_fwd(X[i % nb], None, spec, bias=bias, act=1,
+                                               out=Y[i % nb], wino_u=u, want_relu_bits=True))
+            us = timeit(lambda i: Fn.conv_fwd(X[i % nb], None, spec, bias=bias, act=1,
+                                              out=Y[i % nb], wino_u=u, want_relu_bits=True,
+                                              in_affine=aff))
+            row += f" INBN fwd {us0:6.1f} -> {us:6.1f}us |"
+            us0 = timeit(lambda i: Fn.conv_wgrad(X[i % nb], DY[i % nb], spec, True, like=wt,
+                                                 two_pass=True))
+            us = timeit(lambda i: Fn.conv_wgrad(X[i % nb], DY[i % nb], spec, True, like=wt,
+                                                two_pass=True, in_affine=aff))
+            row += f" wgrad {us0:6.1f} -> {us:6.1f}us |"
+            us0 = timeit(lambda i: Fn.conv_dgrad(DY[i % nb], None, spec, (h, w), out=DX[i % nb],
+                                                 wino_u=ud))
+            us = timeit(lambda i: Fn.conv_dgrad_bnb(DY[i % nb], None, spec, (h, w), X[i % nb],
+                                                    aff[0], aff[1], mean, istd, wino_u=ud))
+            row += f" dgrad {us0:6.1f} -> bnb {us:6.1f}us |"
+            pw = timeit(lambda i: Fn.bn_act(X[i % nb], aff[0], aff[1], None, None, 1,
+                                            want_mask=True))
+            row += f" (bn_act pass {pw:6.1f}us)"
         if what in ('wgrad', 'all'):
             us = timeit(lambda i: Fn.conv_wgrad(X[i % nb], DY[i % nb], spec, True))
             row += f" wgrad {us:7.1f}us {flops / us / 1e6:6.1f}TF |"
