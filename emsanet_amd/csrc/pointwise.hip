@@ -722,13 +722,11 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict_
     for (int k = 0; k < V; ++k) cred[rl * c + cv * V + k] = acc[k];
   }
   __syncthreads();
-  // (kThreads, not blockDim.x: with blockDim.x here the hipGraph-captured training step read a
-  //  different value at replay than the eager launch does -- bisected with single-kernel builds)
-#ifdef EMSA_PROBE_BLOCKDIM            // tools/jobs/r03a.sh: the round-2 form, for the root-cause probe
-  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-#else
+  // (round 2 blamed a `blockDim.x` read in this loop for a hipGraph-replay discrepancy; round 3
+  //  reproduced the same wrong loss with either form and traced it to the MEMSET nodes of the
+  //  captured graph -- csrc/graph_tools.hip, DESIGN.md 5b.  The compile-time stride stays: it is
+  //  the launch configuration anyway.)
   for (int ch = threadIdx.x; ch < c; ch += kThreads) {
-#endif
     float t = 0.f;
     for (int k = 0; k < lanes; ++k) t += cred[k * c + ch];
     ws[(long)blockIdx.x * c + ch] = t;

@@ -450,18 +450,28 @@ def bn_fused_reduce(dtype):
 
 # The NBt1D block's bn1 without a forward pass of its own (fp32 training): conv3x1_2 and its weight
 # gradient form relu(bn1(y2)) in their loaders, the data gradient's epilogue recomputes the ReLU
-# decisions and emits the backward sums (conv_dgrad_bnb).  EMSA_BN1_FOLD=0 restores the separate
-# normalise + ReLU pass.  tests: BN1_FOLD = True / False overrides.
+# decisions and emits the backward sums (conv_dgrad_bnb).  Measured per block at bs=32
+# (tools/conv_bench.py inbn, profiles/r03_b_conv_bench_inbn.txt): the fold removes the normalise pass
+# (56 / 30 / 15 / 13 us at the /4 /8 /16 /32 stages) and the separate reduction pass (about the
+# same) and costs +2..7 us on the forward conv, +4..7 us on the weight gradient (12 / 32 vector
+# instructions per K step next to 16 / 32 MFMAs) and +12..21 us on the data gradient: a clear gain
+# on the large tensors, a small loss at 512 channels / 15x20.  Default: fold when the BatchNorm's
+# tensor is at least EMSA_BN1_FOLD_MIN_MB (24) MiB; EMSA_BN1_FOLD=0 / 1 forces never / always.
+# tests: BN1_FOLD = True / False overrides (always / never).
 _BN1_FOLD_ENV = os.environ.get('EMSA_BN1_FOLD')
+_BN1_FOLD_MIN_BYTES = int(float(os.environ.get('EMSA_BN1_FOLD_MIN_MB', '24')) * (1 << 20))
 BN1_FOLD = None
 
 
-def bn1_fold(dtype):
+def bn1_fold(t):
+    """fold the BatchNorm + ReLU applied to activation `t` into the loaders of the conv behind it?"""
+    if t.dtype != torch.float32:
+        return False
     if BN1_FOLD is not None:
-        return BN1_FOLD and dtype == torch.float32
+        return BN1_FOLD
     if _BN1_FOLD_ENV is not None:
-        return _BN1_FOLD_ENV != '0' and dtype == torch.float32
-    return dtype == torch.float32
+        return _BN1_FOLD_ENV != '0'
+    return t.numel() * 4 >= _BN1_FOLD_MIN_BYTES
 
 
 def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invstd, residual=None,

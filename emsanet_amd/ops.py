@@ -92,10 +92,11 @@ class ConvRT:
             return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
         return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
 
-    def folds_input_bn(self, dtype):
-        """this conv can take the BatchNorm + ReLU in front of it into its loader (fp32 1-D
-        Winograd form, forward and weight gradient; Fn.bn1_fold is the switch)"""
-        return self.wino and Fn.wino_rows(self.spec) == 1 and Fn.bn1_fold(dtype)
+    def folds_input_bn(self, t):
+        """this conv can take the BatchNorm + ReLU in front of it (input tensor `t`) into its
+        loader: fp32 1-D Winograd form, forward and weight gradient; Fn.bn1_fold decides whether
+        it pays at this size"""
+        return self.wino and Fn.wino_rows(self.spec) == 1 and Fn.bn1_fold(t)
 
     def dgrad(self, dy, in_hw, mask_bits=None, **kw):
         """mask_bits: the ReLU mask of the producing layer as bits (conv_fwd(want_relu_bits));
@@ -411,7 +412,7 @@ class NBt1DFunction(Function):
         # y1, y3 = relu(conv): their ReLU masks go to the backward pass as bits (q1, q3; None when
         # the layer does not run on the Winograd kernel)
         y1, q1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU, want_relu_bits=True)
-        fold = rt.bn1.batch_stats() and rt.c31_2.folds_input_bn(x.dtype)
+        fold = rt.bn1.batch_stats() and rt.c31_2.folds_input_bn(y1)
         if fold:
             # bn1's normalise + ReLU happens in the loaders of conv3x1_2 (here) and of its weight
             # gradient; a2 = relu(bn1(y2)) is never written, no ReLU bit mask either (the data

@@ -153,8 +153,9 @@ def test_rejected_call_raises():
 @pytest.mark.parametrize('train', [True, False])
 def test_dry_run_orchestration(fake_lib, train, monkeypatch):
     import emsanet_amd.model as M
-    from emsanet_amd import full_args
+    from emsanet_amd import full_args, functional as Fn
     from oracle.emsanet_oracle import synthetic_batch
+    monkeypatch.setattr(Fn, 'BN1_FOLD', True)     # (default rule: tensors >= 24 MiB only)
     args = full_args(input_height=64, input_width=96)
     model = _model(args)
     model.train(train)
@@ -399,3 +400,17 @@ def test_strided_dgrad_phase_plan(cfg):
                 dx[:, :, s[0] * j + ph, s[1] * i + pw] = acc
     assert not torch.isnan(dx).any()                                                   # covered
     assert float((dx - x.grad).abs().max()) < 1e-12
+
+
+def test_bn1_fold_default_rule(monkeypatch):
+    """bn1 is folded into the conv loaders where the saved passes outweigh the loader work: the
+    bs=32 640x480 stages /4, /8, /16 (157 / 79 / 39 MB), not /32 (20 MB), never in 16-bit storage"""
+    from emsanet_amd import functional as Fn
+    monkeypatch.setattr(Fn, 'BN1_FOLD', None)
+    monkeypatch.setattr(Fn, '_BN1_FOLD_ENV', None)
+    t = lambda c, h, w, dt=torch.float32: torch.empty(32, c, h, w, device='meta', dtype=dt)   # noqa: E731
+    assert Fn.bn1_fold(t(64, 120, 160)) and Fn.bn1_fold(t(128, 60, 80)) and Fn.bn1_fold(t(256, 30, 40))
+    assert not Fn.bn1_fold(t(512, 15, 20))
+    assert not Fn.bn1_fold(t(64, 120, 160, torch.bfloat16))
+    monkeypatch.setattr(Fn, '_BN1_FOLD_ENV', '0')
+    assert not Fn.bn1_fold(t(64, 120, 160))

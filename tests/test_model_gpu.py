@@ -538,19 +538,25 @@ def _pinned_grad_parity(args, bs, seed, monkeypatch, tol_out, tol_grad, oracle_d
     return worst
 
 
-def test_pinned_gradients_small(monkeypatch):
+@pytest.mark.parametrize('fold', [True, False])
+def test_pinned_gradients_small(fold, monkeypatch):
     """96x128 bs 4, all heads: all 766 gradients at 2e-3 relative L2 (was: distribution gate with
     max <= 0.1).  Measured 9.5e-4: at this size the /32 BatchNorms see 48 samples per channel and
-    are ill-conditioned; the BASELINE-resolution test below holds 1e-3 (measured 4.6e-4)."""
-    from emsanet_amd import full_args
+    are ill-conditioned; the BASELINE-resolution test below holds 1e-3 (measured 4.6e-4).
+    fold: bn1 of all 50 NBt1D blocks folded into the conv loaders / the data-gradient epilogue
+    (the default rule only folds tensors >= 24 MiB: forced here) vs the separate passes."""
+    from emsanet_amd import full_args, functional as Fn
+    monkeypatch.setattr(Fn, 'BN1_FOLD', fold)
     _pinned_grad_parity(full_args(input_height=96, input_width=128), 4, 1234, monkeypatch,
                         tol_out=TOL, tol_grad=2e-3)
 
 
 def test_pinned_gradients_baseline_resolution(monkeypatch):
     """BASELINE configs[1] shape: 640x480 RGB-D, all heads, train mode, bs=2 (what the fp64 CPU
-    oracle finishes in seconds): every output and every one of the 742 gradients vs fp64"""
-    from emsanet_amd import full_args
+    oracle finishes in seconds): every output and every one of the 742 gradients vs fp64; bn1 folded
+    in every block (at bs=32 the default rule folds the /4, /8 and /16 stages)"""
+    from emsanet_amd import full_args, functional as Fn
+    monkeypatch.setattr(Fn, 'BN1_FOLD', True)
     _pinned_grad_parity(full_args(), 2, 77, monkeypatch, tol_out=TOL, tol_grad=1e-3)
 
 
