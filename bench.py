@@ -262,8 +262,36 @@ def run(args):
     params = [p for p in model.parameters() if p.requires_grad]
     # FusedSGD folds the 1/world averaging into its update kernel; torch's optimizer needs it done
     comm_dtype = {'f32': None, 'bf16': torch.bfloat16}[args.grad_dtype]
-    buckets = GradientBuckets(params, force_collectives=args.force_dist,
-                              average=args.torch_optimizer, comm_dtype=comm_dtype)
+    dist_on = dist.is_initialized() and (world > 1 or args.force_dist)
+    segmented = bool(args.graph and not args.eval and dist_on)
+    if segmented:
+        # multi-rank step under hipGraphs: one graph per backward segment, the buckets of a segment
+        # all-reduced eagerly while the next segment's graph runs (SegmentedGraphedTrainStep)
+        if args.torch_optimizer:
+            raise SystemExit("--graph with several ranks uses the fused optimizer")
+        from emsanet_amd.graph import segment_parameter_groups
+        buckets = GradientBuckets(params, groups=segment_parameter_groups(model, (2, 1)),
+                                  manual=True, force_collectives=args.force_dist, average=False,
+                                  comm_dtype=comm_dtype, tail_bytes=4 << 20)
+    elif dist_on and not args.eval:
+        # bucket boundaries from the MEASURED gradient-arrival order of one backward pass (not
+        # the registration order), the last bucket -- the first layers' gradients, which cannot
+        # overlap anything -- at most 4 MiB
+        from emsanet_amd.parallel import record_arrival_order
+
+        def dry_backward():
+            flat = flatten_outputs(model(batch))
+            torch.autograd.backward(flat, [torch.zeros_like(t) for t in flat])
+        order = record_arrival_order(params, dry_backward)
+        for p in params:
+            p.grad = None
+        model.dropout_step = 0
+        buckets = GradientBuckets(params, force_collectives=args.force_dist,
+                                  average=args.torch_optimizer, comm_dtype=comm_dtype, order=order,
+                                  tail_bytes=4 << 20)
+    else:
+        buckets = GradientBuckets(params, force_collectives=args.force_dist,
+                                  average=args.torch_optimizer, comm_dtype=comm_dtype)
     # LR rule of the reference: 0.01 * batch/8 (args.py:1338-1344); tiny here so that the random
     # net stays finite over the benchmark steps
     if args.torch_optimizer:
@@ -325,9 +353,7 @@ def run(args):
     if args.graph and not args.eval:
         # the whole training step (forward, backward, SGD) as ONE hipGraph replay; kernel timing by
         # HIP events is not available inside a graph
-        from emsanet_amd.graph import GraphedTrainStep
-        if world > 1 or args.force_dist:
-            raise SystemExit("--graph captures the single-process training step")
+        from emsanet_amd.graph import GraphedTrainStep, SegmentedGraphedTrainStep
         flat0 = flatten_outputs(model(batch))
         g = torch.Generator(device='cpu').manual_seed(4321)
         cots = [(torch.randn(t.shape, generator=g) * 1e-3).to(dev).contiguous(
@@ -335,11 +361,11 @@ def run(args):
             for t in flat0]
         del flat0
         args.no_kernel_timing = True
+        cls = SegmentedGraphedTrainStep if segmented else GraphedTrainStep
         if crit is not None:
-            train_graph = GraphedTrainStep(model, batch, buckets, opt,
-                                           loss_fn=lambda out: crit(out, targets)[0])
+            train_graph = cls(model, batch, buckets, opt, loss_fn=lambda out: crit(out, targets)[0])
         else:
-            train_graph = GraphedTrainStep(model, batch, buckets, opt, cotangents=cots)
+            train_graph = cls(model, batch, buckets, opt, cotangents=cots)
     for _ in range(args.warmup):
         step()
     buckets.reset_stats()
@@ -401,7 +427,15 @@ def run(args):
                 'collectives_per_step': st['collectives'] // steps_seen,
                 'bucket_dtype': args.grad_dtype,
                 'grads_written_in_place': st['direct_tensors'] // steps_seen,
-                'grads_gathered_by_copy': st['gathered_tensors'] // steps_seen}
+                'grads_gathered_by_copy': st['gathered_tensors'] // steps_seen,
+                'bucket_bytes': [f.numel() * f.element_size() for f, _, _ in buckets.buckets],
+                'bucket_order': 'backward segments (graph per segment)' if segmented
+                else 'measured gradient-arrival order, last bucket <= 4 MiB'}
+        if segmented and train_graph is not None:
+            # per bucket: issued this long before the device finished the backward pass
+            comm['bucket_launch_ms_before_backward_end'] = \
+                train_graph.bucket_launch_ms_before_backward_end()
+            comm['graphs'] = [i['nodes'] for i in train_graph.graph_info]
         dt = max(r[2] for r in rows)
 
     if rank != 0:

@@ -236,3 +236,233 @@ class GraphedTrainStep:
             bn._emsa_pending += inc
         self.opt.after_replay()     # version counters of the parameters, first-step flag
         return self.static_loss, self.static_out
+
+
+def segment_parameter_groups(model, cut_stages=(2, 1)):
+    """Parameters of `model` grouped by the backward SEGMENT that produces their gradients, in
+    backward order: [context module + decoders], [encoder stages behind the last cut], ...,
+    [encoder stages up to the first cut].  Pass as `GradientBuckets(params, groups=...,
+    manual=True)`: no bucket then straddles two segments (= two captured graphs)."""
+    from .nn import CutPlan
+    plan = CutPlan(cut_stages)
+    enc = model.encoder
+    groups = [list(reversed(list(model.context_module.parameters()) + list(model.decoders.parameters())))]
+    hi = 4
+    for c in plan.stages:                         # descending
+        ps = []
+        for i in range(hi, c, -1):
+            ps += list(reversed(enc.stage_parameters(i)))
+        groups.append(ps)
+        hi = c
+    ps = []
+    for i in range(hi, -1, -1):
+        ps += list(reversed(enc.stage_parameters(i)))
+    groups.append(ps)
+    groups = [[p for p in g if p.requires_grad] for g in groups]
+    listed = {id(p) for g in groups for p in g}
+    rest = [p for p in model.parameters() if p.requires_grad and id(p) not in listed]
+    if rest:
+        raise RuntimeError(f"segment_parameter_groups: {len(rest)} parameters outside encoder / "
+                           "context module / decoders")
+    return groups
+
+
+class SegmentedGraphedTrainStep:
+    """The MULTI-RANK training step under hipGraphs: RCCL collectives cannot
+    be captured from autograd hooks, so the backward pass is cut into segments (nn.CutPlan:
+    decoders | encoder stages behind / in front of each cut), each captured as its own graph
+    (segment 0 also holds the forward pass and the loss); between two replays the buckets of the
+    finished segment are all-reduced EAGERLY on RCCL's stream while the next segment's graph
+    already runs.  The optimizer update is the last graph.  Host work per step: one replay per
+    segment + one `all_reduce` call per bucket instead of ~4,900 kernel launches (35 ms).
+
+        groups  = segment_parameter_groups(model, cut_stages)
+        buckets = GradientBuckets(params, groups=groups, manual=True, average=False,
+                                  tail_bytes=4 << 20)
+        opt     = FusedSGD(buckets, ...)
+        step    = SegmentedGraphedTrainStep(model, batch, buckets, opt, cotangents=cots)
+        step.replay(next_batch)
+
+    Works with inactive buckets too (single process: the same graphs, no collectives).  The
+    eager twin of one step (`eager_step()`, the same segmented backward without capture) is what
+    the tests compare against and what the warm-up runs."""
+
+    def __init__(self, model, example_batch, buckets, optimizer, loss_fn=None, cotangents=None,
+                 cut_stages=(2, 1), warmup=2, keep_warmup_updates=False):
+        from .nn import CutPlan
+        if not model.training:
+            raise ValueError("SegmentedGraphedTrainStep captures the train-mode step")
+        if (loss_fn is None) == (cotangents is None):
+            raise ValueError("give either loss_fn or cotangents")
+        if buckets.active and not buckets.manual:
+            raise ValueError("GradientBuckets(manual=True, groups=segment_parameter_groups(...))")
+        self.model, self.buckets, self.opt = model, buckets, optimizer
+        self.loss_fn, self.cots = loss_fn, cotangents
+        self.plan = CutPlan(cut_stages)
+        self.n_seg = len(self.plan.stages) + 2
+        if len(buckets.group_buckets) != self.n_seg:
+            raise ValueError(f"buckets have {len(buckets.group_buckets)} parameter groups, the cut "
+                             f"plan {self.n_seg} backward segments")
+        self.seg_params = [[p for bi in g for p in buckets.buckets[bi][1]]
+                           for g in buckets.group_buckets]
+        self.static_in = {k: v.clone() for k, v in example_batch.items() if torch.is_tensor(v)}
+        self.extra = {k: v for k, v in example_batch.items() if not torch.is_tensor(v)}
+        model.use_device_dropout_state(True)
+        optimizer.use_device_hyperparameters(True)
+        self._bns = [m for m in model.modules() if hasattr(m, '_emsa_pending') and m.training]
+        self.graphs = None
+        snap = None if keep_warmup_updates else _TrainStateSnapshot(model, optimizer, self._bns)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if snap is not None:
+            snap.restore()
+            torch.cuda.synchronize()
+        pend = {id(m): m._emsa_pending for m in self._bns}
+        self.graphs, self.graph_info = [], []
+        keeps = []
+        for _ in range(self.n_seg + 1):
+            g, kept = _new_graph()
+            self.graphs.append(g)
+            keeps.append(kept)
+        self._capturing = True
+        st0 = dict(buckets.stats)
+        try:
+            self.static_loss, self.static_out = self._run()
+        finally:
+            self._capturing = False
+        # what one step gathers (host-side counters of the captured `gather` calls)
+        self._per_step = {k: buckets.stats[k] - st0[k] for k in ('gathered_tensors', 'direct_tensors')}
+        for k, v in st0.items():
+            buckets.stats[k] = v
+        for g, kept in zip(self.graphs, keeps):
+            self.graph_info.append(_repair_and_instantiate(g, kept))
+        self._bn_inc = [(m, m._emsa_pending - pend[id(m)]) for m in self._bns]
+        for m, inc in self._bn_inc:
+            m._emsa_pending -= inc
+        model.dropout_step -= 1
+        model._seed_dev_host = (model.dropout_seed & 0xFFFFFFFF, model.dropout_step & 0xFFFFFFFF)
+        if snap is not None:
+            optimizer._first = snap.first
+            optimizer._upload_hyper()
+        self.replays = 0
+        self._ev = None
+
+    # -- one step, eager or under capture -------------------------------------------------------
+    def _segment(self, k):
+        """context of backward segment k (k = n_seg: the optimizer update)"""
+        import contextlib
+        if not getattr(self, '_capturing', False):
+            return contextlib.nullcontext()
+        pool = self.graphs[0].pool() if k > 0 else None
+        return torch.cuda.graph(self.graphs[k], pool=pool)
+
+    def _reduce(self, k):
+        if self.buckets.active and not getattr(self, '_capturing', False):
+            for bi in self.buckets.group_buckets[k]:
+                self.buckets.reduce(bi)
+
+    def _run(self):
+        model, plan, b = self.model, self.plan, self.buckets
+        model._cut_plan = plan
+        try:
+            with self._segment(0):
+                b.reset()
+                out = model({**self.static_in, **self.extra})
+                flat = _flatten(out)
+                leaves = [c for _, c, _, g in plan.records if g == plan.DECODERS]
+                if self.loss_fn is not None:
+                    loss = self.loss_fn(out)
+                    torch.autograd.backward([loss], inputs=leaves + self.seg_params[0])
+                else:
+                    loss = None
+                    torch.autograd.backward(flat, self.cots, inputs=leaves + self.seg_params[0])
+                for bi in b.group_buckets[0]:
+                    b.gather(bi)
+            self._reduce(0)
+            pending = [(o, c.grad, st) for o, c, st, g in plan.records
+                       if g == plan.DECODERS and c.grad is not None]
+            bounds = list(plan.stages) + [-1]
+            for k, cstage in enumerate(bounds, start=1):
+                with self._segment(k):
+                    roots = [(o, g) for o, g, st in pending if st > cstage]
+                    pending = [(o, g, st) for o, g, st in pending if st <= cstage]
+                    merged = {}
+                    for o, g in roots:        # one tensor may have been cut twice (skip + encoder cut)
+                        merged[id(o)] = (o, g if id(o) not in merged else merged[id(o)][1] + g)
+                    leaves = [c for _, c, _, g in plan.records if g == cstage]
+                    torch.autograd.backward([o for o, _ in merged.values()],
+                                            [g for _, g in merged.values()],
+                                            inputs=leaves + self.seg_params[k])
+                    for bi in b.group_buckets[k]:
+                        b.gather(bi)
+                self._reduce(k)
+                pending += [(o, c.grad, st) for o, c, st, g in plan.records
+                            if g == cstage and c.grad is not None]
+            if not getattr(self, '_capturing', False):
+                b.finish()
+            with self._segment(self.n_seg):
+                self.opt.step()
+        finally:
+            model._cut_plan = None
+            plan.records = []
+        return loss, out
+
+    def eager_step(self, batch=None):
+        """the same segmented step without graphs (warm-up; the tests' eager twin)"""
+        if batch is not None:
+            for k, v in self.static_in.items():
+                v.copy_(batch[k], non_blocking=True)
+        return self._run()
+
+    def replay(self, batch=None):
+        """one training step on `batch` (same shapes as the example; None: the static inputs)"""
+        if batch is not None:
+            for k, v in self.static_in.items():
+                v.copy_(batch[k], non_blocking=True)
+        b = self.buckets
+        b.begin_step_host()
+        for k, v in self._per_step.items():
+            b.stats[k] += v
+        timed = b.active
+        ev = []
+        for k in range(self.n_seg):
+            self.graphs[k].replay()
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((e, list(b.group_buckets[k])))
+                for bi in b.group_buckets[k]:
+                    b.reduce(bi)
+        if timed:
+            e_end = torch.cuda.Event(enable_timing=True)
+            e_end.record()
+            self._ev = (ev, e_end)
+            b.finish()
+        self.graphs[self.n_seg].replay()
+        self.replays += 1
+        m = self.model
+        m.dropout_step += 1
+        m._seed_dev_host = (m.dropout_seed & 0xFFFFFFFF, m.dropout_step & 0xFFFFFFFF)
+        for bn, inc in self._bn_inc:
+            bn._emsa_pending += inc
+        self.opt.after_replay()
+        return self.static_loss, self.static_out
+
+    def bucket_launch_ms_before_backward_end(self):
+        """per bucket: how long before the END of the backward pass (device time line) its
+        all-reduce was issued, for the last replay; call after a device synchronisation.  0 for the
+        buckets of the last segment -- by construction the only exposed ones."""
+        if self._ev is None:
+            return None
+        ev, e_end = self._ev
+        lead = {}
+        for e, bis in ev:
+            ms = e.elapsed_time(e_end)
+            for bi in bis:
+                lead[bi] = round(ms, 3)
+        return [lead[bi] for bi in sorted(lead)]

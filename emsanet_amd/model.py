@@ -106,6 +106,7 @@ class EMSANet(nn.Module):
         # Dropout2d bookkeeping (counter-based masks, one id per dropout layer)
         self.dropout_seed = 0
         self.dropout_step = 0
+        self._cut_plan = None        # nn.CutPlan: segmented backward (graph.SegmentedGraphedTrainStep)
         self._seed_dev = None        # device copy {seed, step} (see use_device_dropout_state)
         self._seed_dev_host = None   # the host values the device copy corresponds to
         lid = 0
@@ -208,7 +209,19 @@ class EMSANet(nn.Module):
                 not torch.cuda.is_current_stream_capturing():
             self._sync_dropout_state()
 
-        deep, skips = self.encoder(feeds)
+        plan = self._cut_plan if self.training else None
+        if plan is not None:
+            plan.begin()
+        deep, skips = self.encoder(feeds, plan)
+        if plan is not None:
+            # encoder / decoder boundary: everything the context module and the decoders read is a
+            # detached leaf; the originals become roots of the encoder's backward segments
+            D = plan.DECODERS
+            deep = {k: plan.cut(v, st, D) for k, (v, st) in deep.items()}
+            # (only the rgb skips feed the decoders; the depth stream's gradient comes through
+            #  the fusion modules)
+            skips = {ds: {k: (plan.cut(v, st, D) if k == 'rgb' or len(sk) == 1 else v.detach())
+                          for k, (v, st) in sk.items()} for ds, sk in skips.items()}
         # the context module sees the fused rgb stream, or the only stream there is
         ctx_in = deep['rgb'] if len(feeds) == 2 else next(iter(deep.values()))
         ctx, ctx_branches = self.context_module(ctx_in)

@@ -157,7 +157,35 @@ class SEAddUniRGB(nn.Module):
 
     def forward(self, rgb, depth):
         ps = ops._se_params(self.se_rgb) + ops._se_params(self.se_depth)
-        return ops.SEAddFunction.apply(rgb, depth, *ps), depth
+        # (the depth stream continues on the Function's pass-through output: its gradient from the
+        #  next stage is added inside the SE backward kernel instead of by autograd)
+        return ops.SEAddFunction.apply(rgb, depth, *ps)
+
+
+class CutPlan:
+    """Autograd-graph cuts for the SEGMENTED backward pass (emsanet_amd.graph.
+    SegmentedGraphedTrainStep): at a cut the forward continues on a detached copy that is a leaf
+    of its own; the backward pass then runs segment by segment -- outputs -> decoder inputs ->
+    encoder cut(s) -> network input -- handing the boundary gradients on by hand, so that every
+    segment can be its own hipGraph with the gradient all-reduce issued eagerly in between.
+    `stages`: encoder stage indices (0 stem, 1..4 layer1..4) AFTER which the encoder is cut;
+    the encoder / decoder boundary is always a cut."""
+
+    DECODERS = 99          # `stage` of the encoder/decoder boundary group
+
+    def __init__(self, stages=(2, 1)):
+        self.stages = tuple(sorted(set(int(s) for s in stages), reverse=True))
+        if any(s < 0 or s > 3 for s in self.stages):
+            raise ValueError("CutPlan: encoder cuts go after stage 0..3")
+        self.records = []      # (original, cut copy, producing stage, group)
+
+    def begin(self):
+        self.records = []
+
+    def cut(self, t, stage, group):
+        c = t.detach().requires_grad_(True)
+        self.records.append((t, c, stage, group))
+        return c
 
 
 class FusedEncoder(nn.Module):
@@ -180,7 +208,9 @@ class FusedEncoder(nn.Module):
         ch = dict(zip(bb.stage_downsamplings, bb.stage_channels))
         self.skips_n_channels = tuple(ch[d] for d in self.skip_downsamplings)
 
-    def forward(self, inputs):
+    def forward(self, inputs, plan=None):
+        """plan: a CutPlan (segmented backward); skips / outputs are then returned as
+        (tensor, producing stage) pairs for the caller to cut at the decoder boundary"""
         rgb, depth = inputs.get('rgb'), inputs.get('depth')
         skips = {}
         bb = self.backbone_rgb if self.backbone_rgb is not None else self.backbone_depth
@@ -192,10 +222,32 @@ class FusedEncoder(nn.Module):
             if self.two:
                 rgb, depth = self.fusion_modules[i](rgb, depth)
             if ds in self.skip_downsamplings:
-                skips[str(ds)] = {k: v for k, v in (('rgb', rgb), ('depth', depth))
-                                  if v is not None}
-        outs = {k: v for k, v in (('rgb', rgb), ('depth', depth)) if v is not None}
+                skips[str(ds)] = {k: (v if plan is None else (v, i))
+                                  for k, v in (('rgb', rgb), ('depth', depth)) if v is not None}
+            if plan is not None and i in plan.stages:
+                # the next stage continues on leaves of its own; the originals are the roots of
+                # the backward segment that ends here
+                if rgb is not None:
+                    rgb = plan.cut(rgb, i, i)
+                if depth is not None:
+                    depth = plan.cut(depth, i, i)
+        last = len(bb.stage_downsamplings) - 1
+        outs = {k: (v if plan is None else (v, last))
+                for k, v in (('rgb', rgb), ('depth', depth)) if v is not None}
         return outs, skips
+
+    def stage_parameters(self, i):
+        """parameters of encoder stage i (both modalities + the fusion module behind it)"""
+        ps = []
+        for bb in (self.backbone_rgb, self.backbone_depth):
+            if bb is None:
+                continue
+            mods = [bb.conv1, bb.bn1] if i == 0 else [getattr(bb, f'layer{i}')]
+            for m in mods:
+                ps += list(m.parameters())
+        if self.two:
+            ps += list(self.fusion_modules[i].parameters())
+        return ps
 
 
 class PyramidPoolingModule(nn.Module):

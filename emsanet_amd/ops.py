@@ -561,6 +561,7 @@ class MultiConvRT:
         self._bias = None
         self._u = None
         self._h = {}                 # 16-bit packs: dtype -> (key, wp, bias)
+        self._hd = {}                # data-gradient packs: dtype -> (key, wpd, Winograd U or None)
         self.has_bias = any(m.bias is not None for m, _, _ in placements)
         # 3x3 stride-1 merged convs (the task heads) run on the Winograd kernel as well
         self.wino = Fn.wino_eligible(self.spec) and os.environ.get('EMSA_WINO', '1') != '0'
@@ -626,11 +627,21 @@ class MultiConvRT:
 
     def dgrad(self, dy, in_hw):
         Fn.prof_flops(self.real_flops(dy))
-        wpd = self.packed_dgrad(dy.dtype)
-        if self.wino and dy.dtype == torch.float32:
-            s = self.spec
-            ud = Fn.pack_wino_packed(wpd, s.cin, s.cout, Fn.wino_rows(s), flip=True)
-            return Fn.conv_dgrad(dy, None, s, in_hw, wino_u=ud)
+        # the data-gradient operands are rebuilt only when a parameter moved (they used to be
+        # re-packed at every call: a zero-fill and 2-4 small kernels per head and step)
+        key = self._key_now()
+        ent = self._hd.get(dy.dtype)
+        if ent is None or ent[0] != key:
+            wpd = self.packed_dgrad(dy.dtype)
+            ud = None
+            if self.wino and dy.dtype == torch.float32:
+                s = self.spec
+                ud = Fn.pack_wino_packed(wpd, s.cin, s.cout, Fn.wino_rows(s), flip=True)
+            ent = (key, wpd, ud)
+            self._hd[dy.dtype] = ent
+        _, wpd, ud = ent
+        if ud is not None:
+            return Fn.conv_dgrad(dy, None, self.spec, in_hw, wino_u=ud)
         return Fn.conv_dgrad(dy, wpd, self.spec, in_hw)
 
     def packed_dgrad(self, dtype=torch.float32):
@@ -785,7 +796,13 @@ def _se_params(se):
 
 
 class SEAddFunction(Function):
-    """out = rgb * SE_rgb(rgb) + depth * SE_depth(depth)   ('se-add-uni-rgb')"""
+    """out = rgb * SE_rgb(rgb) + depth * SE_depth(depth)   ('se-add-uni-rgb'), and the depth stream
+    handed on as a second output.  The depth stream has TWO consumers -- this fusion and the next
+    depth stage -- so autograd used to add their two gradients with a torch kernel per stage (the
+    largest one on the 629 MB stem output: 0.33 ms).  With the pass-through output this Function is
+    the depth tensor's only consumer: the next stage's gradient arrives as `ddepth_next` and is
+    added inside the SE backward kernel (`dx_extra` of emsa_se_scale_bwd_apply), one extra read
+    instead of a read-read-write pass."""
 
     @staticmethod
     def forward(ctx, rgb, depth, w1r, b1r, w2r, b2r, w1d, b1d, w2d, b2d):
@@ -800,22 +817,27 @@ class SEAddFunction(Function):
         ctx.save_for_backward(rgb, depth)
         ctx.saved = (gr, gd, hr, sr, hd, sd, flat(w1r), flat(w2r), flat(w1d), flat(w2d))
         ctx.shapes = (w1r.shape, w2r.shape)
-        return out
+        return out, depth[:]              # (an alias: same memory, this node as its grad_fn)
 
     @staticmethod
     @once_differentiable
     @_traced
-    def backward(ctx, dout):
+    def backward(ctx, dout, ddepth_next):
         rgb, depth = ctx.saved_tensors
         gr, gd, hr, sr, hd, sd, w1r, w2r, w1d, w2d = ctx.saved
         ctx.saved = None
         dout = Fn.as_act(dout, dense=True)
+        if ddepth_next is not None:
+            ddepth_next = Fn.as_act(ddepth_next, dense=True)
+            if ddepth_next.dtype != dout.dtype:
+                ddepth_next = Fn.cast(ddepth_next, dout.dtype)
         s1, s2 = ctx.shapes
         res = []
-        for x, g, h, s, w1, w2 in ((rgb, gr, hr, sr, w1r, w2r), (depth, gd, hd, sd, w1d, w2d)):
+        for x, g, h, s, w1, w2, extra in ((rgb, gr, hr, sr, w1r, w2r, None),
+                                          (depth, gd, hd, sd, w1d, w2d, ddepth_next)):
             ds = Fn.se_scale_bwd_reduce(dout, x)
             dgap, dw1, db1, dw2, db2 = Fn.se_mlp_bwd(g, w1, w2, h, s, ds)
-            dx = Fn.se_scale_bwd_apply(dout, s, dgap)
+            dx = Fn.se_scale_bwd_apply(dout, s, dgap, extra)
             res.append((dx, dw1.reshape(s1), db1, dw2.reshape(s2), db2))
         (dr, a1, a2, a3, a4), (dd, e1, e2, e3, e4) = res
         return dr, dd, a1, a2, a3, a4, e1, e2, e3, e4

@@ -49,27 +49,58 @@ class GradientBuckets:
     exists, so a later gradient would silently stay local.  The hook raises in that case."""
 
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True,
-                 force_collectives=False, comm_dtype=None):
+                 force_collectives=False, comm_dtype=None, order=None, tail_bytes=None,
+                 groups=None, manual=False):
+        """order: the parameters in the order their gradients ARRIVE in the backward pass (see
+        `record_arrival_order`); default: reverse registration order, which is only approximately
+        that.  tail_bytes: the LAST bucket (the first layers' gradients, which only exist when the
+        backward pass ends -- its all-reduce cannot hide behind anything) is kept at most this
+        large.  groups: lists of parameters that close a bucket at every group boundary (the
+        backward SEGMENTS of `SegmentedGraphedTrainStep`: a bucket never straddles two captured
+        graphs).  manual: no autograd hooks -- the caller gathers / reduces bucket by bucket
+        (`gather`, `reduce`) at its own segment boundaries."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collectives: run the gather + all-reduce path even with one rank (validation)
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.average = average
         self.comm_dtype = comm_dtype
+        self.manual = manual
         params = [p for p in params if p.requires_grad]
         self.params = params
-        # reverse registration order ~ order in which backward produces gradients
-        order = list(reversed(params))
+        if groups is None:
+            # reverse registration order ~ order in which backward produces gradients
+            groups = [list(order) if order is not None else list(reversed(params))]
+        else:
+            groups = [[p for p in g if p.requires_grad] for g in groups]
+        listed = [p for g in groups for p in g]
+        if len(listed) != len(params) or {id(p) for p in listed} != {id(p) for p in params}:
+            raise ValueError("GradientBuckets: `order` / `groups` must list every parameter once")
         self.buckets = []          # (flat, [params], [views])
-        cur, cur_bytes = [], 0
-        for p in order:
-            cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= bucket_bytes:
+        self.group_buckets = []    # bucket indices per group
+        for gi, g in enumerate(groups):
+            first = len(self.buckets)
+            size = lambda p: p.numel() * p.element_size()          # noqa: E731
+            tail = []
+            if tail_bytes is not None and gi == len(groups) - 1:
+                # peel the small tail off the END of the arrival order
+                acc = 0
+                while g and acc + size(g[-1]) <= tail_bytes:
+                    acc += size(g[-1])
+                    tail.insert(0, g[-1])
+                    g = g[:-1]
+            cur, cur_bytes = [], 0
+            for p in g:
+                cur.append(p)
+                cur_bytes += size(p)
+                if cur_bytes >= bucket_bytes:
+                    self._close(cur)
+                    cur, cur_bytes = [], 0
+            if cur:
                 self._close(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self._close(cur)
+            if tail:
+                self._close(tail)
+            self.group_buckets.append(list(range(first, len(self.buckets))))
         nb = len(self.buckets)
         self._arrived = [0] * nb
         self._launched = [False] * nb
@@ -86,7 +117,7 @@ class GradientBuckets:
             for p, v in zip(ps, views):
                 self._bucket_of[p] = bi
                 p._emsa_grad_slot = (v, self)
-                if self.active:
+                if self.active and not manual:
                     p.register_post_accumulate_grad_hook(self._hook)
         self.reset()
 
@@ -115,7 +146,18 @@ class GradientBuckets:
         self._handles = []
         self._epoch += 1
 
-    def _launch(self, bi):
+    def begin_step_host(self):
+        """host-side part of `reset()` for a step whose device work is replayed from a graph"""
+        for bi in range(len(self.buckets)):
+            self._arrived[bi] = 0
+            self._launched[bi] = False
+        self._handles = []
+        self._epoch += 1
+
+    def gather(self, bi):
+        """bucket `bi` becomes the complete gradient of its parameters: gradients that were not
+        written in place are copied in, parameters without a gradient contribute zeros; afterwards
+        `param.grad` are the bucket views.  Plain device work on the current stream (capturable)."""
         flat, ps, views = self.buckets[bi]
         have = [(v, p.grad) for v, p in zip(views, ps) if p.grad is not None]
         if len(have) != len(ps):
@@ -128,6 +170,13 @@ class GradientBuckets:
             torch._foreach_copy_([v for v, _ in stray], [g for _, g in stray])
         self.stats['gathered_tensors'] += len(stray)
         self.stats['direct_tensors'] += len(have) - len(stray)
+        for v, p in zip(views, ps):
+            p.grad = v                    # optimizer reads the (soon reduced) bucket view
+
+    def reduce(self, bi):
+        """asynchronous all-reduce (SUM) of bucket `bi` on the communication stream; `finish()`
+        waits.  Not capturable: issued eagerly, between graph replays in the segmented step."""
+        flat = self.buckets[bi][0]
         buf = flat
         if self.comm_dtype is not None and self.comm_dtype != flat.dtype:
             if self._comm[bi] is None:
@@ -138,9 +187,11 @@ class GradientBuckets:
                                                   async_op=True)))
         self.stats['collectives'] += 1
         self.stats['bytes'] += buf.numel() * buf.element_size()
-        for v, p in zip(views, ps):
-            p.grad = v                    # optimizer reads the (soon reduced) bucket view
         self._launched[bi] = True
+
+    def _launch(self, bi):
+        self.gather(bi)
+        self.reduce(bi)
 
     def _hook(self, p):
         # one asynchronous all-reduce per bucket, fired as soon as the bucket's last gradient
@@ -196,6 +247,25 @@ class GradientBuckets:
 
     def n_bytes(self):
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets)
+
+
+def record_arrival_order(params, run_backward):
+    """the order in which the gradients of `params` arrive during `run_backward()` (one ordinary
+    forward + backward of the training step): temporary post-accumulate hooks log it.  Feed the
+    result to `GradientBuckets(params, order=...)` so that bucket boundaries follow the measured
+    arrival order instead of the registration order."""
+    seen, handles = [], []
+    for p in params:
+        if p.requires_grad:
+            handles.append(p.register_post_accumulate_grad_hook(lambda q: seen.append(q)))
+    try:
+        run_backward()
+    finally:
+        for h in handles:
+            h.remove()
+    got = {id(p) for p in seen}
+    # parameters that received no gradient go last (they contribute zeros)
+    return seen + [p for p in params if p.requires_grad and id(p) not in got]
 
 
 def broadcast_parameters(module, src=0, process_group=None):

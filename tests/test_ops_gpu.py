@@ -478,6 +478,15 @@ def test_se_fusion(c):
     close(d.grad, dep.grad, what='se d_depth')
     for (k, p), g in zip(gm.named_parameters(), ref_grads):
         close(p.grad, g, tol=2e-4, what=f'se {k}')
+    # the depth stream continues on the Function's pass-through output: a gradient arriving there
+    # (the next depth stage's) is added inside the SE backward kernel, not by a torch add
+    r.grad = d.grad = None
+    o, d_next = gm(r, d)
+    assert d_next.data_ptr() == d.data_ptr()
+    dn = rnd(n, c, h, w, seed=9)
+    torch.autograd.backward([o, d_next], [to_act(dy), to_act(dn)])
+    close(r.grad, rgb.grad, what='se d_rgb (pass-through)')
+    close(d.grad, dep.grad + dn.double(), what='se d_depth + next stage')
 
 
 @pytest.mark.parametrize('c,cp', [(64, 64), (40, 40), (5, 8)])
@@ -819,3 +828,28 @@ def test_folded_input_bn_rejects_unsupported():
         Fn.conv_fwd(x, None, spec, wino_u=Fn.pack_wino(wt)[0], in_affine=aff)
     with pytest.raises(EmsaError):
         Fn.conv_wgrad(x, x, spec, False, like=wt, two_pass=True, in_affine=aff)
+
+
+@pytest.mark.parametrize('c', [8, 40, 64, 128])
+@pytest.mark.parametrize('shape', [(2, 3, 130), (1, 4, 62), (2, 2, 63), (1, 1, 1)])
+@pytest.mark.parametrize('with_skip', [False, True])
+def test_upsample_dw_forward_row_tiles(c, shape, with_skip):
+    """the row-tiled, output-centric forward of the learned x2 up-sampling (c <= 64; c = 128 stays
+    on the quad kernel): several column tiles per row, ragged last tile, image borders, against
+    nearest x2 + zero-padded depth-wise 3x3 in fp64"""
+    Fn = _fn()
+    n, h, w = shape
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, 1, 3, 3, seed=2)
+    b = rnd(c, seed=3)
+    skip = rnd(n, c, 2 * h, 2 * w, seed=4) if with_skip else None
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode='nearest'), wt.double(),
+                   b.double(), padding=1, groups=c)
+    if with_skip:
+        ref = ref + skip.double()
+    y = Fn.up2x_dw_fwd(to_act(x), wt.to(DEV), b.to(DEV), to_act(skip) if with_skip else None)
+    torch.cuda.synchronize()
+    close(y, ref, what='up2x rows')
+    y0 = Fn.up2x_dw_fwd(to_act(x), wt.to(DEV), None, None)
+    close(y0, ref - b.double()[None, :, None, None] - (skip.double() if with_skip else 0),
+          what='up2x rows, no bias')

@@ -59,7 +59,7 @@ def main():
             b = torch.randn(c, device=DEV)
             skip = Fn.act_empty(n, c, 2 * h, 2 * w, DEV).normal_()
             t = timeit(lambda: Fn.up2x_dw_fwd(x, wdw, b, skip))
-            row += f" | up2x fwd {9 * mb / t:5.2f}"
+            row += f" | up2x fwd {9 * mb / t:5.2f} ({t:.0f}us)"
             t = timeit(lambda: Fn.up2x_dw_bwd(skip, x, wdw))
             row += f" | up2x bwd(data+weight) {10 * mb / t:5.2f}"
         print(row, flush=True)
@@ -70,6 +70,12 @@ def main():
     mb = x.numel() * 4 / 1e6
     t = timeit(lambda: Fn.up2x_dw_fwd(x, wdw, b, None))
     print(f"c40 240x320->480x640 up2x fwd {5 * mb / t:5.2f} TB/s ({t:.0f} us)")
+    for cc, hh, ww in ((40, 120, 160), (8, 240, 320), (8, 120, 160)):
+        xq = Fn.act_empty(n, cc, hh, ww, DEV).normal_()
+        wq, bq_ = torch.randn(cc, 1, 3, 3, device=DEV), torch.randn(cc, device=DEV)
+        mq = xq.numel() * 4 / 1e6
+        t = timeit(lambda: Fn.up2x_dw_fwd(xq, wq, bq_, None))
+        print(f"c{cc} {hh}x{ww} -> x2 up2x fwd {5 * mq / t:5.2f} TB/s ({t:.0f} us)")
     xs = Fn.act_empty(n, 64, 240, 320, DEV).normal_()
     t = timeit(lambda: Fn.maxpool_fwd(xs))
     print(f"maxpool fwd {1.25 * xs.numel() * 4 / 1e6 / t:5.2f} TB/s")
