@@ -835,6 +835,10 @@ struct Wgrad1dArgs {
   float* ws_bias;
   uint32_t in_bytes, dout_bytes;
   FastDiv div_al, div_l;
+  // 16-bit direct kernel, MODE 2 (stride-2 3-tap conv): x element stride of ONE pixel along the
+  // line (in_sb is then twice that) and the line length of x (the odd pixels 2b+1 may run past it)
+  int in_sb1, in_Lx;
+  int taps;                          // accumulator tiles per workgroup: 3, or 1 (1x1 convs, MODE 1)
   // XBN (emsa_conv_wgrad_inbn): the x operand is a = relu(in * in_scale[c] + in_shift[c]) formed
   // in the loader -- the weight gradient of a conv whose forward ran with the BatchNorm + ReLU of
   // its input folded into ITS loader (emsa_conv1d_wino_inbn); `in` is the BatchNorm's input
@@ -1351,15 +1355,24 @@ __global__ __launch_bounds__(256, XBN ? EMSA_W1DW_XBN_WPE : EMSA_W1DW_WPE) void 
 constexpr int kWH_PK = 64;          // pixels per K step
 constexpr int kWH_ROW = 72;         // LDS row (elements): 64 pixels + halo dword + pad = 144 B = 36
                                     // banks -> conflict-free ds_read_b128 over 16 distinct rows
-template <typename T>
+// MODE 0: stride-1 3-tap convs (and the row taps of a 3x3).  MODE 1: ONE tap -- the 1x1 convs
+// (skip fusions, pyramid pooling, strided down-sampling shortcuts: the stride lives in the x pixel
+// strides, nothing else changes).  MODE 2: stride-2 3-tap convs (first convs of a down-sampling
+// NBt1D block): output pixel b reads x(2b-1), x(2b), x(2b+1) -> TWO x images, the even pixels
+// E(b) = x(2b) (centre tap) and the odd pixels O(b) = x(2b+1) (right tap; the left tap is O shifted
+// by one element, O(b-1)).  Round 2 ran modes 1 / 2 on the fp32-MFMA tap-group kernel with a
+// bf16 -> fp32 conversion at the LDS store (3.5 ms of the 51 ms bf16 step at 78-111 TFLOP/s).
+template <typename T, int MODE = 0>
 __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArgs p) {
   constexpr int BCO = 64, BCI = 64;
   constexpr uint32_t ES = sizeof(T);
+  constexpr int NT_ = MODE == 1 ? 1 : 3;             // accumulator tiles (taps)
   typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   T* const dS = reinterpret_cast<T*>(smem);          // [64 co][kWH_ROW]: pixel k0 + e at e < 64
   T* const xS = dS + BCO * kWH_ROW;                  // [64 ci][kWH_ROW]: same; elements 64 / 65 =
                                                      // pixels k0 + 64 / k0 - 1 (the halo dword)
+  T* const oS = xS + BCI * kWH_ROW;                  // MODE 2: the odd-pixel image (halo: k0 - 1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -1389,7 +1402,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
   const uint32_t dadd = dok ? (uint32_t)(co0 + 4 * q) * ES : 0u, dmask = dok ? 0u : kOOB;
   const uint32_t xadd = xok ? (uint32_t)(ci0 + 4 * q) * ES : 0u, xmask = xok ? 0u : kOOB;
 
-  // byte offsets (or kOOB) of pixel k of the padded enumeration in dy (od) and in x (ox)
+  // byte offsets (or kOOB) of pixel k of the padded enumeration in dy (od) and in x (ox); MODE 2:
+  // ox = the even pixel x(2b), oo = the odd pixel x(2b+1) (out of range behind the line's end)
+  uint32_t oo_last = kOOB;
   auto px_off = [&](int k, uint32_t& od, uint32_t& ox) {
     const bool valid = k >= 0 && k < p.M;
     const uint32_t ku = valid ? (uint32_t)k : 0u;
@@ -1404,9 +1419,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
     ox = (in_line && a2 >= 0 && a2 < p.A)
         ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa) +
            __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * ES : kOOB;
+    if constexpr (MODE == 2)
+      oo_last = (ox != kOOB && 2 * b_ + 1 < p.in_Lx) ? ox + (uint32_t)p.in_sb1 * ES : kOOB;
   };
 
-  u32x2w rd[4], rx[4], rhalo;
+  u32x2w rd[4], rx[4], ro[4], rhalo;
   float4 bsum = emsa_zero4();
   auto load_regs = [&](int s) {
     const int k0 = s * kWH_PK;
@@ -1414,6 +1431,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
     // their four pixels with wave shuffles
     uint32_t off_d, off_x;
     px_off(k0 + lane, off_d, off_x);
+    const uint32_t off_o = oo_last;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int src = (4 * pg + j) * 4;
@@ -1421,15 +1439,23 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
       const uint32_t ox = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_x);
       rd[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)((od + dadd) | dmask), 0, 0);
       rx[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((ox + xadd) | xmask), 0, 0);
+      if constexpr (MODE == 2) {
+        const uint32_t oo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_o);
+        ro[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((oo + xadd) | xmask), 0, 0);
+      }
     }
-    if (tid < 32) {
-      // halo: x of pixel k0 - 1 (threads 0..15) and k0 + 64 (16..31), four channels each
-      uint32_t hd, hx;
-      px_off(tid < 16 ? k0 - 1 : k0 + kWH_PK, hd, hx);
-      const int hq = tid & 15;
-      const bool hok = ci0 + 4 * hq < p.k_ch;
-      rhalo = __builtin_amdgcn_raw_buffer_load_b64(
-          rs_in, (int)(hok ? hx + (uint32_t)(ci0 + 4 * hq) * ES : kOOB), 0, 0);
+    if constexpr (MODE != 1) {
+      if (tid < 32) {
+        // halo: x of pixel k0 - 1 (threads 0..15) and k0 + 64 (16..31), four channels each
+        // (MODE 2: of the ODD image, only its left neighbour k0 - 1 is ever read)
+        uint32_t hd, hx;
+        px_off(tid < 16 ? k0 - 1 : k0 + kWH_PK, hd, hx);
+        if constexpr (MODE == 2) hx = oo_last;
+        const int hq = tid & 15;
+        const bool hok = ci0 + 4 * hq < p.k_ch;
+        rhalo = __builtin_amdgcn_raw_buffer_load_b64(
+            rs_in, (int)(hok && hx != kOOB ? hx + (uint32_t)(ci0 + 4 * hq) * ES : kOOB), 0, 0);
+      }
     }
   };
   // 4 pixels x 4 channels (one u32x2 = 4 channels per pixel) -> per channel 4 pixels = 8 bytes
@@ -1457,10 +1483,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
     }
     tr_store(dS, rd);
     tr_store(xS, rx);
-    if (tid < 32) {
+    if constexpr (MODE == 2) tr_store(oS, ro);
+    if (MODE != 1 && tid < 32) {
       // halo dword of a row: element 64 (low half) = pixel k0 + 64, element 65 (high) = pixel k0 - 1
-      unsigned short* xh = reinterpret_cast<unsigned short*>(xS) + (4 * (tid & 15)) * kWH_ROW +
-                           (tid < 16 ? kWH_PK + 1 : kWH_PK);
+      unsigned short* xh = reinterpret_cast<unsigned short*>(MODE == 2 ? oS : xS) +
+                           (4 * (tid & 15)) * kWH_ROW + (tid < 16 ? kWH_PK + 1 : kWH_PK);
       xh[0] = (unsigned short)(rhalo.x & 0xFFFFu);
       xh[kWH_ROW] = (unsigned short)(rhalo.x >> 16);
       xh[2 * kWH_ROW] = (unsigned short)(rhalo.y & 0xFFFFu);
@@ -1482,47 +1509,65 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
 
   typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type E;
   typedef E ev8 __attribute__((ext_vector_type(8)));
+  auto mma = [&](f32x16& c_, const ev8& av, const u32x4h& bv) {
+    if constexpr (std::is_same<T, emsa_f16>::value)
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, bv), c_, 0, 0, 0);
+    else
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, bv), c_, 0, 0, 0);
+  };
   for (int s = s_begin; s < s_end; ++s) {
     const bool has_next = s + 1 < s_end;
     if (has_next) load_regs(s + 1);
     const T* drow = dS + (wco * 32 + l31) * kWH_ROW + 8 * lh;
     const T* xrow0 = xS + (wci * 32 + l31) * kWH_ROW;
     const T* xrow = xrow0 + 8 * lh;
-    const unsigned halo = *reinterpret_cast<const unsigned*>(xrow0 + kWH_PK);
+    // the image whose +-1 shifts are read: x itself (MODE 0) or the odd pixels (MODE 2)
+    const T* srow0 = (MODE == 2 ? oS : xS) + (wci * 32 + l31) * kWH_ROW;
+    const T* srow = srow0 + 8 * lh;
+    unsigned halo = 0;
+    if constexpr (MODE != 1) halo = *reinterpret_cast<const unsigned*>(srow0 + kWH_PK);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k16 = 0; k16 < kWH_PK / 16; ++k16) {
       const u32x4h a = *reinterpret_cast<const u32x4h*>(drow + 16 * k16);
       const u32x4h c = *reinterpret_cast<const u32x4h*>(xrow + 16 * k16);
+      const ev8 av = __builtin_bit_cast(ev8, a);
+      if constexpr (MODE == 1) {
+        mma(acc[0], av, c);
+        continue;
+      }
       // the dwords in front of / behind the eight pixels; at the tile's ends the halo dword
       // (alignbit uses the high half on the left, the low half on the right)
-      unsigned wl, wr;
+      u32x4h sh_ = c;                                        // the shifted image's own eight pixels
+      if constexpr (MODE == 2) sh_ = *reinterpret_cast<const u32x4h*>(srow + 16 * k16);
+      unsigned wl, wr = 0;
       if (k16 == 0) {
-        const unsigned w_in = *reinterpret_cast<const unsigned*>(xrow0 + 6);     // lh = 1: elements 6, 7
+        const unsigned w_in = *reinterpret_cast<const unsigned*>(srow0 + 6);     // lh = 1: elements 6, 7
         wl = lh ? w_in : halo;
       } else {
-        wl = *reinterpret_cast<const unsigned*>(xrow + 16 * k16 - 2);
+        wl = *reinterpret_cast<const unsigned*>(srow + 16 * k16 - 2);
       }
-      if (k16 == kWH_PK / 16 - 1) {
-        const unsigned w_in = *reinterpret_cast<const unsigned*>(xrow0 + kWH_PK - 8);   // lh = 0: 56, 57
-        wr = lh ? halo : w_in;
+      u32x4h lft;
+      lft.x = __builtin_amdgcn_alignbit(sh_.x, wl, 16);    lft.y = __builtin_amdgcn_alignbit(sh_.y, sh_.x, 16);
+      lft.z = __builtin_amdgcn_alignbit(sh_.z, sh_.y, 16); lft.w = __builtin_amdgcn_alignbit(sh_.w, sh_.z, 16);
+      if constexpr (MODE == 2) {
+        // taps: x(2b-1) = O(b-1) = O shifted, x(2b) = E, x(2b+1) = O
+        mma(acc[0], av, lft);
+        mma(acc[1], av, c);
+        mma(acc[2], av, sh_);
       } else {
-        wr = *reinterpret_cast<const unsigned*>(xrow + 16 * k16 + 8);
-      }
-      u32x4h lft, rgt;
-      lft.x = __builtin_amdgcn_alignbit(c.x, wl, 16);  lft.y = __builtin_amdgcn_alignbit(c.y, c.x, 16);
-      lft.z = __builtin_amdgcn_alignbit(c.z, c.y, 16); lft.w = __builtin_amdgcn_alignbit(c.w, c.z, 16);
-      rgt.x = __builtin_amdgcn_alignbit(c.y, c.x, 16); rgt.y = __builtin_amdgcn_alignbit(c.z, c.y, 16);
-      rgt.z = __builtin_amdgcn_alignbit(c.w, c.z, 16); rgt.w = __builtin_amdgcn_alignbit(wr, c.w, 16);
-      const ev8 av = __builtin_bit_cast(ev8, a);
-      if constexpr (std::is_same<T, emsa_f16>::value) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, lft), acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, c), acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(ev8, rgt), acc[2], 0, 0, 0);
-      } else {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, lft), acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, c), acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(ev8, rgt), acc[2], 0, 0, 0);
+        if (k16 == kWH_PK / 16 - 1) {
+          const unsigned w_in = *reinterpret_cast<const unsigned*>(xrow0 + kWH_PK - 8);   // lh = 0: 56, 57
+          wr = lh ? halo : w_in;
+        } else {
+          wr = *reinterpret_cast<const unsigned*>(xrow + 16 * k16 + 8);
+        }
+        u32x4h rgt;
+        rgt.x = __builtin_amdgcn_alignbit(c.y, c.x, 16); rgt.y = __builtin_amdgcn_alignbit(c.z, c.y, 16);
+        rgt.z = __builtin_amdgcn_alignbit(c.w, c.z, 16); rgt.w = __builtin_amdgcn_alignbit(wr, c.w, 16);
+        mma(acc[0], av, lft);
+        mma(acc[1], av, c);
+        mma(acc[2], av, rgt);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1532,10 +1577,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
   }
 
   if (p.ws != nullptr) {
-    // deterministic split-K: this workgroup's partial tile [3][BCO][BCI] goes to the workspace
-    float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (3 * BCO * BCI);
+    // deterministic split-K: this workgroup's partial tile [taps][BCO][BCI] goes to the workspace
+    float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (NT_ * BCO * BCI);
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT_; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1544,13 +1589,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
   } else {
     const int ci = ci0 + wci * 32 + l31;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT_; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int co = co0 + wco * 32 + row;
         if (co < p.n_ch && ci < p.k_ch)
-          unsafeAtomicAdd(p.dw + ((size_t)(kr * 3 + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
+          unsafeAtomicAdd(p.dw + ((size_t)(kr * NT_ + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
       }
   }
   if (do_bias) {
@@ -1580,18 +1625,20 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
 __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
     const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
     int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
-    float* __restrict__ dbias) {
+    float* __restrict__ dbias, int taps) {
+  // taps: 3 (1-D / 3x3 row taps) or 1 (1x1 convs of the 16-bit direct kernel)
   __shared__ float4 red[16][16];
   const int tid = threadIdx.x;
-  const int weight_blocks = n_tiles * R * 192;
+  const int rows = taps * 64, tile_f = taps * 4096;
+  const int weight_blocks = n_tiles * R * rows;
   if ((int)blockIdx.x < weight_blocks) {
     // workgroup = (kernel row kr, tile, row = t*64 + co_l); ws[split][kr][tile][t][co_l][ci_l]
-    const int kt = blockIdx.x / 192, row = blockIdx.x % 192;
+    const int kt = blockIdx.x / rows, row = blockIdx.x % rows;
     const int kr = kt / n_tiles, tile = kt % n_tiles;
     const int col = tid & 15, sg = tid >> 4;
-    const float* src = ws + (size_t)kt * 12288 + row * 64 + col * 4;
+    const float* src = ws + (size_t)kt * tile_f + row * 64 + col * 4;
     float4 a = emsa_zero4();
-    const size_t sstride = (size_t)R * n_tiles * 12288;
+    const size_t sstride = (size_t)R * n_tiles * tile_f;
     // eight independent loads in flight per thread: with one (a plain loop) the few hundred
     // workgroups of a 64-channel layer (768 partial tiles of 48 KB) are latency bound, 47 us
     for (int sp = sg; sp < splits; sp += 128) {
@@ -1616,8 +1663,8 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
       const int ci = (tile % n_ci_tiles) * 64 + col * 4;
       if (co < n_ch) {
         // OIHW: [co][ci][kr][t] (R = 1: the 3 taps of a 1-D conv; R = 3: a 3x3 kernel)
-        float* o = dw + (((size_t)co * k_ch + ci) * R + kr) * 3 + t;
-        const int cs = 3 * R;
+        float* o = dw + (((size_t)co * k_ch + ci) * R + kr) * taps + t;
+        const int cs = taps * R;
         if (ci + 0 < k_ch) o[0] = a.x;
         if (ci + 1 < k_ch) o[cs] = a.y;
         if (ci + 2 < k_ch) o[2 * cs] = a.z;
@@ -1809,18 +1856,32 @@ struct Wgrad1dPlan {
   Wgrad1dArgs w;
   int ksplit;
   bool wino;
+  int mode;        // 16-bit direct kernel: 0 = stride-1 3 taps, 1 = one tap (1x1), 2 = stride-2 3 taps
 };
 bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, size_t esize = sizeof(float),
                   bool direct16 = false) {
   // a 3x3 conv = three row taps, each a 3-tap 1-D weight gradient along W on x shifted by a line
   const bool sq = g->kh == 3 && g->kw == 3 && g->off_w == -1 && g->off_h == -1;
-  const bool along_w = (g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0) || sq;
+  bool along_w = (g->kh == 1 && g->kw == 3 && g->off_w == -1 && g->off_h == 0) || sq;
   const bool along_h = g->kh == 3 && g->kw == 1 && g->off_h == -1 && g->off_w == 0;
-  if (!((along_w || along_h) && g->mul_h == 1 && g->mul_w == 1 && g->step_h == 1 &&
-        g->step_w == 1 && g->div_h == 1 && g->div_w == 1 && g->in_h == g->out_h &&
-        g->in_w == g->out_w && dout_aligned) ||
-      getenv("EMSA_WGRAD_GENERIC"))
-    return false;
+  const bool plain = g->step_h == 1 && g->step_w == 1 && g->div_h == 1 && g->div_w == 1 &&
+                     dout_aligned && !getenv("EMSA_WGRAD_GENERIC");
+  const bool same = g->mul_h == 1 && g->mul_w == 1 && g->in_h == g->out_h && g->in_w == g->out_w;
+  // 16-bit direct kernel only: 1x1 convs of stride 1 / 2 (MODE 1) and the stride-2 3-tap convs
+  // of a down-sampling block, strided along their own direction only (MODE 2)
+  static const bool modes_on = [] {
+    const char* e = getenv("EMSA_WGRAD16_MODES");
+    return !(e && e[0] == '0');
+  }();
+  const bool one = direct16 && modes_on && plain && g->kh == 1 && g->kw == 1 && g->off_h == 0 &&
+                   g->off_w == 0 && g->mul_h >= 1 && g->mul_h <= 2 && g->mul_w >= 1 && g->mul_w <= 2 &&
+                   (g->out_h - 1) * g->mul_h < g->in_h && (g->out_w - 1) * g->mul_w < g->in_w;
+  const bool s2 = direct16 && modes_on && plain && !sq &&
+                  ((along_w && g->mul_w == 2 && g->mul_h == 1 && g->in_h == g->out_h) ||
+                   (along_h && g->mul_h == 2 && g->mul_w == 1 && g->in_w == g->out_w));
+  pl.mode = one ? 1 : (s2 ? 2 : 0);
+  if (one) along_w = true;
+  if (!(one || s2 || ((along_w || along_h) && plain && same))) return false;
   Wgrad1dArgs& w = pl.w;
   w.n_ch = g->n_ch; w.k_ch = g->k_ch;
   const int H = g->out_h, W = g->out_w;
@@ -1831,12 +1892,15 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, siz
   w.in_simg = (int)g->in_img_stride;
   w.dy_simg = H * W * g->ld_out;
   if (along_w) {
-    w.in_sa = (int)g->in_row_stride; w.in_sb = g->in_px_stride;
+    w.in_sa = (int)g->in_row_stride * g->mul_h; w.in_sb = g->in_px_stride * g->mul_w;
     w.dy_sa = W * g->ld_out; w.dy_sb = g->ld_out;
+    w.in_sb1 = g->in_px_stride; w.in_Lx = g->in_w;
   } else {
-    w.in_sa = g->in_px_stride; w.in_sb = (int)g->in_row_stride;
+    w.in_sa = g->in_px_stride * g->mul_w; w.in_sb = (int)g->in_row_stride * g->mul_h;
     w.dy_sa = g->ld_out; w.dy_sb = W * g->ld_out;
+    w.in_sb1 = (int)g->in_row_stride; w.in_Lx = g->in_h;
   }
+  w.taps = pl.mode == 1 ? 1 : 3;
   // the loader multiplies (image, line, position) by the strides with 24-bit multiplies
   if (w.in_simg >= (1 << 24) || w.dy_simg >= (1 << 24) || w.in_sa >= (1 << 24) ||
       w.dy_sa >= (1 << 24) || g->n_img >= (1 << 24))
@@ -1904,7 +1968,7 @@ int64_t wgrad_ws_bytes(const EmsaConvGeom* g, size_t esize) {
   const bool d16 = half && direct16_geom(g);
   if (!plan_wgrad1d(g, dout_is_aligned(g, nullptr), pl, esize, d16)) return 0;
   if (half && !d16 && !pl.wino) return 0;
-  return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * pl.w.R * 12288 +
+  return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * pl.w.R * pl.w.taps * 4096 +
                                (int64_t)pl.w.n_co_tiles * 64) * (int64_t)sizeof(float);
 }
 }  // namespace
@@ -1952,7 +2016,7 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     w.ws = ws;
     w.in_scale = in_scale; w.in_shift = in_shift;
     if (in_scale && (kHalf || !pl.wino || w.R != 1)) return EMSA_E_SHAPE;
-    w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * 12288 : nullptr;
+    w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * w.taps * 4096 : nullptr;
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
     // algorithmic bytes: x and dy read once, the fp32 gradient written once
@@ -1966,8 +2030,16 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     }();
     if constexpr (kHalf) {
       if (direct16) {
-        hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T>), dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
-                           (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);
+        const dim3 grid(w.n_tiles * w.R * pl.ksplit);
+        if (pl.mode == 1)
+          hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 1>), grid, dim3(256),
+                             (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);
+        else if (pl.mode == 2)
+          hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 2>), grid, dim3(256),
+                             (size_t)3 * 64 * kWH_ROW * sizeof(T), st, w);
+        else
+          hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 0>), grid, dim3(256),
+                             (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);
       } else
       // EMSA_WGRAD16=wino: E / D are formed in fp32 and rounded to bf16 as they enter LDS, one
       // v_mfma_f32_32x32x16_bf16 per Winograd component and K step
@@ -1990,9 +2062,9 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
       hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), lds, st, w);
     if (ws != nullptr)
-      hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * w.R * 192 + w.n_co_tiles),
+      hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * w.R * w.taps * 64 + w.n_co_tiles),
                          dim3(256), 0, st, ws, w.ws_bias, pl.ksplit, w.n_tiles, w.n_ci_tiles,
-                         w.n_co_tiles, w.n_ch, w.k_ch, w.R, dw, dbias);
+                         w.n_co_tiles, w.n_ch, w.k_ch, w.R, dw, dbias, w.taps);
     prof_end(ps, st);
     return emsa_launch_status();
   }

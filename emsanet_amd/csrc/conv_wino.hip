@@ -84,7 +84,6 @@ struct WinoArgs {
   int in_simg, in_sa, in_sb;        // input element strides (image, line, position on the line)
   int px_simg, px_sa, px_sb;        // output PIXEL strides (x ld_out / ld_res / ld_mask)
   int tiles_m, tiles_n, ksteps;
-  int pin_share;                    // > 0: output-channel tiles pinned to XCDs (see the kernel)
   uint32_t in_bytes, u_bytes;
   uint32_t mul_pl, sh_pl, mul_a, sh_a;     // magic division by PL and by A
 };
@@ -127,28 +126,14 @@ __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_win
   // wave = component j; uniform -> kept in an SGPR (so are the row choice and sign below)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  // Tile order.  Default: every XCD (own 4 MiB L2; workgroup b runs on XCD b % 8) gets a contiguous
-  // range of pixel tiles with ALL their channel tiles -- input rows are fetched into one L2 once.
-  // When the transformed weights do not fit an L2 (3x3 512->512: U = 12.6 MB streamed again for
-  // every pixel tile, 545 MB fetched per launch for 32 MB of algorithmic bytes, PMC) the roles
-  // swap: each XCD owns 8 / pin_share channel tiles for ALL pixel tiles, its slice of U stays
-  // resident and the (smaller) input is what the eight L2s fetch in parallel.
-  int nt, mt;
-  if (p.pin_share > 0) {
-    const int xcd = blockIdx.x % EMSA_NXCD, idx = blockIdx.x / EMSA_NXCD;
-    if (p.pin_share == 1) {                        // tiles_n = 8 * per
-      const int per = p.tiles_n / EMSA_NXCD;
-      nt = xcd * per + idx % per;
-      mt = idx / per;
-    } else {                                       // pin_share XCDs share one channel tile
-      nt = xcd / p.pin_share;
-      mt = idx * p.pin_share + xcd % p.pin_share;
-    }
-  } else {
-    const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
-    nt = wg % p.tiles_n;
-    mt = wg / p.tiles_n;
-  }
+  // Tile order: every XCD (own 4 MiB L2; workgroup b runs on XCD b % 8) gets a contiguous range of
+  // pixel tiles with ALL their channel tiles -- input rows are fetched into one L2 once.  (Round 3
+  // measured the opposite assignment for the convs whose transformed weights exceed an L2 -- 3x3
+  // 512->512, U = 12.6 MB: each XCD owning one channel tile for all pixel tiles -- at 293 vs 286 us
+  // forward and 270 vs 270 us data gradient: the 545 MB of U re-fetches come from the Infinity
+  // Cache, not from HBM, and are not what bounds the launch.  Not kept.)
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
   const int q0 = mt * kPairs, n0 = nt * kWN;
   const __amdgpu_buffer_rsrc_t rs_in = wrsrc(p.in, p.in_bytes);
   const __amdgpu_buffer_rsrc_t rs_u = wrsrc(p.u, p.u_bytes);
@@ -866,19 +851,6 @@ static int conv1d_wino_impl(const EmsaConvGeom* g, const float* in, const float*
   }
   a.ksteps_c = (g->k_ch + kWK - 1) / kWK;
   a.ksteps = a.R * a.ksteps_c;
-  // channel tiles pinned to XCDs when U exceeds one XCD's L2 and the tile counts divide evenly
-  // (EMSA_WINO_PIN=0 disables: A/B measurements)
-  static const bool pin_off = [] {
-    const char* e = getenv("EMSA_WINO_PIN");
-    return e && e[0] == '0';
-  }();
-  a.pin_share = 0;
-  if (!pin_off && (size_t)4 * g->n_ch * a.R * g->k_ch * sizeof(float) > ((size_t)5 << 20)) {
-    if (a.tiles_n % EMSA_NXCD == 0)
-      a.pin_share = 1;
-    else if (EMSA_NXCD % a.tiles_n == 0 && a.tiles_m % (EMSA_NXCD / a.tiles_n) == 0)
-      a.pin_share = EMSA_NXCD / a.tiles_n;
-  }
   a.in_bytes = (uint32_t)((size_t)g->n_img * g->in_img_stride * sizeof(float));
   a.u_bytes = (uint32_t)((size_t)4 * g->n_ch * a.k_ch * sizeof(float));
   magic((uint32_t)a.PL, a.mul_pl, a.sh_pl);

@@ -976,7 +976,9 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 // 9 taps collapse onto 2x2 / 2x3 / 3x2 / ... neighbourhood entries.
 // T = storage type of x / skip, TO = storage type of y (the last up-sampling of a head writes the
 // model's fp32 output straight from 16-bit features)
-template <typename T, typename TO>
+// NT: the output goes out with non-temporal stores (a pure write stream of up to 1.57 GB that no
+// later kernel finds in a cache anyway)
+template <typename T, typename TO, bool NT = false>
 __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const T* __restrict__ skip,
                                    TO* __restrict__ y, int n, int h, int w, int c4n) {
@@ -1030,86 +1032,23 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
           const float4 sk = emsa_ld4(skip + o);
           acc.x += sk.x; acc.y += sk.y; acc.z += sk.z; acc.w += sk.w;
         }
-        emsa_st4(y + o, acc);
-      }
-  }
-}
-
-// Row-tiled form of the same operator for the WIDE maps (c <= 64: the 40-channel semantic logits --
-// 1.57 GB per bs=32 step -- the 8-channel instance maps, the 64-channel /4 features): the kernel
-// above lets a wave store 160-byte chunks with 160-byte holes between them (lane = input pixel x
-// channel quad, each lane writes its 2x2 output quad), and the write-dominated launches sat at
-// 2.0-2.7 TB/s.  Here a workgroup stages three input rows of a column segment in LDS (coalesced
-// loads) and produces the two output rows OUTPUT-centrically: consecutive lanes write consecutive
-// 16 bytes of the output row, every store instruction covers whole 128-byte lines.  Per output the
-// 3x3 taps on the nearest-upsampled image collapse onto the 2x2 input pixels they read,
-//   out(2ih+a, 2iw+b) = bias + sum_{r,s in {0,1}} wc[a][b][r][s] * x(ih+a-1+r, iw+b-1+s),
-// with the 16 collapsed weight vectors in LDS ([U] nothing: same function, taps pre-summed).
-constexpr int kUpWT = 62;                 // input columns per workgroup (+2 halo = 64 staged)
-template <typename T, typename TO>
-__global__ __launch_bounds__(256) void up2x_dw_fwd_rows_kernel(
-    const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bias,
-    const T* __restrict__ skip, TO* __restrict__ y, int h, int w, int c4n, int tiles_w) {
-  extern __shared__ __attribute__((aligned(16))) float ul[];
-  const int C = c4n * 4;
-  float* const wc = ul;                            // [a][b][r][s][C]
-  float* const xs = ul + 16 * C;                   // [3 rows][kUpWT + 2][C]
-  const int tw = blockIdx.x % tiles_w;
-  const int ih = (blockIdx.x / tiles_w) % h;
-  const int img = blockIdx.x / (tiles_w * h);
-  const int iw0 = tw * kUpWT;
-  const int wt = min(kUpWT, w - iw0);              // input columns of this tile
-  for (int j = threadIdx.x; j < 16 * C; j += 256) {
-    const int ch = j % C, q = j / C, s_ = q & 1, r_ = (q >> 1) & 1, b = (q >> 2) & 1, a = q >> 3;
-    // taps kh with floor((a + kh - 1) / 2) == a - 1 + r_  (same for kw, b, s_)
-    float acc = 0.f;
-    for (int kh = 0; kh < 3; ++kh) {
-      if (((a + kh + 1) >> 1) - 1 != a - 1 + r_) continue;
-      for (int kw = 0; kw < 3; ++kw) {
-        if (((b + kw + 1) >> 1) - 1 != b - 1 + s_) continue;
-        acc += wdw[ch * 9 + kh * 3 + kw];
-      }
-    }
-    wc[j] = acc;
-  }
-  // three input rows, columns iw0 - 1 .. iw0 + wt (zeros outside the image)
-  const int row_f4 = (wt + 2) * c4n;
-  for (int j = threadIdx.x; j < 3 * row_f4; j += 256) {
-    const int rr = j / row_f4, e = j - rr * row_f4;
-    const int col = e / c4n, c4 = e - col * c4n;
-    const int hh = ih - 1 + rr, ww = iw0 - 1 + col;
-    float4 v = emsa_zero4();
-    if (hh >= 0 && hh < h && ww >= 0 && ww < w)
-      v = emsa_ld4(x + ((((size_t)img * h + hh) * w + ww) * c4n + c4) * 4);
-    emsa_st4(xs + ((rr * (kUpWT + 2) + col) * c4n + c4) * 4, v);
-  }
-  __syncthreads();
-  const int out_f4 = 2 * wt * c4n;                 // float4 per output row segment
-  const int ow_n = 2 * w;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const size_t obase = ((((size_t)img * 2 * h + 2 * ih + a) * ow_n + 2 * iw0) * c4n) * 4;
-    for (int e = threadIdx.x; e < out_f4; e += 256) {
-      const int ow = e / c4n, c4 = e - ow * c4n;
-      const int b = ow & 1, col = (ow >> 1) + b;   // staged column of tap s = 0 (halo offset +1 - 1 + b)
-      float4 acc = bias ? emsa_ld4(bias + c4 * 4) : emsa_zero4();
-#pragma unroll
-      for (int r_ = 0; r_ < 2; ++r_)
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) {
-          const float4 v = emsa_ld4(xs + (((a + r_) * (kUpWT + 2) + col + s_) * c4n + c4) * 4);
-          const float4 kk = emsa_ld4(wc + ((((a * 2 + b) * 2 + r_) * 2 + s_) * C) + c4 * 4);
-          acc.x += v.x * kk.x; acc.y += v.y * kk.y; acc.z += v.z * kk.z; acc.w += v.w * kk.w;
+        if constexpr (NT && std::is_same<TO, float>::value) {
+          const f32x4 v = {acc.x, acc.y, acc.z, acc.w};
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(y + o));
+        } else {
+          emsa_st4(y + o, acc);
         }
-      if (skip) {
-        const float4 sk = emsa_ld4(skip + obase + (size_t)e * 4);
-        acc.x += sk.x; acc.y += sk.y; acc.z += sk.z; acc.w += sk.w;
       }
-      emsa_st4(y + obase + (size_t)e * 4, acc);
-    }
   }
 }
 
+// (Round 3: a ROW-TILED output-centric form -- three input rows of a 62-column segment staged in
+//  LDS, 2x2-collapsed taps from LDS, consecutive lanes writing consecutive 16 bytes of the output
+//  row -- was built for the wide maps (c <= 64) and measured SLOWER than the quad kernel above on
+//  every shape: 40 channels 240x320 -> 480x640 909 vs 704 us, 64 channels + skip 519 vs 277 us,
+//  8 channels 164 vs 126 us (tools/pointwise_bench.py, profiles/r03_d_pointwise_bench.txt): eight
+//  ds_read_b128 per 16 output bytes and 46,000 three-barrier workgroups cost more than the
+//  half-covered store sectors do.  Removed.)
 // (An output-centric form -- one thread per OUTPUT pixel, consecutive lanes writing consecutive
 //  bytes, per-parity collapsed 2x2 taps -- was built to get rid of the half-covered sectors this
 //  kernel's stores leave behind at 40 channels; measured it is 0.2-0.4 % SLOWER per training step
@@ -2216,25 +2155,23 @@ template <typename T, typename TO>
 static int up2x_dw3x3_fwd_impl(const T* x, const float* wdw, const float* bias, const T* skip, TO* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   if (!x || !wdw || !y) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
-  // wide maps: the row-tiled form with whole-line stores (EMSA_UP2X_ROWS=0: the quad form, A/B)
-  static const bool rows_off = [] {
-    const char* e = getenv("EMSA_UP2X_ROWS");
-    return e && e[0] == '0';
-  }();
-  if (c <= 64 && !rows_off) {
-    const int tiles_w = (w + kUpWT - 1) / kUpWT;
-    const long blocks = (long)n * h * tiles_w;
-    if (blocks < (1L << 31)) {
-      const size_t lds = (size_t)(16 * c + 3 * (kUpWT + 2) * c) * sizeof(float);
-      hipLaunchKernelGGL((up2x_dw_fwd_rows_kernel<T, TO>), dim3((unsigned)blocks), dim3(256), lds,
-                         (hipStream_t)stream, x, wdw, bias, skip, y, h, w, c / 4, tiles_w);
-      return emsa_launch_status();
-    }
-  }
   const long total = (long)n * 4 * h * w * (c / 4);
-  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
-                     (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
-                     h, w, c / 4);
+  // non-temporal output stores for the wide fp32 maps: measured +4..10 % at 40 / 64 / 128 / 256
+  // channels (c40 full resolution 659 -> 633 us), -20..-40 % at 8 channels (32-byte pixels)
+  // (profiles/r03_d_pointwise_bench.txt); EMSA_UP2X_NT=0 / 1 forces it off / on
+  static const int nt_env = [] {
+    const char* e = getenv("EMSA_UP2X_NT");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+  }();
+  const bool nt = nt_env >= 0 ? nt_env == 1 : c >= 32;
+  if (nt && std::is_same<TO, float>::value)
+    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO, true>), dim3(grid_for(total)), dim3(kThreads),
+                       (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
+                       h, w, c / 4);
+  else
+    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
+                       (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
+                       h, w, c / 4);
   return emsa_launch_status();
 }
 extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias, const float* skip, float* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {

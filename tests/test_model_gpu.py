@@ -786,3 +786,126 @@ def test_hipgraph_train_replay_then_eval_sees_new_weights():
             # pack would reproduce the previous step's outputs)
             d_cur, d_prev = dist(e2, e3), dist(e2, evals3[step - 1])
             assert d_prev > 0.0 and d_cur <= 0.25 * d_prev, (step, d_cur, d_prev)
+
+
+def _train_losses(a, bs, h, w):
+    """TrainingLosses (HIP kernels, all supervised scales) + synthetic targets, as bench.py --losses"""
+    from emsanet_amd.loss import TrainingLosses
+    a.tasks_weighting = (1.0, 0.25, 3.0, 0.5)
+    g = torch.Generator(device='cpu').manual_seed(99)
+    crit = TrainingLosses(a, torch.rand(40, generator=g) * 2 + 0.3, 10).to(DEV)
+    sem, inst = [], []
+    for hh, ww in [(h, w)] + [(h // s, w // s) for s in (32, 16, 8)]:
+        sem.append(torch.randint(0, 41, (bs, hh, ww), generator=g).to(DEV))
+        fg = torch.rand(bs, hh, ww, generator=g) > 0.5
+        inst.append({'center': (torch.rand(bs, 1, hh, ww, generator=g) ** 4).to(DEV),
+                     'offset': (torch.rand(bs, 2, hh, ww, generator=g) * 2 - 1).to(DEV),
+                     'foreground': fg.to(DEV),
+                     'orientation': ((torch.rand(bs, hh, ww, generator=g) * 2 - 1) * 3.1415).to(DEV),
+                     'orientation_foreground': (fg & (torch.rand(bs, hh, ww, generator=g) > 0.5)).to(DEV)})
+    targets = {'semantic': sem, 'instance': inst,
+               'scene': torch.randint(0, 11, (bs,), generator=g).to(DEV)}
+    return crit, targets
+
+
+@pytest.mark.parametrize('variant', ['bf16', 'losses', 'r101_960x736'])
+def test_hipgraph_train_step_variants(variant):
+    """the captured training step == the eager step beyond the fp32 96x128 case:
+    bf16 storage, the complete step with all task losses on the device, ResNet-101 at 960x736
+    (configs[3] shape).  Learning rate 0 and fresh Dropout2d masks per step: the losses of three
+    replays on changing batches equal the eager twin's bit for bit (every forward reduction and the
+    loss kernels are atomics-free), with eager work -- the twin's steps, host reads -- running
+    between the replays."""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.graph import GraphedTrainStep
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.optim import FusedSGD
+    from emsanet_amd.parallel import GradientBuckets
+    from oracle.emsanet_oracle import synthetic_batch
+    h, w, bs = (736, 960, 1) if variant.startswith('r101') else (96, 128, 4)
+    kw = dict(input_height=h, input_width=w)
+    if variant.startswith('r101'):
+        kw.update(rgb_encoder_backbone='resnet101', depth_encoder_backbone='resnet101')
+    if variant == 'bf16':
+        kw.update(compute_dtype='bfloat16')
+    args = full_args(**kw)
+    crit = targets = None
+    if variant == 'losses':
+        crit, targets = _train_losses(args, bs, h, w)
+
+    def loss_of(out):
+        if crit is not None:
+            return crit(out, targets)[0]
+        return sum((t * t).mean() for t in _flatten(out))
+
+    def build():
+        torch.manual_seed(0)
+        m = EMSANet(args, nyuv2_config()).to(DEV).train()
+        m.dropout_seed = 17
+        b = GradientBuckets([p for p in m.parameters() if p.requires_grad])
+        return m, b, FusedSGD(b, lr=0.0, momentum=0.9, weight_decay=0.0)
+    batches = [{k: v.to(DEV) for k, v in synthetic_batch(bs, h, w, seed=s).items()}
+               for s in (1, 2, 3, 4)]
+    m2, b2, o2 = build()
+    m3, b3, o3 = build()
+    g = GraphedTrainStep(m2, batches[0], b2, o2, loss_fn=loss_of, warmup=2)
+    assert g.graph_info['memset_nodes'] == g.graph_info['replaced']
+    for batch in batches[1:]:
+        l2, _ = g.replay(batch)
+        b3.reset()
+        l3 = loss_of(m3(batch))
+        l3.backward()
+        b3.finish()
+        o3.step()
+        torch.cuda.synchronize()
+        assert float(l2) == float(l3), (variant, float(l2), float(l3))
+    gmax = max(float(p.grad.abs().max()) for p in m3.parameters())
+    for (k, p2), (_, p3) in zip(m2.named_parameters(), m3.named_parameters()):
+        if variant != 'bf16':
+            assert float((p2.grad - p3.grad).abs().max()) <= 1e-4 * gmax, k
+        else:
+            # bf16 backward is not run-to-run identical: the few fp32-atomics kernels (bilinear /
+            # pooling scatter, merged-head weight gradients) jitter in the last bit, the next bf16
+            # store turns that into 1-ulp (0.4 %) flips, and ~100 layers later the first layers'
+            # gradients of two EAGER runs differ by percents too -- direction and size must agree
+            a, b = p2.grad.double().flatten(), p3.grad.double().flatten()
+            if float(b.norm()) > 1e-6 * gmax * b.numel() ** 0.5:
+                cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+                assert cos >= 0.98 and 0.9 <= float(a.norm() / b.norm()) <= 1.1, (k, cos)
+
+
+@pytest.mark.parametrize('panoptic', [False, True])
+def test_hipgraph_inference_with_postprocessing(panoptic):
+    """eval graph with `do_postprocessing=True` (+ `enable_panoptic`): every entry of the merged
+    dict -- raw outputs, arg-max maps, instance centres / ids, panoptic ids -- replayed from the
+    hipGraph == the eager forward, on two different inputs"""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.graph import GraphedInference
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import synthetic_batch
+    torch.manual_seed(0)
+    model = EMSANet(full_args(input_height=192, input_width=256, enable_panoptic=panoptic),
+                    nyuv2_config()).to(DEV).eval()
+    b1 = {k: v.to(DEV) for k, v in synthetic_batch(2, 192, 256, seed=1).items()}
+    b2 = {k: v.to(DEV) for k, v in synthetic_batch(2, 192, 256, seed=2).items()}
+    g = GraphedInference(model, b1, do_postprocessing=True)
+    assert g.graph_info['memset_nodes'] == g.graph_info['replaced']
+
+    def flat(d):
+        out = []
+        for k in sorted(d):
+            v = d[k]
+            vs = [v] if torch.is_tensor(v) else [t for t in (v if isinstance(v, (list, tuple)) else [])
+                                                 if torch.is_tensor(t)]
+            out += [(k, t) for t in vs]
+        return out
+    with torch.no_grad():
+        e1 = [(k, t.clone()) for k, t in flat(model(b1, do_postprocessing=True))]
+        e2 = [(k, t.clone()) for k, t in flat(model(b2, do_postprocessing=True))]
+    o1 = [(k, t.clone()) for k, t in flat(g(b1))]
+    o2 = [(k, t.clone()) for k, t in flat(g(b2))]
+    torch.cuda.synchronize()
+    assert len(o1) == len(e1) and len(o1) >= 6
+    for (k, a), (_, b) in zip(o1 + o2, e1 + e2):
+        assert a.shape == b.shape and torch.equal(a, b), k
+    assert any(not torch.equal(a, b) for (_, a), (_, b) in zip(o1, o2))

@@ -56,6 +56,13 @@ CONVS = [
     (72, 40, (3, 1), (1, 1), (1, 0), 2, 7, 5),
     (8, 8, (1, 3), (1, 1), (0, 1), 1, 1, 2),
     (24, 136, (3, 3), (1, 1), (1, 1), 1, 5, 3),
+    # the bf16-MFMA weight-gradient modes of round 3: 1x1 (stride 1 / 2) and stride-2 3-tap convs,
+    # several 64-pixel K steps, odd line lengths (the odd-pixel image runs past the line's end)
+    (64, 64, (1, 1), (1, 1), (0, 0), 2, 30, 40),
+    (128, 256, (1, 1), (2, 2), (0, 0), 2, 15, 21),
+    (128, 256, (3, 1), (2, 1), (1, 0), 2, 30, 40),
+    (128, 256, (1, 3), (1, 2), (0, 1), 2, 15, 41),
+    (72, 40, (1, 3), (1, 2), (0, 1), 1, 3, 9),
     # enough pixels for the 128-row tiles
     (64, 64, (1, 3), (1, 1), (0, 1), 4, 120, 160),
     (128, 128, (3, 1), (1, 1), (1, 0), 4, 60, 80),

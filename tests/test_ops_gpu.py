@@ -834,9 +834,9 @@ def test_folded_input_bn_rejects_unsupported():
 @pytest.mark.parametrize('shape', [(2, 3, 130), (1, 4, 62), (2, 2, 63), (1, 1, 1)])
 @pytest.mark.parametrize('with_skip', [False, True])
 def test_upsample_dw_forward_row_tiles(c, shape, with_skip):
-    """the row-tiled, output-centric forward of the learned x2 up-sampling (c <= 64; c = 128 stays
-    on the quad kernel): several column tiles per row, ragged last tile, image borders, against
-    nearest x2 + zero-padded depth-wise 3x3 in fp64"""
+    """forward of the learned x2 up-sampling on WIDE maps (more columns than one wave covers, odd
+    widths, single pixel), with and without skip / bias, against nearest x2 + zero-padded
+    depth-wise 3x3 in fp64"""
     Fn = _fn()
     n, h, w = shape
     x = rnd(n, c, h, w, seed=1)
