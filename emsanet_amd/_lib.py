@@ -18,7 +18,13 @@ LIB_PATH = os.environ.get('EMSA_LIB') or os.path.join(
 class EmsaPackJob(Structure):
     _fields_ = [('src', c_void_p), ('dst0', c_void_p), ('dst1', c_void_p), ('cout', c_int32),
                 ('cin', c_int32), ('kh', c_int32), ('kw', c_int32), ('kind', c_int32),
-                ('first_block', c_int32)]
+                ('first_block', c_int32), ('cout_total', c_int32), ('cout_off', c_int32),
+                ('cin_total', c_int32), ('cin_off', c_int32)]
+
+
+class EmsaDropoutJob(Structure):
+    _fields_ = [('offset', c_int64), ('c', c_int32), ('layer_id', c_uint32), ('p', c_float),
+                ('pad_', c_int32)]
 
 
 class EmsaConvGeom(Structure):
@@ -60,6 +66,7 @@ SIGNATURES = {
                                  _P, _P]),
     'emsa_graph_count_nodes': (c_int, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     'emsa_graph_replace_memsets': (c_int, [_P, POINTER(c_int32)]),
+    'emsa_dropout2d_mask_batch': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_uint32, _P, _P]),
     'emsa_to_nhwc_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,
                                c_int64, c_int64, _P]),
     'emsa_conv1d_wino_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P]),

@@ -654,6 +654,14 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
   const EmsaPackJob jb = jobs[lo];
   const int nblk = (lo + 1 < n_jobs ? jobs[lo + 1].first_block : (int)gridDim.x) - jb.first_block;
   const int cout = jb.cout, cin = jb.cin;
+  // placement inside a wider operand (padded / merged heads); totals default to the own size
+  const int coT = jb.cout_total > 0 ? jb.cout_total : cout, ciT = jb.cin_total > 0 ? jb.cin_total : cin;
+  const int coO = jb.cout_off, ciO = jb.cin_off;
+  if (jb.kind == 4) {                    // bias vector copy
+    for (int i = (blockIdx.x - jb.first_block) * 256 + threadIdx.x; i < cout; i += nblk * 256)
+      jb.dst0[coO + i] = jb.src[i];
+    return;
+  }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
   const int tco = (cout + 31) / 32, tci = (cin + 31) / 32;
   const bool wino = jb.kind == 1;
@@ -676,14 +684,15 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
         const float sm = 0.5f * (g0 + g2), h = 0.5f * g1;
         vals[k][0] = g0; vals[k][1] = sm + h; vals[k][2] = sm - h; vals[k][3] = g2;
         if (ok && jb.dst0) {
-          const size_t NK = (size_t)cout * R * cin, o = ((size_t)co * R + r) * cin + ci;
+          const size_t NK = (size_t)coT * R * ciT, o = ((size_t)(co + coO) * R + r) * ciT + ci + ciO;
 #pragma unroll
           for (int j = 0; j < 4; ++j) jb.dst0[j * NK + o] = vals[k][j];
         }
       } else {
         const float v = ok ? jb.src[((size_t)co * cin + ci) * taps + r] : 0.f;
         vals[k][0] = v;
-        if (ok && jb.dst0) pack_store(jb.dst0, ((size_t)r * cout + co) * cin + ci, v, jb.kind);
+        if (ok && jb.dst0)
+          pack_store(jb.dst0, ((size_t)r * coT + co + coO) * ciT + ci + ciO, v, jb.kind);
       }
     }
     if (jb.dst1) {
@@ -699,13 +708,15 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
         if (ci < cin && co < cout) {
           if (wino) {
             // data gradient: taps flipped (components 0 <-> 3) and kernel rows reversed
-            const size_t NK = (size_t)cin * R * cout, o = ((size_t)ci * R + (R - 1 - r)) * cout + co;
+            const size_t NK = (size_t)ciT * R * coT,
+                         o = ((size_t)(ci + ciO) * R + (R - 1 - r)) * coT + co + coO;
             jb.dst1[0 * NK + o] = tr[3][tx][ty + 8 * k];
             jb.dst1[1 * NK + o] = tr[1][tx][ty + 8 * k];
             jb.dst1[2 * NK + o] = tr[2][tx][ty + 8 * k];
             jb.dst1[3 * NK + o] = tr[0][tx][ty + 8 * k];
           } else {
-            pack_store(jb.dst1, ((size_t)r * cin + ci) * cout + co, tr[0][tx][ty + 8 * k], jb.kind);
+            pack_store(jb.dst1, ((size_t)r * ciT + ci + ciO) * coT + co + coO, tr[0][tx][ty + 8 * k],
+                       jb.kind);
           }
         }
       }

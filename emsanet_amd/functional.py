@@ -772,6 +772,20 @@ def dropout2d_mask(n, c, p, seed, layer_id, device):
     return m
 
 
+def dropout2d_mask_batch(jobs_dev, n_jobs, total_floats, n, max_c, seed, device):
+    """all Dropout2d masks of a training step in one launch -> flat fp32 buffer (layer j at
+    jobs[j].offset); `seed` as in dropout2d_mask"""
+    m = _empty((total_floats,), device)
+    if torch.is_tensor(seed):
+        check(_lib.lib().emsa_dropout2d_mask_batch(_p(m), _p(jobs_dev), n_jobs, n, max_c, 0, _p(seed),
+                                                   _stream()), 'emsa_dropout2d_mask_batch')
+    else:
+        check(_lib.lib().emsa_dropout2d_mask_batch(_p(m), _p(jobs_dev), n_jobs, n, max_c,
+                                                   seed & 0xFFFFFFFF, None, _stream()),
+              'emsa_dropout2d_mask_batch')
+    return m
+
+
 # ---------------------------------------------------------------------------------------------
 # pooling / SE / upsampling / PPM / heads
 # ---------------------------------------------------------------------------------------------

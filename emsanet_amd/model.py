@@ -115,6 +115,8 @@ class EMSANet(nn.Module):
                 m.layer_id = lid
                 m.seed_fn = self._dropout_seed
                 lid += 1
+        self._drop_plan = None       # (key, device job table, [(layer, offset, c)], total, max_c)
+        self._nbt_blocks = None
 
         # every convolution's weight transforms (packed / Winograd layouts) in one launch per step
         rts = []
@@ -125,6 +127,8 @@ class EMSANet(nn.Module):
             crt = getattr(m, '_crt', None)
             if isinstance(crt, ops.ConvRT):
                 rts.append(crt)
+            if isinstance(rt, ops.MultiConvRT):
+                rts.append(rt)
         self._pack_plan = ops.PackPlan(rts)
         # storage type of the activations (NOT a reference option: the reference has no mixed
         # precision): 'float32' = the reference's arithmetic (default), 'bfloat16' =
@@ -179,6 +183,32 @@ class EMSANet(nn.Module):
             self._seed_dev.copy_(host)
             self._seed_dev_host = now
 
+    def _prepare_dropout_masks(self, n, device):
+        """every Dropout2d mask of this training step in ONE launch (50 launches of ~5 us each
+        before): the layers then pick their views up in `Dropout2dHash.mask`"""
+        if self._nbt_blocks is None:
+            self._nbt_blocks = [m for m in self.modules() if isinstance(m, NonBottleneck1D)]
+        blocks = [m for m in self._nbt_blocks if m.training and m.dropout.p > 0.0]
+        if not blocks or device.type != 'cuda':
+            return
+        key = (n, device, tuple((id(b), b.dropout.p, b.dropout.layer_id) for b in blocks))
+        if self._drop_plan is None or self._drop_plan[0] != key:
+            jobs = (_lib.EmsaDropoutJob * len(blocks))()
+            layout, off = [], 0
+            for j, b in enumerate(blocks):
+                c = b.conv1x3_2.out_channels
+                jobs[j] = _lib.EmsaDropoutJob(off, c, b.dropout.layer_id, b.dropout.p, 0)
+                layout.append((b.dropout, off, c))
+                off += (n * c + 3) // 4 * 4            # 16-byte aligned views
+            table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+            self._drop_plan = (key, table, layout, off, max(c for _, _, c in layout))
+        _, table, layout, total, max_c = self._drop_plan
+        from . import functional as Fn
+        buf = Fn.dropout2d_mask_batch(table, len(layout), total, n, max_c, self._dropout_seed(),
+                                      device)
+        for layer, off, c in layout:
+            layer._premade = buf[off:off + n * c].view(n, c)
+
     def _advance_dropout_step(self):
         self.dropout_step += 1
         if self._seed_dev is not None:
@@ -209,6 +239,9 @@ class EMSANet(nn.Module):
                 not torch.cuda.is_current_stream_capturing():
             self._sync_dropout_state()
 
+        if self.training:
+            first = next(iter(feeds.values()))
+            self._prepare_dropout_masks(first.shape[0], first.device)
         plan = self._cut_plan if self.training else None
         if plan is not None:
             plan.begin()

@@ -76,6 +76,12 @@ class Dropout2dHash(nn.Module):
     def mask(self, n, c, device):
         if not self.training or self.p == 0.0:
             return None
+        pre = getattr(self, '_premade', None)
+        if pre is not None and pre.shape == (n, c) and pre.device == device:
+            # a view into the step's mask buffer (EMSANet._prepare_dropout_masks: all layers in
+            # ONE launch); consumed once
+            self._premade = None
+            return pre
         return Fn.dropout2d_mask(n, c, self.p, self.seed_fn(), self.layer_id, device)
 
 

@@ -175,6 +175,11 @@ class PackPlan:
 
     def __init__(self, rts):
         self.rts = [rt for rt in rts if isinstance(rt, ConvRT)]
+        # merged / channel-padded head convs (MultiConvRT: task heads, side heads, scene head): one
+        # job per placed parameter (+ one per bias) into persistent zero-initialised operands --
+        # they used to re-pack themselves every step with a zero-fill and 2-4 kernels each
+        self.multi = [rt for rt in rts if isinstance(rt, MultiConvRT)]
+        self._mviews = None
         self._key = None
         self._ptrs = None
         self._jobs = None
@@ -185,7 +190,9 @@ class PackPlan:
 
     def _build(self, dev, dtype):
         n = len(self.rts)
-        jobs = (_lib.EmsaPackJob * n)()
+        n_multi = sum(len(m.placements) + sum(1 for q, _, _ in m.placements if q.bias is not None)
+                      for m in self.multi)
+        jobs = (_lib.EmsaPackJob * (n + n_multi))()
         half = dtype != torch.float32
         esz = 2 if half else 4
         sizes = []
@@ -208,8 +215,36 @@ class PackPlan:
             jobs[j] = _lib.EmsaPackJob(w.data_ptr(), v0.data_ptr(), v1.data_ptr() if b else None,
                                        cout, cin, kh, kw, kind, blk)
             blk += max(1, min(64, (w.numel() + 2047) // 2048))
+        j = n
+        mviews = []
+        for m in self.multi:
+            sp = m.spec
+            taps = sp.kh * sp.kw
+            wino = m.wino and not half
+            numel = taps * sp.cout * sp.cin
+            per = numel * 4 // 3 if wino else numel
+            d0 = torch.zeros(per, device=dev, dtype=dtype)          # forward operand / Winograd U
+            d1 = torch.zeros(per, device=dev, dtype=dtype)          # data-gradient operand / U
+            bias = torch.zeros(sp.cout, device=dev, dtype=torch.float32) if m.has_bias else None
+            kind = Fn.DT[dtype] + 1 if half else (1 if wino else 0)
+            for q, co, ci in m.placements:
+                w4 = m._w4(q)
+                cout, cin, kh, kw = w4.shape
+                jobs[j] = _lib.EmsaPackJob(q.weight.data_ptr(), d0.data_ptr(), d1.data_ptr(), cout,
+                                           cin, kh, kw, kind, blk, sp.cout, co, sp.cin, ci)
+                blk += max(1, min(64, (w4.numel() + 2047) // 2048))
+                j += 1
+                if q.bias is not None:
+                    jobs[j] = _lib.EmsaPackJob(q.bias.data_ptr(), bias.data_ptr(), None,
+                                               q.bias.shape[0], 1, 1, 1, 4, blk, sp.cout, co, 1, 0)
+                    blk += 1
+                    j += 1
+            mviews.append((d0, d1, bias, wino))
+        self._mviews = mviews
+        self._n_jobs = j
         raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self._jobs, self._n_blocks, self._arena, self._views = raw, blk, arena, views
+        self._mptrs = tuple(q.weight.data_ptr() for m in self.multi for q, _, _ in m.placements)
         self._ptrs = tuple(rt.conv.weight.data_ptr() for rt in self.rts)
         self._dtype = dtype
 
@@ -217,16 +252,30 @@ class PackPlan:
         if not self.rts:
             return
         ws = [rt.conv.weight for rt in self.rts]
-        key = (dtype,) + tuple((w._version, w.data_ptr(), w.requires_grad) for w in ws)
+        mkeys = [m._key_now() for m in self.multi]
+        key = (dtype,) + tuple((w._version, w.data_ptr(), w.requires_grad) for w in ws) + \
+            tuple(mkeys)
         if key == self._key:
             return
         if not ws[0].is_cuda:
             return                                   # host-side dry runs: per-layer path
+        mptrs = tuple(q.weight.data_ptr() for m in self.multi for q, _, _ in m.placements)
         if self._dtype != dtype or self._ptrs != tuple(w.data_ptr() for w in ws) or \
+                getattr(self, '_mptrs', None) != mptrs or \
                 any((v1 is None) == w.requires_grad for (_, v1), w in zip(self._views or [], ws)):
             self._build(ws[0].device, dtype)
-        check(_lib.lib().emsa_pack_batch(self._jobs.data_ptr(), len(self.rts), self._n_blocks,
+        check(_lib.lib().emsa_pack_batch(self._jobs.data_ptr(), self._n_jobs, self._n_blocks,
                                          Fn._stream()), 'emsa_pack_batch')
+        for m, mk, (d0, d1, bias, wino) in zip(self.multi, mkeys, self._mviews):
+            if dtype != torch.float32:
+                m._h[dtype] = (mk, d0, bias)
+                m._hd[dtype] = (mk, d1, None)
+            elif wino:
+                m._wp, m._bias, m._u, m._key = None, bias, d0, mk
+                m._hd[dtype] = (mk, None, d1)
+            else:
+                m._wp, m._bias, m._u, m._key = d0, bias, None, mk
+                m._hd[dtype] = (mk, d1, None)
         for rt, (v0, v1), w in zip(self.rts, self._views, ws):
             k = (w._version, w.data_ptr())
             if dtype != torch.float32:

@@ -186,6 +186,11 @@ typedef struct EmsaPackJob {
   int32_t cout, cin, kh, kw;
   int32_t kind;
   int32_t first_block;
+  /* placement inside a wider destination (channel padding, block-diagonal merged heads; the rest
+   * of the destination is never written: zero it once): the parameter's (co, ci) lands at
+   * (co + cout_off, ci + cin_off) of a cout_total x cin_total operand.  kind 4: copy the `cout`
+   * floats of `src` (a bias vector) to dst0 + cout_off.                                          */
+  int32_t cout_total, cout_off, cin_total, cin_off;
 } EmsaPackJob;
 int emsa_pack_batch(const EmsaPackJob* jobs_device, int32_t n_jobs, int32_t total_blocks,
                     void* stream);
@@ -275,6 +280,15 @@ int emsa_bn_bwd_apply(const float* dy, const float* y, const uint64_t* mask_bits
                       float* partial, int32_t rows, int32_t n_img, int64_t hw, int32_t c,
                       int32_t act, int32_t train, float* dx, float* dres, float* dgamma,
                       float* dbeta, void* stream);
+/* one Dropout2d layer of emsa_dropout2d_mask_batch: masks of layer `layer_id` (probability p, c
+ * channels) go to masks[offset ...]                                                               */
+typedef struct EmsaDropoutJob {
+  int64_t offset;
+  int32_t c;
+  uint32_t layer_id;
+  float p;
+  int32_t pad_;
+} EmsaDropoutJob;
 /* Dropout2d channel mask [n][c]: 0 or 1/(1-p); counter-based hash shared with the oracle */
 int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, uint32_t seed,
                         uint32_t layer_id, void* stream);
@@ -283,6 +297,11 @@ int emsa_dropout2d_mask(float* mask, int32_t n, int32_t c, float p, uint32_t see
  * step counter on the stream.  A training step captured in a hipGraph draws fresh masks per replay. */
 int emsa_dropout2d_mask_dev(float* mask, int32_t n, int32_t c, float p, const uint32_t* state,
                             uint32_t layer_id, void* stream);
+/* all Dropout2d masks of a step in one launch (jobs in device memory); values identical to the
+ * per-layer entry points                                                                          */
+int emsa_dropout2d_mask_batch(float* masks, const EmsaDropoutJob* jobs_device, int32_t n_jobs,
+                              int32_t n, int32_t max_c, uint32_t seed, const uint32_t* state,
+                              void* stream);
 int emsa_u32_add(uint32_t* counter, uint32_t value, void* stream);
 
 /* ------------------------------------------------------------------------------------------

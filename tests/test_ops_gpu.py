@@ -853,3 +853,29 @@ def test_upsample_dw_forward_row_tiles(c, shape, with_skip):
     y0 = Fn.up2x_dw_fwd(to_act(x), wt.to(DEV), None, None)
     close(y0, ref - b.double()[None, :, None, None] - (skip.double() if with_skip else 0),
           what='up2x rows, no bias')
+
+
+def test_dropout_masks_in_one_launch():
+    """all Dropout2d masks of a step from one launch == the per-layer kernel (and with it the
+    oracle's counter-based hash), host seed and device {seed, step} state"""
+    Fn = _fn()
+    from emsanet_amd import _lib
+    n = 5
+    layers = [(64, 3, 0.1), (128, 7, 0.2), (40, 11, 0.5), (8, 0, 0.05)]
+    jobs = (_lib.EmsaDropoutJob * len(layers))()
+    off = 0
+    for j, (c, lid, p) in enumerate(layers):
+        jobs[j] = _lib.EmsaDropoutJob(off, c, lid, p, 0)
+        off += (n * c + 3) // 4 * 4
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
+    seed = 0x1234ABCD
+    buf = Fn.dropout2d_mask_batch(table, len(layers), off, n, 128, seed, torch.device(DEV))
+    state = torch.tensor([77, 5], dtype=torch.int32, device=DEV)
+    buf2 = Fn.dropout2d_mask_batch(table, len(layers), off, n, 128, state, torch.device(DEV))
+    o = 0
+    for c, lid, p in layers:
+        ref = Fn.dropout2d_mask(n, c, p, seed, lid, DEV)
+        assert torch.equal(buf[o:o + n * c].view(n, c), ref)
+        ref2 = Fn.dropout2d_mask(n, c, p, (77 + 0x632BE5AB * 5) & 0xFFFFFFFF, lid, DEV)
+        assert torch.equal(buf2[o:o + n * c].view(n, c), ref2)
+        o += (n * c + 3) // 4 * 4
