@@ -839,6 +839,10 @@ struct Wgrad1dArgs {
   // line (in_sb is then twice that) and the line length of x (the odd pixels 2b+1 may run past it)
   int in_sb1, in_Lx;
   int taps;                          // accumulator tiles per workgroup: 3, or 1 (1x1 convs, MODE 1)
+  // 16-bit direct kernel: x line of output line a and kernel row kr = a * x_mul_a + kr * dl_mul +
+  // dl_off, valid inside [0, in_Ax); its element stride is in_sa1 (the 7x7 / 2 stem as seven
+  // single-tap rows over the packed input; 3x3: x_mul_a 1, dl_mul 1, dl_off -1)
+  int x_mul_a, in_Ax, in_sa1, dl_mul, dl_off;
   // XBN (emsa_conv_wgrad_inbn): the x operand is a = relu(in * in_scale[c] + in_shift[c]) formed
   // in the loader -- the weight gradient of a conv whose forward ran with the BatchNorm + ReLU of
   // its input folded into ITS loader (emsa_conv1d_wino_inbn); `in` is the BatchNorm's input
@@ -1384,7 +1388,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
 #endif
   const int tile = wg % p.n_tiles, kr = (wg / p.n_tiles) % p.R;
   const int ks = wg / (p.n_tiles * p.R);
-  const int dline = p.R == 3 ? kr - 1 : 0;         // x is read `dline` lines away (3x3 row tap)
+  const int dline = kr * p.dl_mul + p.dl_off;      // x line offset of this kernel row
   const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
   const int co0 = co_t * BCO, ci0 = ci_t * BCI;
   const int s_begin = ks * p.steps_per_split;
@@ -1412,12 +1416,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
     const uint32_t line = fast_div(ku, p.div_l);                 // = img * A + a
     const int b_ = (int)(ku - __umul24(line, (uint32_t)p.L));
     const int a_ = (int)(line - __umul24(img, (uint32_t)p.A));
-    const int a2 = a_ + dline;
+    const int a2 = a_ * p.x_mul_a + dline;
     const bool in_line = valid && b_ < p.Lr;                     // the virtual pixel reads zero
     od = in_line ? (__umul24(img, (uint32_t)p.dy_simg) + __umul24((uint32_t)a_, (uint32_t)p.dy_sa) +
                     __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * ES : kOOB;
-    ox = (in_line && a2 >= 0 && a2 < p.A)
-        ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa) +
+    ox = (in_line && a2 >= 0 && a2 < p.in_Ax)
+        ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa1) +
            __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * ES : kOOB;
     if constexpr (MODE == 2)
       oo_last = (ox != kOOB && 2 * b_ + 1 < p.in_Lx) ? ox + (uint32_t)p.in_sb1 * ES : kOOB;
@@ -1879,16 +1883,22 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, siz
   const bool s2 = direct16 && modes_on && plain && !sq &&
                   ((along_w && g->mul_w == 2 && g->mul_h == 1 && g->in_h == g->out_h) ||
                    (along_h && g->mul_h == 2 && g->mul_w == 1 && g->in_w == g->out_w));
-  pl.mode = one ? 1 : (s2 ? 2 : 0);
-  if (one) along_w = true;
-  if (!(one || s2 || ((along_w || along_h) && plain && same))) return false;
+  // the 7x7 / 2 stem over the packed NHWC4 input (7 kernel rows of one 32-wide "tap" each) and
+  // its rows-as-channels twin for one input channel (2 rows, x lines 4 apart): single-tap rows
+  const bool stem = direct16 && modes_on && g->kw == 1 && (g->kh == 7 || g->kh == 2) &&
+                    g->k_ch == 32 && g->mul_h == 2 && g->mul_w == 2 && g->off_w == 0 &&
+                    g->step_w == 1 && g->div_h == 1 && g->div_w == 1 && dout_aligned &&
+                    !getenv("EMSA_WGRAD_GENERIC");
+  pl.mode = (one || stem) ? 1 : (s2 ? 2 : 0);
+  if (one || stem) along_w = true;
+  if (!(one || s2 || stem || ((along_w || along_h) && plain && same))) return false;
   Wgrad1dArgs& w = pl.w;
   w.n_ch = g->n_ch; w.k_ch = g->k_ch;
   const int H = g->out_h, W = g->out_w;
   w.Lr = along_w ? W : H;
   const int A = along_w ? H : W;
   w.A = A;
-  w.R = sq ? 3 : 1;
+  w.R = sq ? 3 : (stem ? g->kh : 1);
   w.in_simg = (int)g->in_img_stride;
   w.dy_simg = H * W * g->ld_out;
   if (along_w) {
@@ -1901,6 +1911,14 @@ bool plan_wgrad1d(const EmsaConvGeom* g, bool dout_aligned, Wgrad1dPlan& pl, siz
     w.in_sb1 = (int)g->in_row_stride; w.in_Lx = g->in_h;
   }
   w.taps = pl.mode == 1 ? 1 : 3;
+  // x line of (output line a, kernel row kr): see Wgrad1dArgs
+  if (along_w) {
+    w.x_mul_a = g->mul_h; w.in_Ax = g->in_h; w.in_sa1 = (int)g->in_row_stride;
+  } else {
+    w.x_mul_a = g->mul_w; w.in_Ax = g->in_w; w.in_sa1 = g->in_px_stride;
+  }
+  w.dl_mul = stem ? g->step_h : (sq ? 1 : 0);
+  w.dl_off = stem ? g->off_h : (sq ? -1 : 0);
   // the loader multiplies (image, line, position) by the strides with 24-bit multiplies
   if (w.in_simg >= (1 << 24) || w.dy_simg >= (1 << 24) || w.in_sa >= (1 << 24) ||
       w.dy_sa >= (1 << 24) || g->n_img >= (1 << 24))
