@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t wdiv(uint32_t n, uint32_t mul, uint32_t sh) 
 // precision): the operands are rounded to bf16 when they leave LDS and one
 // v_mfma_f32_32x32x16_bf16 replaces eight fp32 MFMAs; accumulation, the Winograd transforms and
 // everything in HBM stay fp32.
+#ifndef EMSA_WINO_ST_AUX
+#define EMSA_WINO_ST_AUX 0   // cache policy of the output stores (tuning builds: 2 = non-temporal)
+#endif
 #ifndef EMSA_WINO_PRIO
 #define EMSA_WINO_PRIO 2   // 0 = no s_setprio, 1 = raised around the MFMA cluster, 2 = also: the next step's loads
                           // issue at the highest priority (measured +1..2 %)
@@ -538,7 +541,8 @@ __global__ __launch_bounds__(256, kWN == 64 ? (BNB ? 4 : 5) : 6) void conv1d_win
       }
       {
         const uint32_t off = live ? (opix[k] * (uint32_t)p.ld_out + (uint32_t)n) * 4u : kOOBw;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, v), rs_out, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, v), rs_out, (int)off, 0,
+                                               EMSA_WINO_ST_AUX);
       }
       if constexpr (kWN == 64) {
         if (p.relu_bits) {                           // uniform branch: ballots see every lane

@@ -17,6 +17,16 @@ from .decoder import get_decoders
 from .nn import (Dropout2dHash, FusedEncoder, NonBottleneck1D, PyramidPoolingModule, ResNetNBt1D)
 
 
+def _tensors_of(o):
+    if torch.is_tensor(o):
+        return [o]
+    if isinstance(o, dict):
+        return [t for v in o.values() for t in _tensors_of(v)]
+    if isinstance(o, (list, tuple)):
+        return [t for v in o for t in _tensors_of(v)]
+    return []
+
+
 class EMSANet(nn.Module):
     def __init__(self, args, dataset_config) -> None:
         super().__init__()
@@ -115,6 +125,7 @@ class EMSANet(nn.Module):
                 m.layer_id = lid
                 m.seed_fn = self._dropout_seed
                 lid += 1
+        self._side_stream = None     # second HIP stream of the decoders (see _run_decoders)
         self._drop_plan = None       # (key, device job table, [(layer, offset, c)], total, max_c)
         self._nbt_blocks = None
 
@@ -182,6 +193,34 @@ class EMSANet(nn.Module):
             host = torch.from_numpy(np.array(now, dtype=np.uint32).view(np.int32).copy())
             self._seed_dev.copy_(host)
             self._seed_dev_host = now
+
+    def _run_decoders(self, x, skips, batch, do_postprocessing):
+        """the decoders in `self.decoders` order; with two dense decoders (semantic, instance) the
+        second one runs on a second HIP stream: same inputs, independent work, and the launches of
+        their /32 and /16 modules are too small to fill 256 CUs alone (nn._dual_stream)"""
+        from .decoder import DecoderBody
+        from .nn import _dual_stream
+        decs = list(self.decoders.values())
+        dense = [d for d in decs if isinstance(d, DecoderBody)]
+        if len(dense) < 2 or not _dual_stream(x[0]):
+            return [d(x, skips, batch, do_postprocessing=do_postprocessing) for d in decs]
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(cur)
+        results = []
+        for d in decs:
+            if d is dense[1]:
+                with torch.cuda.stream(side):
+                    r = d(x, skips, batch, do_postprocessing=do_postprocessing)
+                for t in _tensors_of(r):
+                    t.record_stream(cur)
+            else:
+                r = d(x, skips, batch, do_postprocessing=do_postprocessing)
+            results.append(r)
+        cur.wait_stream(side)
+        return results
 
     def _prepare_dropout_masks(self, n, device):
         """every Dropout2d mask of this training step in ONE launch (50 launches of ~5 us each
@@ -259,8 +298,7 @@ class EMSANet(nn.Module):
         ctx_in = deep['rgb'] if len(feeds) == 2 else next(iter(deep.values()))
         ctx, ctx_branches = self.context_module(ctx_in)
 
-        results = [dec((ctx, ctx_branches), skips, batch, do_postprocessing=do_postprocessing)
-                   for dec in self.decoders.values()]
+        results = self._run_decoders((ctx, ctx_branches), skips, batch, do_postprocessing)
         if self.training:
             self._advance_dropout_step()
         if not do_postprocessing:
