@@ -176,11 +176,14 @@ class SEAddUniRGB(nn.Module):
 # encoder alone -- the launches of the /16 and /32 stages are a few hundred workgroups for 256 CUs,
 # each a chain of dependent K steps, and fill each other's idle CUs
 _DUAL_ENV = os.environ.get('EMSA_DUAL_STREAM')
+DUAL_STREAM = None          # bench.py / tests: True / False overrides (None: the rule below)
 
 
 def _dual_stream(t):
     if t is None or not t.is_cuda or not torch.cuda.is_available():
         return False
+    if DUAL_STREAM is not None:
+        return DUAL_STREAM
     if _DUAL_ENV is not None:
         return _DUAL_ENV != '0'
     return True
