@@ -441,11 +441,6 @@ def run(args):
             comm['graphs'] = [i['nodes'] for i in train_graph.graph_info]
         dt = max(r[2] for r in rows)
 
-    if rank != 0:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return None
-
     images = bs * world * args.steps
     value = images / dt
     # ---- roofline of the dominant kernel --------------------------------------------------
@@ -489,7 +484,7 @@ def run(args):
     in_region = None
     from emsanet_amd import nn as enn
     overlapped = timing and not args.eval and not args.graph and enn._dual_stream(batch['rgb'])
-    single_pass = overlapped and not dist.is_initialized()      # (every rank would have to take part)
+    single_pass = overlapped          # (every rank takes part: the steps contain the collectives)
     if overlapped and kernels:
         k0 = kernels[0]
         in_region = {'kernel': k0['kernel'], 'avg_us': k0['avg_us'], 'achieved': k0['tflops'],
@@ -521,6 +516,10 @@ def run(args):
         dt_roof, steps_roof = dt_r, args.roofline_steps
     else:
         dt_roof, steps_roof = dt, args.steps
+    if rank != 0:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return None
     roofline = None
     traffic, traffic_src = None, None
     pmc, pmc_file = None, None
@@ -572,8 +571,7 @@ def run(args):
                 f'{steps_roof} single-stream steps of the same workload behind the timed region '
                 f'({round(1e3 * dt_roof / steps_roof, 2)} ms/step; every {args.timing_every}th launch '
                 'bracketed by HIP events on its stream): the kernel\'s own rate')
-            in_region['frac'] = round(in_region['achieved'] / roofline['peak'], 4) \
-                if args.dtype == 'f32' else None
+            in_region['frac'] = round(in_region['achieved'] / roofline['peak'], 4)
             roofline['in_timed_region'] = in_region
         if 'mfma_executed_tflops' in k:
             roofline['mfma_executed_tflops'] = k['mfma_executed_tflops']

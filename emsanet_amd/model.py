@@ -208,6 +208,9 @@ class EMSANet(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
+        from .parallel import register_stream
+        register_stream(cur)
+        register_stream(side)
         side.wait_stream(cur)
         results = []
         for d in decs:

@@ -248,6 +248,9 @@ class FusedEncoder(nn.Module):
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream()
             side = self._side_stream
+            from .parallel import register_stream
+            register_stream(cur)
+            register_stream(side)
         for i, ds in enumerate(bb.stage_downsamplings):
             if dual:
                 # the two encoders' stages are independent until the fusion: the depth stage runs

@@ -23,6 +23,28 @@ import torch
 import torch.distributed as dist
 
 
+# HIP streams the engine runs backward kernels on (the model's second stream for the depth encoder /
+# instance decoder, and the stream the step was issued on).  A bucket can hold gradients written on
+# either; before it goes on the wire the issuing stream waits for all of them (the collective only
+# orders itself behind the stream that is current when it is issued).
+_ENGINE_STREAMS = []
+
+
+def register_stream(stream):
+    if all(s.cuda_stream != stream.cuda_stream for s in _ENGINE_STREAMS):
+        _ENGINE_STREAMS.append(stream)
+        del _ENGINE_STREAMS[:-8]              # (bounded: a few long-lived streams)
+
+
+def _join_engine_streams():
+    if not _ENGINE_STREAMS or not torch.cuda.is_available():
+        return
+    cur = torch.cuda.current_stream()
+    for s in _ENGINE_STREAMS:
+        if s.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(s)
+
+
 def grad_target(p):
     """The flat-bucket view this parameter's gradient should be written into by the backward
     kernel that produces it (so that neither the all-reduce nor the fused optimizer needs a
@@ -177,6 +199,8 @@ class GradientBuckets:
         """asynchronous all-reduce (SUM) of bucket `bi` on the communication stream; `finish()`
         waits.  Not capturable: issued eagerly, between graph replays in the segmented step."""
         flat = self.buckets[bi][0]
+        if flat.is_cuda:
+            _join_engine_streams()
         buf = flat
         if self.comm_dtype is not None and self.comm_dtype != flat.dtype:
             if self._comm[bi] is None:
