@@ -483,7 +483,7 @@ def run(args):
     # region; what the events saw INSIDE the timed region is reported next to it.
     in_region = None
     from emsanet_amd import nn as enn
-    overlapped = timing and not args.eval and not args.graph and enn._dual_stream(batch['rgb'])
+    overlapped = timing and not args.graph and enn._dual_stream(batch['rgb'])
     single_pass = overlapped          # (every rank takes part: the steps contain the collectives)
     if overlapped and kernels:
         k0 = kernels[0]

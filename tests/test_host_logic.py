@@ -414,3 +414,66 @@ def test_bn1_fold_default_rule(monkeypatch):
     assert not Fn.bn1_fold(t(64, 120, 160, torch.bfloat16))
     monkeypatch.setattr(Fn, '_BN1_FOLD_ENV', '0')
     assert not Fn.bn1_fold(t(64, 120, 160))
+
+
+def test_segment_parameter_groups_partition_the_model():
+    """the backward segments of SegmentedGraphedTrainStep: every parameter in exactly one group,
+    decoders + context module first, the stem in the last one; buckets never straddle two groups
+    and the tail bucket of the LAST group stays small"""
+    from emsanet_amd import full_args
+    from emsanet_amd.graph import segment_parameter_groups
+    from emsanet_amd.parallel import GradientBuckets
+    model = _model(full_args(input_height=64, input_width=96))
+    params = [p for p in model.parameters() if p.requires_grad]
+    groups = segment_parameter_groups(model, (2, 1))
+    assert len(groups) == 4
+    ids = [id(p) for g in groups for p in g]
+    assert len(ids) == len(set(ids)) == len(params)
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert all(names[id(p)].startswith(('decoders.', 'context_module.')) for p in groups[0])
+    assert all('layer3' in names[id(p)] or 'layer4' in names[id(p)] or 'fusion_modules.3' in names[id(p)]
+               or 'fusion_modules.4' in names[id(p)] for p in groups[1])
+    assert any(names[id(p)].endswith('backbone_rgb.conv1.weight') for p in groups[3])
+    b = GradientBuckets(params, bucket_bytes=8 << 20, groups=groups, manual=True, tail_bytes=1 << 20)
+    assert len(b.group_buckets) == 4 and sum(len(g) for g in b.group_buckets) == len(b.buckets)
+    for gi, bis in enumerate(b.group_buckets):
+        members = {id(p) for bi in bis for p in b.buckets[bi][1]}
+        assert members == {id(p) for p in groups[gi]}
+    last = b.buckets[b.group_buckets[-1][-1]][0]
+    assert last.numel() * 4 <= 1 << 20
+    # arrival order + tail without groups: order respected, every parameter once
+    order = list(reversed(params))
+    b2 = GradientBuckets(params, bucket_bytes=8 << 20, order=order, tail_bytes=2 << 20)
+    flat = [p for _, ps, _ in b2.buckets for p in ps]
+    assert [id(p) for p in flat] == [id(p) for p in order]
+    assert b2.buckets[-1][0].numel() * 4 <= 2 << 20
+    with pytest.raises(ValueError):
+        GradientBuckets(params, groups=groups[:-1])
+
+
+def test_cut_plan_dry_run(fake_lib, monkeypatch):
+    """forward with autograd cuts (segmented backward): the decoders and the encoder stages behind a
+    cut run on detached leaves; records carry (original, leaf, producing stage, group)"""
+    import emsanet_amd.model as M
+    from emsanet_amd import full_args
+    from emsanet_amd.nn import CutPlan
+    from oracle.emsanet_oracle import synthetic_batch
+    model = _model(full_args(input_height=64, input_width=96)).train()
+    monkeypatch.setattr(M.EMSANet, 'forward', _bypass_device_check(model))
+    plan = CutPlan((2, 1))
+    model._cut_plan = plan
+    outs = model(synthetic_batch(2, 64, 96))
+    model._cut_plan = None
+    groups = [g for _, _, _, g in plan.records]
+    assert groups.count(1) == 2 and groups.count(2) == 2          # rgb + depth behind each cut
+    dec = [(o, c, st) for o, c, st, g in plan.records if g == CutPlan.DECODERS]
+    assert sorted(st for _, _, st in dec) == [1, 2, 3, 4, 4]      # skips /4 /8 /16, deep rgb + depth
+    for o, c, _, _ in plan.records:
+        assert c.is_leaf and c.requires_grad and c.data_ptr() == o.data_ptr()
+    flat = [t for o, sides in outs for t in (list(o) if isinstance(o, tuple) else [o])]
+    # backward from the outputs stops at the decoder leaves: no encoder parameter gets a gradient
+    torch.autograd.backward(flat, [torch.zeros_like(t) for t in flat])
+    got = {n for n, p in model.named_parameters() if p.grad is not None}
+    assert got and all(n.startswith(('decoders.', 'context_module.')) for n in got)
+    with pytest.raises(ValueError):
+        CutPlan((4,))
