@@ -214,6 +214,8 @@ class GradientBuckets:
         self._launched[bi] = True
 
     def _launch(self, bi):
+        if self.buckets[bi][0].is_cuda:
+            _join_engine_streams()        # (the gather copies read gradients of either stream)
         self.gather(bi)
         self.reduce(bi)
 
