@@ -304,6 +304,9 @@ class EMSANet(nn.Module):
         results = self._run_decoders((ctx, ctx_branches), skips, batch, do_postprocessing)
         if self.training:
             self._advance_dropout_step()
+            if self._drop_plan is not None:
+                for layer, _, _ in self._drop_plan[2]:
+                    layer._premade = None        # (a mask view is good for ONE forward pass)
         if not do_postprocessing:
             return results
         merged = {}
