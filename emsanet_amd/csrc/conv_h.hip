@@ -37,6 +37,13 @@ namespace {
 // bf16 training step with the per-launch choice below (same box, 623.5 vs 609.2 images/s).
 constexpr int kHKMax = 64;
 
+// Build-time probes of where a launch's time goes (tools/jobs/r04b.sh builds one library per value;
+// the product build has 0): 1 = no K loop and no loads (output pass only), 2 = no output stores,
+// 3 = loads but no MFMAs, 4 = no activation loads, 5 = no weight loads.  Results: DESIGN.md 7.
+#ifndef EMSA_CONVH_DBG
+#define EMSA_CONVH_DBG 0
+#endif
+
 typedef unsigned int hu32x4 __attribute__((ext_vector_type(4)));
 typedef float hf32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
@@ -203,7 +210,7 @@ void conv_h_kernel(
     b_off[j] = n < g.n_ch ? (uint32_t)(n * g.k_ch + c8) * 2u : kHOOB;
   }
   const int taps = g.kh * g.kw;
-  const int steps = taps * p.kchunks;
+  const int steps = EMSA_CONVH_DBG == 1 ? (p.M < 0 ? 1 : 0) : taps * p.kchunks;
   const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 2u;
   int tap_n = 0, kc_n = 0;
   hu32x4 rset[PF > 0 ? PF : 1][AR + BR];
@@ -264,11 +271,13 @@ void conv_h_kernel(
     T* const b_dst = a_dst + BM * kHK;
 #pragma unroll
     for (int j = 0; j < AR; ++j)
+      if (EMSA_CONVH_DBG != 4 || p.M < 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs_in, (__attribute__((address_space(3))) void*)(a_dst + kRowsPerPass * j * kHK), 16,
           (int)(a_off[j] | (last_oob & pm)), (int)sa, 0, 0);
 #pragma unroll
     for (int j = 0; j < BR; ++j)
+      if (EMSA_CONVH_DBG != 5 || p.M < 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs_w, (__attribute__((address_space(3))) void*)(b_dst + kRowsPerPass * j * kHK), 16,
           (int)(b_off[j] | (last_oob & pm)), (int)sb, 0, 0);
@@ -289,6 +298,7 @@ void conv_h_kernel(
   // operands of buffer `buf` (PF == 0): row stride 64 elements, logical chunk ks * 2 + lh sits at
   // physical chunk (ks * 2 + lh) ^ (row & 7), row & 7 == l31 & 7
   auto compute_dma = [&](int buf) {
+    if (EMSA_CONVH_DBG == 3 && p.M >= 0) return;
     const T* a = As + buf * kStageElems + (wm * TM * 32 + l31) * kHK;
     const T* b = As + buf * kStageElems + BM * kHK + (wn * TN * 32 + l31) * kHK;
     const int sw = kHRowLanes == 8 ? (l31 & 7) : ((l31 >> 2) & 3);
@@ -333,7 +343,7 @@ void conv_h_kernel(
     // two LDS buffers: step s + 1 is in flight (DMA) while step s is multiplied; ONE barrier per
     // step: behind it every wave's pieces of step s have landed (each wave waited for its own) and
     // every wave is done reading the other buffer (step s - 1)
-    issue_dma(0);
+    if (EMSA_CONVH_DBG != 1 || p.M < 0) issue_dma(0);
     for (int s = 0; s < steps; ++s) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -534,7 +544,8 @@ void conv_h_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        *reinterpret_cast<V8*>(outp + (size_t)m * g.ld_out + n) = __builtin_convertvector(v, V8);
+        if (EMSA_CONVH_DBG != 2 || p.M < 0)
+          *reinterpret_cast<V8*>(outp + (size_t)m * g.ld_out + n) = __builtin_convertvector(v, V8);
       }
     }
   }
