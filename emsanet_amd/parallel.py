@@ -275,7 +275,7 @@ class GradientBuckets:
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets)
 
 
-def record_arrival_order(params, run_backward):
+def record_arrival_order(params, run_backward, process_group=None):
     """the order in which the gradients of `params` arrive during `run_backward()` (one ordinary
     forward + backward of the training step): temporary post-accumulate hooks log it.  Feed the
     result to `GradientBuckets(params, order=...)` so that bucket boundaries follow the measured
@@ -291,7 +291,24 @@ def record_arrival_order(params, run_backward):
             h.remove()
     got = {id(p) for p in seen}
     # parameters that received no gradient go last (they contribute zeros)
-    return seen + [p for p in params if p.requires_grad and id(p) not in got]
+    order = seen + [p for p in params if p.requires_grad and id(p) not in got]
+    return agree_on_order(params, order, process_group)
+
+
+def agree_on_order(params, order, process_group=None, src=0):
+    """every rank adopts rank `src`'s ordering of `params` (bucket layouts must be identical on all
+    ranks; the hook order is deterministic today, this makes it so by construction)"""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return order
+    params = [p for p in params if p.requires_grad]
+    index = {id(p): i for i, p in enumerate(params)}
+    dev = params[0].device if dist.get_backend(process_group) == 'nccl' else torch.device('cpu')
+    idx = torch.tensor([index[id(p)] for p in order], dtype=torch.int64, device=dev)
+    dist.broadcast(idx, src=src, group=process_group)
+    got = idx.tolist()
+    if sorted(got) != list(range(len(params))):
+        raise RuntimeError("agree_on_order: rank %d did not list every parameter once" % src)
+    return [params[i] for i in got]
 
 
 def broadcast_parameters(module, src=0, process_group=None):

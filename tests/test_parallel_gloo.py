@@ -163,6 +163,39 @@ def test_bucket_modes_two_ranks():
     assert ret['stats']['bytes'] * 2 == ret['bytes_f32']                       # half the bytes
 
 
+def _worker_order(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from emsanet_amd.parallel import GradientBuckets, agree_on_order, record_arrival_order
+    net = _net()
+    params = list(net.parameters())
+    pos = {id(p): i for i, p in enumerate(params)}
+    # rank 1 proposes a different order: every rank must end up with rank 0's
+    local = list(reversed(params)) if rank == 0 else params[1:] + params[:1]
+    agreed = agree_on_order(params, local)
+    ret[f'order{rank}'] = [pos[id(p)] for p in agreed]
+
+    def run():
+        ((net(torch.ones(2, 3, 6, 6)) ** 2).mean()).backward()
+    measured = record_arrival_order(params, run)
+    ret[f'measured{rank}'] = [pos[id(p)] for p in measured]
+    buckets = GradientBuckets(params, order=measured, bucket_bytes=1024, tail_bytes=256)
+    ret[f'layout{rank}'] = [[pos[id(p)] for p in b[1]] for b in buckets.buckets]
+    dist.destroy_process_group()
+
+
+def test_arrival_order_is_rank_zeros_on_every_rank():
+    """bucket layouts must agree across ranks: the measured arrival order is broadcast from rank 0"""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_order, args=(2, _free_port(), ret), nprocs=2, join=True)
+    n = len(list(_net().parameters()))
+    assert ret['order0'] == list(reversed(range(n))) and ret['order1'] == ret['order0']
+    assert ret['measured0'] == ret['measured1'] and sorted(ret['measured0']) == list(range(n))
+    assert ret['layout0'] == ret['layout1'] and len(ret['layout0']) > 1
+
+
 def test_grad_target_hands_out_each_view_once_per_step():
     sys.path.insert(0, ROOT)
     from emsanet_amd.parallel import GradientBuckets, grad_target
