@@ -54,6 +54,15 @@ _DEFAULTS = {
     'instance_decoder_n_channels': ((512, 256, 128), 429),
     'instance_decoder_downsamplings': ((16, 8, 4), 440),
     'instance_decoder_upsampling': ('learned-3x3-zeropad', 449),
+    'normal_encoder_decoder_fusion': ('add-rgb', 543),
+    'normal_decoder': ('emsanet', 551),
+    'normal_decoder_block': ('nonbottleneck1d', 558),
+    'normal_decoder_block_dropout_p': (0.2, 565),
+    'normal_decoder_n_blocks': (3, 572),
+    'normal_decoder_dropout_p': (0.1, 579),
+    'normal_decoder_n_channels': ((512, 256, 128), 586),
+    'normal_decoder_downsamplings': ((16, 8, 4), 597),
+    'normal_decoder_upsampling': ('learned-3x3-zeropad', 606),
     'instance_center_heatmap_threshold': (0.1, 469),
     'instance_center_heatmap_nms_kernel_size': (17, 478),
     'instance_center_heatmap_apply_foreground_mask': (False, 487),

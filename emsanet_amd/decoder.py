@@ -7,8 +7,8 @@ the decoder classes the reference imports from `nicr_mt_scene_analysis.model.dec
 
 Supported: the 'emsanet' decoder type for the semantic and instance(+orientation) tasks and the
 scene-classification head, the `PanopticHelper` wrapper with the eval-time panoptic merge --
-the full multi-task configuration of BASELINE.json.  The 'segformermlp' decoders and the normal
-decoder are outside the hot path and raise NotImplementedError.
+the full multi-task configuration of BASELINE.json.  The 'segformermlp' decoders are outside the hot path and raise
+NotImplementedError.
 """
 from collections import OrderedDict
 from typing import Tuple, Union
@@ -21,6 +21,8 @@ from . import ops
 from .nn import (ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt,
                  plain_conv)
 from .postprocessing import InstancePostprocessing, PanopticPostprocessing, softmax_argmax
+
+_FUSIONS = ('add-rgb', 'add-depth', 'add-rgbd', 'add')     # encoder -> decoder skip fusions built here
 
 KNOWN_DECODERS = (
     'emsanet',         # decoder used in EMSANet publication
@@ -102,8 +104,8 @@ class DecoderBody(nn.Module):
         for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
                             self.fusion_downsamplings):
             sk = skips[str(ds)]
-            if self.fusion == 'add-rgb':
-                skip = sk['rgb']
+            if self.fusion.startswith('add-'):
+                skip = sk[self.fusion[4:]]          # 'add-rgb' (default), 'add-depth', 'add-rgbd'
             else:
                 # 'add' (single-modality models, /root/reference/emsanet/tests/
                 # test_interface_model.py:32): the only encoder stream there is
@@ -150,6 +152,23 @@ class SemanticDecoder(DecoderBody):
             score, idx = softmax_argmax(out)             # one fused pass over the logits
             r['semantic_segmentation_score'], r['semantic_segmentation_idx'] = score, idx
         return r
+
+
+class NormalDecoder(SemanticDecoder):
+    """`NormalDecoder(...)` of /root/reference/emsanet/decoder.py:160-175 (the class itself lives in
+    the un-vendored library): restated as the dense decoder with `normal_n_channels_out` output maps
+    -- body, side heads and head exactly as the semantic decoder's, no activation on the maps.  The
+    outputs are the raw maps; unit-length normalisation is left to the caller's post-processing
+    (undetermined upstream)."""
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        x, sides = self.body(x[0], skips)
+        nc = self.n_classes
+        out = self.head(x)[:, :nc]
+        sides = tuple(ops.to_float(s)[:, :nc] for s in sides) if self.training else ()
+        if not do_postprocessing:
+            return out, sides
+        return {'normal_output': out, 'normal_side_outputs': sides}
 
 
 class InstanceHead(nn.Module):
@@ -309,7 +328,7 @@ def get_decoders(
     if 'semantic' in args.tasks:
         if args.semantic_decoder.lower() != 'emsanet':
             raise NotImplementedError(f"semantic decoder '{args.semantic_decoder}'")
-        if args.semantic_encoder_decoder_fusion not in ('add-rgb', 'add'):
+        if args.semantic_encoder_decoder_fusion not in _FUSIONS:
             raise NotImplementedError(args.semantic_encoder_decoder_fusion)
         decoders['semantic_decoder'] = SemanticDecoder(
             n_classes=semantic_n_classes, n_channels_in=n_channels_in,
@@ -322,7 +341,7 @@ def get_decoders(
     if 'instance' in args.tasks:
         if args.instance_decoder.lower() != 'emsanet':
             raise NotImplementedError(f"instance decoder '{args.instance_decoder}'")
-        if args.instance_encoder_decoder_fusion not in ('add-rgb', 'add'):
+        if args.instance_encoder_decoder_fusion not in _FUSIONS:
             raise NotImplementedError(args.instance_encoder_decoder_fusion)
         decoders['instance_decoder'] = InstanceDecoder(
             with_orientation='orientation' in args.tasks,
@@ -351,7 +370,21 @@ def get_decoders(
                                 panoptic_semantic_classes_is_thing)
         decoders = OrderedDict([('panoptic_helper', helper)] + list(decoders.items()))
     if 'normal' in args.tasks:
-        raise NotImplementedError("normal decoder is not part of the BASELINE.json configs")
+        # /root/reference/emsanet/decoder.py:160-189
+        if getattr(args, 'normal_decoder', 'emsanet').lower() != 'emsanet':
+            raise NotImplementedError(f"normal decoder '{args.normal_decoder}'")
+        fusion = getattr(args, 'normal_encoder_decoder_fusion', 'add-rgb')
+        if fusion not in _FUSIONS:
+            raise NotImplementedError(fusion)
+        if getattr(args, 'normal_decoder_upsampling', 'learned-3x3-zeropad') != 'learned-3x3-zeropad':
+            raise NotImplementedError(f"normal_decoder_upsampling={args.normal_decoder_upsampling}")
+        decoders['normal_decoder'] = NormalDecoder(
+            n_classes=normal_n_channels_out, n_channels_in=n_channels_in,
+            n_channels=tuple(getattr(args, 'normal_decoder_n_channels', (512, 256, 128))),
+            n_blocks=getattr(args, 'normal_decoder_n_blocks', 3),
+            dropout_p=getattr(args, 'normal_decoder_block_dropout_p', 0.2),
+            fusion_n_channels=tuple(fusion_n_channels),
+            fusion_downsamplings=fusion_downsamplings, fusion=fusion)
     if 'scene' in args.tasks:
         decoders['scene_decoder'] = SceneClassificationDecoder(scene_n_channels_in,
                                                                scene_n_classes)

@@ -37,12 +37,10 @@ class EMSANet(nn.Module):
         n_sem, n_scene = len(labels), len(dataset_config.scene_label_list_without_void)
 
         # --- encoders (model.py:46-106): one NBt1D ResNet per modality, SE-add fusion ----------
-        if 'rgbd' in args.input_modalities:
-            raise NotImplementedError("single rgbd encoder is not part of the hot path")
         if getattr(args, 'activation', 'relu') != 'relu':
             raise NotImplementedError("only the default 'relu' activation has kernels")
         nets = {}
-        for modality, n_in in (('rgb', 3), ('depth', 1)):
+        for modality, n_in in (('rgb', 3), ('depth', 1), ('rgbd', 3 + 1)):
             if modality not in args.input_modalities:
                 nets[modality] = None
                 continue
@@ -52,7 +50,8 @@ class EMSANet(nn.Module):
             nets[modality] = ResNetNBt1D(getattr(args, f'{modality}_encoder_backbone'), n_in,
                                          args.dropout_p)
         self.encoder = FusedEncoder(nets['rgb'], nets['depth'], args.encoder_fusion,
-                                    args.encoder_decoder_skip_downsamplings)
+                                    args.encoder_decoder_skip_downsamplings,
+                                    backbone_rgbd=nets['rgbd'])
         c_enc, ds_enc = self.encoder.n_channels_out, self.encoder.downsampling
 
         # --- context module (model.py:109-119) --------------------------------------------------
@@ -160,7 +159,8 @@ class EMSANet(nn.Module):
         if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise ValueError(f"compute dtype {dtype}")
         self.compute_dtype = dtype
-        for bb in (self.encoder.backbone_rgb, self.encoder.backbone_depth):
+        for bb in (self.encoder.backbone_rgb, self.encoder.backbone_depth,
+                   self.encoder.backbone_rgbd):
             if bb is not None:
                 bb.compute_dtype = dtype
         return self
@@ -262,7 +262,11 @@ class EMSANet(nn.Module):
     def forward(self, batch, do_postprocessing=False) -> Dict[str, Any]:
         """contract of /root/reference/emsanet/model.py:192-233: list of per-decoder
         (outputs, side outputs) in `self.decoders` order, or one merged dict when post-processing"""
-        feeds = {m: batch[m] for m in ('rgb', 'depth') if m in self.args.input_modalities}
+        if 'rgbd' in self.args.input_modalities:
+            # /root/reference/emsanet/model.py:195-199: the encoder's input is cat(rgb, depth)
+            feeds = {'rgb': batch['rgb'], 'depth': batch['depth']}
+        else:
+            feeds = {m: batch[m] for m in ('rgb', 'depth') if m in self.args.input_modalities}
         for name, t in feeds.items():
             if t.dim() != 4 or t.shape[-2] % 32 or t.shape[-1] % 32:
                 # five stride-2 encoder stages and x2 decoder upsampling with skip additions
@@ -276,6 +280,12 @@ class EMSANet(nn.Module):
         if self.compute_dtype == torch.float16 and self.training:
             raise _lib.EmsaError("float16 storage is an inference mode (no loss scaling); train "
                                  "in bfloat16 or float32")
+        if 'rgbd' in self.args.input_modalities:
+            if feeds['rgb'].shape[0] != feeds['depth'].shape[0] or \
+                    feeds['rgb'].shape[2:] != feeds['depth'].shape[2:]:
+                raise _lib.EmsaError("batch['rgb'] and batch['depth'] differ in batch size or "
+                                     "resolution")
+            feeds = {'rgbd': torch.cat([feeds['rgb'], feeds['depth']], dim=1)}
         self._pack_plan.refresh(self.compute_dtype)
         if self.training and self._seed_dev is not None and \
                 not torch.cuda.is_current_stream_capturing():

@@ -219,11 +219,17 @@ class FusedEncoder(nn.Module):
     """dual ResNet-NBt1D with SE-add fusion after the stem and after every layer
     (`get_encoder(...)`, /root/reference/emsanet/model.py:95-106)."""
 
-    def __init__(self, backbone_rgb, backbone_depth, fusion, skip_downsamplings):
+    def __init__(self, backbone_rgb, backbone_depth, fusion, skip_downsamplings,
+                 backbone_rgbd=None):
         super().__init__()
         self.backbone_rgb = backbone_rgb
         self.backbone_depth = backbone_depth
+        # ONE encoder over the concatenated RGB-D image (/root/reference/emsanet/model.py:76-92)
+        self.backbone_rgbd = backbone_rgbd
+        if backbone_rgbd is not None and (backbone_rgb is not None or backbone_depth is not None):
+            raise ValueError("input modality 'rgbd' excludes 'rgb' and 'depth'")
         bb = backbone_rgb if backbone_rgb is not None else backbone_depth
+        bb = bb if bb is not None else backbone_rgbd
         self.two = backbone_rgb is not None and backbone_depth is not None
         if self.two:
             if fusion != 'se-add-uni-rgb':
@@ -239,6 +245,8 @@ class FusedEncoder(nn.Module):
     def forward(self, inputs, plan=None):
         """plan: a CutPlan (segmented backward); skips / outputs are then returned as
         (tensor, producing stage) pairs for the caller to cut at the decoder boundary"""
+        if self.backbone_rgbd is not None:
+            return self._forward_single('rgbd', self.backbone_rgbd, inputs['rgbd'], plan)
         rgb, depth = inputs.get('rgb'), inputs.get('depth')
         skips = {}
         bb = self.backbone_rgb if self.backbone_rgb is not None else self.backbone_depth
@@ -287,10 +295,22 @@ class FusedEncoder(nn.Module):
                 for k, v in (('rgb', rgb), ('depth', depth)) if v is not None}
         return outs, skips
 
+    def _forward_single(self, key, bb, x, plan):
+        """one encoder, no fusion modules: the stream is handed on under its modality's name"""
+        skips = {}
+        for i, ds in enumerate(bb.stage_downsamplings):
+            x = bb.forward_stage(i, x)
+            if ds in self.skip_downsamplings:
+                skips[str(ds)] = {key: x if plan is None else (x, i)}
+            if plan is not None and i in plan.stages:
+                x = plan.cut(x, i, i)
+        last = len(bb.stage_downsamplings) - 1
+        return {key: x if plan is None else (x, last)}, skips
+
     def stage_parameters(self, i):
         """parameters of encoder stage i (both modalities + the fusion module behind it)"""
         ps = []
-        for bb in (self.backbone_rgb, self.backbone_depth):
+        for bb in (self.backbone_rgb, self.backbone_depth, self.backbone_rgbd):
             if bb is None:
                 continue
             mods = [bb.conv1, bb.bn1] if i == 0 else [getattr(bb, f'layer{i}')]

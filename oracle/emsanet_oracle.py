@@ -268,11 +268,15 @@ class SEAddUniRGB(nn.Module):
 
 
 class FusedEncoder(nn.Module):
-    def __init__(self, backbone_rgb, backbone_depth, fusion, skip_downsamplings):
+    def __init__(self, backbone_rgb, backbone_depth, fusion, skip_downsamplings,
+                 backbone_rgbd=None):
         super().__init__()
         self.backbone_rgb = backbone_rgb
         self.backbone_depth = backbone_depth
+        self.backbone_rgbd = backbone_rgbd          # model.py:76-92: one encoder over cat(rgb, depth)
+        assert backbone_rgbd is None or (backbone_rgb is None and backbone_depth is None)
         bb = backbone_rgb if backbone_rgb is not None else backbone_depth
+        bb = bb if bb is not None else backbone_rgbd
         self.two = backbone_rgb is not None and backbone_depth is not None
         if self.two:
             assert fusion == 'se-add-uni-rgb', fusion
@@ -284,6 +288,13 @@ class FusedEncoder(nn.Module):
         self.skips_n_channels = tuple(ch[d] for d in self.skip_downsamplings)
 
     def forward(self, inputs):
+        if self.backbone_rgbd is not None:
+            x, skips = inputs['rgbd'], {}
+            for i, ds in enumerate(self.backbone_rgbd.stage_downsamplings):
+                x = self.backbone_rgbd.forward_stage(i, x)
+                if ds in self.skip_downsamplings:
+                    skips[str(ds)] = {'rgbd': x}
+            return {'rgbd': x}, skips
         rgb, depth = inputs.get('rgb'), inputs.get('depth')
         skips = {}
         bb = self.backbone_rgb if self.backbone_rgb is not None else self.backbone_depth
@@ -388,8 +399,9 @@ class DecoderModule(nn.Module):
 
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
-                 fusion_downsamplings, side_head_factory):
+                 fusion_downsamplings, side_head_factory, fusion='add-rgb'):
         super().__init__()
+        self.fusion = fusion            # 'add-<modality>', or 'add' = the only stream there is
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
             mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc))
@@ -402,7 +414,13 @@ class DecoderBody(nn.Module):
         sides = []
         for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
                             self.fusion_downsamplings):
-            x, s = m(x, skips[str(ds)]['rgb'], h)
+            sk = skips[str(ds)]
+            if self.fusion.startswith('add-'):
+                skip = sk[self.fusion[4:]]
+            else:
+                assert len(sk) == 1, "fusion 'add' needs a single modality"
+                skip = next(iter(sk.values()))
+            x, s = m(x, skip, h)
             sides.append(s)
         return x, tuple(sides)
 
@@ -435,6 +453,19 @@ class SemanticDecoder(DecoderBody):
             score, idx = F.softmax(out, dim=1).max(dim=1)
             r['semantic_segmentation_score'], r['semantic_segmentation_idx'] = score, idx
         return r
+
+
+class NormalDecoder(SemanticDecoder):
+    """decoder.py:160-175: the class lives in the un-vendored library [U]; restated as the dense
+    decoder with `normal_n_channels_out` raw output maps (no activation, no normalisation)"""
+
+    def forward(self, x, skips, batch=None, do_postprocessing=False):
+        x, sides = DecoderBody.forward(self, x[0], skips)
+        out = self.head(x)
+        sides = sides if self.training else ()
+        if not do_postprocessing:
+            return out, sides
+        return {'normal_output': out, 'normal_side_outputs': sides}
 
 
 class InstanceHead(nn.Module):
@@ -525,7 +556,6 @@ class EMSANetOracle(nn.Module):
         n_sem = len(dataset_config.semantic_label_list_without_void)
         n_scene = len(dataset_config.scene_label_list_without_void)
         mods = tuple(args.input_modalities)
-        assert 'rgbd' not in mods, "rgbd single-encoder variant not restated"
 
         def bb(name, block, cin):
             assert block == 'nonbottleneck1d', block
@@ -535,8 +565,10 @@ class EMSANetOracle(nn.Module):
             if 'rgb' in mods else None
         b_d = bb(args.depth_encoder_backbone, args.depth_encoder_backbone_resnet_block, 1) \
             if 'depth' in mods else None
+        b_rgbd = bb(args.rgbd_encoder_backbone, args.rgbd_encoder_backbone_resnet_block, 3 + 1) \
+            if 'rgbd' in mods else None
         self.encoder = FusedEncoder(b_rgb, b_d, args.encoder_fusion,
-                                    args.encoder_decoder_skip_downsamplings)
+                                    args.encoder_decoder_skip_downsamplings, backbone_rgbd=b_rgbd)
         assert args.context_module == 'ppm'
         self.context_module = PyramidPoolingModule(
             512, 512, (args.input_height // 32, args.input_width // 32))
@@ -550,7 +582,8 @@ class EMSANetOracle(nn.Module):
                 n_channels=tuple(args.semantic_decoder_n_channels),
                 n_blocks=args.semantic_decoder_n_blocks,
                 dropout_p=args.semantic_decoder_block_dropout_p,
-                fusion_n_channels=fus_c, fusion_downsamplings=fus_d)
+                fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
+                fusion=args.semantic_encoder_decoder_fusion)
         if 'instance' in args.tasks:
             if args.instance_offset_encoding not in ('tanh', 'relative', 'deeplab'):
                 raise NotImplementedError
@@ -562,7 +595,16 @@ class EMSANetOracle(nn.Module):
                 n_channels=tuple(args.instance_decoder_n_channels),
                 n_blocks=args.instance_decoder_n_blocks,
                 dropout_p=args.instance_decoder_block_dropout_p,
-                fusion_n_channels=fus_c, fusion_downsamplings=fus_d)
+                fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
+                fusion=args.instance_encoder_decoder_fusion)
+        if 'normal' in args.tasks:
+            dec['normal_decoder'] = NormalDecoder(
+                n_classes=3, n_channels_in=512,
+                n_channels=tuple(getattr(args, 'normal_decoder_n_channels', (512, 256, 128))),
+                n_blocks=getattr(args, 'normal_decoder_n_blocks', 3),
+                dropout_p=getattr(args, 'normal_decoder_block_dropout_p', 0.2),
+                fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
+                fusion=getattr(args, 'normal_encoder_decoder_fusion', 'add-rgb'))
         if 'scene' in args.tasks:
             dec['scene_decoder'] = SceneClassificationDecoder(
                 self.context_module.n_channels_reduction, n_scene)
@@ -593,7 +635,10 @@ class EMSANetOracle(nn.Module):
         return (self.dropout_seed + 0x632BE5AB * self.dropout_step) & 0xFFFFFFFF
 
     def forward(self, batch, do_postprocessing=False):
-        enc_inputs = {k: batch[k] for k in ('rgb', 'depth') if k in self.args.input_modalities}
+        if 'rgbd' in self.args.input_modalities:        # model.py:195-199
+            enc_inputs = {'rgbd': torch.cat([batch['rgb'], batch['depth']], dim=1)}
+        else:
+            enc_inputs = {k: batch[k] for k in ('rgb', 'depth') if k in self.args.input_modalities}
         enc_outputs, skips = self.encoder(enc_inputs)
         con_in = enc_outputs['rgb'] if len(enc_inputs) == 2 else list(enc_outputs.values())[0]
         con_out, con_ctx = self.context_module(con_in)

@@ -47,7 +47,9 @@ def _flat(o):
 @pytest.mark.parametrize('tasks,panoptic', [(('semantic',), False),
                                             (('semantic', 'instance'), False),
                                             (('semantic', 'instance', 'orientation', 'scene'), False),
-                                            (('semantic', 'instance', 'orientation', 'scene'), True)])
+                                            (('semantic', 'instance', 'orientation', 'scene'), True),
+                                            (('semantic', 'instance', 'orientation', 'scene', 'normal'),
+                                             False)])
 @pytest.mark.parametrize('training', [False, True])
 @pytest.mark.parametrize('do_postprocessing', [False, True])
 def test_get_decoders_standalone_reference_inputs(tasks, panoptic, training, do_postprocessing):
@@ -88,11 +90,17 @@ def test_get_decoders_standalone_reference_inputs(tasks, panoptic, training, do_
                 assert main.shape == (3, 40, H, W)
                 for s, d in zip(sides, (32, 16, 8)):
                     assert s.shape == (3, 40, H // d, W // d)
+            if name == 'normal_decoder':
+                assert main.shape == (3, 3, H, W)
+                for s, d in zip(sides, (32, 16, 8)):
+                    assert s.shape == (3, 3, H // d, W // d)
             if name == 'instance_decoder':
                 assert [t.shape[1] for t in main] == ([1, 2, 2] if 'orientation' in tasks else [1, 2])
                 assert all(t.shape[2:] == (H, W) for t in main)
         else:
             assert isinstance(o, dict) and len(o), name
+            if name == 'normal_decoder':
+                assert set(o) == {'normal_output', 'normal_side_outputs'}
     a, b = _flat(outs), _flat(outs_cl)
     assert len(a) == len(b) and len(a) > 0
     for t, u in zip(a, b):

@@ -576,6 +576,26 @@ def test_pinned_gradients_small(fold, monkeypatch):
                         tol_out=TOL, tol_grad=2e-3)
 
 
+def test_pinned_gradients_five_tasks_with_normal(monkeypatch):
+    """the reference's widest task set (tests/test_interface_model.py:129-132: semantic, instance,
+    orientation, scene, normal): outputs and all gradients vs the fp64 oracle, three dense decoders"""
+    from emsanet_amd import full_args
+    args = full_args(input_height=96, input_width=128,
+                     tasks=('semantic', 'instance', 'orientation', 'scene', 'normal'))
+    _pinned_grad_parity(args, 4, 99, monkeypatch, tol_out=TOL, tol_grad=2e-3)
+
+
+@pytest.mark.parametrize('fusion', ['add-rgbd', 'add'])
+def test_pinned_gradients_rgbd_single_encoder(fusion, monkeypatch):
+    """input modality 'rgbd' (/root/reference/emsanet/model.py:76-92,195-199): ONE ResNet-NBt1D over
+    cat(rgb, depth) (4-channel stem), no encoder fusion modules, the decoders take the 'rgbd'
+    skips; outputs and all gradients vs the fp64 oracle"""
+    from emsanet_amd import full_args
+    args = full_args(input_height=96, input_width=128, input_modalities=('rgbd',),
+                     semantic_encoder_decoder_fusion=fusion, instance_encoder_decoder_fusion=fusion)
+    _pinned_grad_parity(args, 4, 31, monkeypatch, tol_out=TOL, tol_grad=2e-3)
+
+
 def test_pinned_gradients_baseline_resolution(monkeypatch):
     """BASELINE configs[1] shape: 640x480 RGB-D, all heads, train mode, bs=2 (what the fp64 CPU
     oracle finishes in seconds): every output and every one of the 742 gradients vs fp64; bn1 folded
