@@ -45,10 +45,8 @@ class EMSANet(nn.Module):
                 nets[modality] = None
                 continue
             block = getattr(args, f'{modality}_encoder_backbone_resnet_block')
-            if block != 'nonbottleneck1d':
-                raise NotImplementedError(f"resnet block '{block}' (hot path is NBt1D)")
             nets[modality] = ResNetNBt1D(getattr(args, f'{modality}_encoder_backbone'), n_in,
-                                         args.dropout_p)
+                                         args.dropout_p, block=block)
         self.encoder = FusedEncoder(nets['rgb'], nets['depth'], args.encoder_fusion,
                                     args.encoder_decoder_skip_downsamplings,
                                     backbone_rgbd=nets['rgbd'])
@@ -139,6 +137,7 @@ class EMSANet(nn.Module):
                 rts.append(crt)
             if isinstance(rt, ops.MultiConvRT):
                 rts.append(rt)
+            rts += list(getattr(m, '_crts', ()))        # basic / bottleneck blocks
         self._pack_plan = ops.PackPlan(rts)
         # storage type of the activations (NOT a reference option: the reference has no mixed
         # precision): 'float32' = the reference's arithmetic (default), 'bfloat16' =

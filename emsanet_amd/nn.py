@@ -112,25 +112,91 @@ class NonBottleneck1D(nn.Module):
         return ops.NBt1DFunction.apply(x, self._rt, drop, *self._rt.params())
 
 
-class ResNetNBt1D(nn.Module):
-    """ResNet-18/34/101 layout with NonBottleneck1D blocks (expansion 1)."""
+class _ResidualBlock(nn.Module):
+    """conv -> BN -> ReLU chains closed by conv -> BN -> + identity -> ReLU, built from the
+    conv + BatchNorm functions of the decoders (no block-level fusion: an ablation option of the
+    reference, `--*-encoder-backbone-resnet-block`, args.py:159-166)."""
 
-    def __init__(self, name, n_input_channels, dropout_p):
+    def _add(self, name, cin, cout, k, stride=1):
+        conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+        bn = nn.BatchNorm2d(cout, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM)
+        setattr(self, f'conv{name}', conv)
+        setattr(self, f'bn{name}', bn)
+        rt = (ops.ConvRT(conv), ops.BNRT(bn), conv, bn)
+        self._crts.append(rt[0])
+        return rt
+
+    def _finish(self, cin, cout, stride):
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(cout, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM))
+            self._ds = (ops.ConvRT(self.downsample[0]), ops.BNRT(self.downsample[1]),
+                        self.downsample[0], self.downsample[1])
+            self._crts.append(self._ds[0])
+        else:
+            self.downsample, self._ds = None, None
+
+    def forward(self, x):
+        fast = _fast_eval(self)
+        x = Fn.as_act(x, dense=True) if fast else x
+        y = x
+        for crt, brt, conv, bn in self._chain[:-1]:
+            y = ops.conv_bn_act_eval(y, crt, brt, ACT_RELU) if fast else \
+                ops.ConvBNActFunction.apply(y, crt, brt, ACT_RELU, conv.weight, bn.weight, bn.bias)
+        idn = x
+        if self._ds is not None:
+            crt, brt, conv, bn = self._ds
+            idn = ops.conv_bn_act_eval(x, crt, brt, ACT_NONE) if fast else \
+                ops.ConvBNActFunction.apply(x, crt, brt, ACT_NONE, conv.weight, bn.weight, bn.bias)
+        crt, brt, conv, bn = self._chain[-1]
+        if fast:
+            return ops.conv_bn_act_eval(y, crt, brt, ACT_RELU, residual=idn)
+        return ops.ConvBNAddActFunction.apply(y, idn, crt, brt, ACT_RELU, conv.weight, bn.weight,
+                                              bn.bias)
+
+
+class BasicBlock(_ResidualBlock):
+    """'basicblock': conv3x3(stride) -> BN -> ReLU -> conv3x3 -> BN -> + identity -> ReLU; children
+    conv1 / bn1 / conv2 / bn2 / downsample (torchvision's names [U])."""
+    expansion = 1
+
+    def __init__(self, cin, c, stride=1, dropout_p=0.0):
+        super().__init__()
+        self._crts = []
+        self._chain = [self._add('1', cin, c, 3, stride), self._add('2', c, c, 3)]
+        self._finish(cin, c, stride)
+
+
+# ('bottleneck' is refused: its 1024 / 2048-channel stages exceed the 1024 channels the BatchNorm /
+#  SE reduction kernels take per workgroup row, csrc/pointwise.hip c4_ok)
+RESNET_BLOCKS = {'nonbottleneck1d': None, 'basicblock': BasicBlock}
+
+
+class ResNetNBt1D(nn.Module):
+    """ResNet-18/34/101 layout; NonBottleneck1D blocks (the published models) or, `block=`, basic
+    blocks (both expansion 1)."""
+
+    def __init__(self, name, n_input_channels, dropout_p, block='nonbottleneck1d'):
         super().__init__()
         if name not in Spec.RESNET_LAYERS:
-            raise NotImplementedError(f"backbone '{name}' (only NBt1D ResNet-18/34/101)")
+            raise NotImplementedError(f"backbone '{name}' (ResNet-18/34/101 layouts)")
+        if block not in RESNET_BLOCKS:
+            raise NotImplementedError(f"resnet block '{block}'")
         layers = Spec.RESNET_LAYERS[name]
         self.conv1 = nn.Conv2d(n_input_channels, 64, 7, stride=2, padding=3, bias=Spec.STEM_BIAS)
         self.bn1 = nn.BatchNorm2d(64, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM)
         cin = 64
+        cls = RESNET_BLOCKS[block] or NonBottleneck1D
+        exp = getattr(cls, 'expansion', 1)
         for i, (c, n) in enumerate(zip((64, 128, 256, 512), layers)):
             blocks = []
             for j in range(n):
-                blocks.append(NonBottleneck1D(cin, c, stride=2 if (i > 0 and j == 0) else 1,
-                                              dropout_p=dropout_p))
-                cin = c
+                blocks.append(cls(cin, c, stride=2 if (i > 0 and j == 0) else 1,
+                                  dropout_p=dropout_p))
+                cin = c * exp
             setattr(self, f'layer{i + 1}', nn.Sequential(*blocks))
-        self.stage_channels = (64, 64, 128, 256, 512)
+        self.stage_channels = (64, 64 * exp, 128 * exp, 256 * exp, 512 * exp)
         self.stage_downsamplings = (2, 4, 8, 16, 32)
         self._stem = ops.StemRT(self.conv1, self.bn1)
         # storage type of the activations this backbone produces (set by EMSANet.set_compute_dtype):
@@ -238,7 +304,7 @@ class FusedEncoder(nn.Module):
         self.skip_downsamplings = tuple(skip_downsamplings)
         self._side_stream = None
         self.downsampling = 32
-        self.n_channels_out = 512
+        self.n_channels_out = bb.stage_channels[-1]
         ch = dict(zip(bb.stage_downsamplings, bb.stage_channels))
         self.skips_n_channels = tuple(ch[d] for d in self.skip_downsamplings)
 

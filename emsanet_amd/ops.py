@@ -590,9 +590,39 @@ class ConvBNActFunction(Function):
         return dx, None, None, None, dw, dg, db
 
 
-def conv_bn_act_eval(x, crt, brt, act):
+class ConvBNAddActFunction(Function):
+    """act(bn(conv(x)) + residual): the closing conv of a basic / bottleneck ResNet block"""
+
+    @staticmethod
+    def forward(ctx, x, residual, crt, brt, act, weight, gamma, beta):
+        x, residual = Fn.as_act(x), Fn.as_act(residual, dense=True)
+        out, y, mean, invstd, mask = _conv_bn_forward(x, crt, brt, act, residual=residual)
+        if act == ACT_RELU:
+            _trace_mask('conv_bn_add_act', out)
+        ctx.crt, ctx.brt, ctx.act = crt, brt, act
+        ctx.save_for_backward(x)
+        ctx.saved = (y, mean, invstd, mask)
+        ctx.bn_train = brt.batch_stats()
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_traced
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        y, mean, invstd, mask = ctx.saved
+        ctx.saved = None
+        dout = Fn.as_act(dout, dense=True)
+        dy, dres, dg, db = Fn.bn_bwd(dout, mask, y, ctx.brt.bn.weight.detach(), mean, invstd, None,
+                                     ctx.act, ctx.bn_train, want_dres=ctx.needs_input_grad[1],
+                                     **_bn_targets(ctx.brt))
+        dx, dw, _ = _conv_backward(x, dy, ctx.crt, ctx.needs_input_grad[0])
+        return dx, dres, None, None, None, dw, dg, db
+
+
+def conv_bn_act_eval(x, crt, brt, act, residual=None):
     s, t = brt.folded()
-    return crt.forward(x, scale=s, shift=t, act=act)
+    return crt.forward(x, scale=s, shift=t, act=act, residual=residual)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ class Spec:
     #                              ('always': also when they match; False: never)
     ORIENTATION_L2_NORMALIZE = False   # [U] raw 2-ch biternion
     RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
-                     'resnet101': (3, 4, 23, 3)}   # NBt1D has expansion 1 -> 64/128/256/512
+                     'resnet101': (3, 4, 23, 3)}
     # Storage emulation (NOT part of the reference, which computes in fp32): None = plain
     # arithmetic in the module's dtype.  torch.bfloat16 / torch.float16: every tensor the 16-bit
     # engine keeps in HBM is rounded to that type where the engine rounds it (conv / BN+act / SE /
@@ -219,21 +219,65 @@ class NonBottleneck1D(nn.Module):
         return store(F.relu(out + identity))
 
 
+class _ResidualBlock(nn.Module):
+    """conv -> BN -> ReLU ... conv -> BN -> + identity -> ReLU (`--*-encoder-backbone-resnet-block`
+    basicblock, args.py:159-166; the classes live in the un-vendored library:
+    torchvision's layout, names and stride placement assumed [U])"""
+
+    def _make(self, specs, cin, cout_last, stride):
+        self.n_convs = len(specs)
+        for i, (ci, co, k, st) in enumerate(specs, 1):
+            setattr(self, f'conv{i}', nn.Conv2d(ci, co, k, stride=st, padding=k // 2, bias=False))
+            setattr(self, f'bn{i}', nn.BatchNorm2d(co, eps=Spec.DEFAULT_BN_EPS,
+                                                   momentum=Spec.BN_MOMENTUM))
+        if stride != 1 or cin != cout_last:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout_last, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(cout_last, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        fused = _fused_eval(self)
+        out = x
+        for i in range(1, self.n_convs):
+            conv, bn = getattr(self, f'conv{i}'), getattr(self, f'bn{i}')
+            out = store(F.relu(bn_q(bn, conv_q(conv, out), fused)))
+        conv, bn = getattr(self, f'conv{self.n_convs}'), getattr(self, f'bn{self.n_convs}')
+        out = bn_q(bn, conv_q(conv, out), fused)
+        identity = x if self.downsample is None else \
+            store(bn_q(self.downsample[1], conv_q(self.downsample[0], x), fused))
+        return store(F.relu(out + identity))
+
+
+class BasicBlock(_ResidualBlock):
+    expansion = 1
+
+    def __init__(self, cin, c, stride=1, dropout_p=0.0):
+        super().__init__()
+        self._make([(cin, c, 3, stride), (c, c, 3, 1)], cin, c, stride)
+
+
+RESNET_BLOCKS = {'nonbottleneck1d': NonBottleneck1D, 'basicblock': BasicBlock}
+
+
 class ResNetNBt1D(nn.Module):
-    def __init__(self, name, n_input_channels, dropout_p):
+    def __init__(self, name, n_input_channels, dropout_p, block='nonbottleneck1d'):
         super().__init__()
         layers = Spec.RESNET_LAYERS[name]
+        cls = RESNET_BLOCKS[block]
+        exp = getattr(cls, 'expansion', 1)
         self.conv1 = nn.Conv2d(n_input_channels, 64, 7, stride=2, padding=3, bias=Spec.STEM_BIAS)
         self.bn1 = nn.BatchNorm2d(64, eps=Spec.DEFAULT_BN_EPS, momentum=Spec.BN_MOMENTUM)
         cin = 64
         for i, (c, n) in enumerate(zip((64, 128, 256, 512), layers)):
             blocks = []
             for j in range(n):
-                blocks.append(NonBottleneck1D(cin, c, stride=2 if (i > 0 and j == 0) else 1,
-                                              dropout_p=dropout_p))
-                cin = c
+                blocks.append(cls(cin, c, stride=2 if (i > 0 and j == 0) else 1,
+                                  dropout_p=dropout_p))
+                cin = c * exp
             setattr(self, f'layer{i + 1}', nn.Sequential(*blocks))
-        self.stage_channels = (64, 64, 128, 256, 512)
+        self.stage_channels = (64, 64 * exp, 128 * exp, 256 * exp, 512 * exp)
         self.stage_downsamplings = (2, 4, 8, 16, 32)
 
     def forward_stage(self, i, x):
@@ -283,7 +327,7 @@ class FusedEncoder(nn.Module):
             self.fusion_modules = nn.ModuleList([SEAddUniRGB(c) for c in bb.stage_channels])
         self.skip_downsamplings = tuple(skip_downsamplings)
         self.downsampling = 32
-        self.n_channels_out = 512
+        self.n_channels_out = bb.stage_channels[-1]
         ch = dict(zip(bb.stage_downsamplings, bb.stage_channels))
         self.skips_n_channels = tuple(ch[d] for d in self.skip_downsamplings)
 
@@ -558,8 +602,7 @@ class EMSANetOracle(nn.Module):
         mods = tuple(args.input_modalities)
 
         def bb(name, block, cin):
-            assert block == 'nonbottleneck1d', block
-            return ResNetNBt1D(name, cin, args.dropout_p)
+            return ResNetNBt1D(name, cin, args.dropout_p, block=block)
 
         b_rgb = bb(args.rgb_encoder_backbone, args.rgb_encoder_backbone_resnet_block, 3) \
             if 'rgb' in mods else None
@@ -570,15 +613,16 @@ class EMSANetOracle(nn.Module):
         self.encoder = FusedEncoder(b_rgb, b_d, args.encoder_fusion,
                                     args.encoder_decoder_skip_downsamplings, backbone_rgbd=b_rgbd)
         assert args.context_module == 'ppm'
+        c_enc = self.encoder.n_channels_out
         self.context_module = PyramidPoolingModule(
-            512, 512, (args.input_height // 32, args.input_width // 32))
+            c_enc, c_enc, (args.input_height // 32, args.input_width // 32))
 
         fus_c = self.encoder.skips_n_channels[::-1]
         fus_d = tuple(args.encoder_decoder_skip_downsamplings)[::-1]
         dec = OrderedDict()
         if 'semantic' in args.tasks:
             dec['semantic_decoder'] = SemanticDecoder(
-                n_classes=n_sem, n_channels_in=512,
+                n_classes=n_sem, n_channels_in=c_enc,
                 n_channels=tuple(args.semantic_decoder_n_channels),
                 n_blocks=args.semantic_decoder_n_blocks,
                 dropout_p=args.semantic_decoder_block_dropout_p,
@@ -591,7 +635,7 @@ class EMSANetOracle(nn.Module):
                 with_orientation='orientation' in args.tasks,
                 sigmoid_for_center=args.instance_center_encoding == 'sigmoid',
                 tanh_for_offset=args.instance_offset_encoding == 'tanh',
-                n_channels_in=512,
+                n_channels_in=c_enc,
                 n_channels=tuple(args.instance_decoder_n_channels),
                 n_blocks=args.instance_decoder_n_blocks,
                 dropout_p=args.instance_decoder_block_dropout_p,
@@ -599,7 +643,7 @@ class EMSANetOracle(nn.Module):
                 fusion=args.instance_encoder_decoder_fusion)
         if 'normal' in args.tasks:
             dec['normal_decoder'] = NormalDecoder(
-                n_classes=3, n_channels_in=512,
+                n_classes=3, n_channels_in=c_enc,
                 n_channels=tuple(getattr(args, 'normal_decoder_n_channels', (512, 256, 128))),
                 n_blocks=getattr(args, 'normal_decoder_n_blocks', 3),
                 dropout_p=getattr(args, 'normal_decoder_block_dropout_p', 0.2),

@@ -124,6 +124,8 @@ def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         _model(full_args(rgb_encoder_backbone='resnet50'))
     with pytest.raises(NotImplementedError):
+        _model(full_args(rgb_encoder_backbone_resnet_block='bottleneck'))
+    with pytest.raises(NotImplementedError):
         _model(full_args(semantic_decoder='segformermlp'))
     with pytest.raises(NotImplementedError):
         _model(full_args(instance_offset_encoding='bogus'))

@@ -596,6 +596,28 @@ def test_pinned_gradients_rgbd_single_encoder(fusion, monkeypatch):
     _pinned_grad_parity(args, 4, 31, monkeypatch, tol_out=TOL, tol_grad=2e-3)
 
 
+@pytest.mark.parametrize('backbone,block', [('resnet18', 'basicblock'), ('resnet34', 'basicblock')])
+def test_pinned_gradients_other_resnet_blocks(backbone, block, monkeypatch):
+    """`--*-encoder-backbone-resnet-block basicblock` (/root/reference/emsanet/args.py:159-166):
+    train-mode outputs and all gradients vs the fp64 oracle, then the no-grad eval path (BatchNorm
+    folded into the conv epilogues, residual added there) vs the oracle's eval forward."""
+    from emsanet_amd import full_args
+    from oracle.emsanet_oracle import synthetic_batch
+    kw = dict(input_height=96, input_width=128, rgb_encoder_backbone=backbone,
+              depth_encoder_backbone=backbone, rgb_encoder_backbone_resnet_block=block,
+              depth_encoder_backbone_resnet_block=block)
+    _pinned_grad_parity(full_args(**kw), 4, 17, monkeypatch, tol_out=TOL, tol_grad=2e-3)
+    model, o32, o64 = _triple(full_args(**kw), seed=3)
+    batch = synthetic_batch(2, 96, 128)
+    for m in (model, o64):
+        m.eval()
+    with torch.no_grad():
+        ref = o64({k: v.double() for k, v in batch.items()})
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+    for i, (a, b) in enumerate(zip(_flatten(out), _flatten(ref))):
+        assert _rel(a, b) <= TOL, f"eval output {i}: {_rel(a, b):.3e}"
+
+
 def test_pinned_gradients_baseline_resolution(monkeypatch):
     """BASELINE configs[1] shape: 640x480 RGB-D, all heads, train mode, bs=2 (what the fp64 CPU
     oracle finishes in seconds): every output and every one of the 742 gradients vs fp64; bn1 folded
