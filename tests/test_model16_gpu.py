@@ -107,6 +107,40 @@ def test_eval_16bit_vs_fp32_oracle(shape, dtype):
     print(f"{dtype} eval {shape}: worst output rel-L2 {worst:.2e}, semantic arg-max agreement {fs:.5f}")
 
 
+@pytest.mark.parametrize('variant', ['rgbd', 'basicblock', 'normal'])
+def test_option_space_bf16(variant):
+    """the model options beyond BASELINE's configs in bf16 storage: eval forward vs the fp32 oracle
+    at the eval tolerance, and a train step (forward + backward) with finite gradients everywhere"""
+    from emsanet_amd import full_args
+    from oracle.emsanet_oracle import synthetic_batch
+    kw = dict(input_height=96, input_width=128)
+    if variant == 'rgbd':
+        kw.update(input_modalities=('rgbd',), semantic_encoder_decoder_fusion='add-rgbd',
+                  instance_encoder_decoder_fusion='add-rgbd')
+    elif variant == 'basicblock':
+        kw.update(rgb_encoder_backbone='resnet18', depth_encoder_backbone='resnet18',
+                  rgb_encoder_backbone_resnet_block='basicblock',
+                  depth_encoder_backbone_resnet_block='basicblock')
+    else:
+        kw.update(tasks=('semantic', 'instance', 'orientation', 'scene', 'normal'))
+    model, oracle = _pair(full_args(**kw))
+    model.set_compute_dtype(torch.bfloat16)
+    batch = synthetic_batch(4, 96, 128)
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    model.eval(), oracle.eval()
+    with torch.no_grad():
+        ref = _flatten(oracle(batch))
+        out = _flatten(model(dev_batch))
+    for i, (a, b) in enumerate(zip(out, ref)):
+        e = _rel_l2(a, b)
+        assert a.dtype == torch.float32 and e <= OUT_TOL[torch.bfloat16], f"{variant} output {i}: {e:.3e}"
+    model.train()
+    outs = _flatten(model(dev_batch))
+    sum((t * t).mean() for t in outs).backward()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_eval_16bit_vs_storage_emulating_oracle(dtype, monkeypatch):
     """the same eval forward against the fp64 oracle that ROUNDS WHERE THE ENGINE ROUNDS
