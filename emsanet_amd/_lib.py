@@ -171,6 +171,13 @@ SIGNATURES = {
     'emsa_conv_wgrad_ws_bytes_t': (c_int64, [c_int32, _GP]),
     'emsa_conv_wgrad_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P]),
     'emsa_pack_weight_t': (c_int, [c_int32, _P, _P, _P] + [c_int32] * 8 + [_P]),
+    'emsa_conv1d_rs_supported': (c_int, [c_int32, _GP]),
+    'emsa_conv1d_rs_stats_rows': (c_int, [c_int32, _GP]),
+    'emsa_conv1d_rs_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
+                                 c_int32, _P]),
+    'emsa_conv1d_rs_bnb_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P,
+                                     _P, _P, c_int32, _P]),
+    'emsa_pack_weight_frag_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     'emsa_stem_pack_weight_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, _P]),
     'emsa_dropout2d_mask_dev': (c_int, [_P, c_int32, c_int32, c_float, _P, c_uint32, _P]),
     'emsa_u32_add': (c_int, [_P, c_uint32, _P]),

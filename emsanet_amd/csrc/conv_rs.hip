@@ -1,0 +1,734 @@
+// Register-stationary streaming convolution for the stride-1 3-tap 1-D convs of the NBt1D blocks
+// (/root/reference/emsanet/model.py:47-58, args.py:158-164: conv3x1 / conv1x3 with C_in = C_out in
+// {64, 128, 256, 512}) in 16-bit storage: forward and data gradient of BASELINE.json configs[2] / [4].
+//
+// What conv_h.hip's generic implicit GEMM does per 128x64 tile -- fetch the weight panel again,
+// fetch the activation rows once per tap, 6-24 barrier-separated K steps, drain -- is a serial
+// latency chain per workgroup (0.24 of the HBM roofline for three rounds).  This kernel
+// turns the loop nest inside out:
+//   * WEIGHTS STAY IN REGISTERS.  A workgroup is persistent (one or two per CU for the whole launch)
+//     and each wave keeps its slice of the weights as ready-made MFMA B operands: 24 fragments of
+//     v_mfma_f32_32x32x16 (3 taps x 128 input channels x 32 output channels, or 3 x 64 x 64 at
+//     C = 64) = 96 VGPRs, loaded ONCE per launch with fully coalesced 1 KB loads from the
+//     fragment-ordered weight image of emsa_pack_weight_frag_t.  Waves of a workgroup split the
+//     output channels (WN) and, for C >= 256, the input channels (WK; partial sums meet in LDS).
+//   * ACTIVATIONS STREAM THROUGH LDS ONCE.  A tile of output pixels is loaded with its halo by
+//     LDS-DMA (buffer_load ... lds), double buffered across tiles, and all three taps read it at
+//     shifted rows: no per-tap re-fetch, no K loop over global memory, one barrier pair per tile.
+//     1x3: 32*TM*WM consecutive pixels + 2 halo pixels, the left / right image borders redirected to
+//     a row of zeros; 3x1: a TH x TW patch + 2 halo rows, zero padding by out-of-range DMA offsets.
+//   * per MFMA one ds_read_b128 of the A operand (two MFMAs at C = 64) and nothing else: the LDS
+//     pipe runs at <= 50 % of the matrix pipe's issue time, A reads are software-pipelined by hand.
+//   * same fused epilogue as emsa_conv_igemm_t (bias, BatchNorm batch statistics, folded BatchNorm,
+//     residual, ReLU, ReLU-backward mask, fused BatchNorm-backward sums), taken from fp32 values in
+//     an LDS stage so that every global access is 16 bytes per lane / full 128-byte lines.
+// HBM traffic = input + output once; L2 -> LDS traffic = input x (C_out / channels per workgroup).
+#include <cstdlib>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+typedef unsigned int ru32x4 __attribute__((ext_vector_type(4)));
+typedef float rf32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rf16x8 __attribute__((ext_vector_type(8)));
+constexpr uint32_t kROOB = 0x80000000u;
+
+template <typename T> struct RVec8;
+template <> struct RVec8<emsa_bf16> { typedef rbf16x8 type; };
+template <> struct RVec8<emsa_f16> { typedef rf16x8 type; };
+
+__device__ __forceinline__ f32x16 rmfma(rbf16x8 a, rbf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 rmfma(rf16x8 a, rf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+struct RFastDiv {
+  uint32_t mul, shift, d;
+};
+inline RFastDiv r_make_fastdiv(uint32_t d) {
+  RFastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.mul = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ uint32_t r_fast_div(uint32_t n, const RFastDiv& f) {
+  return (__umulhi(n, f.mul) + n) >> f.shift;
+}
+
+struct ConvRSArgs {
+  const void* in;
+  const void* wf;
+  void* out;
+  const float* bias;
+  float* stats;
+  const float* scale;
+  const float* shift;
+  const void* residual;
+  const void* mask_src;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  float* bnb_out;
+  int bnb_rows_alloc;
+  int ld_res, ld_mask, act, ld_out;
+  uint32_t in_bytes, wf_bytes, out_bytes, res_bytes, mask_bytes;
+  int M, H, W, n_img;
+  int px_bytes, row_bytes, img_bytes;  // input strides in bytes
+  int sign;                 // tap t reads the pixel at sign * (t - 1) along the conv direction
+  int n_ch;
+  int tiles, tiles_w, twl, th;   // 3x1: TW = 1 << twl columns x th rows per tile
+  int gx;                   // workgroups per XCD and channel slice
+  int nslice;
+  int ni;                   // DMA instructions (1 KB each) per tile
+  int abuf;                 // bytes of one A buffer
+  int stat_rows;            // rows of the statistics / BatchNorm-backward partial buffers
+  RFastDiv div_w, div_tpi, div_tw;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t r_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// bank swizzle of the A tile (rows of RB bytes written lane-linearly by the DMA): the 16-byte chunk
+// c of row R lives at chunk c ^ swz(R).  ds_read_b128 serves 16 lanes (= 16 rows, one chunk index)
+// per LDS cycle; they must hit 16 different 16-byte slots of the 256-byte bank row.
+template <int CPR>
+__device__ __forceinline__ int r_swz(int R) {
+  return CPR == 8 ? ((R >> 1) & 7) : (R & 15);
+}
+
+// T storage type; KC = C_in; wave tile 32*TM pixels x 32*TN channels x (KC / WK) input channels;
+// workgroup = WM x WN x WK waves; DIRH: taps along H (3x1) instead of W (1x3); BNB: the data
+// gradient with the BatchNorm-backward sums of the layer in front (emsa_conv_igemm_bnb_t).
+template <typename T, int KC, int TN, int WM, int WN, int WK, int TM, bool DIRH, bool BNB>
+__global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const ConvRSArgs p) {
+  typedef typename RVec8<T>::type V8;
+  constexpr int NWV = WM * WN * WK, NT = 64 * NWV;
+  constexpr int KS = KC / 16, KSW = KS / WK;          // k16 steps: all / per wave
+  constexpr int RB = KC * 2, CPR = KC / 8, RPI = 64 / CPR;
+  constexpr int BM = 32 * TM * WM, NWG = 32 * TN * WN;
+  constexpr int SLD = NWG + 4;
+  constexpr int NF = 3 * KSW;                         // A fragments per 32-pixel row tile
+  static_assert(KS % WK == 0 && 64 % CPR == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+
+  // ---- persistent schedule: XCD x gets the tiles [x T/8, (x+1) T/8) so that neighbouring tiles
+  // (halo rows) and the channel slices of one tile meet in one L2 ------------------------------
+  const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+  const int slice = qb % p.nslice, idx = qb / p.nslice;
+  const int tile_hi = (int)(((long)(xcd + 1) * p.tiles) >> 3);
+  int tile = (int)(((long)xcd * p.tiles) >> 3) + idx;
+  const int n_base = slice * NWG;                     // first output channel of this workgroup
+
+  const int zoff = 2 * p.abuf;                        // row of zeros (1x3 borders)
+  const int soff = zoff + RB;                         // fp32 stage [WK][BM][SLD]
+  float* const stage = reinterpret_cast<float*>(smem + soff);
+
+  if (!DIRH) {
+    for (int i = tid; i < RB / 4; i += NT) reinterpret_cast<uint32_t*>(smem + zoff)[i] = 0u;
+  }
+
+  // ---- weights: 3 * KSW * TN fragments, resident for the whole launch ------------------------
+  const __amdgpu_buffer_rsrc_t rs_w = r_rsrc(p.wf, p.wf_bytes);
+  const __amdgpu_buffer_rsrc_t rs_in = r_rsrc(p.in, p.in_bytes);
+  V8 bf[3][KSW][TN];
+  {
+    const int NB = p.n_ch >> 5;
+    const int nb0 = (n_base >> 5) + wn * TN;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int kk = 0; kk < KSW; ++kk) {
+          const int frag = ((t * NB + nb0 + j) * KS + wk * KSW + kk);
+          const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, frag * 1024, 0);
+          bf[t][kk][j] = __builtin_bit_cast(V8, v);
+        }
+  }
+
+  // ---- DMA of one tile (+ halo) into buffer `buf` --------------------------------------------
+  const int lrow = lane / CPR, pc = lane % CPR;
+  const int niw = (p.ni + NWV - 1) / NWV;
+  auto issue_dma = [&](int tl, int buf) {
+    int m0 = 0, img_off = 0, h0 = 0, w0 = 0;
+    if constexpr (!DIRH) {
+      m0 = tl * BM - 1;
+    } else {
+      const int img = (int)r_fast_div((uint32_t)tl, p.div_tpi);
+      const int rem = tl - img * (int)p.div_tpi.d;
+      const int ty = (int)r_fast_div((uint32_t)rem, p.div_tw);
+      h0 = ty * p.th - 1;
+      w0 = (rem - ty * p.tiles_w) << p.twl;
+      img_off = img * p.img_bytes;
+    }
+    for (int jj = 0; jj < niw; ++jj) {
+      const int qi = wave + jj * NWV;                 // wave-uniform
+      if (qi < p.ni) {
+        const int R = qi * RPI + lrow;
+        const int lc = pc ^ (CPR == 8 ? r_swz<CPR>(R) : (r_swz<CPR>(R)));
+        uint32_t voff;
+        if constexpr (!DIRH) {
+          voff = (uint32_t)((m0 + R) * p.px_bytes + lc * 16);   // < 0 or beyond the tensor: zeros
+        } else {
+          const int h = h0 + (R >> p.twl), w = w0 + (R & ((1 << p.twl) - 1));
+          const bool ok = (unsigned)h < (unsigned)p.H && w < p.W;
+          voff = ok ? (uint32_t)(img_off + h * p.row_bytes + w * p.px_bytes + lc * 16) : kROOB;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs_in, (__attribute__((address_space(3))) void*)(smem + buf * p.abuf + qi * 1024), 16,
+            (int)voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- output pass geometry (fixed per thread) -----------------------------------------------
+  constexpr int C8 = NWG / 8, RPP = NT / C8;
+  constexpr int PASSES = BM / RPP > 0 ? BM / RPP : 1;
+  const int col8 = tid % C8, orow = tid / C8;
+  const int n = n_base + col8 * 8;
+  const bool has_affine = p.scale != nullptr && !BNB;
+  rf32x8 b0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  const __amdgpu_buffer_rsrc_t rs_out = r_rsrc(p.out, p.out_bytes);
+  const __amdgpu_buffer_rsrc_t rs_res = r_rsrc(p.residual ? p.residual : p.out, p.res_bytes);
+  const __amdgpu_buffer_rsrc_t rs_msk = r_rsrc(p.mask_src ? p.mask_src : p.out, p.mask_bytes);
+  const bool has_res = p.residual != nullptr, has_msk = p.mask_src != nullptr;
+  // BatchNorm batch statistics in the row domain: per thread 8 channels, shifted sums about the
+  // first value the thread sees (d = v - v0: no E[x^2] - mean^2 cancellation), merged per
+  // workgroup with Chan's formula at the end
+  const bool want_stats = p.stats != nullptr;
+  rf32x8 st_s = b0, st_d = b0, st_q = b0;
+  float st_n = 0.f;
+  float bias_v[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+    bias_v[j] = (p.bias && wk == 0) ? p.bias[n_base + (wn * TN + j) * 32 + l31] : 0.f;
+
+  if (tile < tile_hi) issue_dma(tile, 0);
+  int it = 0;
+  for (; tile < tile_hi; tile += p.gx, ++it) {
+    const int buf = it & 1;
+    // tile `it` has landed (every VMEM op younger than its DMA is one of the PASSES stores of the
+    // previous output pass: in-order completion on gfx9), is visible to every wave behind the
+    // barrier, and the stage and the other buffer are free
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tile + p.gx < tile_hi) issue_dma(tile + p.gx, buf ^ 1);
+
+    // ---- A operand addresses of this tile ------------------------------------------------------
+    int m0 = 0, h0 = 0, w0 = 0, img_pix = 0;
+    if constexpr (!DIRH) {
+      m0 = tile * BM;
+    } else {
+      const int img = (int)r_fast_div((uint32_t)tile, p.div_tpi);
+      const int rem = tile - img * (int)p.div_tpi.d;
+      const int ty = (int)r_fast_div((uint32_t)rem, p.div_tw);
+      h0 = ty * p.th;
+      w0 = (rem - ty * p.tiles_w) << p.twl;
+      img_pix = img * p.H * p.W;
+    }
+    int abase[TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = (wm * TM + i) * 32 + l31;
+      int wq = 0;
+      if constexpr (!DIRH) {
+        const uint32_t m = (uint32_t)(m0 + r);
+        wq = (int)(m - r_fast_div(m, p.div_w) * p.div_w.d);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int dt = p.sign * (t - 1);
+        int R, ok = 1;
+        if constexpr (!DIRH) {
+          R = r + 1 + dt;
+          ok = (unsigned)(wq + dt) < (unsigned)p.W;
+        } else {
+          R = r + ((1 + dt) << p.twl);
+        }
+        const int s = r_swz<CPR>(R);
+        const int a = buf * p.abuf + R * RB + (((lh ^ (s & 1)) << 4) | ((s >> 1) << 5)) +
+                      (wk * KSW * 32);                 // (wk * KSW) << 5: this wave's K range
+        abase[i][t] = ok ? a : zoff + (lh << 4);
+      }
+    }
+
+    // ---- MFMAs: per (row tile, tap, k16 step) one ds_read_b128, TN MFMAs; the reads run PD
+    // fragments ahead of their use ----------------------------------------------------------------
+    constexpr int NACC = (TM * TN == 1) ? 2 : 1;       // split the dependent chain of a lone tile
+    f32x16 acc[TM][TN][NACC];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][a][r] = 0.f;
+    {
+      // fragment order (tap, k16 step, row tile): consecutive MFMAs hit different accumulators
+      constexpr int TOT = TM * NF, PD = 4;
+      V8 af[PD];
+      auto a_addr = [&](int f) {
+        const int i = f % TM, t = (f / TM) / KSW, kk = (f / TM) % KSW;
+        return abase[i][t] ^ (kk << 5);
+      };
+#pragma unroll
+      for (int f = 0; f < PD && f < TOT; ++f)
+        af[f] = *reinterpret_cast<const V8*>(smem + a_addr(f));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int f = 0; f < TOT; ++f) {
+        const int i = f % TM, t = (f / TM) / KSW, kk = (f / TM) % KSW;
+        const V8 cur = af[f % PD];
+        if (f + PD < TOT) af[f % PD] = *reinterpret_cast<const V8*>(smem + a_addr(f + PD));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j][kk % NACC] = rmfma(cur, bf[t][kk][j], acc[i][j][kk % NACC]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- accumulators (+ bias) -> fp32 stage [wk][row][channel] ----------------------------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[i][j][0][r] + bias_v[j];
+          if constexpr (NACC == 2) v += acc[i][j][1][r];
+          stage[(wk * BM + row) * SLD + (wn * TN + j) * 32 + l31] = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- output pass: 8 channels x PASSES rows per thread, every global access 16 bytes ----------
+    constexpr int PG = PASSES > 2 ? 2 : PASSES;         // passes per group (register budget)
+#pragma unroll
+    for (int pg = 0; pg < PASSES; pg += PG) {
+      uint32_t ooff[PG];
+      rf32x8 v[PG];
+      ru32x4 rres[PG], rmsk[PG];
+#pragma unroll
+      for (int q = 0; q < PG; ++q) {
+        const int row = (pg + q) * RPP + orow;
+        bool ok = row < BM;
+        int pix;
+        if constexpr (!DIRH) {
+          pix = m0 + row;
+          ok = ok && pix < p.M;
+        } else {
+          const int hh = h0 + (row >> p.twl), ww = w0 + (row & ((1 << p.twl) - 1));
+          ok = ok && hh < p.H && ww < p.W;
+          pix = img_pix + hh * p.W + ww;
+        }
+        ooff[q] = ok ? (uint32_t)pix : kROOB;
+        if (has_res)
+          rres[q] = __builtin_amdgcn_raw_buffer_load_b128(
+              rs_res, ok ? (pix * p.ld_res + n) * 2 : (int)kROOB, 0, 0);
+        if (has_msk)
+          rmsk[q] = __builtin_amdgcn_raw_buffer_load_b128(
+              rs_msk, ok ? (pix * p.ld_mask + n) * 2 : (int)kROOB, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < PG; ++q) {
+        const int row = (pg + q) * RPP + orow;
+        const float* sp = stage + (row < BM ? row : 0) * SLD + col8 * 8;
+        float4 v0 = emsa_ld4(sp), v1 = emsa_ld4(sp + 4);
+#pragma unroll
+        for (int k = 1; k < WK; ++k) {
+          const float4 u0 = emsa_ld4(sp + k * BM * SLD), u1 = emsa_ld4(sp + k * BM * SLD + 4);
+          v0.x += u0.x; v0.y += u0.y; v0.z += u0.z; v0.w += u0.w;
+          v1.x += u1.x; v1.y += u1.y; v1.z += u1.z; v1.w += u1.w;
+        }
+        v[q] = rf32x8{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      }
+#pragma unroll
+      for (int q = 0; q < PG; ++q) {
+        const bool ok = ooff[q] != kROOB;
+        rf32x8 x = v[q];
+        if (want_stats && ok) {
+          if (st_n == 0.f) st_s = x;
+          st_n += 1.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = x[e] - st_s[e];
+            st_d[e] += d;
+            st_q[e] += d * d;
+          }
+        }
+        if (has_affine) {
+          const float4 sc0 = emsa_ld4(p.scale + n), sc1 = emsa_ld4(p.scale + n + 4);
+          const float4 sh0 = emsa_ld4(p.shift + n), sh1 = emsa_ld4(p.shift + n + 4);
+          x = rf32x8{x[0] * sc0.x + sh0.x, x[1] * sc0.y + sh0.y, x[2] * sc0.z + sh0.z,
+                     x[3] * sc0.w + sh0.w, x[4] * sc1.x + sh1.x, x[5] * sc1.y + sh1.y,
+                     x[6] * sc1.z + sh1.z, x[7] * sc1.w + sh1.w};
+        }
+        if (has_res) x += __builtin_convertvector(__builtin_bit_cast(V8, rres[q]), rf32x8);
+        if constexpr (BNB) {
+          const rf32x8 tt = __builtin_convertvector(__builtin_bit_cast(V8, rmsk[q]), rf32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            x[e] = (ok && (tt[e] * p.scale[n + e] + p.shift[n + e]) > 0.f) ? x[e] : 0.f;
+            b0[e] += x[e];
+            b1[e] += x[e] * (tt[e] - p.bnb_mean[n + e]);
+          }
+        } else if (has_msk) {
+          const rf32x8 mm = __builtin_convertvector(__builtin_bit_cast(V8, rmsk[q]), rf32x8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = mm[e] > 0.f ? x[e] : 0.f;
+        }
+        if (p.act == EMSA_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        const V8 o = __builtin_convertvector(x, V8);
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(ru32x4, o), rs_out,
+            ok ? (int)((ooff[q] * (uint32_t)p.ld_out + (uint32_t)n) * 2u) : (int)kROOB, 0, 0);
+      }
+    }
+  }
+
+  // ---- per-workgroup partial rows: statistics (sum, M2, count) / BatchNorm-backward sums ---------
+  if (want_stats || BNB) {
+    const int srow = xcd * p.gx + idx;                 // one row per workgroup of a channel slice
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* red = stage;                                // [RPP][3 or 2][NWG]
+    if constexpr (BNB) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(orow * 2 + 0) * NWG + col8 * 8 + e] = b0[e];
+        red[(orow * 2 + 1) * NWG + col8 * 8 + e] = b1[e];
+      }
+    } else {
+      // (n, mean, M2) of this thread's rows
+      const float inv = st_n > 0.f ? 1.f / st_n : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(orow * 3 + 0) * NWG + col8 * 8 + e] = st_s[e] + st_d[e] * inv;
+        red[(orow * 3 + 1) * NWG + col8 * 8 + e] = fmaxf(st_q[e] - st_d[e] * st_d[e] * inv, 0.f);
+      }
+      if (col8 == 0) red[RPP * 3 * NWG + orow] = st_n;
+    }
+    __syncthreads();
+    for (int c = tid; c < NWG; c += NT) {
+      const int nn = n_base + c;
+      if constexpr (BNB) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int r = 0; r < RPP; ++r) {
+          a0 += red[(r * 2 + 0) * NWG + c];
+          a1 += red[(r * 2 + 1) * NWG + c];
+        }
+        p.bnb_out[((size_t)0 * p.bnb_rows_alloc + srow) * p.n_ch + nn] = a0;
+        p.bnb_out[((size_t)1 * p.bnb_rows_alloc + srow) * p.n_ch + nn] = a1 * p.bnb_invstd[nn];
+      } else {
+        float na = 0.f, ma = 0.f, qa = 0.f;            // Chan et al.: merge (n, mean, M2) pairs
+        for (int r = 0; r < RPP; ++r) {
+          const float nb = red[RPP * 3 * NWG + r];
+          if (nb > 0.f) {
+            const float mb = red[(r * 3 + 0) * NWG + c], q2 = red[(r * 3 + 1) * NWG + c];
+            const float nn2 = na + nb, dl = mb - ma;
+            qa += q2 + dl * dl * (na * nb / nn2);
+            ma += dl * (nb / nn2);
+            na = nn2;
+          }
+        }
+        p.stats[((size_t)0 * p.stat_rows + srow) * p.n_ch + nn] = ma * na;
+        p.stats[((size_t)1 * p.stat_rows + srow) * p.n_ch + nn] = qa;
+        p.stats[((size_t)2 * p.stat_rows + srow) * p.n_ch + nn] = na;
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+struct RSPlan {
+  int kc = 0;         // 64 / 128 / 256 / 512
+  bool dirh = false;
+  int bm = 0, nwg = 0, nwv = 0, wk = 1, rpi = 0;
+  int tiles = 0, tiles_w = 0, twl = 0, th = 0;
+  int ni = 0, abuf = 0, lds = 0, gx = 0, nslice = 0, sign = 1;
+};
+
+int rs_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
+      cus = pr.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// EMSA_CONV_RS=0 switches the kernel off (the generic implicit GEMM of conv_h.hip runs instead)
+bool rs_enabled() {
+  const char* e = getenv("EMSA_CONV_RS");
+  return !(e && e[0] == '0');
+}
+
+bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
+  if (!g) return false;
+  if (g->k_ch != g->n_ch) return false;
+  if (g->k_ch != 64 && g->k_ch != 128 && g->k_ch != 256 && g->k_ch != 512) return false;
+  const bool w3 = g->kh == 1 && g->kw == 3, h3 = g->kh == 3 && g->kw == 1;
+  if (!w3 && !h3) return false;
+  if (g->in_h != g->out_h || g->in_w != g->out_w) return false;
+  if (g->mul_h != 1 || g->mul_w != 1 || g->div_h != 1 || g->div_w != 1) return false;
+  if (g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off) return false;
+  // tap t reads pixel + off + t * step along the conv direction: forward off = -1, step = 1;
+  // data gradient off = +1, step = -1
+  const int off = w3 ? g->off_w : g->off_h, step = w3 ? g->step_w : g->step_h;
+  if (!((off == -1 && step == 1) || (off == 1 && step == -1))) return false;
+  if ((w3 ? g->off_h : g->off_w) != 0) return false;
+  if ((g->in_px_stride & 7) || (g->in_row_stride & 7) || (g->in_img_stride & 7) || (g->ld_out & 7))
+    return false;
+  if (g->in_px_stride < g->k_ch || g->ld_out < g->n_ch) return false;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  const long in_bytes = (long)g->n_img * g->in_img_stride * 2;
+  if (in_bytes >= (1L << 31) - (1L << 22) || M * g->ld_out * 2 >= (1L << 31) - (1L << 22)) return false;
+  pl.kc = g->k_ch;
+  pl.dirh = h3;
+  pl.sign = step;
+  pl.rpi = 1024 / (pl.kc * 2);
+  switch (pl.kc) {
+    case 64: pl.bm = 128; pl.nwg = 64; pl.nwv = 4; pl.wk = 1; break;
+    case 128: pl.bm = 64; pl.nwg = 128; pl.nwv = 4; pl.wk = 1; break;
+    case 256: pl.bm = 32; pl.nwg = 64; pl.nwv = 4; pl.wk = 2; break;
+    default: pl.bm = 32; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; break;
+  }
+  pl.nslice = g->n_ch / pl.nwg;
+  int rs;
+  if (!h3) {
+    // flattened pixels: needs the dense NHWC pixel grid
+    if (g->in_row_stride != (long)g->in_w * g->in_px_stride ||
+        g->in_img_stride != (long)g->in_h * g->in_row_stride)
+      return false;
+    pl.tiles = (int)((M + pl.bm - 1) / pl.bm);
+    rs = pl.bm + 2;
+  } else {
+    // TH x TW patches, TW a power of two >= the DMA granule: least padded pixels, then widest
+    long best = -1;
+    for (int twl = 0; (1 << twl) <= 32 && (1 << twl) <= pl.bm; ++twl) {
+      const int tw = 1 << twl, th = pl.bm / tw;
+      if (tw < pl.rpi) continue;
+      const long tws = (g->out_w + tw - 1) / tw, ths = (g->out_h + th - 1) / th;
+      const long cost = tws * ths * (long)(th + 2) * tw;       // pixels loaded per image
+      if (best < 0 || cost <= best) {
+        best = cost;
+        pl.twl = twl;
+        pl.th = th;
+        pl.tiles_w = (int)tws;
+        pl.tiles = (int)(tws * ths * g->n_img);
+      }
+    }
+    if (best < 0) return false;
+    rs = pl.bm + 2 * (1 << pl.twl);
+  }
+  pl.ni = (rs + pl.rpi - 1) / pl.rpi;
+  pl.abuf = pl.ni * 1024;
+  const int rpp = pl.nwv * 64 / (pl.nwg / 8);
+  const int stage = pl.wk * pl.bm * (pl.nwg + 4) * 4;
+  const int red = rpp * 3 * pl.nwg * 4 + rpp * 4;
+  pl.lds = 2 * pl.abuf + pl.kc * 2 + (stage > red ? stage : red);
+  if (pl.lds > 160 * 1024) return false;
+  // persistent grid: 8 XCDs x gx workgroups x channel slices; every workgroup gets >= 1 tile
+  const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
+  int gx = rs_cu_count() * per_cu / (8 * pl.nslice);
+  if (gx > pl.tiles / 8) gx = pl.tiles / 8;
+  if (gx < 1) return false;
+  pl.gx = gx;
+  return true;
+}
+
+template <typename T, int KC, int TN, int WM, int WN, int WK, int TM>
+int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
+  const dim3 grid(8 * pl.gx * pl.nslice), block(64 * WM * WN * WK);
+  // more than 64 KB of dynamic LDS has to be asked for once per kernel
+  static bool attr_set = false;
+  if (!attr_set) {
+    const int mx = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+    attr_set = true;
+  }
+  if (pl.dirh) {
+    if (bnb)
+      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true>), grid, block, pl.lds, st, a);
+    else
+      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false>), grid, block, pl.lds, st, a);
+  } else {
+    if (bnb)
+      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true>), grid, block, pl.lds, st, a);
+    else
+      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false>), grid, block, pl.lds, st, a);
+  }
+  return emsa_launch_status();
+}
+
+template <typename T>
+int rs_dispatch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
+  switch (pl.kc) {
+    case 64: return rs_launch<T, 64, 2, 4, 1, 1, 1>(a, pl, bnb, st);
+    case 128: return rs_launch<T, 128, 1, 1, 4, 1, 2>(a, pl, bnb, st);
+    case 256: return rs_launch<T, 256, 1, 1, 2, 2, 1>(a, pl, bnb, st);
+    default: return rs_launch<T, 512, 1, 1, 2, 4, 1>(a, pl, bnb, st);
+  }
+}
+
+int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* wf, void* out,
+                 const float* bias, float* stats, const float* scale, const float* shift,
+                 const void* residual, int32_t ld_res, const void* mask_src, int32_t ld_mask,
+                 int32_t act, const float* bnb_mean, const float* bnb_invstd, float* bnb_out,
+                 int32_t bnb_rows_alloc, void* stream) {
+  if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
+  RSPlan pl;
+  if (!rs_plan(g, pl)) return EMSA_E_SHAPE;
+  if (!in || !wf || !out) return EMSA_E_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!al16(in) || !al16(wf) || !al16(out) || !al16(bias) || !al16(scale) || !al16(shift) ||
+      (residual && (!al16(residual) || (ld_res & 7))) || (mask_src && (!al16(mask_src) || (ld_mask & 7))))
+    return EMSA_E_SHAPE;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  if ((residual && M * ld_res * 2 >= (1L << 31)) || (mask_src && M * ld_mask * 2 >= (1L << 31)))
+    return EMSA_E_SHAPE;
+  const bool bnb = bnb_out != nullptr;
+  if (bnb && (!mask_src || !scale || !bnb_mean || !bnb_invstd || stats || act != EMSA_ACT_NONE ||
+              bnb_rows_alloc < 8 * pl.gx))
+    return EMSA_E_ARG;
+  ConvRSArgs a;
+  a.in = in; a.wf = wf; a.out = out; a.bias = bias; a.stats = stats; a.scale = scale; a.shift = shift;
+  a.residual = residual; a.mask_src = mask_src;
+  a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out; a.bnb_rows_alloc = bnb_rows_alloc;
+  a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act; a.ld_out = g->ld_out;
+  a.in_bytes = (uint32_t)((long)g->n_img * g->in_img_stride * 2);
+  a.wf_bytes = (uint32_t)(3L * g->n_ch * g->k_ch * 2);
+  a.out_bytes = (uint32_t)(M * g->ld_out * 2);
+  a.res_bytes = residual ? (uint32_t)(M * ld_res * 2) : a.out_bytes;
+  a.mask_bytes = mask_src ? (uint32_t)(M * ld_mask * 2) : a.out_bytes;
+  a.M = (int)M; a.H = g->out_h; a.W = g->out_w; a.n_img = g->n_img;
+  a.px_bytes = g->in_px_stride * 2; a.row_bytes = (int)(g->in_row_stride * 2);
+  a.img_bytes = (int)(g->in_img_stride * 2);
+  a.sign = pl.sign; a.n_ch = g->n_ch;
+  a.tiles = pl.tiles; a.tiles_w = pl.tiles_w > 0 ? pl.tiles_w : 1; a.twl = pl.twl; a.th = pl.th;
+  a.gx = pl.gx; a.nslice = pl.nslice; a.ni = pl.ni; a.abuf = pl.abuf; a.stat_rows = 8 * pl.gx;
+  a.div_w = r_make_fastdiv((uint32_t)g->out_w);
+  const int tpi = pl.dirh ? pl.tiles / g->n_img : 1;
+  a.div_tpi = r_make_fastdiv((uint32_t)(tpi > 0 ? tpi : 1));
+  a.div_tw = r_make_fastdiv((uint32_t)a.tiles_w);
+  hipStream_t st = (hipStream_t)stream;
+  const double flops = 2.0 * M * g->k_ch * g->n_ch * 3.0;
+  const double px = (double)M * g->n_ch * 2.0;
+  const double bytes = 2.0 * px + 3.0 * g->n_ch * g->k_ch * 2.0 + (residual ? px : 0.0) + (mask_src ? px : 0.0);
+  const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
+  const int rc = dtype == EMSA_DT_BF16 ? rs_dispatch<emsa_bf16>(a, pl, bnb, st)
+                                       : rs_dispatch<emsa_f16>(a, pl, bnb, st);
+  emsa_prof_end(ps, st);
+  return rc;
+}
+
+// OIHW fp32 parameter [cout][cin][3] -> the fragment-ordered 16-bit operand of conv_rs_kernel:
+//   wf[tap][n / 32][k / 16][lane = n % 32 + 32 * ((k % 16) / 8)][k % 8]
+// (one B operand of v_mfma_f32_32x32x16 = 1 KB contiguous); forward: (n, k) = (cout, cin), data
+// gradient: (n, k) = (cin, cout).
+template <typename T>
+__global__ void pack_frag_kernel(const float* __restrict__ w, T* __restrict__ fwd,
+                                 T* __restrict__ dgr, int cout, int cin) {
+  const long total = 3L * cout * cin;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), ln = (int)((i >> 3) & 63);
+    const long fr = i >> 9;
+    if (fwd) {
+      const int ks = (int)(fr % (cin / 16)), nb = (int)((fr / (cin / 16)) % (cout / 32)),
+                t = (int)(fr / ((long)(cin / 16) * (cout / 32)));
+      const int nn = nb * 32 + (ln & 31), k = ks * 16 + (ln >> 5) * 8 + e;
+      fwd[i] = (T)w[((long)nn * cin + k) * 3 + t];
+    }
+    if (dgr) {
+      const int ks = (int)(fr % (cout / 16)), nb = (int)((fr / (cout / 16)) % (cin / 32)),
+                t = (int)(fr / ((long)(cout / 16) * (cin / 32)));
+      const int nn = nb * 32 + (ln & 31), k = ks * 16 + (ln >> 5) * 8 + e;
+      dgr[i] = (T)w[((long)k * cin + nn) * 3 + t];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int emsa_conv1d_rs_supported(int32_t dtype, const EmsaConvGeom* g) {
+  if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return 0;
+  RSPlan pl;
+  return rs_enabled() && rs_plan(g, pl) ? 1 : 0;
+}
+
+extern "C" int emsa_conv1d_rs_stats_rows(int32_t dtype, const EmsaConvGeom* g) {
+  if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
+  RSPlan pl;
+  if (!rs_plan(g, pl)) return EMSA_E_SHAPE;
+  return 8 * pl.gx;
+}
+
+extern "C" int emsa_conv1d_rs_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                const void* wfrag, void* out, const float* bias, float* stats,
+                                const float* scale, const float* shift, const void* residual,
+                                int32_t ld_res, const void* mask_src, int32_t ld_mask, int32_t act,
+                                void* stream) {
+  return conv_rs_impl(dtype, g, in, wfrag, out, bias, stats, scale, shift, residual, ld_res,
+                      mask_src, ld_mask, act, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int emsa_conv1d_rs_bnb_t(int32_t dtype, const EmsaConvGeom* g, const void* dy,
+                                    const void* wfrag, void* out, const void* residual,
+                                    int32_t ld_res, const void* t, int32_t ld_t,
+                                    const float* bn_scale, const float* bn_shift,
+                                    const float* bn_mean, const float* bn_invstd, float* partial,
+                                    int32_t rows_alloc, void* stream) {
+  if (!partial || !t) return EMSA_E_ARG;
+  return conv_rs_impl(dtype, g, dy, wfrag, out, nullptr, nullptr, bn_scale, bn_shift, residual,
+                      ld_res, t, ld_t, EMSA_ACT_NONE, bn_mean, bn_invstd, partial, rows_alloc, stream);
+}
+
+extern "C" int emsa_pack_weight_frag_t(int32_t dtype, const float* w_oihw, void* wf_fwd,
+                                       void* wf_dgrad, int32_t cout, int32_t cin, void* stream) {
+  if (!w_oihw || (!wf_fwd && !wf_dgrad)) return EMSA_E_ARG;
+  if ((cout & 31) || (cin & 31)) return EMSA_E_SHAPE;
+  const long total = 3L * cout * cin;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (dtype == EMSA_DT_BF16)
+    hipLaunchKernelGGL(pack_frag_kernel<emsa_bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (emsa_bf16*)wf_fwd, (emsa_bf16*)wf_dgrad, cout, cin);
+  else if (dtype == EMSA_DT_F16)
+    hipLaunchKernelGGL(pack_frag_kernel<emsa_f16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (emsa_f16*)wf_fwd, (emsa_f16*)wf_dgrad, cout, cin);
+  else
+    return EMSA_E_ARG;
+  return emsa_launch_status();
+}

@@ -534,6 +534,37 @@ int emsa_stem_pack_weight_t(int32_t dtype, const float* w, void* wp, int32_t cou
                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Register-stationary streaming kernel for the stride-1 3-tap 1-D convs of the NBt1D blocks in
+ * 16-bit storage (csrc/conv_rs.hip; /root/reference/emsanet/model.py:47-58 composes the block,
+ * args.py:158-164 selects it): conv3x1 / conv1x3 with C_in = C_out in {64, 128, 256, 512}, forward
+ * and data gradient.  Persistent workgroups keep their slice of the weights in registers as MFMA
+ * operands for the whole launch and stream pixel tiles (+ halo) through LDS once; HBM traffic =
+ * input + output.  Same arguments and fused epilogue as emsa_conv_igemm_t / emsa_conv_igemm_bnb_t
+ * except the weight operand:
+ *   wfrag  fragment-ordered 16-bit weights from emsa_pack_weight_frag_t (or emsa_pack_batch kinds
+ *          5 = bf16, 6 = fp16): [tap][n / 32][k / 16][n % 32 + 32 * ((k % 16) / 8)][k % 8], i.e. one
+ *          B operand of v_mfma_f32_32x32x16 per contiguous KB; forward (n, k) = (cout, cin), data
+ *          gradient (n, k) = (cin, cout), taps unflipped (the geometry's step = -1 flips them).
+ *   stats / partial rows: emsa_conv1d_rs_stats_rows(dtype, g) (one row per persistent workgroup
+ *          of a channel slice; the rows carry (sum, M2, count) like emsa_conv_igemm's).
+ * emsa_conv1d_rs_supported: 1 when this kernel takes the geometry (and EMSA_CONV_RS != 0), else 0 --
+ * callers fall back to emsa_conv_igemm_t with the [tap][n][k] operand.
+ * ------------------------------------------------------------------------------------------ */
+int emsa_conv1d_rs_supported(int32_t dtype, const EmsaConvGeom* g);
+int emsa_conv1d_rs_stats_rows(int32_t dtype, const EmsaConvGeom* g);
+int emsa_conv1d_rs_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* wfrag,
+                     void* out, const float* bias, float* stats, const float* scale,
+                     const float* shift, const void* residual, int32_t ld_res,
+                     const void* mask_src, int32_t ld_mask, int32_t act, void* stream);
+int emsa_conv1d_rs_bnb_t(int32_t dtype, const EmsaConvGeom* g, const void* dy, const void* wfrag,
+                         void* out, const void* residual, int32_t ld_res, const void* t,
+                         int32_t ld_t, const float* bn_scale, const float* bn_shift,
+                         const float* bn_mean, const float* bn_invstd, float* partial,
+                         int32_t rows_alloc, void* stream);
+int emsa_pack_weight_frag_t(int32_t dtype, const float* w_oihw, void* wf_fwd, void* wf_dgrad,
+                            int32_t cout, int32_t cin, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Typed ("_t") forms of the HBM-bound kernels: same semantics and argument order as the fp32 entry
  * points above, activation tensors in the storage type `dtype` (EMSA_DT_*).  Kernels at the model
  * boundary take `out_f32`: the tensors on the OUTPUT side of the op (y of a forward kernel, dy / y
