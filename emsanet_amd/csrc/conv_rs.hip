@@ -36,6 +36,23 @@ typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rf16x8 __attribute__((ext_vector_type(8)));
 constexpr uint32_t kROOB = 0x80000000u;
 
+// EMSA_RS_DBG=1 (probe builds only, tools/jobs/r04_rs2.sh): wave 0 of every workgroup accumulates the
+// shader-clock time of each phase of the tile loop; emsa_conv1d_rs_dbg_read returns the table
+#ifndef EMSA_RS_DBG
+#define EMSA_RS_DBG 0
+#endif
+#if EMSA_RS_DBG
+__device__ long long g_rs_dbg[8 * 2048];
+#define RS_MARK(ph)                                         \
+  do {                                                      \
+    const long long t_ = (long long)__builtin_readcyclecounter(); \
+    dbg_t[ph] += t_ - dbg_prev;                             \
+    dbg_prev = t_;                                          \
+  } while (0)
+#else
+#define RS_MARK(ph) do {} while (0)
+#endif
+
 template <typename T> struct RVec8;
 template <> struct RVec8<emsa_bf16> { typedef rbf16x8 type; };
 template <> struct RVec8<emsa_f16> { typedef rf16x8 type; };
@@ -119,6 +136,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
   static_assert(KS % WK == 0 && 64 % CPR == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+#if EMSA_RS_DBG
+  long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dbg_prev = (long long)__builtin_readcyclecounter();
+  const long long dbg_start = dbg_prev;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -133,31 +155,26 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
   const int n_base = slice * NWG;                     // first output channel of this workgroup
 
   const int zoff = 2 * p.abuf;                        // row of zeros (1x3 borders)
-  const int soff = zoff + RB;                         // fp32 stage [WK][BM][SLD]
+  const int eoff = zoff + RB;                         // per-channel epilogue vectors [3][NWG]
+  const int soff = eoff + 3 * NWG * 4;                // fp32 stage [WK][BM][SLD]
   float* const stage = reinterpret_cast<float*>(smem + soff);
+  float* const evec = reinterpret_cast<float*>(smem + eoff);
 
   if (!DIRH) {
     for (int i = tid; i < RB / 4; i += NT) reinterpret_cast<uint32_t*>(smem + zoff)[i] = 0u;
   }
-
-  // ---- weights: 3 * KSW * TN fragments, resident for the whole launch ------------------------
-  const __amdgpu_buffer_rsrc_t rs_w = r_rsrc(p.wf, p.wf_bytes);
-  const __amdgpu_buffer_rsrc_t rs_in = r_rsrc(p.in, p.in_bytes);
-  V8 bf[3][KSW][TN];
-  {
-    const int NB = p.n_ch >> 5;
-    const int nb0 = (n_base >> 5) + wn * TN;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int kk = 0; kk < KSW; ++kk) {
-          const int frag = ((t * NB + nb0 + j) * KS + wk * KSW + kk);
-          const ru32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, frag * 1024, 0);
-          bf[t][kk][j] = __builtin_bit_cast(V8, v);
-        }
+  // folded-BatchNorm scale / shift (or the BatchNorm-backward affine + mean) of this workgroup's
+  // channels: read from LDS in the output pass -- a global load there would wait for (in-order
+  // vmcnt) the DMA of the next tile
+  if (p.scale) {
+    for (int i = tid; i < NWG; i += NT) {
+      evec[i] = p.scale[n_base + i];
+      evec[NWG + i] = p.shift[n_base + i];
+      evec[2 * NWG + i] = BNB ? p.bnb_mean[n_base + i] : 0.f;
+    }
   }
+
+  const __amdgpu_buffer_rsrc_t rs_in = r_rsrc(p.in, p.in_bytes);
 
   // ---- DMA of one tile (+ halo) into buffer `buf` --------------------------------------------
   const int lrow = lane / CPR, pc = lane % CPR;
@@ -217,6 +234,37 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
     bias_v[j] = (p.bias && wk == 0) ? p.bias[n_base + (wn * TN + j) * 32 + l31] : 0.f;
 
   if (tile < tile_hi) issue_dma(tile, 0);
+  // ---- weights: 3 * KSW * TN fragments, resident for the whole launch ------------------------
+  // (loaded behind the first tile's DMA; the empty asm pins every fragment as "arrived" here --
+  //  otherwise the compiler's own waits for these loads sit in front of the first MFMAs INSIDE the
+  //  tile loop, end in s_waitcnt vmcnt(0) and drain the next tile's DMA in every iteration)
+  V8 bf[3][KSW][TN];
+  {
+    const __amdgpu_buffer_rsrc_t rs_w = r_rsrc(p.wf, p.wf_bytes);
+    const int NB = p.n_ch >> 5;
+    const int nb0 = (n_base >> 5) + wn * TN;
+    ru32x4 raw[3][KSW][TN];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int kk = 0; kk < KSW; ++kk) {
+          const int frag = ((t * NB + nb0 + j) * KS + wk * KSW + kk);
+          raw[t][kk][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, frag * 1024, 0);
+        }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int kk = 0; kk < KSW; ++kk) {
+          asm volatile("" : "+v"(raw[t][kk][j]));
+          bf[t][kk][j] = __builtin_bit_cast(V8, raw[t][kk][j]);
+        }
+  }
+
+  RS_MARK(0);
   int it = 0;
   for (; tile < tile_hi; tile += p.gx, ++it) {
     const int buf = it & 1;
@@ -227,6 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RS_MARK(1);
     if (tile + p.gx < tile_hi) issue_dma(tile + p.gx, buf ^ 1);
 
     // ---- A operand addresses of this tile ------------------------------------------------------
@@ -267,6 +316,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
       }
     }
 
+    RS_MARK(2);
     // ---- MFMAs: per (row tile, tap, k16 step) one ds_read_b128, TN MFMAs; the reads run PD
     // fragments ahead of their use ----------------------------------------------------------------
     constexpr int NACC = (TM * TN == 1) ? 2 : 1;       // split the dependent chain of a lone tile
@@ -303,6 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
       __builtin_amdgcn_s_setprio(0);
     }
 
+    RS_MARK(3);
     // ---- accumulators (+ bias) -> fp32 stage [wk][row][channel] ----------------------------------
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -317,6 +368,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    RS_MARK(4);
 
     // ---- output pass: 8 channels x PASSES rows per thread, every global access 16 bytes ----------
     constexpr int PG = PASSES > 2 ? 2 : PASSES;         // passes per group (register budget)
@@ -374,8 +426,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
           }
         }
         if (has_affine) {
-          const float4 sc0 = emsa_ld4(p.scale + n), sc1 = emsa_ld4(p.scale + n + 4);
-          const float4 sh0 = emsa_ld4(p.shift + n), sh1 = emsa_ld4(p.shift + n + 4);
+          const float4 sc0 = emsa_ld4(evec + col8 * 8), sc1 = emsa_ld4(evec + col8 * 8 + 4);
+          const float4 sh0 = emsa_ld4(evec + NWG + col8 * 8), sh1 = emsa_ld4(evec + NWG + col8 * 8 + 4);
           x = rf32x8{x[0] * sc0.x + sh0.x, x[1] * sc0.y + sh0.y, x[2] * sc0.z + sh0.z,
                      x[3] * sc0.w + sh0.w, x[4] * sc1.x + sh1.x, x[5] * sc1.y + sh1.y,
                      x[6] * sc1.z + sh1.z, x[7] * sc1.w + sh1.w};
@@ -385,9 +437,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
           const rf32x8 tt = __builtin_convertvector(__builtin_bit_cast(V8, rmsk[q]), rf32x8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            x[e] = (ok && (tt[e] * p.scale[n + e] + p.shift[n + e]) > 0.f) ? x[e] : 0.f;
+            x[e] = (ok && (tt[e] * evec[col8 * 8 + e] + evec[NWG + col8 * 8 + e]) > 0.f) ? x[e] : 0.f;
             b0[e] += x[e];
-            b1[e] += x[e] * (tt[e] - p.bnb_mean[n + e]);
+            b1[e] += x[e] * (tt[e] - evec[2 * NWG + col8 * 8 + e]);
           }
         } else if (has_msk) {
           const rf32x8 mm = __builtin_convertvector(__builtin_bit_cast(V8, rmsk[q]), rf32x8);
@@ -404,6 +456,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
             ok ? (int)((ooff[q] * (uint32_t)p.ld_out + (uint32_t)n) * 2u) : (int)kROOB, 0, 0);
       }
     }
+  
+
+#if EMSA_RS_DBG
+    RS_MARK(5);
+    dbg_t[7] += 1;
+#endif
+  }
+  {
+#if EMSA_RS_DBG
+    if (tid == 0 && blockIdx.x < 2048) {
+      dbg_t[6] = (long long)__builtin_readcyclecounter() - dbg_start;
+      for (int k = 0; k < 8; ++k) g_rs_dbg[blockIdx.x * 8 + k] = dbg_t[k];
+    }
+#endif
   }
 
   // ---- per-workgroup partial rows: statistics (sum, M2, count) / BatchNorm-backward sums ---------
@@ -433,6 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
       const int nn = n_base + c;
       if constexpr (BNB) {
         float a0 = 0.f, a1 = 0.f;
+#pragma unroll 1
         for (int r = 0; r < RPP; ++r) {
           a0 += red[(r * 2 + 0) * NWG + c];
           a1 += red[(r * 2 + 1) * NWG + c];
@@ -441,6 +508,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
         p.bnb_out[((size_t)1 * p.bnb_rows_alloc + srow) * p.n_ch + nn] = a1 * p.bnb_invstd[nn];
       } else {
         float na = 0.f, ma = 0.f, qa = 0.f;            // Chan et al.: merge (n, mean, M2) pairs
+#pragma unroll 1
         for (int r = 0; r < RPP; ++r) {
           const float nb = red[RPP * 3 * NWG + r];
           if (nb > 0.f) {
@@ -549,7 +617,7 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   const int rpp = pl.nwv * 64 / (pl.nwg / 8);
   const int stage = pl.wk * pl.bm * (pl.nwg + 4) * 4;
   const int red = rpp * 3 * pl.nwg * 4 + rpp * 4;
-  pl.lds = 2 * pl.abuf + pl.kc * 2 + (stage > red ? stage : red);
+  pl.lds = 2 * pl.abuf + pl.kc * 2 + 3 * pl.nwg * 4 + (stage > red ? stage : red);
   if (pl.lds > 160 * 1024) return false;
   // persistent grid: 8 XCDs x gx workgroups x channel slices; every workgroup gets >= 1 tile
   const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
@@ -681,6 +749,12 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, T* __restrict__ fw
 }
 
 }  // namespace
+
+#if EMSA_RS_DBG
+extern "C" int emsa_conv1d_rs_dbg_read(long long* host, int n_entries) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rs_dbg), (size_t)n_entries * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int emsa_conv1d_rs_supported(int32_t dtype, const EmsaConvGeom* g) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return 0;

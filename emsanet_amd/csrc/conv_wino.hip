@@ -636,10 +636,19 @@ __global__ void pack_wino_packed_kernel(const float* __restrict__ wp, float* __r
 // layouts (dst0 = [tap][cout][cin], dst1 = [tap][cin][cout]); kind 1: OIHW -> Winograd U
 // (dst0 forward, dst1 data gradient; rows = 3 for a 3x3 kernel); NULL outputs are skipped
 // kind 2 / 3: as kind 0 with bf16 / fp16 outputs (operands of conv_h.hip)
-__device__ __forceinline__ void pack_store(float* base, size_t idx, float v, int kind) {
-  if (kind == 2)
+// kind 5 / 6: as 2 / 3 in the fragment order of conv_rs.hip (channel counts multiples of 32)
+// kind 5 / 6: bf16 / fp16 in the MFMA-fragment order of conv_rs.hip (emsa_pack_weight_frag_t):
+// element (tap r, row n, column k) of an [r][nT][kT] operand lives at
+//   (((r * nT/32 + n/32) * kT/16 + k/16) * 64 + n%32 + 32 * ((k%16)/8)) * 8 + k%8
+__device__ __forceinline__ void pack_store(float* base, int r, int n, int k, int nT, int kT,
+                                           float v, int kind) {
+  size_t idx = ((size_t)r * nT + n) * kT + k;
+  if (kind == 5 || kind == 6)
+    idx = ((((size_t)r * (nT >> 5) + (n >> 5)) * (kT >> 4) + (k >> 4)) * 64 + (n & 31) +
+           32 * ((k & 15) >> 3)) * 8 + (k & 7);
+  if (kind == 2 || kind == 5)
     reinterpret_cast<emsa_bf16*>(base)[idx] = (emsa_bf16)v;
-  else if (kind == 3)
+  else if (kind == 3 || kind == 6)
     reinterpret_cast<emsa_f16*>(base)[idx] = (emsa_f16)v;
   else
     base[idx] = v;
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
         const float v = ok ? jb.src[((size_t)co * cin + ci) * taps + r] : 0.f;
         vals[k][0] = v;
         if (ok && jb.dst0)
-          pack_store(jb.dst0, ((size_t)r * coT + co + coO) * ciT + ci + ciO, v, jb.kind);
+          pack_store(jb.dst0, r, co + coO, ci + ciO, coT, ciT, v, jb.kind);
       }
     }
     if (jb.dst1) {
@@ -719,8 +728,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const EmsaPackJob* __re
             jb.dst1[2 * NK + o] = tr[2][tx][ty + 8 * k];
             jb.dst1[3 * NK + o] = tr[0][tx][ty + 8 * k];
           } else {
-            pack_store(jb.dst1, ((size_t)r * ciT + ci + ciO) * coT + co + coO, tr[0][tx][ty + 8 * k],
-                       jb.kind);
+            pack_store(jb.dst1, r, ci + ciO, co + coO, ciT, coT, tr[0][tx][ty + 8 * k], jb.kind);
           }
         }
       }

@@ -199,6 +199,44 @@ def pack_weight_t(w, dtype, fwd=True, dgrad=False, cout_total=None, cout_off=0, 
     return out_fwd if fwd else None, out_dgrad if dgrad else None
 
 
+# The register-stationary streaming kernel (csrc/conv_rs.hip) for the stride-1 3-tap 1-D convs of the
+# NBt1D blocks in 16-bit storage (/root/reference/emsanet/model.py:47-58): C_in = C_out in
+# {64, 128, 256, 512}.  EMSA_CONV_RS=0 keeps every conv on the generic implicit GEMM.
+CONV_RS = os.environ.get('EMSA_CONV_RS', '1') != '0'     # tests: set False / True
+
+
+def rs_eligible(spec):
+    return ((spec.kh, spec.kw, spec.ph, spec.pw) in ((3, 1, 1, 0), (1, 3, 0, 1)) and spec.sh == 1
+            and spec.sw == 1 and spec.cin == spec.cout and spec.cin in (64, 128, 256, 512))
+
+
+def rs_supported(code, g):
+    """the kernel takes this geometry (cached on the geometry object: a plan per shape)"""
+    if not CONV_RS or code == 0:
+        return False
+    r = getattr(g, '_rs', None)
+    if r is None or r[0] != code:
+        ok = _lib.lib().emsa_conv1d_rs_supported(code, g) == 1
+        r = (code, ok, _lib.lib().emsa_conv1d_rs_stats_rows(code, g) if ok else 0)
+        g._rs = r
+    return r[1]
+
+
+def pack_weight_frag_t(w, dtype, fwd=True, dgrad=False, out_fwd=None, out_dgrad=None):
+    """fp32 OIHW [cout][cin][3 taps] -> fragment-ordered 16-bit operands of emsa_conv1d_rs_t"""
+    cout, cin = w.shape[0], w.shape[1]
+    n = 3 * cout * cin
+    if fwd and out_fwd is None:
+        out_fwd = _empty((n,), w.device, dtype)
+    if dgrad and out_dgrad is None:
+        out_dgrad = _empty((n,), w.device, dtype)
+    check(_lib.lib().emsa_pack_weight_frag_t(DT[dtype], _p(w.contiguous()),
+                                             _p(out_fwd) if fwd else None,
+                                             _p(out_dgrad) if dgrad else None, cout, cin,
+                                             _stream()), 'emsa_pack_weight_frag_t')
+    return out_fwd if fwd else None, out_dgrad if dgrad else None
+
+
 # ---------------------------------------------------------------------------------------------
 # weights
 # ---------------------------------------------------------------------------------------------
@@ -274,13 +312,15 @@ def pack_wino_packed(wp, n_ch, k_ch, rows, flip):
 
 
 def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, residual=None,
-             act=ACT_NONE, out=None, wino_u=None, want_relu_bits=False, in_affine=None):
+             act=ACT_NONE, out=None, wino_u=None, want_relu_bits=False, in_affine=None, wfrag=None):
     """wp = packed [tap][cout][cin] weights in the dtype of `x` (MFMA implicit GEMM) -- or, fp32
     only, wino_u = Winograd weights of an eligible conv (emsa_conv1d_wino).  want_relu_bits
     (Winograd kernel with act = ReLU): additionally returns (out > 0) as a bit mask for
     `conv_dgrad(mask_bits=...)`, else None.  in_affine = (scale, shift) per INPUT channel: the
     conv runs on relu(x * scale + shift) formed in its loader (emsa_conv1d_wino_inbn: the
-    BatchNorm + ReLU in front of a 1-D Winograd conv without a pass of its own)."""
+    BatchNorm + ReLU in front of a 1-D Winograd conv without a pass of its own).  wfrag = the
+    fragment-ordered 16-bit weights of a 3-tap 1-D conv: where emsa_conv1d_rs_t takes the geometry
+    it runs instead of the implicit GEMM (same epilogue, its own statistics rows)."""
     n, c, h, w = x.shape
     oh, ow = spec.out_hw(h, w)
     code = dt(x)
@@ -290,10 +330,13 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
     L = _lib.lib()
     stats = None
     if code != 0:
-        wino_u = None                       # the 16-bit path is the implicit GEMM of conv_h.hip
+        wino_u = None                       # the 16-bit path is conv_rs.hip / conv_h.hip
+    use_rs = wfrag is not None and wfrag.dtype == x.dtype and rs_supported(code, g)
     if want_stats:
         if wino_u is not None:
             rows = L.emsa_conv1d_wino_stats_rows(g)
+        elif use_rs:
+            rows = g._rs[2]
         else:
             rows = call_t('emsa_conv_stats_rows', code, g)
         if rows <= 0:
@@ -317,6 +360,10 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
         check(L.emsa_conv1d_wino(g, _p(x), _p(wino_u), _p(out), _p(bias), _p(stats), _p(scale),
                                  _p(shift), _p(residual), lr, None, 0, act, None, _p(bits),
                                  _stream()), 'emsa_conv1d_wino')
+    elif use_rs:
+        check(L.emsa_conv1d_rs_t(code, g, _p(x), _p(wfrag), _p(out), _p(bias), _p(stats), _p(scale),
+                                 _p(shift), _p(residual), lr, None, 0, act, _stream()),
+              'emsa_conv1d_rs_t')
     else:
         if wp is None or wp.dtype != x.dtype:
             raise _lib.EmsaError(f"conv weights packed as {None if wp is None else wp.dtype} for "
@@ -399,7 +446,7 @@ def _conv_dgrad_phased(dy, wpd, spec, in_hw, mask_src, residual, out):
 
 
 def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, wino_u=None,
-               mask_bits=None):
+               mask_bits=None, wfrag=None):
     """dx = conv_transpose(dy); optional fused `* (mask_src > 0)` -- or the same mask as bits
     (`mask_bits`, Winograd kernel only) -- and `+ residual`."""
     n = dy.shape[0]
@@ -424,6 +471,11 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
         check(L.emsa_conv1d_wino(g, _p(dy), _p(wino_u), _p(out), None, None, None, None,
                                  _p(residual), lr, _p(mask_src), lm, ACT_NONE, _p(mask_bits), None,
                                  _stream()), 'emsa_conv1d_wino(dgrad)')
+    elif wfrag is not None and wfrag.dtype == dy.dtype and rs_supported(code, g):
+        lm = ld_of(mask_src) if mask_src is not None else 0
+        check(L.emsa_conv1d_rs_t(code, g, _p(dy), _p(wfrag), _p(out), None, None, None, None,
+                                 _p(residual), lr, _p(mask_src), lm, ACT_NONE, _stream()),
+              'emsa_conv1d_rs_t(dgrad)')
     else:
         if wpd is None or wpd.dtype != dy.dtype:
             raise _lib.EmsaError("data-gradient weights are not packed in the gradient's dtype")
@@ -475,7 +527,7 @@ def bn1_fold(t):
 
 
 def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invstd, residual=None,
-                   wino_u=None):
+                   wino_u=None, wfrag=None):
     """data gradient of the conv behind a BatchNorm+ReLU with that BatchNorm's backward reduction
     in the epilogue: returns (g, partial, rows) with g = dz * (relu(bn(t)) > 0) and `partial` the
     (sum g, sum g * xhat) rows for `bn_bwd_from_rows`; fp32 needs the Winograd weights `wino_u`"""
@@ -487,8 +539,11 @@ def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invs
     g = spec.geom_dgrad(n, h, w, ld_of(dy), ld_of(out))
     L = _lib.lib()
     lr = ld_of(residual) if residual is not None else 0
+    use_rs = wfrag is not None and wfrag.dtype == dy.dtype and rs_supported(code, g)
     if code == 0:
         rows = L.emsa_conv1d_wino_stats_rows(g)
+    elif use_rs:
+        rows = g._rs[2]
     else:
         rows = L.emsa_conv_stats_rows_t(code, g)
     if rows <= 0:
@@ -499,6 +554,11 @@ def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invs
                                      ld_of(t), _p(bn_scale), _p(bn_shift), _p(bn_mean),
                                      _p(bn_invstd), _p(partial), rows + 16, _stream()),
               'emsa_conv1d_wino_bnb')
+    elif use_rs:
+        check(L.emsa_conv1d_rs_bnb_t(code, g, _p(dy), _p(wfrag), _p(out), _p(residual), lr, _p(t),
+                                     ld_of(t), _p(bn_scale), _p(bn_shift), _p(bn_mean),
+                                     _p(bn_invstd), _p(partial), rows + 16, _stream()),
+              'emsa_conv1d_rs_bnb_t')
     else:
         if wpd is None or wpd.dtype != dy.dtype:
             raise _lib.EmsaError("data-gradient weights are not packed in the gradient's dtype")

@@ -75,6 +75,10 @@ class ConvRT:
         self._u = None
         self._ud = None
         self._h = {}              # 16-bit packs: dtype -> [key, fwd, key_d, dgrad]
+        # stride-1 3x1 / 1x3 convs with 64..512 channels in 16-bit storage: the register-stationary
+        # streaming kernel (conv_rs.hip) with fragment-ordered weights, where it takes the geometry
+        self.rs = Fn.rs_eligible(self.spec)
+        self._hf = {}             # fragment-ordered 16-bit packs: dtype -> [key, fwd, key_d, dgrad]
 
     def _wino_weights(self):
         w = self.conv.weight
@@ -87,7 +91,7 @@ class ConvRT:
     def forward(self, x, **kw):
         """conv forward through the best kernel for this layer (fused-epilogue kwargs of conv_fwd)"""
         if x.dtype != torch.float32:
-            return Fn.conv_fwd(x, self.packed(x.dtype), self.spec, **kw)
+            return Fn.conv_fwd(x, self.packed(x.dtype), self.spec, wfrag=self.frag(x.dtype), **kw)
         if self.wino:
             return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
         return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
@@ -102,7 +106,8 @@ class ConvRT:
         """mask_bits: the ReLU mask of the producing layer as bits (conv_fwd(want_relu_bits));
         used by the Winograd kernel, otherwise the float `mask_src` applies"""
         if dy.dtype != torch.float32:
-            return Fn.conv_dgrad(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw, **kw)
+            return Fn.conv_dgrad(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw,
+                                 wfrag=self.frag_dgrad(dy.dtype), **kw)
         if self.wino:
             u, ud = self._wino_weights()
             if ud is None:
@@ -120,7 +125,8 @@ class ConvRT:
         scale, shift = affine
         if dy.dtype != torch.float32:
             return Fn.conv_dgrad_bnb(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw, t, scale,
-                                     shift, mean, invstd, residual=residual)
+                                     shift, mean, invstd, residual=residual,
+                                     wfrag=self.frag_dgrad(dy.dtype))
         if not self.wino:
             return None
         u, ud = self._wino_weights()
@@ -128,6 +134,31 @@ class ConvRT:
             ud = Fn.pack_wino(self.conv.weight.detach(), fwd=False, dgrad=True)[1]
         return Fn.conv_dgrad_bnb(dy, None, self.spec, in_hw, t, scale, shift, mean, invstd,
                                  residual=residual, wino_u=ud)
+
+    def frag(self, dtype):
+        """fragment-ordered forward weights for conv_rs.hip (None: not that kind of conv)"""
+        if not (self.rs and Fn.CONV_RS):
+            return None
+        w = self.conv.weight
+        key = (w._version, w.data_ptr())
+        ent = self._hf.setdefault(dtype, [None, None, None, None])
+        if ent[0] != key:
+            ent[1], d = Fn.pack_weight_frag_t(w.detach(), dtype, fwd=True, dgrad=w.requires_grad)
+            ent[0] = key
+            if d is not None:
+                ent[2], ent[3] = key, d
+        return ent[1]
+
+    def frag_dgrad(self, dtype):
+        if not (self.rs and Fn.CONV_RS):
+            return None
+        w = self.conv.weight
+        key = (w._version, w.data_ptr())
+        ent = self._hf.setdefault(dtype, [None, None, None, None])
+        if ent[2] != key:
+            ent[3] = Fn.pack_weight_frag_t(w.detach(), dtype, fwd=False, dgrad=True)[1]
+            ent[2] = key
+        return ent[3]
 
     def packed(self, dtype=torch.float32):
         w = self.conv.weight
@@ -192,8 +223,11 @@ class PackPlan:
         n = len(self.rts)
         n_multi = sum(len(m.placements) + sum(1 for q, _, _ in m.placements if q.bias is not None)
                       for m in self.multi)
-        jobs = (_lib.EmsaPackJob * (n + n_multi))()
         half = dtype != torch.float32
+        # the stride-1 3-tap 1-D convs additionally get the fragment-ordered operands of conv_rs.hip
+        # (pack kinds 5 / 6) -- the [tap][n][k] form stays for geometries that kernel refuses
+        frag_rts = [rt for rt in self.rts if half and rt.rs and Fn.CONV_RS]
+        jobs = (_lib.EmsaPackJob * (n + n_multi + len(frag_rts)))()
         esz = 2 if half else 4
         sizes = []
         for rt in self.rts:
@@ -202,7 +236,10 @@ class PackPlan:
             per = numel if half else (numel * 4 // 3 if rt.wino else numel)   # U: 4 comps per 3 taps
             per_b = (per * esz + 15) // 16 * 16            # every pack starts 16-byte aligned
             sizes.append((per, per_b, per_b if w.requires_grad else 0))
-        arena = torch.empty(sum(a + b for _, a, b in sizes), device=dev, dtype=torch.uint8)
+        fsizes = [((rt.conv.weight.numel() * esz + 15) // 16 * 16) * (2 if rt.conv.weight.requires_grad else 1)
+                  for rt in frag_rts]
+        arena = torch.empty(sum(a + b for _, a, b in sizes) + sum(fsizes), device=dev,
+                            dtype=torch.uint8)
         views, off, blk = [], 0, 0
         for j, (rt, (per, a, b)) in enumerate(zip(self.rts, sizes)):
             w = rt.conv.weight
@@ -216,6 +253,22 @@ class PackPlan:
                                        cout, cin, kh, kw, kind, blk)
             blk += max(1, min(64, (w.numel() + 2047) // 2048))
         j = n
+        fviews = []
+        for rt, fs in zip(frag_rts, fsizes):
+            w = rt.conv.weight
+            nb = w.numel() * esz
+            one = fs // 2 if w.requires_grad else fs
+            f0 = arena[off:off + nb].view(dtype)
+            f1 = arena[off + one:off + one + nb].view(dtype) if w.requires_grad else None
+            off += fs
+            fviews.append((f0, f1))
+            cout, cin, kh, kw = w.shape
+            jobs[j] = _lib.EmsaPackJob(w.data_ptr(), f0.data_ptr(),
+                                       f1.data_ptr() if f1 is not None else None, cout, cin, kh, kw,
+                                       Fn.DT[dtype] + 4, blk)            # 5 = bf16, 6 = fp16
+            blk += max(1, min(64, (w.numel() + 2047) // 2048))
+            j += 1
+        self._frag = (frag_rts, fviews)
         mviews = []
         for m in self.multi:
             sp = m.spec
@@ -276,6 +329,10 @@ class PackPlan:
             else:
                 m._wp, m._bias, m._u, m._key = d0, bias, None, mk
                 m._hd[dtype] = (mk, d1, None)
+        for rt, (f0, f1) in zip(*self._frag):
+            w = rt.conv.weight
+            k = (w._version, w.data_ptr())
+            rt._hf[dtype] = [k, f0, k if f1 is not None else None, f1]
         for rt, (v0, v1), w in zip(self.rts, self._views, ws):
             k = (w._version, w.data_ptr())
             if dtype != torch.float32:

@@ -1,0 +1,216 @@
+"""GPU parity of the register-stationary streaming kernel (csrc/conv_rs.hip: the stride-1 3-tap 1-D
+convs of the NBt1D blocks, /root/reference/emsanet/model.py:47-58, in 16-bit storage) against plain
+PyTorch fp64 references computed from the SAME 16-bit-rounded inputs and weights, through the C-ABI
+(emsa_conv1d_rs_t / emsa_conv1d_rs_bnb_t / emsa_pack_weight_frag_t) -- same bars as
+tests/test_ops16_gpu.py: bf16 6e-3 / fp16 1e-3 of the tensor magnitude for stored results, 2e-4 /
+4e-4 for the fp32 statistics.  Every case asserts that the new kernel took the launch (no silent
+fallback to the implicit GEMM) and cross-checks the implicit GEMM on the same inputs.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import DEV, close, rnd, to_act
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+TOL = {torch.bfloat16: 6e-3, torch.float16: 1e-3}
+
+# channels, kernel, n, h, w -- every (C, direction) of the model, image sizes whose tiles are
+# ragged in both directions (odd heights / widths, pixel counts off the 32 / 64 / 128-pixel tiles,
+# images smaller than a tile row), the /32 map of BASELINE configs[3] (23 x 30)
+RS_CONVS = [
+    (64, (1, 3), 2, 40, 48),
+    (64, (3, 1), 2, 40, 48),
+    (64, (1, 3), 3, 23, 30),
+    (64, (3, 1), 3, 23, 30),
+    (128, (1, 3), 2, 30, 40),
+    (128, (3, 1), 2, 30, 40),
+    (128, (3, 1), 5, 11, 13),
+    (256, (1, 3), 2, 15, 20),
+    (256, (3, 1), 2, 15, 20),
+    (256, (1, 3), 3, 9, 11),
+    (512, (1, 3), 2, 15, 20),
+    (512, (3, 1), 2, 15, 20),
+    (512, (3, 1), 1, 23, 30),
+    (512, (1, 3), 7, 5, 7),
+]
+
+
+def _fn():
+    from emsanet_amd import functional as Fn
+    return Fn
+
+
+def q(t, dtype):
+    return t.to(dtype).double()
+
+
+def act16(t_nchw, dtype):
+    return t_nchw.to(dtype).to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def _spec(Fn, c, k):
+    return Fn.ConvSpec(c, c, k, 1, (1, 0) if k == (3, 1) else (0, 1))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', RS_CONVS)
+def test_conv_rs_fwd(cfg, dtype):
+    Fn = _fn()
+    c, k, n, h, w = cfg
+    spec = _spec(Fn, c, k)
+    pad = (spec.ph, spec.pw)
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, c, *k, seed=2, scale=0.1)
+    b = rnd(c, seed=3)
+    ref = F.conv2d(q(x, dtype), q(wt, dtype), b.double(), padding=pad)
+    wf, _ = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=True)
+    wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
+    xa = act16(x, dtype)
+    g = spec.geom_fwd(n, h, w, c, c)
+    assert Fn.rs_eligible(spec) and Fn.rs_supported(Fn.dt(xa), g), "the rs kernel must take this case"
+    y, stats = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV), want_stats=True, wfrag=wf)
+    torch.cuda.synchronize()
+    assert y.dtype == dtype and stats.shape[1] == g._rs[2]
+    close(y, ref, tol=TOL[dtype], what='conv_rs')
+    # BatchNorm statistics rows (sum, M2 about the row's mean, count) from the fp32 values
+    cnt = ref.numel() / c
+    assert float(stats[2][:, 0].sum()) == cnt
+    mean = stats[0].sum(0) / cnt
+    close(mean, ref.mean((0, 2, 3)), tol=2e-4, what='stats mean')
+    row_mean = stats[0] / stats[2].clamp(min=1)
+    m2 = stats[1].sum(0) + (stats[2] * (row_mean - mean[None]) ** 2).sum(0)
+    close(m2 / cnt, ref.var((0, 2, 3), unbiased=False), tol=4e-4, what='stats var')
+    # the rows feed emsa_bn_finalize like the implicit GEMM's
+    gamma, beta = rnd(c, seed=8).abs() + 0.5, rnd(c, seed=9)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    scale, shift, bmean, invstd = Fn.bn_finalize(stats, int(cnt), gamma.to(DEV), beta.to(DEV), 1e-3, 0.1, rm, rv)
+    close(bmean, ref.mean((0, 2, 3)), tol=2e-4, what='bn_finalize mean')
+    close(invstd, 1 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-3), tol=4e-4, what='bn_finalize invstd')
+    # against the implicit GEMM on the same operands: both round the same fp32 sums once
+    y0 = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV))
+    close(y, y0.double().cpu(), tol=TOL[dtype], what='conv_rs vs conv_h')
+    # fused epilogue: folded BatchNorm + residual + ReLU (an NBt1D block's last conv in eval mode)
+    sc, sh = rnd(c, seed=4), rnd(c, seed=5)
+    res = rnd(*ref.shape, seed=6)
+    y2 = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV),
+                     residual=act16(res, dtype), act=Fn.ACT_RELU, wfrag=wf)
+    ref2 = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + q(res, dtype))
+    close(y2, ref2, tol=TOL[dtype], what='conv_rs epilogue')
+    # bias + ReLU (the block's first conv)
+    y3 = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV), act=Fn.ACT_RELU, wfrag=wf)
+    close(y3, F.relu(ref), tol=TOL[dtype], what='conv_rs relu')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', RS_CONVS)
+def test_conv_rs_dgrad(cfg, dtype):
+    Fn = _fn()
+    c, k, n, h, w = cfg
+    spec = _spec(Fn, c, k)
+    x = rnd(n, c, h, w, seed=1).double().requires_grad_(True)
+    wt = rnd(c, c, *k, seed=2, scale=0.1)
+    y = F.conv2d(x, q(wt, dtype), None, padding=(spec.ph, spec.pw))
+    dy = rnd(*y.shape, seed=7)
+    y.backward(q(dy, dtype))
+    _, wfd = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=False, dgrad=True)
+    _, wpd = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=False, dgrad=True)
+    dya = act16(dy, dtype)
+    g = spec.geom_dgrad(n, h, w, c, c)
+    assert Fn.rs_supported(Fn.dt(dya), g)
+    dx = Fn.conv_dgrad(dya, wpd, spec, (h, w), wfrag=wfd)
+    torch.cuda.synchronize()
+    close(dx, x.grad, tol=TOL[dtype], what='rs dgrad')
+    mask = rnd(n, c, h, w, seed=8)
+    res = rnd(n, c, h, w, seed=9)
+    dx2 = Fn.conv_dgrad(dya, wpd, spec, (h, w), mask_src=act16(mask, dtype), wfrag=wfd)
+    close(dx2, x.grad * (q(mask, dtype) > 0), tol=TOL[dtype], what='rs dgrad mask')
+    dx3 = Fn.conv_dgrad(dya, wpd, spec, (h, w), residual=act16(res, dtype), mask_src=act16(mask, dtype),
+                        wfrag=wfd)
+    close(dx3, (x.grad + q(res, dtype)) * (q(mask, dtype) > 0), tol=TOL[dtype], what='rs dgrad res+mask')
+
+
+@pytest.mark.parametrize('cfg', [RS_CONVS[0], RS_CONVS[3], RS_CONVS[5], RS_CONVS[7], RS_CONVS[12]])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_conv_rs_dgrad_with_fused_bn_backward_sums(cfg, with_res):
+    """conv3x1_2 -> bn1 of the NBt1D backward on the rs kernel (emsa_conv1d_rs_bnb_t): == fp64
+    autograd of conv(relu(batch_norm(t))) and == the implicit GEMM's fused form"""
+    Fn = _fn()
+    dtype = torch.bfloat16
+    c, k, n, h, w = cfg
+    spec = _spec(Fn, c, k)
+    pad = (spec.ph, spec.pw)
+    qq = lambda t: t.to(dtype).float()   # noqa: E731
+    t = qq(rnd(n, c, h, w, seed=1))
+    wt = qq(rnd(c, c, *k, seed=2, scale=0.1))
+    dy = qq(rnd(n, c, h, w, seed=3))
+    res = qq(rnd(n, c, h, w, seed=4)) if with_res else None
+    gamma = rnd(c, seed=5) * 0.2 + 1
+    beta = rnd(c, seed=6) * 0.3
+    eps = 1e-3
+    tr = t.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(tr, None, None, gr, br, training=True, eps=eps))
+    z = F.conv2d(a, wt.double(), padding=pad)
+    loss = (z * dy.double()).sum()
+    if with_res:
+        loss = loss + (a * res.double()).sum()
+    loss.backward()
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    xs = t.permute(0, 2, 3, 1).reshape(-1, c)
+    stats = torch.stack([xs.sum(0, keepdim=True), ((xs - xs.mean(0)) ** 2).sum(0, keepdim=True),
+                         torch.full((1, c), float(xs.shape[0]))]).to(DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    scale, shift, mean, invstd = Fn.bn_finalize(stats, xs.shape[0], gd, bd, eps, 0.1, rm, rv)
+    ta, dya = to_act(t).to(dtype), to_act(dy).to(dtype)
+    resa = to_act(res).to(dtype) if with_res else None
+    wpd = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=False, dgrad=True)[1]
+    wfd = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=False, dgrad=True)[1]
+    assert Fn.rs_supported(Fn.dt(dya), spec.geom_dgrad(n, h, w, c, c))
+    gm, partial, rows = Fn.conv_dgrad_bnb(dya, wpd, spec, (h, w), ta, scale, shift, mean, invstd,
+                                          residual=resa, wfrag=wfd)
+    dx, dg, db = Fn.bn_bwd_from_rows(gm, ta, gd, mean, invstd, partial, rows, True)
+    close(dx, tr.grad, tol=2e-2, what='rs fused dx')
+    close(dg, gr.grad, tol=1e-2, what='rs fused dgamma')
+    close(db, br.grad, tol=1e-2, what='rs fused dbeta')
+    gm0, partial0, rows0 = Fn.conv_dgrad_bnb(dya, wpd, spec, (h, w), ta, scale, shift, mean, invstd,
+                                             residual=resa)
+    dx0, dg0, db0 = Fn.bn_bwd_from_rows(gm0, ta, gd, mean, invstd, partial0, rows0, True)
+    close(dx, dx0.float().cpu(), tol=2e-2, what='rs vs conv_h dx')
+    close(dg, dg0.cpu(), tol=1e-2, what='rs vs conv_h dgamma')
+    close(db, db0.cpu(), tol=1e-2, what='rs vs conv_h dbeta')
+
+
+def test_conv_rs_refuses_what_it_cannot_take():
+    """geometries outside the kernel (too few pixel tiles for the persistent grid, strided, other
+    channel counts) are reported unsupported -- the caller's implicit-GEMM fallback runs, with the
+    same results -- and a direct call is rejected with EMSA_E_SHAPE, never computed wrongly"""
+    from emsanet_amd import _lib
+    Fn = _fn()
+    dtype = torch.bfloat16
+    spec = _spec(Fn, 64, (1, 3))
+    g = spec.geom_fwd(1, 4, 6, 64, 64)                   # 24 pixels: not even one tile per XCD
+    assert not Fn.rs_supported(1, g)
+    x = rnd(1, 64, 4, 6, seed=1)
+    wt = rnd(64, 64, 1, 3, seed=2, scale=0.1)
+    wf, _ = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=True)
+    wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
+    y = Fn.conv_fwd(act16(x, dtype), wp, spec, wfrag=wf)             # falls back
+    close(y, F.conv2d(q(x, dtype), q(wt, dtype), None, padding=(0, 1)), tol=TOL[dtype], what='fallback')
+    out = torch.empty_like(y)
+    rc = _lib.lib().emsa_conv1d_rs_t(1, g, act16(x, dtype).data_ptr(), wf.data_ptr(), out.data_ptr(),
+                                     None, None, None, None, None, 0, None, 0, 0, None)
+    assert rc == -1
+    s2 = Fn.ConvSpec(64, 128, (3, 1), (2, 1), (1, 0))
+    assert not Fn.rs_eligible(s2) and not Fn.rs_eligible(Fn.ConvSpec(72, 72, (1, 3), 1, (0, 1)))
+    assert not Fn.rs_eligible(Fn.ConvSpec(64, 64, (3, 3), 1, 1))
+
+
+def test_conv_rs_switch(monkeypatch):
+    """Fn.CONV_RS = False (EMSA_CONV_RS=0) keeps every conv on the implicit GEMM"""
+    Fn = _fn()
+    monkeypatch.setattr(Fn, 'CONV_RS', False)
+    spec = _spec(Fn, 64, (1, 3))
+    assert not Fn.rs_supported(1, spec.geom_fwd(2, 40, 48, 64, 64))

@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude tools/conv_rs_probe.hip -Lemsanet_amd/lib -lemsanet_hip \
 //         -Wl,-rpath,'$ORIGIN/../../emsanet_amd/lib' -o tools/bin/conv_rs_probe
 //   tools/bin/conv_rs_probe [batch] [check|time|all]
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -122,6 +123,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_max, 4));
   CK(hipMalloc(&d_bad, 8));
   int fails = 0;
+  // phase table of a debug build (EMSA_RS_DBG=1), absent from the product library
+  typedef int (*dbg_read_t)(long long*, int);
+  dbg_read_t dbg_read = (dbg_read_t)dlsym(RTLD_DEFAULT, "emsa_conv1d_rs_dbg_read");
   if (do_time) printf("%-16s %-6s %9s %9s %8s %9s %9s\n", "shape", "kind", "old us", "new us", "x", "new TF/s", "new TB/s");
   for (const Shape& s : shapes) {
     if (only && !strstr(s.name, only)) continue;
@@ -269,6 +273,23 @@ int main(int argc, char** argv) {
           float ms;
           CK(hipEventElapsedTime(&ms, e0, e1));
           (which ? t_new : t_old) = ms * 1000.f / iters;
+        }
+        if (dbg_read) {
+          std::vector<long long> tb(8 * 2048);
+          if (dbg_read(tb.data(), 8 * 2048) == 0) {
+            const int wgs = 2048;
+            double ph[8] = {0};
+            int used = 0;
+            for (int b = 0; b < wgs; ++b) {
+              if (tb[b * 8 + 7] <= 0 || tb[b * 8 + 7] > 100000) continue;
+              ++used;
+              for (int k = 0; k < 8; ++k) ph[k] += (double)tb[b * 8 + k];
+            }
+            if (used)
+              printf("   phases (shader-clock ticks per workgroup, mean of %d; tiles/wg %.1f): prologue %.0f | per tile: wait %.0f dma+addr %.0f mfma %.0f stage %.0f out %.0f | total %.0f\n",
+                     used, ph[7] / used, ph[0] / used, ph[1] / ph[7], ph[2] / ph[7], ph[3] / ph[7],
+                     ph[4] / ph[7], ph[5] / ph[7], ph[6] / used);
+          }
         }
         const double fl = 2.0 * M * s.c * s.c * 3, by = 4.0 * elems + wn * 2.0;
         printf("%-16s %-6s %9.1f %9.1f %8.2f %9.1f %9.2f\n", s.name, dg ? "dgrad" : "fwd", t_old, t_new,
