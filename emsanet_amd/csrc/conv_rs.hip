@@ -113,6 +113,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t r_rsrc(const void* p, uint32_t
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KB of LDS at `lds_addr`, lane-linear) as INLINE
+// ASM: the compiler's wait-count pass treats a visible LDS-DMA as a pending write to all of LDS and
+// puts s_waitcnt vmcnt(0) in front of later ds_reads (here: the first read of the output stage,
+// right behind the barrier -- i.e. it drained the NEXT tile's DMA in every iteration).  Hidden from
+// it, the DMA is ordered by this kernel's own counted waits; the compiler's counted waits for its
+// own loads / stores stay correct (in-order vmcnt: extra older or younger operations only make
+// them more conservative).
+__device__ __forceinline__ void r_dma16(ru32x4 rsrc, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "memory");   // (M0 is used by nothing else in this kernel: gfx9 DS ops do not read it)
+}
+
 // bank swizzle of the A tile (rows of RB bytes written lane-linearly by the DMA): the 16-byte chunk
 // c of row R lives at chunk c ^ swz(R).  ds_read_b128 serves 16 lanes (= 16 rows, one chunk index)
 // per LDS cycle; they must hit 16 different 16-byte slots of the 256-byte bank row.
@@ -124,12 +138,33 @@ __device__ __forceinline__ int r_swz(int R) {
 // T storage type; KC = C_in; wave tile 32*TM pixels x 32*TN channels x (KC / WK) input channels;
 // workgroup = WM x WN x WK waves; DIRH: taps along H (3x1) instead of W (1x3); BNB: the data
 // gradient with the BatchNorm-backward sums of the layer in front (emsa_conv_igemm_bnb_t).
-template <typename T, int KC, int TN, int WM, int WN, int WK, int TM, bool DIRH, bool BNB>
-__global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const ConvRSArgs p) {
+#ifndef EMSA_RS_DMA
+#define EMSA_RS_DMA 0
+#endif
+// pixel tiles of the 256- / 512-channel kernels: 32 * TM pixels (A/B builds)
+#ifndef EMSA_RS_TM256
+#define EMSA_RS_TM256 1
+#endif
+#ifndef EMSA_RS_TM512
+#define EMSA_RS_TM512 2
+#endif
+#ifndef EMSA_RS_OCC
+#define EMSA_RS_OCC 2
+#endif
+// EPI: the epilogue reads a residual and / or a mask tensor (as its own instantiation: the waits for
+// those loads would otherwise sit in every launch's output pass and drain the next tile's DMA).
+template <typename T, int KC, int TN, int WM, int WN, int WK, int TM, bool DIRH, bool BNB, bool EPI>
+__global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel(const ConvRSArgs p) {
   typedef typename RVec8<T>::type V8;
   constexpr int NWV = WM * WN * WK, NT = 64 * NWV;
   constexpr int KS = KC / 16, KSW = KS / WK;          // k16 steps: all / per wave
   constexpr int RB = KC * 2, CPR = KC / 8, RPI = 64 / CPR;
+  // register staging (default): the tile travels global -> VGPRs -> LDS, rows padded by 16 bytes
+  // (conflict-free ds_read_b128 without a swizzle, k16 steps as immediate offsets), ONE A buffer;
+  // EMSA_RS_DMA=1 builds the LDS-DMA loader (two unpadded, XOR-swizzled buffers) for A/B runs
+  constexpr bool kDMA = EMSA_RS_DMA != 0;
+  constexpr int RBP = kDMA ? RB : RB + 16;
+  constexpr int NIWM = (KC >= 256 && TM == 2) ? 9 : 5;   // 16-byte loads per lane and tile, at most
   constexpr int BM = 32 * TM * WM, NWG = 32 * TN * WN;
   constexpr int SLD = NWG + 4;
   constexpr int NF = 3 * KSW;                         // A fragments per 32-pixel row tile
@@ -154,8 +189,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
   int tile = (int)(((long)xcd * p.tiles) >> 3) + idx;
   const int n_base = slice * NWG;                     // first output channel of this workgroup
 
-  const int zoff = 2 * p.abuf;                        // row of zeros (1x3 borders)
-  const int eoff = zoff + RB;                         // per-channel epilogue vectors [3][NWG]
+  const int zoff = (kDMA ? 2 : 1) * p.abuf;           // row of zeros (1x3 borders)
+  const int eoff = zoff + RB + 16;                    // per-channel epilogue vectors [3][NWG]
   const int soff = eoff + 3 * NWG * 4;                // fp32 stage [WK][BM][SLD]
   float* const stage = reinterpret_cast<float*>(smem + soff);
   float* const evec = reinterpret_cast<float*>(smem + eoff);
@@ -174,40 +209,54 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
     }
   }
 
-  const __amdgpu_buffer_rsrc_t rs_in = r_rsrc(p.in, p.in_bytes);
+  const uint64_t in_base = (uint64_t)p.in;
+  const ru32x4 rs_in = {(uint32_t)in_base, (uint32_t)(in_base >> 32) & 0xFFFFu, p.in_bytes, 0x00020000u};
+  const __amdgpu_buffer_rsrc_t rs_inb = r_rsrc(p.in, p.in_bytes);
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
 
-  // ---- DMA of one tile (+ halo) into buffer `buf` --------------------------------------------
+  // ---- loader of one tile (+ halo): lane -> (row of the 1 KB piece, 16-byte chunk) -------------
   const int lrow = lane / CPR, pc = lane % CPR;
-  const int niw = (p.ni + NWV - 1) / NWV;
-  auto issue_dma = [&](int tl, int buf) {
-    int m0 = 0, img_off = 0, h0 = 0, w0 = 0;
+  auto tile_voff = [&](int tl, int qi) -> uint32_t {
+    // byte offset of this lane's 16 bytes of piece qi of tile tl; out of range -> zeros
+    const int R = qi * RPI + lrow;
+    const int lc = kDMA ? (pc ^ r_swz<CPR>(R)) : pc;
     if constexpr (!DIRH) {
-      m0 = tl * BM - 1;
+      return (uint32_t)((tl * BM - 1 + R) * p.px_bytes + lc * 16);   // < 0 or beyond the tensor: zeros
     } else {
       const int img = (int)r_fast_div((uint32_t)tl, p.div_tpi);
       const int rem = tl - img * (int)p.div_tpi.d;
       const int ty = (int)r_fast_div((uint32_t)rem, p.div_tw);
-      h0 = ty * p.th - 1;
-      w0 = (rem - ty * p.tiles_w) << p.twl;
-      img_off = img * p.img_bytes;
+      const int h = ty * p.th - 1 + (R >> p.twl);
+      const int w = ((rem - ty * p.tiles_w) << p.twl) + (R & ((1 << p.twl) - 1));
+      const bool ok = (unsigned)h < (unsigned)p.H && w < p.W;
+      return ok ? (uint32_t)(img * p.img_bytes + h * p.row_bytes + w * p.px_bytes + lc * 16) : kROOB;
     }
+  };
+  [[maybe_unused]] auto issue_dma = [&](int tl, int buf) {
+    const int niw = (p.ni + NWV - 1) / NWV;
     for (int jj = 0; jj < niw; ++jj) {
       const int qi = wave + jj * NWV;                 // wave-uniform
-      if (qi < p.ni) {
-        const int R = qi * RPI + lrow;
-        const int lc = pc ^ (CPR == 8 ? r_swz<CPR>(R) : (r_swz<CPR>(R)));
-        uint32_t voff;
-        if constexpr (!DIRH) {
-          voff = (uint32_t)((m0 + R) * p.px_bytes + lc * 16);   // < 0 or beyond the tensor: zeros
-        } else {
-          const int h = h0 + (R >> p.twl), w = w0 + (R & ((1 << p.twl) - 1));
-          const bool ok = (unsigned)h < (unsigned)p.H && w < p.W;
-          voff = ok ? (uint32_t)(img_off + h * p.row_bytes + w * p.px_bytes + lc * 16) : kROOB;
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rs_in, (__attribute__((address_space(3))) void*)(smem + buf * p.abuf + qi * 1024), 16,
-            (int)voff, 0, 0, 0);
-      }
+      if (qi < p.ni)
+        r_dma16(rs_in, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)(buf * p.abuf + qi * 1024))),
+                tile_voff(tl, qi));
+    }
+  };
+  ru32x4 areg[NIWM];
+  [[maybe_unused]] auto load_tile = [&](int tl) {
+#pragma unroll
+    for (int jj = 0; jj < NIWM; ++jj) {
+      const int qi = wave + jj * NWV;
+      // (pieces beyond the tile: an out-of-range offset instead of a branch around the load)
+      areg[jj] = __builtin_amdgcn_raw_buffer_load_b128(
+          rs_inb, (int)(qi < p.ni ? tile_voff(tl, qi) : kROOB), 0, 0);
+    }
+  };
+  [[maybe_unused]] auto store_tile = [&]() {
+#pragma unroll
+    for (int jj = 0; jj < NIWM; ++jj) {
+      const int qi = wave + jj * NWV;
+      if (qi < p.ni)
+        *reinterpret_cast<ru32x4*>(smem + (qi * RPI + lrow) * RBP + pc * 16) = areg[jj];
     }
   };
 
@@ -221,11 +270,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
   const __amdgpu_buffer_rsrc_t rs_out = r_rsrc(p.out, p.out_bytes);
   const __amdgpu_buffer_rsrc_t rs_res = r_rsrc(p.residual ? p.residual : p.out, p.res_bytes);
   const __amdgpu_buffer_rsrc_t rs_msk = r_rsrc(p.mask_src ? p.mask_src : p.out, p.mask_bytes);
-  const bool has_res = p.residual != nullptr, has_msk = p.mask_src != nullptr;
+  const bool has_res = EPI && p.residual != nullptr, has_msk = EPI && p.mask_src != nullptr;
   // BatchNorm batch statistics in the row domain: per thread 8 channels, shifted sums about the
   // first value the thread sees (d = v - v0: no E[x^2] - mean^2 cancellation), merged per
   // workgroup with Chan's formula at the end
-  const bool want_stats = p.stats != nullptr;
+  const bool want_stats = !BNB && !EPI && p.stats != nullptr;   // (statistics: forward convs, no residual / mask)
   rf32x8 st_s = b0, st_d = b0, st_q = b0;
   float st_n = 0.f;
   float bias_v[TN];
@@ -233,7 +282,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
   for (int j = 0; j < TN; ++j)
     bias_v[j] = (p.bias && wk == 0) ? p.bias[n_base + (wn * TN + j) * 32 + l31] : 0.f;
 
-  if (tile < tile_hi) issue_dma(tile, 0);
+  if constexpr (kDMA) issue_dma(tile, 0);
+  else load_tile(tile);
   // ---- weights: 3 * KSW * TN fragments, resident for the whole launch ------------------------
   // (loaded behind the first tile's DMA; the empty asm pins every fragment as "arrived" here --
   //  otherwise the compiler's own waits for these loads sit in front of the first MFMAs INSIDE the
@@ -264,19 +314,30 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
         }
   }
 
+  if constexpr (!kDMA) store_tile();
   RS_MARK(0);
   int it = 0;
   for (; tile < tile_hi; tile += p.gx, ++it) {
-    const int buf = it & 1;
-    // tile `it` has landed (every VMEM op younger than its DMA is one of the PASSES stores of the
-    // previous output pass: in-order completion on gfx9), is visible to every wave behind the
-    // barrier, and the stage and the other buffer are free
-    if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES) : "memory");
+    const int buf = kDMA ? (it & 1) : 0;
+    const bool more = tile + p.gx < tile_hi;
+    if constexpr (kDMA) {
+      // tile `it` has landed (every VMEM op younger than its DMA is one of the PASSES stores of the
+      // previous output pass: in-order completion on gfx9), is visible to every wave behind the
+      // barrier, and the stage and the other buffer are free
+      if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PASSES) : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's pieces of the tile are in LDS
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     RS_MARK(1);
-    if (tile + p.gx < tile_hi) issue_dma(tile + p.gx, buf ^ 1);
+    // the next tile starts its trip now: by LDS-DMA into the other buffer, or into registers that
+    // are written to the (single) A buffer behind this tile's output pass
+    if (more) {
+      if constexpr (kDMA) issue_dma(tile + p.gx, buf ^ 1);
+      else load_tile(tile + p.gx);
+    }
 
     // ---- A operand addresses of this tile ------------------------------------------------------
     int m0 = 0, h0 = 0, w0 = 0, img_pix = 0;
@@ -309,9 +370,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
         } else {
           R = r + ((1 + dt) << p.twl);
         }
-        const int s = r_swz<CPR>(R);
-        const int a = buf * p.abuf + R * RB + (((lh ^ (s & 1)) << 4) | ((s >> 1) << 5)) +
-                      (wk * KSW * 32);                 // (wk * KSW) << 5: this wave's K range
+        int a;
+        if constexpr (kDMA) {
+          const int s = r_swz<CPR>(R);
+          a = buf * p.abuf + R * RB + (((lh ^ (s & 1)) << 4) | ((s >> 1) << 5)) + (wk * KSW * 32);
+        } else {
+          a = R * RBP + (lh << 4) + (wk * KSW * 32);   // (wk * KSW) << 5: this wave's K range
+        }
         abase[i][t] = ok ? a : zoff + (lh << 4);
       }
     }
@@ -335,7 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
       V8 af[PD];
       auto a_addr = [&](int f) {
         const int i = f % TM, t = (f / TM) / KSW, kk = (f / TM) % KSW;
-        return abase[i][t] ^ (kk << 5);
+        return kDMA ? (abase[i][t] ^ (kk << 5)) : (abase[i][t] + (kk << 5));
       };
 #pragma unroll
       for (int f = 0; f < PD && f < TOT; ++f)
@@ -371,7 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
     RS_MARK(4);
 
     // ---- output pass: 8 channels x PASSES rows per thread, every global access 16 bytes ----------
-    constexpr int PG = PASSES > 2 ? 2 : PASSES;         // passes per group (register budget)
+    constexpr int PG = BNB ? 1 : (PASSES > 2 ? 2 : PASSES);   // passes per group (register budget)
 #pragma unroll
     for (int pg = 0; pg < PASSES; pg += PG) {
       uint32_t ooff[PG];
@@ -458,6 +523,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
     }
   
 
+    if constexpr (!kDMA) {
+      if (more) store_tile();      // (every wave is behind the barrier that ended the reads of this tile)
+    }
 #if EMSA_RS_DBG
     RS_MARK(5);
     dbg_t[7] += 1;
@@ -530,6 +598,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, 2) void conv_rs_kernel(const Con
 // ---- host side ----------------------------------------------------------------------------------
 struct RSPlan {
   int kc = 0;         // 64 / 128 / 256 / 512
+  int niwm = 5;       // staging registers (16-byte pieces per lane and tile)
   bool dirh = false;
   int bm = 0, nwg = 0, nwv = 0, wk = 1, rpi = 0;
   int tiles = 0, tiles_w = 0, twl = 0, th = 0;
@@ -581,8 +650,8 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   switch (pl.kc) {
     case 64: pl.bm = 128; pl.nwg = 64; pl.nwv = 4; pl.wk = 1; break;
     case 128: pl.bm = 64; pl.nwg = 128; pl.nwv = 4; pl.wk = 1; break;
-    case 256: pl.bm = 32; pl.nwg = 64; pl.nwv = 4; pl.wk = 2; break;
-    default: pl.bm = 32; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; break;
+    case 256: pl.bm = 32 * EMSA_RS_TM256; pl.nwg = 64; pl.nwv = 4; pl.wk = 2; pl.niwm = EMSA_RS_TM256 == 2 ? 9 : 5; break;
+    default: pl.bm = 32 * EMSA_RS_TM512; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; pl.niwm = EMSA_RS_TM512 == 2 ? 9 : 5; break;
   }
   pl.nslice = g->n_ch / pl.nwg;
   int rs;
@@ -599,6 +668,7 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
     for (int twl = 0; (1 << twl) <= 32 && (1 << twl) <= pl.bm; ++twl) {
       const int tw = 1 << twl, th = pl.bm / tw;
       if (tw < pl.rpi) continue;
+      if ((pl.bm + 2 * tw + pl.rpi - 1) / pl.rpi > pl.niwm * pl.nwv) continue;   // staging registers
       const long tws = (g->out_w + tw - 1) / tw, ths = (g->out_h + th - 1) / th;
       const long cost = tws * ths * (long)(th + 2) * tw;       // pixels loaded per image
       if (best < 0 || cost <= best) {
@@ -613,11 +683,12 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
     rs = pl.bm + 2 * (1 << pl.twl);
   }
   pl.ni = (rs + pl.rpi - 1) / pl.rpi;
-  pl.abuf = pl.ni * 1024;
+  if (pl.ni > pl.niwm * pl.nwv) return false;         // staging registers per wave
+  pl.abuf = EMSA_RS_DMA ? pl.ni * 1024 : (pl.ni * pl.rpi * (pl.kc * 2 + 16) + 1023) / 1024 * 1024;
   const int rpp = pl.nwv * 64 / (pl.nwg / 8);
   const int stage = pl.wk * pl.bm * (pl.nwg + 4) * 4;
   const int red = rpp * 3 * pl.nwg * 4 + rpp * 4;
-  pl.lds = 2 * pl.abuf + pl.kc * 2 + 3 * pl.nwg * 4 + (stage > red ? stage : red);
+  pl.lds = (EMSA_RS_DMA ? 2 : 1) * pl.abuf + pl.kc * 2 + 16 + 3 * pl.nwg * 4 + (stage > red ? stage : red);
   if (pl.lds > 160 * 1024) return false;
   // persistent grid: 8 XCDs x gx workgroups x channel slices; every workgroup gets >= 1 tile
   const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
@@ -631,30 +702,27 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
 template <typename T, int KC, int TN, int WM, int WN, int WK, int TM>
 int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
   const dim3 grid(8 * pl.gx * pl.nslice), block(64 * WM * WN * WK);
-  // more than 64 KB of dynamic LDS has to be asked for once per kernel
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int mx = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    (void)hipFuncSetAttribute((const void*)conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-    attr_set = true;
-  }
+  const bool epi = a.residual != nullptr || a.mask_src != nullptr;
+  auto go = [&](void (*kern)(const ConvRSArgs)) {
+    // more than 64 KB of dynamic LDS has to be asked for, once per kernel
+    static const void* seen[96];
+    static int n_seen = 0;
+    bool known = false;
+    for (int i = 0; i < n_seen; ++i) known = known || seen[i] == (const void*)kern;
+    if (!known) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (n_seen < 96) seen[n_seen++] = (const void*)kern;
+    }
+    hipLaunchKernelGGL(kern, grid, block, pl.lds, st, a);
+  };
   if (pl.dirh) {
-    if (bnb)
-      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true>), grid, block, pl.lds, st, a);
-    else
-      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false>), grid, block, pl.lds, st, a);
+    if (bnb) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true, true>);
+    else if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, true>);
+    else go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, false>);
   } else {
-    if (bnb)
-      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true>), grid, block, pl.lds, st, a);
-    else
-      hipLaunchKernelGGL((conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false>), grid, block, pl.lds, st, a);
+    if (bnb) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true, true>);
+    else if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, true>);
+    else go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, false>);
   }
   return emsa_launch_status();
 }
@@ -664,8 +732,8 @@ int rs_dispatch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st)
   switch (pl.kc) {
     case 64: return rs_launch<T, 64, 2, 4, 1, 1, 1>(a, pl, bnb, st);
     case 128: return rs_launch<T, 128, 1, 1, 4, 1, 2>(a, pl, bnb, st);
-    case 256: return rs_launch<T, 256, 1, 1, 2, 2, 1>(a, pl, bnb, st);
-    default: return rs_launch<T, 512, 1, 1, 2, 4, 1>(a, pl, bnb, st);
+    case 256: return rs_launch<T, 256, 1, 1, 2, 2, EMSA_RS_TM256>(a, pl, bnb, st);
+    default: return rs_launch<T, 512, 1, 1, 2, 4, EMSA_RS_TM512>(a, pl, bnb, st);
   }
 }
 
@@ -686,6 +754,7 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
   const long M = (long)g->n_img * g->out_h * g->out_w;
   if ((residual && M * ld_res * 2 >= (1L << 31)) || (mask_src && M * ld_mask * 2 >= (1L << 31)))
     return EMSA_E_SHAPE;
+  if (stats && (residual || mask_src)) return EMSA_E_SHAPE;   // no such launch in the model: conv_h takes it
   const bool bnb = bnb_out != nullptr;
   if (bnb && (!mask_src || !scale || !bnb_mean || !bnb_invstd || stats || act != EMSA_ACT_NONE ||
               bnb_rows_alloc < 8 * pl.gx))

@@ -331,7 +331,8 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
     stats = None
     if code != 0:
         wino_u = None                       # the 16-bit path is conv_rs.hip / conv_h.hip
-    use_rs = wfrag is not None and wfrag.dtype == x.dtype and rs_supported(code, g)
+    use_rs = wfrag is not None and wfrag.dtype == x.dtype and rs_supported(code, g) and \
+        not (want_stats and residual is not None)
     if want_stats:
         if wino_u is not None:
             rows = L.emsa_conv1d_wino_stats_rows(g)

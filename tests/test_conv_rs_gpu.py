@@ -34,7 +34,7 @@ RS_CONVS = [
     (512, (1, 3), 2, 15, 20),
     (512, (3, 1), 2, 15, 20),
     (512, (3, 1), 1, 23, 30),
-    (512, (1, 3), 7, 5, 7),
+    (512, (1, 3), 17, 5, 7),
 ]
 
 

@@ -7,7 +7,7 @@ import sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
 cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Iinclude',
-       '-Iemsanet_amd/csrc', '-munsafe-fp-atomics', '-c', src, '-o', '/tmp/kernel_regs.o',
+       '-Iemsanet_amd/csrc', '-munsafe-fp-atomics'] + sys.argv[3:] + ['-c', src, '-o', '/tmp/kernel_regs.o',
        '-Rpass-analysis=kernel-resource-usage']
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
