@@ -85,6 +85,9 @@ def parse():
     ap.add_argument('--graph', action='store_true',
                     help='replay the step from a hipGraph: with --eval the whole-model forward '
                          '(BASELINE config 5 shape), otherwise the whole training step')
+    ap.add_argument('--eager', action='store_true',
+                    help='N > 1 only: keep the hook-driven eager step (default for N > 1 is the '
+                         'segmented-hipGraph step: the eager 16-bit step is host-bound)')
     return ap.parse_args()
 
 
@@ -266,6 +269,11 @@ def run(args):
     # FusedSGD folds the 1/world averaging into its update kernel; torch's optimizer needs it done
     comm_dtype = {'f32': None, 'bf16': torch.bfloat16}[args.grad_dtype]
     dist_on = dist.is_initialized() and (world > 1 or args.force_dist)
+    # several ranks: the default is the segmented-hipGraph step (one graph per backward segment,
+    # all-reduce issued eagerly in between) -- the hook-driven eager step costs 16 % in bf16 before a
+    # byte crosses xGMI; --eager / --torch-optimizer / --h2d keep the eager path
+    if world > 1 and not args.eval and not args.eager and not args.torch_optimizer and not args.h2d:
+        args.graph = True
     segmented = bool(args.graph and not args.eval and dist_on)
     if segmented:
         # multi-rank step under hipGraphs: one graph per backward segment, the buckets of a segment
@@ -440,6 +448,7 @@ def run(args):
                 'grads_written_in_place': st['direct_tensors'] // steps_seen,
                 'grads_gathered_by_copy': st['gathered_tensors'] // steps_seen,
                 'bucket_bytes': [f.numel() * f.element_size() for f, _, _ in buckets.buckets],
+                'path': 'segmented-graph' if segmented else 'eager',
                 'bucket_order': 'backward segments (graph per segment)' if segmented
                 else 'measured gradient-arrival order, last bucket <= 4 MiB'}
         if segmented and train_graph is not None:
@@ -493,6 +502,16 @@ def run(args):
     from emsanet_amd import nn as enn
     overlapped = timing and not args.graph and enn._dual_stream(batch['rgb'])
     single_pass = overlapped          # (every rank takes part: the steps contain the collectives)
+    # a graph-replayed training step cannot be bracketed by HIP events per launch: its kernels are
+    # timed in `roofline_steps` EAGER steps of the same step object (same kernels, same buffers, the
+    # collectives included) behind the timed region, on one stream
+    graph_roof = train_graph is not None and not args.eval and args.roofline_steps > 0
+
+    def eager_twin():
+        if hasattr(train_graph, 'eager_step'):
+            train_graph.eager_step(None)
+        else:
+            train_graph._step()
     if overlapped and kernels:
         k0 = kernels[0]
         in_region = {'kernel': k0['kernel'], 'avg_us': k0['avg_us'], 'achieved': k0['tflops'],
@@ -502,18 +521,19 @@ def run(args):
                      'note': 'launches of the two streams overlap: durations include CU sharing'}
         if args.dtype != 'f32' and 'algo_gbps' in k0:
             in_region['achieved'] = k0['algo_gbps']
-    if single_pass and kernels:
+    if (single_pass and kernels) or graph_roof:
+        roof_step = eager_twin if graph_roof else step
         enn.DUAL_STREAM = False
         try:
             for _ in range(2):
-                step()
+                roof_step()
             L.emsa_prof_reset()
             L.emsa_prof_enable(args.timing_every)
             Fn.PROF_REAL_FLOPS = True
             barrier()
             t1 = time.perf_counter()
             for _ in range(args.roofline_steps):
-                step()
+                roof_step()
             barrier()
             dt_r = time.perf_counter() - t1
             L.emsa_prof_enable(0)
@@ -581,6 +601,11 @@ def run(args):
                 'bracketed by HIP events on its stream): the kernel\'s own rate')
             in_region['frac'] = round(in_region['achieved'] / roofline['peak'], 4)
             roofline['in_timed_region'] = in_region
+        if graph_roof:
+            roofline['measured_over'] = (
+                f'{steps_roof} EAGER single-stream steps of the graphed step object behind the timed '
+                f'region ({round(1e3 * dt_roof / steps_roof, 2)} ms/step; every {args.timing_every}th '
+                'launch bracketed by HIP events): a graph replay cannot be bracketed per launch')
         if 'mfma_executed_tflops' in k:
             roofline['mfma_executed_tflops'] = k['mfma_executed_tflops']
             roofline['frac_mfma_executed'] = round(k['mfma_executed_tflops'] / MFMA_F32_PEAK_TFLOPS, 4)

@@ -2064,16 +2064,21 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true, T>),
                          dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
                          (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
-    } else if (pl.wino && bf16)
-      hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true>),
-                         dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
-                         (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
-    else if (pl.wino && in_scale) {
+    } else if (pl.wino && in_scale) {
+      // (tested BEFORE the opt-in bf16-MFMA form: that kernel has no loader fold and would
+      //  multiply against the raw BatchNorm input -- ADVICE r3; the fold stays exact fp32)
       if constexpr (!kHalf)
         hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, false, float, true>),
                            dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
                            (size_t)(16 * 4 * (BCO + BCI) + 2 * BCI) * sizeof(float), st, w);
-    } else if (pl.wino)
+    } else if (in_scale) {
+      prof_end(ps, st);
+      return EMSA_E_SHAPE;                         // direct form (EMSA_WGRAD_WINO=0): no loader fold
+    } else if (pl.wino && bf16)
+      hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI, true>),
+                         dim3(w.n_tiles * w.R * pl.ksplit), dim3(256),
+                         (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
+    else if (pl.wino)
       hipLaunchKernelGGL((conv_wgrad1d_wino_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), (size_t)(16 * 4 * (BCO + BCI)) * sizeof(float), st, w);
     else

@@ -106,6 +106,7 @@ struct ConvRSArgs {
   int ni;                   // DMA instructions (1 KB each) per tile
   int abuf;                 // bytes of one A buffer
   int stat_rows;            // rows of the statistics / BatchNorm-backward partial buffers
+  int bacc_off;             // LDS offset of the BNB accumulators [16][threads]
   RFastDiv div_w, div_tpi, div_tw;
 };
 
@@ -194,6 +195,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
   const int soff = eoff + 3 * NWG * 4;                // fp32 stage [WK][BM][SLD]
   float* const stage = reinterpret_cast<float*>(smem + soff);
   float* const evec = reinterpret_cast<float*>(smem + eoff);
+  // BNB: the per-thread BatchNorm-backward sums (2 x 8 channels) live in LDS, not in registers
+  float* const bacc = reinterpret_cast<float*>(smem + p.bacc_off);
 
   if (!DIRH) {
     for (int i = tid; i < RB / 4; i += NT) reinterpret_cast<uint32_t*>(smem + zoff)[i] = 0u;
@@ -266,7 +269,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
   const int col8 = tid % C8, orow = tid / C8;
   const int n = n_base + col8 * 8;
   const bool has_affine = p.scale != nullptr && !BNB;
+  // (registers where they fit: the 64- / 128-channel kernels keep two accumulator tiles per wave)
+  constexpr bool kBaccLds = BNB && KC <= 128;
   rf32x8 b0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if constexpr (kBaccLds) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bacc[e * NT + tid] = 0.f;
+  }
   const __amdgpu_buffer_rsrc_t rs_out = r_rsrc(p.out, p.out_bytes);
   const __amdgpu_buffer_rsrc_t rs_res = r_rsrc(p.residual ? p.residual : p.out, p.res_bytes);
   const __amdgpu_buffer_rsrc_t rs_msk = r_rsrc(p.mask_src ? p.mask_src : p.out, p.mask_bytes);
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
           for (int r = 0; r < 16; ++r) acc[i][j][a][r] = 0.f;
     {
       // fragment order (tap, k16 step, row tile): consecutive MFMAs hit different accumulators
-      constexpr int TOT = TM * NF, PD = 4;
+      constexpr int TOT = TM * NF, PD = BNB ? 2 : 4;
       V8 af[PD];
       auto a_addr = [&](int f) {
         const int i = f % TM, t = (f / TM) / KSW, kk = (f / TM) % KSW;
@@ -434,6 +443,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     RS_MARK(4);
+    if constexpr (!kDMA && BNB) {
+      // (the fused BatchNorm-backward epilogue needs the staging registers: the next tile goes to
+      //  LDS before the output pass instead of behind it -- the A buffer is free from here on)
+      if (more) store_tile();
+    }
 
     // ---- output pass: 8 channels x PASSES rows per thread, every global access 16 bytes ----------
     constexpr int PG = BNB ? 1 : (PASSES > 2 ? 2 : PASSES);   // passes per group (register budget)
@@ -503,8 +517,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             x[e] = (ok && (tt[e] * evec[col8 * 8 + e] + evec[NWG + col8 * 8 + e]) > 0.f) ? x[e] : 0.f;
-            b0[e] += x[e];
-            b1[e] += x[e] * (tt[e] - evec[2 * NWG + col8 * 8 + e]);
+            const float xm = x[e] * (tt[e] - evec[2 * NWG + col8 * 8 + e]);
+            if constexpr (kBaccLds) {
+              bacc[e * NT + tid] += x[e];
+              bacc[(8 + e) * NT + tid] += xm;
+            } else {
+              b0[e] += x[e];
+              b1[e] += xm;
+            }
           }
         } else if (has_msk) {
           const rf32x8 mm = __builtin_convertvector(__builtin_bit_cast(V8, rmsk[q]), rf32x8);
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
     }
   
 
-    if constexpr (!kDMA) {
+    if constexpr (!kDMA && !BNB) {
       if (more) store_tile();      // (every wave is behind the barrier that ended the reads of this tile)
     }
 #if EMSA_RS_DBG
@@ -549,8 +569,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
     if constexpr (BNB) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        red[(orow * 2 + 0) * NWG + col8 * 8 + e] = b0[e];
-        red[(orow * 2 + 1) * NWG + col8 * 8 + e] = b1[e];
+        red[(orow * 2 + 0) * NWG + col8 * 8 + e] = kBaccLds ? bacc[e * NT + tid] : b0[e];
+        red[(orow * 2 + 1) * NWG + col8 * 8 + e] = kBaccLds ? bacc[(8 + e) * NT + tid] : b1[e];
       }
     } else {
       // (n, mean, M2) of this thread's rows
@@ -602,7 +622,7 @@ struct RSPlan {
   bool dirh = false;
   int bm = 0, nwg = 0, nwv = 0, wk = 1, rpi = 0;
   int tiles = 0, tiles_w = 0, twl = 0, th = 0;
-  int ni = 0, abuf = 0, lds = 0, gx = 0, nslice = 0, sign = 1;
+  int ni = 0, abuf = 0, lds = 0, bacc_off = 0, gx = 0, nslice = 0, sign = 1;
 };
 
 int rs_cu_count() {
@@ -688,7 +708,8 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   const int rpp = pl.nwv * 64 / (pl.nwg / 8);
   const int stage = pl.wk * pl.bm * (pl.nwg + 4) * 4;
   const int red = rpp * 3 * pl.nwg * 4 + rpp * 4;
-  pl.lds = (EMSA_RS_DMA ? 2 : 1) * pl.abuf + pl.kc * 2 + 16 + 3 * pl.nwg * 4 + (stage > red ? stage : red);
+  pl.bacc_off = (EMSA_RS_DMA ? 2 : 1) * pl.abuf + pl.kc * 2 + 16 + 3 * pl.nwg * 4 + (stage > red ? stage : red);
+  pl.lds = pl.bacc_off + (pl.kc <= 128 ? 16 * pl.nwv * 64 * 4 : 0);   // (+ LDS accumulators of the BNB form)
   if (pl.lds > 160 * 1024) return false;
   // persistent grid: 8 XCDs x gx workgroups x channel slices; every workgroup gets >= 1 tile
   const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
@@ -775,6 +796,7 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
   a.sign = pl.sign; a.n_ch = g->n_ch;
   a.tiles = pl.tiles; a.tiles_w = pl.tiles_w > 0 ? pl.tiles_w : 1; a.twl = pl.twl; a.th = pl.th;
   a.gx = pl.gx; a.nslice = pl.nslice; a.ni = pl.ni; a.abuf = pl.abuf; a.stat_rows = 8 * pl.gx;
+  a.bacc_off = pl.bacc_off;
   a.div_w = r_make_fastdiv((uint32_t)g->out_w);
   const int tpi = pl.dirh ? pl.tiles / g->n_img : 1;
   a.div_tpi = r_make_fastdiv((uint32_t)(tpi > 0 ? tpi : 1));

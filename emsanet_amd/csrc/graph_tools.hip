@@ -35,6 +35,16 @@ __global__ void emsa_graph_fill_kernel(unsigned char* dst, unsigned int value, u
   }
 }
 
+// One contiguous row whose start and byte count are multiples of 16 (hipMemsetAsync captures arrive
+// as elementSize 1 x width = bytes: tens of MB of gradient buffers per replay): 16 bytes per
+// thread-iteration instead of one element.  `pattern` = the value replicated to 32 bits.
+__global__ void emsa_graph_fill16_kernel(uint4* dst, unsigned int pattern, size_t n16) {
+  const uint4 v = make_uint4(pattern, pattern, pattern, pattern);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = v;
+}
+
 }  // namespace
 
 // Counts the nodes of `graph` (a hipGraph_t) by kind.  n_nodes / n_memset / n_kernel may be NULL.
@@ -69,46 +79,75 @@ extern "C" int emsa_graph_replace_memsets(void* graph, int32_t* replaced) {
   if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return EMSA_E_LAUNCH;
   std::vector<hipGraphNode_t> nodes(n);
   if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return EMSA_E_LAUNCH;
-  int done = 0;
+  // pass 1: collect and validate every memset node (nothing is modified if one is unsupported:
+  // a half-rewritten graph must never be instantiated -- ADVICE r3)
+  struct Job {
+    hipGraphNode_t node;
+    hipMemsetParams mp;
+    std::vector<hipGraphNode_t> deps, outs;
+  };
+  std::vector<Job> jobs;
   for (size_t i = 0; i < n; ++i) {
     hipGraphNodeType t;
     if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) return EMSA_E_LAUNCH;
     if (t != hipGraphNodeTypeMemset) continue;
-    hipMemsetParams mp;
-    if (hipGraphMemsetNodeGetParams(nodes[i], &mp) != hipSuccess) return EMSA_E_LAUNCH;
-    if (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4) return EMSA_E_SHAPE;
+    Job jb;
+    jb.node = nodes[i];
+    if (hipGraphMemsetNodeGetParams(nodes[i], &jb.mp) != hipSuccess) return EMSA_E_LAUNCH;
+    if (jb.mp.elementSize != 1 && jb.mp.elementSize != 2 && jb.mp.elementSize != 4) return EMSA_E_SHAPE;
     size_t nd = 0, nn = 0;
     if (hipGraphNodeGetDependencies(nodes[i], nullptr, &nd) != hipSuccess) return EMSA_E_LAUNCH;
-    std::vector<hipGraphNode_t> deps(nd);
-    if (nd && hipGraphNodeGetDependencies(nodes[i], deps.data(), &nd) != hipSuccess)
+    jb.deps.resize(nd);
+    if (nd && hipGraphNodeGetDependencies(nodes[i], jb.deps.data(), &nd) != hipSuccess)
       return EMSA_E_LAUNCH;
     if (hipGraphNodeGetDependentNodes(nodes[i], nullptr, &nn) != hipSuccess) return EMSA_E_LAUNCH;
-    std::vector<hipGraphNode_t> outs(nn);
-    if (nn && hipGraphNodeGetDependentNodes(nodes[i], outs.data(), &nn) != hipSuccess)
+    jb.outs.resize(nn);
+    if (nn && hipGraphNodeGetDependentNodes(nodes[i], jb.outs.data(), &nn) != hipSuccess)
       return EMSA_E_LAUNCH;
-
+    jobs.push_back(std::move(jb));
+  }
+  // pass 2: rewrite
+  int done = 0;
+  for (Job& jb : jobs) {
+    const hipMemsetParams& mp = jb.mp;
+    const size_t nd = jb.deps.size(), nn = jb.outs.size();
     unsigned char* dst = (unsigned char*)mp.dst;
     unsigned int value = mp.value, esize = mp.elementSize;
     size_t width = mp.width, height = mp.height ? mp.height : 1;
     size_t pitch = height > 1 ? mp.pitch : width * esize;
-    void* args[6] = {&dst, &value, &esize, &width, &height, &pitch};
-    size_t total = width * height;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    const size_t bytes = width * esize;
     hipKernelNodeParams kp = {};
-    kp.func = (void*)emsa_graph_fill_kernel;
-    kp.gridDim = dim3((unsigned)blocks);
     kp.blockDim = dim3(256);
     kp.sharedMemBytes = 0;
-    kp.kernelParams = args;
     kp.extra = nullptr;
+    // wide form: one row, 16-byte aligned start and size
+    uint4* dst16 = (uint4*)dst;
+    unsigned int pattern = esize == 4 ? value : esize == 2 ? (value & 0xFFFFu) * 0x10001u
+                                                            : (value & 0xFFu) * 0x01010101u;
+    size_t n16 = bytes / 16;
+    void* args16[3] = {&dst16, &pattern, &n16};
+    void* args[6] = {&dst, &value, &esize, &width, &height, &pitch};
+    if (height == 1 && bytes >= 4096 && (bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+      size_t blocks = (n16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      kp.func = (void*)emsa_graph_fill16_kernel;
+      kp.gridDim = dim3((unsigned)blocks);
+      kp.kernelParams = args16;
+    } else {
+      size_t total = width * height;
+      size_t blocks = (total + 255) / 256;
+      if (blocks > 1024) blocks = 1024;
+      if (blocks < 1) blocks = 1;
+      kp.func = (void*)emsa_graph_fill_kernel;
+      kp.gridDim = dim3((unsigned)blocks);
+      kp.kernelParams = args;
+    }
     hipGraphNode_t kn;
-    if (hipGraphAddKernelNode(&kn, g, nd ? deps.data() : nullptr, nd, &kp) != hipSuccess)
+    if (hipGraphAddKernelNode(&kn, g, nd ? jb.deps.data() : nullptr, nd, &kp) != hipSuccess)
       return EMSA_E_LAUNCH;
     for (size_t k = 0; k < nn; ++k)
-      if (hipGraphAddDependencies(g, &kn, &outs[k], 1) != hipSuccess) return EMSA_E_LAUNCH;
-    if (hipGraphDestroyNode(nodes[i]) != hipSuccess) return EMSA_E_LAUNCH;   // drops its edges too
+      if (hipGraphAddDependencies(g, &kn, &jb.outs[k], 1) != hipSuccess) return EMSA_E_LAUNCH;
+    if (hipGraphDestroyNode(jb.node) != hipSuccess) return EMSA_E_LAUNCH;   // drops its edges too
     ++done;
   }
   if (replaced) *replaced = done;

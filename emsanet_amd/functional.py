@@ -520,6 +520,10 @@ def bn1_fold(t):
     """fold the BatchNorm + ReLU applied to activation `t` into the loaders of the conv behind it?"""
     if t.dtype != torch.float32:
         return False
+    # the weight gradient's loader fold exists for the exact-fp32 Winograd F(3,2) form only: not for
+    # the direct form (EMSA_WGRAD_WINO=0) nor beside the opt-in bf16-MFMA fp32 mode (ADVICE r3)
+    if os.environ.get('EMSA_WGRAD_WINO') == '0':
+        return False
     if BN1_FOLD is not None:
         return BN1_FOLD
     if _BN1_FOLD_ENV is not None:

@@ -41,6 +41,14 @@ def _repair_and_instantiate(graph, kept):
     memsets run between them, ROCm 7.2) and instantiate.  -> {'nodes', 'memset_nodes', 'replaced'}"""
     info = {'nodes': None, 'memset_nodes': None, 'replaced': 0}
     if not kept:
+        # no access to the raw graph (torch < 2.8): the capture cannot be repaired, and an
+        # un-repaired capture with memset nodes is the configuration known to replay wrongly
+        # (DESIGN.md 5b) -- say so instead of running it silently (ADVICE r3)
+        import warnings
+        warnings.warn("emsanet_amd.graph: this torch has no CUDAGraph(keep_graph=True); captured "
+                      "memset nodes cannot be replaced by kernel nodes -- replays of a step that "
+                      "zero-fills memory (device-side losses, gradient buffers) may be wrong on "
+                      "ROCm 7.2", RuntimeWarning, stacklevel=2)
         return info
     raw = graph.raw_cuda_graph()
     raw = int(raw) if not hasattr(raw, 'value') else int(raw.value)

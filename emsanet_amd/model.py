@@ -258,6 +258,16 @@ class EMSANet(nn.Module):
                        'emsa_u32_add')
             self._seed_dev_host = (self.dropout_seed & 0xFFFFFFFF, self.dropout_step & 0xFFFFFFFF)
 
+    def _skip_streams_read(self):
+        """names of the encoder skip streams the decoders' skip fusions read (a CutPlan
+        must cut exactly these; 'add' with one modality reads the only stream there is)"""
+        read = set()
+        for m in self.decoders.modules():
+            f = getattr(m, 'fusion', None)
+            if isinstance(f, str) and f.startswith('add-'):
+                read.add(f[4:])
+        return read or {'rgb'}
+
     def forward(self, batch, do_postprocessing=False) -> Dict[str, Any]:
         """contract of /root/reference/emsanet/model.py:192-233: list of per-decoder
         (outputs, side outputs) in `self.decoders` order, or one merged dict when post-processing"""
@@ -302,9 +312,12 @@ class EMSANet(nn.Module):
             # detached leaf; the originals become roots of the encoder's backward segments
             D = plan.DECODERS
             deep = {k: plan.cut(v, st, D) for k, (v, st) in deep.items()}
-            # (only the rgb skips feed the decoders; the depth stream's gradient comes through
-            #  the fusion modules)
-            skips = {ds: {k: (plan.cut(v, st, D) if k == 'rgb' or len(sk) == 1 else v.detach())
+            # every skip stream a decoder READS ('add-rgb' by default; 'add-depth' / 'add-rgbd' per
+            # decoder, emsanet/decoder.py:63-91) is cut into a leaf whose gradient flows back into
+            # its encoder segment; a stream no decoder reads is just detached (its gradient comes
+            # through the fusion modules only)
+            read = self._skip_streams_read()
+            skips = {ds: {k: (plan.cut(v, st, D) if k in read or len(sk) == 1 else v.detach())
                           for k, (v, st) in sk.items()} for ds, sk in skips.items()}
         # the context module sees the fused rgb stream, or the only stream there is
         ctx_in = deep['rgb'] if len(feeds) == 2 else next(iter(deep.values()))

@@ -950,6 +950,9 @@ class SEAddFunction(Function):
         _trace_mask('se.rgb', hr)
         _trace_mask('se.depth', hd)
         out = Fn.se_scale_add(rgb, sr, depth, sd)
+        # an unused pass-through depth output (last stage, cut boundaries) arrives as None in
+        # backward instead of a materialised zeros tensor + one more read in the kernel
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(rgb, depth)
         ctx.saved = (gr, gd, hr, sr, hd, sd, flat(w1r), flat(w2r), flat(w1d), flat(w2d))
         ctx.shapes = (w1r.shape, w2r.shape)
@@ -962,6 +965,8 @@ class SEAddFunction(Function):
         rgb, depth = ctx.saved_tensors
         gr, gd, hr, sr, hd, sd, w1r, w2r, w1d, w2d = ctx.saved
         ctx.saved = None
+        if dout is None:                     # (only the pass-through output was used downstream)
+            dout = torch.zeros_like(rgb)
         dout = Fn.as_act(dout, dense=True)
         if ddepth_next is not None:
             ddepth_next = Fn.as_act(ddepth_next, dense=True)

@@ -90,6 +90,8 @@ class GradientBuckets:
         self.manual = manual
         params = [p for p in params if p.requires_grad]
         self.params = params
+        if groups is not None and order is not None:
+            raise ValueError("GradientBuckets: pass `order` OR `groups` (the groups fix the order)")
         if groups is None:
             # reverse registration order ~ order in which backward produces gradients
             groups = [list(order) if order is not None else list(reversed(params))]
@@ -317,8 +319,22 @@ def broadcast_parameters(module, src=0, process_group=None):
         return
     with torch.no_grad():
         params = list(module.parameters())
+        # ONE flat broadcast per dtype instead of one per tensor (> 1,500 of them): pack, send,
+        # unpack -- RCCL launch + rendezvous latency per call dominates tensors this small
+        by_dtype = {}
         for t in params + list(module.buffers()):
-            dist.broadcast(t.detach(), src=src, group=process_group)
+            by_dtype.setdefault((t.dtype, t.device), []).append(t.detach())
+        for (dtype, device), ts in by_dtype.items():
+            flat = torch.empty(sum(t.numel() for t in ts), dtype=dtype, device=device)
+            off = 0
+            for t in ts:
+                flat[off:off + t.numel()].copy_(t.reshape(-1))
+                off += t.numel()
+            dist.broadcast(flat, src=src, group=process_group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
         # the broadcast wrote in place through detached aliases: tell autograd -- and with it the
         # engine's packed-weight caches, which key on `_version` -- that the parameters changed
         torch.autograd.graph.increment_version(params)

@@ -27,3 +27,13 @@ def test_no_register_spills():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_spills.py')],
                        capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@needs_hipcc
+def test_conv_rs_has_no_vmcnt_wait_inside_its_mfma_sequence():
+    """csrc/conv_rs.hip: a compiler-placed `s_waitcnt vmcnt` between the first and the last MFMA of a
+    tile drains the next tile's loads in every iteration (found in round 4: the waits for the
+    resident weight fragments sat there until the fragments were pinned in the prologue)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_rs_waits.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'conv_rs wait check: ok' in r.stdout, r.stdout + r.stderr

@@ -162,9 +162,12 @@ def test_eval_16bit_vs_storage_emulating_oracle(dtype, monkeypatch):
     assert max(errs) <= EMU_TOL[dtype]
 
 
-def test_train_bf16_pinned_gradients(monkeypatch):
+@pytest.mark.parametrize('shape', [(8, 256, 320), (2, 480, 640)])
+def test_train_bf16_pinned_gradients(shape, monkeypatch):
     """configs[2] arithmetic on one rank: bf16 train step (BatchNorm batch statistics, Dropout2d),
-    fwd + bwd at the BASELINE resolution, against the fp64 oracle that (1) replays the engine's
+    fwd + bwd at 256x320 with bs 8 and AT THE BASELINE RESOLUTION 640x480 with bs 2 (the kernels'
+    tile / K-step / persistent-grid choices depend on the shape: conv_rs takes the /4../32 stages
+    there like in the bs 32 bench), against the fp64 oracle that (1) replays the engine's
     ReLU decisions and (2) rounds activations, their gradients and the conv weights to bf16 where
     the engine stores them.  (Against the PLAIN fp64 oracle the train-mode outputs of this
     random-weight network differ by 0.2-0.4 relative L2: every BatchNorm with batch statistics
@@ -174,14 +177,15 @@ def test_train_bf16_pinned_gradients(monkeypatch):
     from emsanet_amd import full_args, ops
     from oracle import emsanet_oracle as O
     from test_model_gpu import _PinnedRelu
-    args = full_args(input_height=256, input_width=320)
+    bs, hh, ww = shape
+    args = full_args(input_height=hh, input_width=ww)
     model, oracle = _pair(args)
     oracle = oracle.double()
     model.set_compute_dtype(torch.bfloat16)
     for m in (model, oracle):
         m.train()
         m.dropout_seed = 321
-    batch = O.synthetic_batch(8, 256, 320)
+    batch = O.synthetic_batch(bs, hh, ww)
     ops.MASK_TRACE = []
     try:
         out = _flatten(model({k: v.to(DEV) for k, v in batch.items()}))
@@ -221,7 +225,7 @@ def test_train_bf16_pinned_gradients(monkeypatch):
     ratio = torch.tensor([mp[k].grad.norm().item() / pr[k].grad.norm().item() for k in names])
     import os
     if os.path.isdir('gpurun_out'):
-        with open('gpurun_out/grad_ratio_bf16.txt', 'w') as f:
+        with open(f'gpurun_out/grad_ratio_bf16_{hh}x{ww}.txt', 'w') as f:
             for k, r_, c_ in zip(names, ratio.tolist(), cos.tolist()):
                 f.write(f"{r_:.4f} {c_:.4f} {k}\n")
     print("gradient norm ratio engine/oracle: median %.4f p5 %.4f p95 %.4f; first layers %s; last %s" % (
@@ -451,3 +455,41 @@ def test_decoder_module_bf16_vs_emulating_oracle(mode, monkeypatch):
     assert e_out <= 1e-2
     assert all(_rel_l2(a, b) <= 3e-2 for a, b in res.values())
     assert all(abs(r - 1) <= 1e-2 for r in ratios.values())
+
+
+def test_full_size_bf16_batch_consistency_and_determinism():
+    """BASELINE configs[2]'s shape (bs=32, 640x480 RGB-D, all heads) in bf16 storage through
+    size-independent properties (the bf16 twin of test_model_gpu.py::
+    test_full_size_batch_consistency_and_determinism): (1) eval outputs of a sample do not depend on
+    the batch it sits in -- at bs 32 every stride-1 3-tap conv runs on the persistent conv_rs kernel,
+    at bs 1 the /16 and /32 stages fall back to the implicit GEMM, BatchNorm is folded either way --
+    up to bf16 rounding-boundary flips of intermediates (same yardstick as the emulating-oracle
+    test); (2) the train-mode forward (batch statistics, hash dropout) is bit-reproducible."""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd import functional as Fn
+    from emsanet_amd.model import EMSANet
+    from util import deterministic_state_dict
+    model = EMSANet(full_args(compute_dtype='bfloat16'), nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    rgb = torch.randn(32, 3, 480, 640, generator=g).to(DEV)
+    depth = torch.randn(32, 1, 480, 640, generator=g).to(DEV)
+    # the persistent kernel really is what runs at this size
+    spec = Fn.ConvSpec(256, 256, (3, 1), 1, (1, 0))
+    assert Fn.rs_supported(1, spec.geom_fwd(32, 30, 40, 256, 256))
+    with torch.no_grad():
+        big = _flatten(model({'rgb': rgb, 'depth': depth}))
+        for i in (0, 17, 31):
+            one = _flatten(model({'rgb': rgb[i:i + 1].contiguous(), 'depth': depth[i:i + 1].contiguous()}))
+            errs = [_rel_l2(a[i:i + 1], b) for a, b in zip(big, one)]
+            assert max(errs) <= EMU_TOL[torch.bfloat16], (i, errs)
+    del big
+    model.train()
+    outs = []
+    for _ in range(2):
+        model.dropout_step = 3
+        with torch.no_grad():
+            outs.append([t.clone() for t in _flatten(model({'rgb': rgb, 'depth': depth}))])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), 'bf16 train-mode forward is not bit-reproducible'

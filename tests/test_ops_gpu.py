@@ -816,6 +816,50 @@ def test_conv1d_winograd_folded_input_bn(cfg):
     assert torch.equal(dw, dw2)                               # deterministic two-pass form
 
 
+def test_folded_input_bn_wgrad_under_bf16_mfma_subprocess():
+    """with the opt-in EMSA_BF16_MFMA=1 the weight gradient of a conv whose forward folded
+    its input's BatchNorm must still be taken against relu(x * scale + shift) (the exact-fp32
+    Winograd F(3,2) kernel with the loader fold), not against the raw BatchNorm input"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, "tests")
+from util import DEV, rnd, to_act
+from emsanet_amd import functional as Fn
+cin = cout = 64; k = (3, 1); p = (1, 0)
+x = rnd(2, cin, 12, 20, seed=1)
+sc = rnd(cin, seed=11).abs() + 0.5
+sh = rnd(cin, seed=12) + 0.3
+wt = rnd(cout, cin, *k, seed=2, scale=0.1).double().requires_grad_(True)
+a = F.relu(torch.addcmul(sh[None, :, None, None], x, sc[None, :, None, None])).double()
+ref = F.conv2d(a, wt, None, padding=p)
+dy = rnd(*ref.shape, seed=7)
+ref.backward(dy.double())
+spec = Fn.ConvSpec(cin, cout, k, (1, 1), p)
+like = wt.detach().float().to(DEV)
+dw, db, packed = Fn.conv_wgrad(to_act(x), to_act(dy), spec, False, like=like, two_pass=True,
+                               in_affine=(sc.to(DEV), sh.to(DEV)))
+torch.cuda.synchronize()
+err = (dw.cpu().double() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
+assert err < 2e-4, err
+print("INBN_BF16_OK %.2e" % err)
+'''
+    env = dict(os.environ, EMSA_BF16_MFMA='1')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert 'INBN_BF16_OK' in r.stdout, r.stderr[-2000:]
+    # the direct form (EMSA_WGRAD_WINO=0) has no loader fold: bn1_fold() says so up front
+    env = dict(os.environ, EMSA_WGRAD_WINO='0')
+    r = subprocess.run([sys.executable, '-c',
+                        'import torch\nfrom emsanet_amd import functional as Fn\n'
+                        'print("FOLD", Fn.bn1_fold(torch.empty(64 << 20)))'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert 'FOLD False' in r.stdout, r.stdout + r.stderr[-1000:]
+
+
 def test_folded_input_bn_rejects_unsupported():
     """3x3 / strided convs have no folded loader: EMSA_E_SHAPE, never a silent plain conv"""
     Fn = _fn()

@@ -245,10 +245,13 @@ def test_two_rank_segmented_graph_step_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_segmented_step_equals_plain_step_single_process():
+@pytest.mark.parametrize('inst_fusion', ['add-rgb', 'add-depth'])
+def test_segmented_step_equals_plain_step_single_process(inst_fusion):
     """one process, no collectives: the segmented backward (cuts at the decoder boundary and
     behind encoder stages 2 and 1) gives the gradients of the ordinary backward pass, eagerly and
-    replayed from its graphs; a second replay draws fresh Dropout2d masks"""
+    replayed from its graphs; a second replay draws fresh Dropout2d masks.  'add-depth' for the
+    instance decoder (emsanet/decoder.py:94-139 takes the fusion per decoder): the depth skips are
+    cut too, so the decoder's skip gradients reach the depth encoder"""
     sys.path.insert(0, ROOT)
     from emsanet_amd import full_args, nyuv2_config
     from emsanet_amd.graph import SegmentedGraphedTrainStep, segment_parameter_groups
@@ -257,7 +260,10 @@ def test_segmented_step_equals_plain_step_single_process():
     from emsanet_amd.parallel import GradientBuckets
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
-    model = EMSANet(full_args(input_height=H, input_width=W), nyuv2_config()).to(dev).train()
+    model = EMSANet(full_args(input_height=H, input_width=W,
+                              instance_encoder_decoder_fusion=inst_fusion),
+                    nyuv2_config()).to(dev).train()
+    assert model._skip_streams_read() == ({'rgb'} if inst_fusion == 'add-rgb' else {'rgb', 'depth'})
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith('bn2.weight'):
@@ -293,3 +299,27 @@ def test_segmented_step_equals_plain_step_single_process():
     l2 = float(step.replay(batch)[0])
     assert l2 != float(loss_e)                   # next step's masks
     assert all(i['memset_nodes'] == i['replaced'] for i in step.graph_info)
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` through its own launcher (torch.distributed.run on 127.0.0.1, the
+    command line the driver uses), two ranks sharing this GPU over gloo (RCCL refuses two ranks on
+    one device): the default N > 1 path is the segmented-hipGraph step, both ranks report, the JSON
+    line carries the whole-job value and the kernels' roofline"""
+    import json
+    import subprocess
+    env = dict(os.environ, EMSA_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch-size', '2',
+                        '--steps', '2', '--warmup', '1', '--roofline-steps', '1', '--no-cpu-baseline'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['steps'] == 2
+    c = d['comm']
+    assert c['ranks_seen'] == [0, 1] and c['backend'] == 'gloo'
+    assert c['path'] == 'segmented-graph' and len(c['graphs']) >= 2
+    assert c['allreduce_bytes_per_step'] > 200e6        # ~63.5 M fp32 gradients
+    assert d['roofline'] is not None and d['roofline']['frac'] > 0
