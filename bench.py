@@ -551,15 +551,27 @@ def run(args):
     roofline = None
     traffic, traffic_src = None, None
     pmc, pmc_file = None, None
-    pmc_names = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json') \
-        if args.dtype == 'f32' else (f'r03_pmc_traffic_{args.dtype}.json', f'r02_pmc_traffic_{args.dtype}.json')
+    pmc_names = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json') \
+        if args.dtype == 'f32' else (f'r04_pmc_traffic_{args.dtype}.json', f'r03_pmc_traffic_{args.dtype}.json')
+    pmc_stale = None
     for name in pmc_names:                                             # newest measurement first
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             pmc_file = 'profiles/' + name
-            break
         except Exception:
             continue
+        # a traffic file describes the kernels it was measured on: refuse it when the kernel
+        # sources changed since (content hash of emsanet_amd/csrc -- the GPU box has no .git)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from pmc_traffic_json import csrc_sha16
+        have = csrc_sha16(ROOT)
+        if pmc.get('csrc_sha16') != have:
+            pmc_stale = (f"{pmc_file} was measured on other kernel sources (csrc_sha16 "
+                         f"{pmc.get('csrc_sha16', 'absent: a round-3 file')} != {have}): traffic withheld; "
+                         "re-run tools/pmc_traffic2.sh")
+            pmc = None
+            continue
+        break
     if kernels:
         k = kernels[0]
         if pmc and (args.height, args.width, bs) == (480, 640, 32) and not args.eval:
@@ -572,9 +584,14 @@ def run(args):
                                                        for v in ents) / n_l)}
             if ent:
                 traffic = ent['hbm_bytes_per_launch']
+                cal = pmc.get('calibration', {})
                 traffic_src = f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
-                              f"command at commit {pmc.get('commit', 'of round 1')}, FETCH x2 gfx950 " \
-                              "correction; the PMC passes cannot run inside the timed bench)"
+                              f"command at commit {pmc.get('commit')}, kernel sources {pmc.get('csrc_sha16')}" \
+                              f" = these; FETCH x {cal.get('fetch_factor')}, WRITE x {cal.get('write_factor')} " \
+                              "from the 1 GiB read / write / copy calibration kernels of the same passes; " \
+                              "the PMC passes cannot run inside the timed bench)"
+        if traffic is None and pmc_stale:
+            traffic_src = pmc_stale
         roofline = {'bound': 'mfma', 'kernel': k['kernel'], 'achieved': k['tflops'],
                     'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(k['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,

@@ -48,7 +48,8 @@ const char* const kProfNames[kProfClasses] = {
     "conv_wgrad_kernel<64,64,1,2,2,1>", "conv_wgrad_kernel<64,64,3,2,2,1>|conv_wgrad1d_wino_kernel<64,64> (1-D convs)",
     "conv1d_wino_kernel (1-D 3x1/1x3 convs)", "conv_h_kernel (16-bit igemm)",
     "wgrad kernels on 16-bit activations", "conv1d_wino_kernel (dense 3x3 convs, row-Winograd)",
-    "conv_wgrad1d_wino_kernel<64,64> (dense 3x3 convs)"};
+    "conv_wgrad1d_wino_kernel<64,64> (dense 3x3 convs)",
+    "conv_rs_kernel (16-bit 1-D 3x1/1x3 convs, register-stationary)"};
 }  // namespace
 
 int emsa_prof_begin(int cls, double flops, hipStream_t st, double bytes) {

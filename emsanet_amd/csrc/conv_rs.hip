@@ -619,6 +619,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
 struct RSPlan {
   int kc = 0;         // 64 / 128 / 256 / 512
   int niwm = 5;       // staging registers (16-byte pieces per lane and tile)
+  int tm = 1;         // 32-pixel row tiles per wave (256 / 512 channels)
   bool dirh = false;
   int bm = 0, nwg = 0, nwv = 0, wk = 1, rpi = 0;
   int tiles = 0, tiles_w = 0, twl = 0, th = 0;
@@ -670,8 +671,15 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   switch (pl.kc) {
     case 64: pl.bm = 128; pl.nwg = 64; pl.nwv = 4; pl.wk = 1; break;
     case 128: pl.bm = 64; pl.nwg = 128; pl.nwv = 4; pl.wk = 1; break;
-    case 256: pl.bm = 32 * EMSA_RS_TM256; pl.nwg = 64; pl.nwv = 4; pl.wk = 2; pl.niwm = EMSA_RS_TM256 == 2 ? 9 : 5; break;
-    default: pl.bm = 32 * EMSA_RS_TM512; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; pl.niwm = EMSA_RS_TM512 == 2 ? 9 : 5; break;
+    case 256: pl.tm = EMSA_RS_TM256; pl.nwg = 64; pl.nwv = 4; pl.wk = 2; break;
+    default:
+      // 64-pixel tiles at 512 channels once there are enough pixels to give every workgroup a
+      // few of them; small maps (batch-1 inference: 300 pixels at /32) keep 32-pixel tiles
+      pl.tm = (EMSA_RS_TM512 == 2 && M >= 4096) ? 2 : 1; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; break;
+  }
+  if (pl.kc >= 256) {
+    pl.bm = 32 * pl.tm;
+    pl.niwm = pl.tm == 2 ? 9 : 5;
   }
   pl.nslice = g->n_ch / pl.nwg;
   int rs;
@@ -713,9 +721,11 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   if (pl.lds > 160 * 1024) return false;
   // persistent grid: 8 XCDs x gx workgroups x channel slices; every workgroup gets >= 1 tile
   const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
+  // (fewer tiles than workgroups: the surplus workgroups find no tile, write empty partial rows
+  //  and leave -- batch-1 inference at /16 and /32)
   int gx = rs_cu_count() * per_cu / (8 * pl.nslice);
-  if (gx > pl.tiles / 8) gx = pl.tiles / 8;
-  if (gx < 1) return false;
+  if (gx > (pl.tiles + 7) / 8) gx = (pl.tiles + 7) / 8;
+  if (gx < 1 || pl.tiles < 1) return false;
   pl.gx = gx;
   return true;
 }
@@ -754,7 +764,9 @@ int rs_dispatch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st)
     case 64: return rs_launch<T, 64, 2, 4, 1, 1, 1>(a, pl, bnb, st);
     case 128: return rs_launch<T, 128, 1, 1, 4, 1, 2>(a, pl, bnb, st);
     case 256: return rs_launch<T, 256, 1, 1, 2, 2, EMSA_RS_TM256>(a, pl, bnb, st);
-    default: return rs_launch<T, 512, 1, 1, 2, 4, EMSA_RS_TM512>(a, pl, bnb, st);
+    default:
+      if (pl.tm == 2) return rs_launch<T, 512, 1, 1, 2, 4, 2>(a, pl, bnb, st);
+      return rs_launch<T, 512, 1, 1, 2, 4, 1>(a, pl, bnb, st);
   }
 }
 
@@ -805,7 +817,7 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
   const double flops = 2.0 * M * g->k_ch * g->n_ch * 3.0;
   const double px = (double)M * g->n_ch * 2.0;
   const double bytes = 2.0 * px + 3.0 * g->n_ch * g->k_ch * 2.0 + (residual ? px : 0.0) + (mask_src ? px : 0.0);
-  const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
+  const int ps = emsa_prof_begin(kProfClassConvRS, flops, st, bytes);
   const int rc = dtype == EMSA_DT_BF16 ? rs_dispatch<emsa_bf16>(a, pl, bnb, st)
                                        : rs_dispatch<emsa_f16>(a, pl, bnb, st);
   emsa_prof_end(ps, st);

@@ -243,6 +243,52 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int slices, in
   }
 }
 
+// One launch instead of two when the statistics arrive in few rows (conv_rs.hip writes one row per
+// persistent workgroup: <= 512; small images): level 1 and level 2 of the merge above in the same
+// workgroup, same fp64 arithmetic, same summation order per row group.
+__global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int rows, int c,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float eps, float momentum, float* running_mean,
+                                        float* running_var, float* __restrict__ scale,
+                                        float* __restrict__ shift, float* __restrict__ save_mean,
+                                        float* __restrict__ save_invstd) {
+  __shared__ double sh[3][8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  double n = 0.0, s1 = 0.0, q = 0.0;
+  if (ch < c)
+    for (int r = rg; r < rows; r += 8) {
+      const double nb = (double)stats[((long)2 * rows + r) * c + ch];
+      if (nb > 0.0) {
+        const double sb = (double)stats[((long)0 * rows + r) * c + ch];
+        n += nb;
+        s1 += sb;
+        q += (double)stats[((long)1 * rows + r) * c + ch] + sb * sb / nb;
+      }
+    }
+  sh[0][rg][cl] = n; sh[1][rg][cl] = s1; sh[2][rg][cl] = q;
+  __syncthreads();
+  if (rg != 0 || ch >= c) return;
+  n = s1 = q = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
+  const double mean = n > 0.0 ? s1 / n : 0.0;
+  double m2 = q - s1 * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = n > 0.0 ? m2 / n : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * invstd;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - (float)mean * sc;
+  save_mean[ch] = (float)mean;
+  save_invstd[ch] = invstd;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm,
                                const float* rv, float eps, int c, float* scale, float* shift,
                                float* invstd) {
@@ -1836,6 +1882,12 @@ extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int
   if (slices > kBnSlices) slices = kBnSlices;
   if (slices < 1) slices = 1;
   hipStream_t st = (hipStream_t)stream;
+  if (rows <= 512) {
+    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3((c + 31) / 32), dim3(256), 0, st, stats, rows, c,
+                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
+                       save_mean, save_invstd);
+    return emsa_launch_status();
+  }
   hipLaunchKernelGGL(bn_partial_kernel, dim3((c + 31) / 32, slices), dim3(256), 0, st, stats, rows,
                      c, (double*)ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, st,

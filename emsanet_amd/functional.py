@@ -774,9 +774,10 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     return buf[0], buf[1], buf[2], buf[3]      # scale, shift, mean, invstd
 
 
-def bn_fold(gamma, beta, running_mean, running_var, eps):
+def bn_fold(gamma, beta, running_mean, running_var, eps, out=None):
+    """`out`: a (3, c) fp32 buffer to write into (callers that cache the fold keep its address)"""
     c = gamma.shape[0]
-    buf = _empty((3, c), gamma.device)
+    buf = out if out is not None else _empty((3, c), gamma.device)
     check(_lib.lib().emsa_bn_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, c,
                                   _p(buf[0]), _p(buf[1]), _p(buf[2]), _stream()), 'emsa_bn_fold')
     return buf[0], buf[1], buf[2]               # scale, shift, invstd

@@ -80,7 +80,10 @@ class GraphedInference:
         # the packed / Winograd-transformed weights are built by the warm-up runs and the graph
         # holds pointers to them: a parameter that changed afterwards (optimizer step,
         # load_state_dict) makes the capture stale
-        return tuple((p._version, p.data_ptr()) for p in self.model.parameters())
+        # (buffers too: the frozen BatchNorm folds are cached per state of the running statistics and
+        #  are no longer re-derived inside the captured forward)
+        return tuple((p._version, p.data_ptr()) for p in self.model.parameters()) + \
+            tuple((b._version, b.data_ptr()) for b in self.model.buffers())
 
     def _capture(self):
         model = self.model

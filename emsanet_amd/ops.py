@@ -413,13 +413,28 @@ class BNRT:
                 # (checkpoints carry it); counted on the host, flushed by `flush_bn_counters`
                 self.pending_batches += 1
             return Fn.bn_finalize(stats, count, g, b, bn.eps, mom, rm, rv)
-        scale, shift, invstd = Fn.bn_fold(g, b, bn.running_mean, bn.running_var, bn.eps)
+        scale, shift, invstd = self._frozen_fold()
         return scale, shift, bn.running_mean, invstd
 
-    def folded(self):
+    def _frozen_fold(self):
+        """scale / shift / invstd of the frozen BatchNorm (running statistics), computed once per
+        state of (weight, bias, running_mean, running_var) instead of once per forward pass: the
+        bs=1 inference graph spent 127 of its ~440 launches re-deriving these constants (17 % of its
+        GPU time, round 4).  Re-derived IN PLACE when a tensor changed, so that a captured graph's
+        pointers stay valid."""
         bn = self.bn
-        s, t, _ = Fn.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                             bn.eps)
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t._version, t.data_ptr()) for t in ts) + (bn.eps,)
+        ent = getattr(self, '_fold_cache', None)
+        if ent is None or ent[0] != key or ent[1].device != bn.weight.device:
+            buf = ent[1] if ent is not None and ent[1].device == bn.weight.device else None
+            s, t, inv = Fn.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                   bn.running_var, bn.eps, out=buf)
+            self._fold_cache = ent = (key, s._base if s._base is not None else s, s, t, inv)
+        return ent[2], ent[3], ent[4]
+
+    def folded(self):
+        s, t, _ = self._frozen_fold()
         return s, t
 
 

@@ -183,29 +183,41 @@ def test_conv_rs_dgrad_with_fused_bn_backward_sums(cfg, with_res):
     close(db, db0.cpu(), tol=1e-2, what='rs vs conv_h dbeta')
 
 
-def test_conv_rs_refuses_what_it_cannot_take():
-    """geometries outside the kernel (too few pixel tiles for the persistent grid, strided, other
-    channel counts) are reported unsupported -- the caller's implicit-GEMM fallback runs, with the
-    same results -- and a direct call is rejected with EMSA_E_SHAPE, never computed wrongly"""
+def test_conv_rs_tiny_maps_and_refusals():
+    """a map with fewer pixel tiles than persistent workgroups (batch-1 inference at /32; here ONE
+    tile) runs on the rs kernel -- the surplus workgroups write empty statistics rows -- and gives
+    the reference's result; geometries outside the kernel (strided, 3x3, other channel counts) are
+    reported unsupported and a direct call is rejected with EMSA_E_SHAPE, never computed wrongly"""
     from emsanet_amd import _lib
     Fn = _fn()
     dtype = torch.bfloat16
-    spec = _spec(Fn, 64, (1, 3))
-    g = spec.geom_fwd(1, 4, 6, 64, 64)                   # 24 pixels: not even one tile per XCD
-    assert not Fn.rs_supported(1, g)
-    x = rnd(1, 64, 4, 6, seed=1)
-    wt = rnd(64, 64, 1, 3, seed=2, scale=0.1)
-    wf, _ = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=True)
-    wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
-    y = Fn.conv_fwd(act16(x, dtype), wp, spec, wfrag=wf)             # falls back
-    close(y, F.conv2d(q(x, dtype), q(wt, dtype), None, padding=(0, 1)), tol=TOL[dtype], what='fallback')
-    out = torch.empty_like(y)
-    rc = _lib.lib().emsa_conv1d_rs_t(1, g, act16(x, dtype).data_ptr(), wf.data_ptr(), out.data_ptr(),
-                                     None, None, None, None, None, 0, None, 0, 0, None)
-    assert rc == -1
+    for c, k, n, h, w in ((64, (1, 3), 1, 4, 6), (512, (3, 1), 1, 5, 4), (256, (1, 3), 1, 3, 3)):
+        spec = _spec(Fn, c, k)
+        g = spec.geom_fwd(n, h, w, c, c)
+        assert Fn.rs_supported(1, g)
+        x = rnd(n, c, h, w, seed=1)
+        wt = rnd(c, c, *k, seed=2, scale=0.1)
+        b = rnd(c, seed=3)
+        wf, _ = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=True)
+        wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
+        y, stats = Fn.conv_fwd(act16(x, dtype), wp, spec, bias=b.to(DEV), want_stats=True, wfrag=wf)
+        ref = F.conv2d(q(x, dtype), q(wt, dtype), b.double(), padding=(spec.ph, spec.pw))
+        close(y, ref, tol=TOL[dtype], what='tiny map')
+        cnt = ref.numel() / c
+        assert float(stats[2][:, 0].sum()) == cnt and int((stats[2][:, 0] > 0).sum()) >= 1
+        close(stats[0].sum(0) / cnt, ref.mean((0, 2, 3)), tol=2e-4, what='tiny map stats')
+    # refusals
     s2 = Fn.ConvSpec(64, 128, (3, 1), (2, 1), (1, 0))
     assert not Fn.rs_eligible(s2) and not Fn.rs_eligible(Fn.ConvSpec(72, 72, (1, 3), 1, (0, 1)))
     assert not Fn.rs_eligible(Fn.ConvSpec(64, 64, (3, 3), 1, 1))
+    g2 = Fn.ConvSpec(64, 64, (3, 1), (2, 1), (1, 0)).geom_fwd(2, 12, 20, 64, 64)      # strided
+    assert _lib.lib().emsa_conv1d_rs_supported(1, g2) == 0
+    x = act16(rnd(2, 64, 12, 20, seed=1), dtype)
+    wf, _ = Fn.pack_weight_frag_t(rnd(64, 64, 3, 1, seed=2).to(DEV), dtype, fwd=True)
+    out = torch.empty(2 * 6 * 20 * 64, device=DEV, dtype=dtype)
+    rc = _lib.lib().emsa_conv1d_rs_t(1, g2, x.data_ptr(), wf.data_ptr(), out.data_ptr(),
+                                     None, None, None, None, None, 0, None, 0, 0, None)
+    assert rc == -1
 
 
 def test_conv_rs_switch(monkeypatch):
