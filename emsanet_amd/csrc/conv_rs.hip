@@ -720,7 +720,13 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   pl.lds = pl.bacc_off + (pl.kc <= 128 ? 16 * pl.nwv * 64 * 4 : 0);   // (+ LDS accumulators of the BNB form)
   if (pl.lds > 160 * 1024) return false;
   // persistent grid: 8 XCDs x gx workgroups x channel slices; every workgroup gets >= 1 tile
-  const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
+  // EMSA_RS_PER_CU=1: one workgroup per CU even where two fit (A/B: two launches on two streams
+  // then share the CUs instead of queueing behind each other)
+  static const int per_cu_max = [] {
+    const char* e = getenv("EMSA_RS_PER_CU");
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
+  const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : per_cu_max;
   // (fewer tiles than workgroups: the surplus workgroups find no tile, write empty partial rows
   //  and leave -- batch-1 inference at /16 and /32)
   int gx = rs_cu_count() * per_cu / (8 * pl.nslice);
@@ -746,13 +752,18 @@ int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, block, pl.lds, st, a);
   };
+  // (the fused BatchNorm-backward form exists for bf16 only: fp16 is an inference storage type)
+  constexpr bool kTrain = sizeof(T) == 2 && !__is_same(T, emsa_f16);
+  if (bnb && !kTrain) return EMSA_E_ARG;
   if (pl.dirh) {
-    if (bnb) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true, true>);
-    else if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, true>);
+    if (bnb) {
+      if constexpr (kTrain) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true, true>);
+    } else if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, true>);
     else go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, false>);
   } else {
-    if (bnb) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true, true>);
-    else if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, true>);
+    if (bnb) {
+      if constexpr (kTrain) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, true, true>);
+    } else if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, true>);
     else go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, false>);
   }
   return emsa_launch_status();

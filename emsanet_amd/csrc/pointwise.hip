@@ -243,8 +243,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int slices, in
   }
 }
 
-// One launch instead of two when the statistics arrive in few rows (conv_rs.hip writes one row per
-// persistent workgroup: <= 512; small images): level 1 and level 2 of the merge above in the same
+// One launch instead of two when the statistics arrive in few rows (<= 1024: conv_rs.hip writes one
+// row per persistent workgroup, the /16 and /32 stages of the fp32 kernels, small images): level 1 and level 2 of the merge above in the same
 // workgroup, same fp64 arithmetic, same summation order per row group.
 __global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int rows, int c,
                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1882,7 +1882,7 @@ extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int
   if (slices > kBnSlices) slices = kBnSlices;
   if (slices < 1) slices = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (rows <= 512) {
+  if (rows <= 1024) {
     hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3((c + 31) / 32), dim3(256), 0, st, stats, rows, c,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
                        save_mean, save_invstd);

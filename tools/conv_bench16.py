@@ -35,6 +35,8 @@ def main():
         DY = [Fn.act_empty(n, cout, oh, ow, DEV, dtype=DT).normal_() for _ in range(nb)]
         wt = torch.randn(cout, cin, *k, device=DEV) * 0.05
         wp, wpd = Fn.pack_weight_t(wt, DT, fwd=True, dgrad=True)
+        # the stride-1 3-tap 1-D convs run on conv_rs.hip with fragment-ordered weights (as in the model)
+        wf, wfd = Fn.pack_weight_frag_t(wt, DT, fwd=True, dgrad=True) if Fn.rs_eligible(spec) else (None, None)
         bias = torch.zeros(cout, device=DEV)
         flops = 2.0 * n * oh * ow * cin * cout * k[0] * k[1]
         wbytes = wt.numel() * 2
@@ -44,17 +46,18 @@ def main():
             if kind == 'fwd':
                 out = [Fn.act_empty(n, cout, oh, ow, DEV, dtype=DT) for _ in range(nb)]
                 t = timeit(lambda i: Fn.conv_fwd(X[i % nb], wp, spec, bias=bias, act=Fn.ACT_RELU,
-                                                 out=out[i % nb]))
+                                                 out=out[i % nb], wfrag=wf))
                 b = act_bytes + wbytes
             elif kind == 'dgrad':
                 out = [Fn.act_empty(n, cin, h, w, DEV, dtype=DT) for _ in range(nb)]
-                t = timeit(lambda i: Fn.conv_dgrad(DY[i % nb], wpd, spec, (h, w), out=out[i % nb]))
+                t = timeit(lambda i: Fn.conv_dgrad(DY[i % nb], wpd, spec, (h, w), out=out[i % nb], wfrag=wfd))
                 b = act_bytes + wbytes
             else:
                 t = timeit(lambda i: Fn.conv_wgrad(X[i % nb], DY[i % nb], spec, True, like=wt))
                 b = act_bytes + 2 * wbytes
+            kern = 'conv_rs' if (kind != 'wgrad' and wf is not None and Fn.CONV_RS) else ''
             print(f"{name:22s} {kind:6s} {t:8.1f} {flops / t / 1e6:8.1f} {b / t / 1e6:10.2f} "
-                  f"{b / 6.3e6:12.1f}")
+                  f"{b / 6.3e6:12.1f}  {kern}")
 
 
 if __name__ == '__main__':
