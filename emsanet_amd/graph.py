@@ -26,6 +26,14 @@ def _flatten(out):
     return []
 
 
+# Stream captures run in THREAD-LOCAL error mode: with a process group alive, c10d's watchdog thread
+# polls the events of earlier collectives (hipEventQuery) whenever it likes -- in the default global
+# mode that call is "not permitted when stream is capturing" and takes the process down (seen in
+# round 4: bench.py --dtype bf16 --force-dist --graph under RCCL).  The capturing thread itself only
+# launches kernels and uses the caching allocator's capture-aware paths.
+_CAPTURE_MODE = 'thread_local'
+
+
 def _new_graph():
     """a CUDAGraph whose raw hipGraph_t survives the capture (torch >= 2.8: keep_graph) so that it
     can be repaired before it is instantiated"""
@@ -94,7 +102,7 @@ class GraphedInference:
                 model({**self.static_in, **self.extra}, do_postprocessing=self.do_postprocessing)
         torch.cuda.current_stream().wait_stream(side)
         self.graph, kept = _new_graph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.static_out = model({**self.static_in, **self.extra},
                                     do_postprocessing=self.do_postprocessing)
         self.graph_info = _repair_and_instantiate(self.graph, kept)
@@ -203,7 +211,7 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
         pend = {id(m): m._emsa_pending for m in self._bns}
         self.graph, kept = _new_graph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.static_loss, self.static_out = self._step()
         # memset nodes (a user loss written with torch reductions brings them in) -> kernel nodes
         self.graph_info = _repair_and_instantiate(self.graph, kept)
@@ -370,7 +378,7 @@ class SegmentedGraphedTrainStep:
         if not getattr(self, '_capturing', False):
             return contextlib.nullcontext()
         pool = self.graphs[0].pool() if k > 0 else None
-        return torch.cuda.graph(self.graphs[k], pool=pool)
+        return torch.cuda.graph(self.graphs[k], pool=pool, capture_error_mode=_CAPTURE_MODE)
 
     def _reduce(self, k):
         if self.buckets.active and not getattr(self, '_capturing', False):

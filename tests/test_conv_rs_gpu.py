@@ -220,6 +220,51 @@ def test_conv_rs_tiny_maps_and_refusals():
     assert rc == -1
 
 
+@pytest.mark.parametrize('cfg', [(64, (1, 3), 2, 24, 40), (128, (3, 1), 2, 24, 40), (256, (1, 3), 2, 12, 20),
+                                 (512, (3, 1), 2, 12, 20)])
+def test_conv_rs_channel_slices(cfg):
+    """input, output, residual and mask tensors that are channel slices of wider NHWC buffers
+    (pixel stride > C: concat / split without copies): bit-identical to the dense launch,
+    and the neighbouring channels of the output buffer stay untouched"""
+    Fn = _fn()
+    dtype = torch.bfloat16
+    c, k, n, h, w = cfg
+    spec = _spec(Fn, c, k)
+    x = rnd(n, c, h, w, seed=1)
+    wt = rnd(c, c, *k, seed=2, scale=0.1)
+    b = rnd(c, seed=3)
+    res, mask = rnd(n, c, h, w, seed=4), rnd(n, c, h, w, seed=5)
+    wf, wfd = Fn.pack_weight_frag_t(wt.to(DEV), dtype, fwd=True, dgrad=True)
+    wp, wpd = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True, dgrad=True)
+    xd, rd, md = act16(x, dtype), act16(res, dtype), act16(mask, dtype)
+
+    def wide(t, ld, off):
+        buf = torch.full((n, h, w, ld), 7.0, device=DEV, dtype=dtype)
+        buf[..., off:off + c] = t.permute(0, 2, 3, 1)
+        return buf, buf[..., off:off + c].permute(0, 3, 1, 2)
+
+    _, xs = wide(xd, c + 64, 32)
+    _, rs_ = wide(rd, c + 8, 8)
+    _, ms = wide(md, 2 * c, c)
+    obuf = torch.full((n, h, w, c + 16), 3.0, device=DEV, dtype=dtype)
+    outs = obuf[..., 8:8 + c].permute(0, 3, 1, 2)
+    assert Fn.ld_of(xs) == c + 64 and Fn.ld_of(outs) == c + 16
+    assert Fn.rs_supported(1, spec.geom_fwd(n, h, w, c + 64, c + 16))
+    y_dense = Fn.conv_fwd(xd, wp, spec, bias=b.to(DEV), residual=rd, act=Fn.ACT_RELU, wfrag=wf)
+    Fn.conv_fwd(xs, wp, spec, bias=b.to(DEV), residual=rs_, act=Fn.ACT_RELU, wfrag=wf, out=outs)
+    torch.cuda.synchronize()
+    assert torch.equal(outs, y_dense)
+    assert bool((obuf[..., :8] == 3.0).all()) and bool((obuf[..., 8 + c:] == 3.0).all())
+    d_dense = Fn.conv_dgrad(xd, wpd, spec, (h, w), mask_src=md, residual=rd, wfrag=wfd)
+    obuf.fill_(3.0)
+    Fn.conv_dgrad(xs, wpd, spec, (h, w), mask_src=ms, residual=rs_, wfrag=wfd, out=outs)
+    torch.cuda.synchronize()
+    assert torch.equal(outs, d_dense)
+    assert bool((obuf[..., :8] == 3.0).all()) and bool((obuf[..., 8 + c:] == 3.0).all())
+    close(y_dense, F.relu(F.conv2d(q(x, dtype), q(wt, dtype), b.double(), padding=(spec.ph, spec.pw))
+                          + q(res, dtype)), tol=TOL[dtype], what='sliced conv_rs')
+
+
 def test_conv_rs_switch(monkeypatch):
     """Fn.CONV_RS = False (EMSA_CONV_RS=0) keeps every conv on the implicit GEMM"""
     Fn = _fn()
