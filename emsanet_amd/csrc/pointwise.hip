@@ -243,8 +243,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int slices, in
   }
 }
 
-// One launch instead of two when the statistics arrive in few rows (<= 1024: conv_rs.hip writes one
-// row per persistent workgroup, the /16 and /32 stages of the fp32 kernels, small images): level 1 and level 2 of the merge above in the same
+// One launch instead of two when the statistics arrive in few rows (<= 512: conv_rs.hip writes one
+// row per persistent workgroup; the /32 stage of the fp32 kernels; small images): level 1 and level 2 of the merge above in the same
 // workgroup, same fp64 arithmetic, same summation order per row group.
 __global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int rows, int c,
                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -252,16 +252,16 @@ __global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int row
                                         float* running_var, float* __restrict__ scale,
                                         float* __restrict__ shift, float* __restrict__ save_mean,
                                         float* __restrict__ save_invstd) {
-  // 16 channels x 16 row groups per workgroup (grid = c / 16); the row loop is branch-free and
-  // unrolled so that its loads are all in flight together -- the first version (32 x 8, a branch
-  // around empty rows) ran its 64 iterations as 64 dependent L2 round trips: 21 us per launch
-  __shared__ double sh[3][16][16];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int ch = blockIdx.x * 16 + cl;
+  // 4 channels x 64 row groups per workgroup (grid = c / 4: 16 ... 128 workgroups), branch-free and
+  // unrolled: <= 8 row iterations per thread, all loads of a thread in flight together.  (32 x 8
+  // with a branch around empty rows ran 64 dependent L2 round trips: 21 us; 16 x 16 still 13-19.)
+  __shared__ double sh[3][64][4];
+  const int cl = threadIdx.x & 3, rg = threadIdx.x >> 2;
+  const int ch = blockIdx.x * 4 + cl;
   const int chc = ch < c ? ch : c - 1;
   double n = 0.0, s1 = 0.0, q = 0.0;
-#pragma unroll 4
-  for (int r = rg; r < rows; r += 16) {
+#pragma unroll 8
+  for (int r = rg; r < rows; r += 64) {
     const float nbf = stats[((long)2 * rows + r) * c + chc];
     const float sbf = stats[((long)0 * rows + r) * c + chc];
     const float m2f = stats[((long)1 * rows + r) * c + chc];
@@ -275,8 +275,7 @@ __global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int row
   __syncthreads();
   if (rg != 0 || ch >= c) return;
   n = s1 = q = 0.0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
+  for (int k = 0; k < 64; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
   const double mean = n > 0.0 ? s1 / n : 0.0;
   double m2 = q - s1 * mean;
   if (m2 < 0.0) m2 = 0.0;
@@ -1890,8 +1889,8 @@ extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int
   if (slices > kBnSlices) slices = kBnSlices;
   if (slices < 1) slices = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (rows <= 1024) {
-    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3((c + 15) / 16), dim3(256), 0, st, stats, rows, c,
+  if (rows <= 512) {
+    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3((c + 3) / 4), dim3(256), 0, st, stats, rows, c,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
                        save_mean, save_invstd);
     return emsa_launch_status();
