@@ -99,6 +99,12 @@ struct ConvHArgs {
   int ld_res, ld_mask, act;
   int M, tiles_m, tiles_n, kchunks;
   int mapped;                       // output pixel map in use (EmsaConvGeom::out_pix_*)
+  // tap-split (emsa_conv_igemm_splitk_t): `ksplit` workgroups share one output tile, each over a
+  // range of taps, and store raw fp32 accumulators to ws[ksplit][M][n_ch]; conv_h_splitk_finish_kernel
+  // sums the slabs in a fixed order and applies the epilogue (batch-1 inference: a 3x3 512 -> 512
+  // conv on a 15 x 20 map is 40 tiles of 72 K steps otherwise -- 56 us on an idle GPU)
+  float* ws;
+  int ksplit;
   uint32_t in_bytes, w_bytes;
   HFastDiv div_ohw, div_ow;
 };
@@ -160,7 +166,8 @@ void conv_h_kernel(
   const int l31 = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
-  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+  const int ksl = p.ksplit > 1 ? (int)(blockIdx.x % p.ksplit) : 0;
+  const int wg = p.ksplit > 1 ? (int)(blockIdx.x / p.ksplit) : emsa_xcd_remap(blockIdx.x, gridDim.x);
   const int nt = wg % p.tiles_n, mt = wg / p.tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -210,9 +217,12 @@ void conv_h_kernel(
     b_off[j] = n < g.n_ch ? (uint32_t)(n * g.k_ch + c8) * 2u : kHOOB;
   }
   const int taps = g.kh * g.kw;
-  const int steps = EMSA_CONVH_DBG == 1 ? (p.M < 0 ? 1 : 0) : taps * p.kchunks;
+  // tap-split: this workgroup's taps [tap0, tap1)
+  const int tps = p.ksplit > 1 ? (taps + p.ksplit - 1) / p.ksplit : taps;
+  const int tap0 = ksl * tps, tap1 = min(taps, tap0 + tps);
+  const int steps = EMSA_CONVH_DBG == 1 ? (p.M < 0 ? 1 : 0) : max(tap1 - tap0, 0) * p.kchunks;
   const uint32_t w_tap_bytes = (uint32_t)g.n_ch * g.k_ch * 2u;
-  int tap_n = 0, kc_n = 0;
+  int tap_n = tap0, kc_n = 0;
   hu32x4 rset[PF > 0 ? PF : 1][AR + BR];
   // kHOOB for the lanes whose channels lie beyond k_ch in the last chunk of a tap
   const uint32_t last_oob = (p.kchunks - 1) * kHK + c8 < g.k_ch ? 0u : kHOOB;
@@ -394,7 +404,7 @@ void conv_h_kernel(
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + l31;
-    bvv[j] = (n < g.n_ch && p.bias) ? p.bias[n] : 0.f;
+    bvv[j] = (n < g.n_ch && p.bias && p.ksplit <= 1) ? p.bias[n] : 0.f;
   }
   if (want_stats) {
     // Per-tile (count, sum, M2 about the tile mean) of the fp32 accumulators (+bias) -> merged with
@@ -517,6 +527,12 @@ void conv_h_kernel(
         }
         const float4 v0 = emsa_ld4(stage + row * SLD + col8 * 8);
         const float4 v1 = emsa_ld4(stage + row * SLD + col8 * 8 + 4);
+        if (p.ksplit > 1) {                        // raw partial sums of this tap range
+          float* wsp = p.ws + ((size_t)ksl * p.M + m) * g.n_ch + n;
+          emsa_st4(wsp, v0);
+          emsa_st4(wsp + 4, v1);
+          continue;
+        }
         hf32x8 v = {v0.x * sc0.x + sh0.x, v0.y * sc0.y + sh0.y, v0.z * sc0.z + sh0.z,
                     v0.w * sc0.w + sh0.w, v1.x * sc1.x + sh1.x, v1.y * sc1.y + sh1.y,
                     v1.z * sc1.z + sh1.z, v1.w * sc1.w + sh1.w};
@@ -572,6 +588,43 @@ void conv_h_kernel(
         p.bnb_out[((size_t)1 * p.bnb_rows_alloc + mt) * g.n_ch + nn] = a1 * p.bnb_invstd[nn];
       }
     }
+  }
+}
+
+// sums the ksplit slabs of a tap-split launch in a fixed order and applies the epilogue of
+// emsa_conv_igemm_t (bias, folded BatchNorm, residual, ReLU): one thread per pixel and 8 channels
+template <typename T>
+__global__ void conv_h_splitk_finish_kernel(const float* __restrict__ ws, int ksplit, long M, int n_ch,
+                                            int ld_out, const float* __restrict__ bias,
+                                            const float* __restrict__ scale,
+                                            const float* __restrict__ shift,
+                                            const T* __restrict__ residual, int ld_res, int act,
+                                            T* __restrict__ out) {
+  typedef typename Vec8<T>::type V8;
+  const int c8 = n_ch >> 3;
+  const long total = M * c8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c8;
+    const int n = (int)(i - m * c8) * 8;
+    hf32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < ksplit; ++k) {
+      const float* q = ws + ((size_t)k * M + m) * n_ch + n;
+      const float4 a = emsa_ld4(q), b = emsa_ld4(q + 4);
+      v += hf32x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] + (bias ? bias[n + e] : 0.f);
+      if (scale) x = x * scale[n + e] + shift[n + e];
+      v[e] = x;
+    }
+    if (residual) v += __builtin_convertvector(*reinterpret_cast<const V8*>(residual + m * ld_res + n), hf32x8);
+    if (act == EMSA_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *reinterpret_cast<V8*>(out + m * ld_out + n) = __builtin_convertvector(v, V8);
   }
 }
 
@@ -656,7 +709,7 @@ int launch_h(const ConvHArgs& a_in, hipStream_t st) {
   constexpr size_t lds_stat = (size_t)(WM + 1) * BN * sizeof(float);
   constexpr size_t lds0 = lds_main > lds_epi ? lds_main : lds_epi;
   constexpr size_t lds = lds0 > lds_stat ? lds0 : lds_stat;
-  const int grid = a.tiles_m * a.tiles_n;
+  const int grid = a.tiles_m * a.tiles_n * (a.ksplit > 1 ? a.ksplit : 1);
   const double flops = 2.0 * a.g.n_img *
                        ((a.g.div_h > 1 || a.g.div_w > 1) ? (double)a.g.in_h * a.g.in_w
                                                          : (double)a.g.out_h * a.g.out_w) *
@@ -706,7 +759,8 @@ static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* i
                              const float* scale, const float* shift, const void* residual,
                              int32_t ld_res, const void* mask_src, int32_t ld_mask,
                              int32_t act, const float* bnb_mean, const float* bnb_invstd,
-                             float* bnb_out, int32_t bnb_rows_alloc, void* stream) {
+                             float* bnb_out, int32_t bnb_rows_alloc, void* stream,
+                             float* ws = nullptr, int ksplit = 1) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
   if (!h_geom_ok(g)) return EMSA_E_SHAPE;
   if (!in || !w || !out) return EMSA_E_ARG;
@@ -723,8 +777,10 @@ static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* i
   a.ld_res = ld_res; a.ld_mask = ld_mask; a.act = act;
   a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out;
   a.bnb_rows_alloc = bnb_rows_alloc;
+  a.ws = ws; a.ksplit = ksplit;
   a.mapped = (g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off) ? 1 : 0;
   if (a.mapped && (stats || bnb_out)) return EMSA_E_ARG;    // (per-tile sums count one launch's rows)
+  if (ksplit > 1 && (a.mapped || stats || bnb_out || mask_src || !ws)) return EMSA_E_ARG;
   const long M = (long)g->n_img * g->out_h * g->out_w;
   a.M = (int)M;
   const HTile t = pick_htile(M, g->n_ch);
@@ -771,4 +827,61 @@ extern "C" int emsa_conv_igemm_bnb_t(int32_t dtype, const EmsaConvGeom* g, const
   return conv_igemm_h_impl(dtype, g, dy, w, out, nullptr, nullptr, bn_scale, bn_shift, residual,
                            ld_res, t, ld_t, EMSA_ACT_NONE, bn_mean, bn_invstd, partial, rows_alloc,
                            stream);
+}
+
+// ---- tap-split forward conv for maps with few output tiles (batch-1 inference) -------------------
+// ksplit workgroups per output tile, each over a range of taps, raw fp32 partial sums in `ws`, then
+// conv_h_splitk_finish_kernel (fixed summation order: deterministic).  emsa_conv_igemm_splitk_ws_bytes_t
+// returns 0 where the plain launch is the better one (enough tiles, short K, fp32).
+namespace {
+int splitk_plan(int32_t dtype, const EmsaConvGeom* g) {
+  if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return 1;
+  if (!h_geom_ok(g) || g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off) return 1;
+  static const bool off = [] {
+    const char* e = getenv("EMSA_CONVH_SPLITK");
+    return e && e[0] == '0';
+  }();
+  if (off) return 1;
+  const int taps = g->kh * g->kw;
+  if (taps < 3 || (long)taps * g->k_ch < 1024) return 1;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  const HTile t = pick_htile(M, g->n_ch);
+  const long tiles = ((M + ht_bm(t) - 1) / ht_bm(t)) * ((g->n_ch + ht_bn(t) - 1) / ht_bn(t));
+  if (taps >= 9) return tiles <= 100 ? 9 : (tiles <= 256 ? 3 : 1);
+  return tiles <= 64 ? taps : 1;
+}
+}  // namespace
+
+extern "C" int64_t emsa_conv_igemm_splitk_ws_bytes_t(int32_t dtype, const EmsaConvGeom* g) {
+  const int ks = splitk_plan(dtype, g);
+  if (ks <= 1) return 0;
+  return (int64_t)ks * g->n_img * g->out_h * g->out_w * g->n_ch * (int64_t)sizeof(float);
+}
+
+extern "C" int emsa_conv_igemm_splitk_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                        const void* w, void* out, const float* bias,
+                                        const float* scale, const float* shift,
+                                        const void* residual, int32_t ld_res, int32_t act,
+                                        float* ws, void* stream) {
+  const int ks = splitk_plan(dtype, g);
+  if (ks <= 1) return EMSA_E_SHAPE;
+  if (!ws || (((uintptr_t)ws) & 15)) return EMSA_E_ARG;
+  if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
+  int rc = conv_igemm_h_impl(dtype, g, in, w, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                             nullptr, 0, EMSA_ACT_NONE, nullptr, nullptr, nullptr, 0, stream, ws, ks);
+  if (rc != EMSA_OK) return rc;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  const long total = M * (g->n_ch >> 3);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMSA_DT_BF16)
+    hipLaunchKernelGGL(conv_h_splitk_finish_kernel<emsa_bf16>, dim3(grid), dim3(256), 0, st, ws, ks, M,
+                       g->n_ch, g->ld_out, bias, scale, shift, (const emsa_bf16*)residual, ld_res, act,
+                       (emsa_bf16*)out);
+  else
+    hipLaunchKernelGGL(conv_h_splitk_finish_kernel<emsa_f16>, dim3(grid), dim3(256), 0, st, ws, ks, M,
+                       g->n_ch, g->ld_out, bias, scale, shift, (const emsa_f16*)residual, ld_res, act,
+                       (emsa_f16*)out);
+  return emsa_launch_status();
 }

@@ -149,6 +149,12 @@ __device__ __forceinline__ int r_swz(int R) {
 #ifndef EMSA_RS_TM512
 #define EMSA_RS_TM512 2
 #endif
+// EMSA_RS_W8: bit mask of channel counts (1 = 64, 2 = 128, 4 = 256) whose workgroups have EIGHT waves
+// (two pixel sub-tiles per workgroup, one workgroup per CU) instead of four (two workgroups per CU):
+// half as many workgroups fetch a weight slice at launch time
+#ifndef EMSA_RS_W8
+#define EMSA_RS_W8 0
+#endif
 #ifndef EMSA_RS_OCC
 #define EMSA_RS_OCC 2
 #endif
@@ -669,16 +675,16 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   pl.sign = step;
   pl.rpi = 1024 / (pl.kc * 2);
   switch (pl.kc) {
-    case 64: pl.bm = 128; pl.nwg = 64; pl.nwv = 4; pl.wk = 1; break;
-    case 128: pl.bm = 64; pl.nwg = 128; pl.nwv = 4; pl.wk = 1; break;
-    case 256: pl.tm = EMSA_RS_TM256; pl.nwg = 64; pl.nwv = 4; pl.wk = 2; break;
+    case 64: pl.bm = (EMSA_RS_W8 & 1) ? 256 : 128; pl.nwg = 64; pl.nwv = (EMSA_RS_W8 & 1) ? 8 : 4; pl.wk = 1; break;
+    case 128: pl.bm = (EMSA_RS_W8 & 2) ? 128 : 64; pl.nwg = 128; pl.nwv = (EMSA_RS_W8 & 2) ? 8 : 4; pl.wk = 1; break;
+    case 256: pl.tm = EMSA_RS_TM256; pl.nwg = 64; pl.nwv = (EMSA_RS_W8 & 4) ? 8 : 4; pl.wk = 2; break;
     default:
       // 64-pixel tiles at 512 channels once there are enough pixels to give every workgroup a
       // few of them; small maps (batch-1 inference: 300 pixels at /32) keep 32-pixel tiles
       pl.tm = (EMSA_RS_TM512 == 2 && M >= 4096) ? 2 : 1; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; break;
   }
   if (pl.kc >= 256) {
-    pl.bm = 32 * pl.tm;
+    pl.bm = 32 * pl.tm * ((pl.kc == 256 && (EMSA_RS_W8 & 4)) ? 2 : 1);
     pl.niwm = pl.tm == 2 ? 9 : 5;
   }
   pl.nslice = g->n_ch / pl.nwg;
@@ -772,9 +778,9 @@ int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
 template <typename T>
 int rs_dispatch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
   switch (pl.kc) {
-    case 64: return rs_launch<T, 64, 2, 4, 1, 1, 1>(a, pl, bnb, st);
-    case 128: return rs_launch<T, 128, 1, 1, 4, 1, 2>(a, pl, bnb, st);
-    case 256: return rs_launch<T, 256, 1, 1, 2, 2, EMSA_RS_TM256>(a, pl, bnb, st);
+    case 64: return rs_launch<T, 64, 2, (EMSA_RS_W8 & 1) ? 8 : 4, 1, 1, 1>(a, pl, bnb, st);
+    case 128: return rs_launch<T, 128, 1, (EMSA_RS_W8 & 2) ? 2 : 1, 4, 1, 2>(a, pl, bnb, st);
+    case 256: return rs_launch<T, 256, 1, (EMSA_RS_W8 & 4) ? 2 : 1, 2, 2, EMSA_RS_TM256>(a, pl, bnb, st);
     default:
       if (pl.tm == 2) return rs_launch<T, 512, 1, 1, 2, 4, 2>(a, pl, bnb, st);
       return rs_launch<T, 512, 1, 1, 2, 4, 1>(a, pl, bnb, st);

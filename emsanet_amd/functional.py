@@ -222,6 +222,15 @@ def rs_supported(code, g):
     return r[1]
 
 
+def _splitk_ws_bytes(code, g):
+    """workspace bytes of the tap-split form of this launch (0: plain launch), cached per geometry"""
+    r = getattr(g, '_sk', None)
+    if r is None or r[0] != code:
+        r = (code, int(_lib.lib().emsa_conv_igemm_splitk_ws_bytes_t(code, g)))
+        g._sk = r
+    return r[1]
+
+
 def pack_weight_frag_t(w, dtype, fwd=True, dgrad=False, out_fwd=None, out_dgrad=None):
     """fp32 OIHW [cout][cin][3 taps] -> fragment-ordered 16-bit operands of emsa_conv1d_rs_t"""
     cout, cin = w.shape[0], w.shape[1]
@@ -365,6 +374,14 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
         check(L.emsa_conv1d_rs_t(code, g, _p(x), _p(wfrag), _p(out), _p(bias), _p(stats), _p(scale),
                                  _p(shift), _p(residual), lr, None, 0, act, _stream()),
               'emsa_conv1d_rs_t')
+    elif code != 0 and not want_stats and _splitk_ws_bytes(code, g) > 0:
+        # few output tiles, long K (the decoders' 3x3 convs at batch 1): tap-split + finish pass
+        if wp is None or wp.dtype != x.dtype:
+            raise _lib.EmsaError("conv weights are not packed in the activations' dtype")
+        ws = _empty((_splitk_ws_bytes(code, g) // 4,), x.device)
+        check(L.emsa_conv_igemm_splitk_t(code, g, _p(x), _p(wp), _p(out), _p(bias), _p(scale),
+                                         _p(shift), _p(residual), lr, act, _p(ws), _stream()),
+              'emsa_conv_igemm_splitk_t')
     else:
         if wp is None or wp.dtype != x.dtype:
             raise _lib.EmsaError(f"conv weights packed as {None if wp is None else wp.dtype} for "

@@ -511,6 +511,17 @@ int emsa_conv_igemm_t(int32_t dtype, const EmsaConvGeom* g, const void* in, cons
                       void* out, const float* bias, float* stats, const float* scale,
                       const float* shift, const void* residual, int32_t ld_res,
                       const void* mask_src, int32_t ld_mask, int32_t act, void* stream);
+/* Tap-split forward conv for maps with few output tiles (batch-1 inference, BASELINE configs[4]: the
+ * decoders' 3x3 convs at /32 and /16 are 40-76 tiles of 72 K steps on 256 CUs): `ksplit` workgroups
+ * per tile, each over a range of taps, raw fp32 partial sums in `ws`, then one pass that sums them in
+ * a fixed order and applies the epilogue of emsa_conv_igemm_t (bias, folded BatchNorm, residual,
+ * ReLU; no statistics, no mask).  emsa_conv_igemm_splitk_ws_bytes_t: bytes of `ws`, 0 = use
+ * emsa_conv_igemm_t (enough tiles, short K, fp32, mapped output).  EMSA_CONVH_SPLITK=0 switches it off. */
+int64_t emsa_conv_igemm_splitk_ws_bytes_t(int32_t dtype, const EmsaConvGeom* g);
+int emsa_conv_igemm_splitk_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* w,
+                             void* out, const float* bias, const float* scale, const float* shift,
+                             const void* residual, int32_t ld_res, int32_t act, float* ws,
+                             void* stream);
 /* 16-bit twin of emsa_conv1d_wino_bnb (tiles: emsa_conv_stats_rows_t(dtype, g)) and the BatchNorm
  * backward that consumes its output: g = the masked gradient stored by the conv, partial =
  * float[2][rows + 16][c] with rows [0, rows) filled; dtype EMSA_DT_F32 pairs with the Winograd

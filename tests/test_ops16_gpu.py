@@ -108,6 +108,40 @@ def test_conv16_fwd(cfg, tile, staging, dtype, monkeypatch):
     close(y2, ref2, tol=TOL[dtype], what='conv16 epilogue')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(512, 512, (3, 3), 1, 15, 20), (512, 256, (3, 3), 1, 30, 40),
+                                 (256, 128, (3, 3), 1, 60, 80), (128, 96, (3, 3), 2, 9, 11),
+                                 (512, 512, (3, 1), 1, 5, 7)])
+def test_conv16_tap_split(cfg, dtype, monkeypatch):
+    """few output tiles, long K (the decoders' 3x3 convs at batch 1, BASELINE configs[4]): the
+    forward conv runs tap-split (emsa_conv_igemm_splitk_t: ksplit workgroups per tile + a finish
+    pass) -- same result as the plain launch within one rounding, epilogue included"""
+    Fn = _fn()
+    cin, cout, k, n, h, w = cfg
+    p_ = (k[0] // 2, k[1] // 2)
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, *k, seed=2, scale=0.05)
+    b = rnd(cout, seed=3)
+    sc, sh = rnd(cout, seed=4), rnd(cout, seed=5)
+    spec = Fn.ConvSpec(cin, cout, k, 1, p_)
+    g = spec.geom_fwd(n, h, w, cin, cout)
+    assert Fn._splitk_ws_bytes(Fn.DT[dtype], g) > 0, "this case must take the tap-split path"
+    ref = F.conv2d(q(x, dtype), q(wt, dtype), b.double(), padding=p_)
+    res = rnd(*ref.shape, seed=6)
+    wp, _ = Fn.pack_weight_t(wt.to(DEV), dtype, fwd=True)
+    xa = act16(x, dtype)
+    y = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV))
+    close(y, ref, tol=TOL[dtype], what='tap-split conv')
+    y2 = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV),
+                     residual=act16(res, dtype), act=Fn.ACT_RELU)
+    ref2 = F.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + q(res, dtype))
+    close(y2, ref2, tol=TOL[dtype], what='tap-split conv epilogue')
+    # the plain launch on the same operands (EMSA_CONVH_SPLITK is read once per process: compare
+    # through the statistics-carrying call, which never splits)
+    y0, _ = Fn.conv_fwd(xa, wp, spec, bias=b.to(DEV), want_stats=True)
+    close(y, y0.double().cpu(), tol=TOL[dtype], what='tap-split vs plain')
+
+
 @pytest.mark.parametrize('cfg', [CONVS[0], CONVS[-2], CONVS[-1]])
 def test_conv16_k_step_choice(cfg, monkeypatch):
     """short-K convs (<= 6 steps of 64 channels over all taps) run with 32-channel K steps under
