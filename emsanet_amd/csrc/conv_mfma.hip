@@ -1357,9 +1357,35 @@ __global__ __launch_bounds__(256, XBN ? EMSA_W1DW_XBN_WPE : EMSA_W1DW_WPE) void 
 // (4 pixels x 8 channels per thread, waves 0-1 staging dy and waves 2-3 x) was SLOWER (51-57 us):
 // its eight-rows-apart LDS stores are 4-way bank conflicted whatever the row stride (rows are
 // 16-byte aligned), and the load width was never the limit.
-constexpr int kWH_PK = 64;          // pixels per K step
-constexpr int kWH_ROW = 72;         // LDS row (elements): 64 pixels + halo dword + pad = 144 B = 36
-                                    // banks -> conflict-free ds_read_b128 over 16 distinct rows
+// EMSA_WH_DBG=1 (tools/wgrad_phases.py builds only): lane 0 of every wave accumulates the shader-clock
+// time of each phase of its K loop; emsa_wgrad1d_h_dbg_read returns the table [wg][wave][8]
+#ifndef EMSA_WH_DBG
+#define EMSA_WH_DBG 0
+#endif
+#if EMSA_WH_DBG
+__device__ long long g_wh_dbg[8 * 4 * 4096];
+#define WH_MARK(ph)                                               \
+  do {                                                            \
+    const long long t_ = (long long)__builtin_readcyclecounter(); \
+    dbg_t[ph] += t_ - dbg_prev;                                   \
+    dbg_prev = t_;                                                \
+  } while (0)
+#else
+#define WH_MARK(ph) do {} while (0)
+#endif
+#ifndef EMSA_WH_PK
+#define EMSA_WH_PK 64
+#endif
+constexpr int kWH_PK = EMSA_WH_PK;  // pixels per K step (64 or 128): 24 MFMAs per wave between barriers
+constexpr int kWH_NH = kWH_PK / 64; // 64-pixel halves of a step (a thread loads 4 pixels of each)
+constexpr int kWH_ROW = kWH_PK + 4; // LDS row (elements): the pixels + halo dword + pad = 136 / 264 B
+                                    // = 2 banks mod 32: the transposing ds_write_b64 of a 16-lane group
+                                    // (4 channel quads x 4 pixel groups, 32-bank rule) hit 16 distinct
+                                    // bank pairs and the fragment reads, two ds_read_b64 per operand (rows
+                                    // are 8-byte aligned; 64-bank rule, 32-lane groups), 32 distinct ones.
+                                    // (Round 3 used 144 B rows and ds_read_b128: the stores were 2-way
+                                    // conflicted and the dword reads of the shifted taps 4-way --
+                                    // SQ_LDS_BANK_CONFLICT was 44 % of SQ_LDS_IDX_ACTIVE.)
 // MODE 0: stride-1 3-tap convs (and the row taps of a 3x3).  MODE 1: ONE tap -- the 1x1 convs
 // (skip fusions, pyramid pooling, strided down-sampling shortcuts: the stride lives in the x pixel
 // strides, nothing else changes).  MODE 2: stride-2 3-tap convs (first convs of a down-sampling
@@ -1368,7 +1394,7 @@ constexpr int kWH_ROW = 72;         // LDS row (elements): 64 pixels + halo dwor
 // by one element, O(b-1)).  Round 2 ran modes 1 / 2 on the fp32-MFMA tap-group kernel with a
 // bf16 -> fp32 conversion at the LDS store (3.5 ms of the 51 ms bf16 step at 78-111 TFLOP/s).
 template <typename T, int MODE = 0>
-__global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArgs p) {
+__global__ __launch_bounds__(256, 3) __attribute__((target("no-load-store-opt"))) void conv_wgrad1d_h_kernel(const Wgrad1dArgs p) {
   constexpr int BCO = 64, BCI = 64;
   constexpr uint32_t ES = sizeof(T);
   constexpr int NT_ = MODE == 1 ? 1 : 3;             // accumulator tiles (taps)
@@ -1428,39 +1454,45 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
       oo_last = (ox != kOOB && 2 * b_ + 1 < p.in_Lx) ? ox + (uint32_t)p.in_sb1 * ES : kOOB;
   };
 
-  u32x2w rd[4], rx[4], ro[4], rhalo;
+  u32x2w rd[kWH_NH][4], rx[kWH_NH][4], ro[kWH_NH][4];
+  // the pixel in front of a step (its four channels of this thread's quad): the LAST pixel of the
+  // previous step, kept from that step's registers -- only the split's first step loads it
+  u32x2w sv_d = {0u, 0u}, sv_x = {0u, 0u}, sv_o = {0u, 0u};
   float4 bsum = emsa_zero4();
   auto load_regs = [&](int s) {
     const int k0 = s * kWH_PK;
-    // lane l of every wave decomposes pixel k0 + l once; the loading threads fetch the offsets of
-    // their four pixels with wave shuffles
-    uint32_t off_d, off_x;
-    px_off(k0 + lane, off_d, off_x);
-    const uint32_t off_o = oo_last;
+    // a wave loads pixels k0 + 16 wave .. + 15 (of each 64-pixel half): every 16-lane row decomposes those 16 once, and a
+    // thread's four pixels are the four lanes of its own quad (DPP quad broadcasts; the round-3
+    // form fetched them with 8-12 ds_bpermute per step through the LDS pipe, the kernel's bottleneck)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int src = (4 * pg + j) * 4;
-      const uint32_t od = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_d);
-      const uint32_t ox = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_x);
-      rd[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)((od + dadd) | dmask), 0, 0);
-      rx[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((ox + xadd) | xmask), 0, 0);
-      if constexpr (MODE == 2) {
-        const uint32_t oo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)off_o);
-        ro[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((oo + xadd) | xmask), 0, 0);
+    for (int hh = 0; hh < kWH_NH; ++hh) {
+      uint32_t off_d, off_x;
+      px_off(k0 + hh * 64 + wave * 16 + (lane & 15), off_d, off_x);
+      const uint32_t off_o = oo_last;
+#define EMSA_WH_LOADJ(j)                                                                          \
+      {                                                                                           \
+        const uint32_t od = (uint32_t)__builtin_amdgcn_mov_dpp((int)off_d, (j) * 0x55, 0xf, 0xf, false); \
+        const uint32_t ox = (uint32_t)__builtin_amdgcn_mov_dpp((int)off_x, (j) * 0x55, 0xf, 0xf, false); \
+        rd[hh][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)((od + dadd) | dmask), 0, 0); \
+        rx[hh][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((ox + xadd) | xmask), 0, 0); \
+        if constexpr (MODE == 2) {                                                                \
+          const uint32_t oo = (uint32_t)__builtin_amdgcn_mov_dpp((int)off_o, (j) * 0x55, 0xf, 0xf, false); \
+          ro[hh][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((oo + xadd) | xmask), 0, 0); \
+        }                                                                                         \
       }
+      EMSA_WH_LOADJ(0) EMSA_WH_LOADJ(1) EMSA_WH_LOADJ(2) EMSA_WH_LOADJ(3)
+#undef EMSA_WH_LOADJ
     }
-    if constexpr (MODE != 1) {
-      if (tid < 32) {
-        // halo: x of pixel k0 - 1 (threads 0..15) and k0 + 64 (16..31), four channels each
-        // (MODE 2: of the ODD image, only its left neighbour k0 - 1 is ever read)
-        uint32_t hd, hx;
-        px_off(tid < 16 ? k0 - 1 : k0 + kWH_PK, hd, hx);
-        if constexpr (MODE == 2) hx = oo_last;
-        const int hq = tid & 15;
-        const bool hok = ci0 + 4 * hq < p.k_ch;
-        rhalo = __builtin_amdgcn_raw_buffer_load_b64(
-            rs_in, (int)(hok && hx != kOOB ? hx + (uint32_t)(ci0 + 4 * hq) * ES : kOOB), 0, 0);
-      }
+  };
+  // the pixel in front of the split's first step
+  auto load_front = [&](int s) {
+    uint32_t hd, hx;
+    px_off(s * kWH_PK - 1, hd, hx);
+    if constexpr (MODE == 0) {
+      sv_d = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, (int)((hd + dadd) | dmask), 0, 0);
+      sv_x = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((hx + xadd) | xmask), 0, 0);
+    } else if constexpr (MODE == 2) {
+      sv_o = __builtin_amdgcn_raw_buffer_load_b64(rs_in, (int)((oo_last + xadd) | xmask), 0, 0);
     }
   };
   // 4 pixels x 4 channels (one u32x2 = 4 channels per pixel) -> per channel 4 pixels = 8 bytes
@@ -1478,25 +1510,39 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
     *reinterpret_cast<u32x2w*>(o + 3 * kWH_ROW) = c3;
   };
   auto store_lds = [&]() {
-    if (do_bias) {
-      // bias gradient = column sums of dy, summed where the prefetched registers are consumed
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v = raw_f4(rd[j], (T*)nullptr);
-        bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+    for (int hh = 0; hh < kWH_NH; ++hh) {
+      if (do_bias) {
+        // bias gradient = column sums of dy, summed where the prefetched registers are consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = raw_f4(rd[hh][j], (T*)nullptr);
+          bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+        }
       }
+      tr_store(dS + hh * 64, rd[hh]);
+      tr_store(xS + hh * 64, rx[hh]);
+      if constexpr (MODE == 2) tr_store(oS + hh * 64, ro[hh]);
     }
-    tr_store(dS, rd);
-    tr_store(xS, rx);
-    if constexpr (MODE == 2) tr_store(oS, ro);
-    if (MODE != 1 && tid < 32) {
-      // halo dword of a row: element 64 (low half) = pixel k0 + 64, element 65 (high) = pixel k0 - 1
-      unsigned short* xh = reinterpret_cast<unsigned short*>(MODE == 2 ? oS : xS) +
-                           (4 * (tid & 15)) * kWH_ROW + (tid < 16 ? kWH_PK + 1 : kWH_PK);
-      xh[0] = (unsigned short)(rhalo.x & 0xFFFFu);
-      xh[kWH_ROW] = (unsigned short)(rhalo.x >> 16);
-      xh[2 * kWH_ROW] = (unsigned short)(rhalo.y & 0xFFFFu);
-      xh[3 * kWH_ROW] = (unsigned short)(rhalo.y >> 16);
+    if constexpr (MODE != 1) {
+      if (pg == 15) {
+        // halo dword of a row: its high half = pixel k0 - 1 (the low half is unused)
+        auto put = [&](T* img, const u32x2w& v) {
+          unsigned short* h = reinterpret_cast<unsigned short*>(img) + (4 * q) * kWH_ROW + kWH_PK + 1;
+          h[0] = (unsigned short)(v.x & 0xFFFFu);
+          h[kWH_ROW] = (unsigned short)(v.x >> 16);
+          h[2 * kWH_ROW] = (unsigned short)(v.y & 0xFFFFu);
+          h[3 * kWH_ROW] = (unsigned short)(v.y >> 16);
+        };
+        if constexpr (MODE == 0) {
+          put(dS, sv_d);
+          put(xS, sv_x);
+        } else {
+          put(oS, sv_o);
+        }
+      }
+      sv_d = rd[kWH_NH - 1][3]; sv_x = rx[kWH_NH - 1][3];
+      if constexpr (MODE == 2) sv_o = ro[kWH_NH - 1][3];
     }
   };
 
@@ -1506,11 +1552,18 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+#if EMSA_WH_DBG
+  long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dbg_prev = (long long)__builtin_readcyclecounter();
+  const long long dbg_t0 = dbg_prev;
+#endif
   if (s_begin < s_end) {
+    load_front(s_begin);
     load_regs(s_begin);
     store_lds();
   }
   __syncthreads();
+  WH_MARK(5);
 
   typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type E;
   typedef E ev8 __attribute__((ext_vector_type(8)));
@@ -1523,62 +1576,77 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
   for (int s = s_begin; s < s_end; ++s) {
     const bool has_next = s + 1 < s_end;
     if (has_next) load_regs(s + 1);
-    const T* drow = dS + (wco * 32 + l31) * kWH_ROW + 8 * lh;
-    const T* xrow0 = xS + (wci * 32 + l31) * kWH_ROW;
-    const T* xrow = xrow0 + 8 * lh;
-    // the image whose +-1 shifts are read: x itself (MODE 0) or the odd pixels (MODE 2)
+    WH_MARK(0);
+    const T* drow0 = dS + (wco * 32 + l31) * kWH_ROW;
+    const T* drow = drow0 + 8 * lh;
+    const T* xrow = xS + (wci * 32 + l31) * kWH_ROW + 8 * lh;
+    // the image whose shift by one pixel is read: x itself (MODE 0) or the odd pixels (MODE 2)
     const T* srow0 = (MODE == 2 ? oS : xS) + (wci * 32 + l31) * kWH_ROW;
     const T* srow = srow0 + 8 * lh;
-    unsigned halo = 0;
-    if constexpr (MODE != 1) halo = *reinterpret_cast<const unsigned*>(srow0 + kWH_PK);
+    // a fragment = two ds_read_b64 (2 LDS cycles each, 64-bank rule).  The kernel is compiled
+    // without the load-store optimizer (target attribute): it would merge them into ds_read2_b64
+    // (8 cycles, 32-bank rule) -- and the eight ds_write_b64 of the transposes into ds_write2_b64
+    auto ld8 = [&](const T* row, int e) {
+      const u32x2w a = *reinterpret_cast<const u32x2w*>(row + e);
+      const u32x2w b = *reinterpret_cast<const u32x2w*>(row + e + 4);
+      u32x4h v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+      return v;
+    };
+    // eight pixels shifted by one: v' = pixels [p - 1, p + 6] of v = [p, p + 7].  The pixel in front
+    // lives in the partner lane (same row, the other 8-pixel half: lane ^ 32) -- of this K block
+    // (lh = 1) or of the previous one (lh = 0) -- or, at the step's start, in the row's halo dword.
+    // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its
+    // second: one swap serves both halves of the wave.
+    auto shifted = [&](const u32x4h& v, unsigned& prev_w) {
+      const auto r = __builtin_amdgcn_permlane32_swap(prev_w, v.w, false, false);
+      const unsigned wl = lh ? (unsigned)r[0] : (unsigned)r[1];
+      prev_w = v.w;
+      u32x4h o;
+      o.x = __builtin_amdgcn_alignbit(v.x, wl, 16);  o.y = __builtin_amdgcn_alignbit(v.y, v.x, 16);
+      o.z = __builtin_amdgcn_alignbit(v.z, v.y, 16); o.w = __builtin_amdgcn_alignbit(v.w, v.z, 16);
+      return o;
+    };
+    unsigned prev_s = 0, prev_d = 0;
+    if constexpr (MODE != 1) prev_s = *reinterpret_cast<const unsigned*>(srow0 + kWH_PK);
+    if constexpr (MODE == 0) prev_d = *reinterpret_cast<const unsigned*>(drow0 + kWH_PK);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k16 = 0; k16 < kWH_PK / 16; ++k16) {
-      const u32x4h a = *reinterpret_cast<const u32x4h*>(drow + 16 * k16);
-      const u32x4h c = *reinterpret_cast<const u32x4h*>(xrow + 16 * k16);
+      const u32x4h a = ld8(drow, 16 * k16);
+      const u32x4h c = ld8(xrow, 16 * k16);
       const ev8 av = __builtin_bit_cast(ev8, a);
       if constexpr (MODE == 1) {
         mma(acc[0], av, c);
-        continue;
-      }
-      // the dwords in front of / behind the eight pixels; at the tile's ends the halo dword
-      // (alignbit uses the high half on the left, the low half on the right)
-      u32x4h sh_ = c;                                        // the shifted image's own eight pixels
-      if constexpr (MODE == 2) sh_ = *reinterpret_cast<const u32x4h*>(srow + 16 * k16);
-      unsigned wl, wr = 0;
-      if (k16 == 0) {
-        const unsigned w_in = *reinterpret_cast<const unsigned*>(srow0 + 6);     // lh = 1: elements 6, 7
-        wl = lh ? w_in : halo;
-      } else {
-        wl = *reinterpret_cast<const unsigned*>(srow + 16 * k16 - 2);
-      }
-      u32x4h lft;
-      lft.x = __builtin_amdgcn_alignbit(sh_.x, wl, 16);    lft.y = __builtin_amdgcn_alignbit(sh_.y, sh_.x, 16);
-      lft.z = __builtin_amdgcn_alignbit(sh_.z, sh_.y, 16); lft.w = __builtin_amdgcn_alignbit(sh_.w, sh_.z, 16);
-      if constexpr (MODE == 2) {
+      } else if constexpr (MODE == 2) {
         // taps: x(2b-1) = O(b-1) = O shifted, x(2b) = E, x(2b+1) = O
+        const u32x4h o_ = ld8(srow, 16 * k16);
+        const u32x4h lft = shifted(o_, prev_s);
         mma(acc[0], av, lft);
         mma(acc[1], av, c);
-        mma(acc[2], av, sh_);
+        mma(acc[2], av, o_);
       } else {
-        if (k16 == kWH_PK / 16 - 1) {
-          const unsigned w_in = *reinterpret_cast<const unsigned*>(xrow0 + kWH_PK - 8);   // lh = 0: 56, 57
-          wr = lh ? halo : w_in;
-        } else {
-          wr = *reinterpret_cast<const unsigned*>(xrow + 16 * k16 + 8);
-        }
-        u32x4h rgt;
-        rgt.x = __builtin_amdgcn_alignbit(c.y, c.x, 16); rgt.y = __builtin_amdgcn_alignbit(c.z, c.y, 16);
-        rgt.z = __builtin_amdgcn_alignbit(c.w, c.z, 16); rgt.w = __builtin_amdgcn_alignbit(wr, c.w, 16);
+        // left tap: dy(p) x(p - 1).  Right tap: dy(p) x(p + 1) summed as dy(p - 1) x(p) -- over the
+        // padded enumeration the same set of products (the virtual zero pixel behind every line
+        // closes both ends), and BOTH shifted operands then want the pixel in FRONT of the step,
+        // which the previous step's registers hold: no halo loads in the K loop (round 3 loaded
+        // x(k0 - 1) and x(k0 + 64) per step in wave 0, and the other waves waited for it at the
+        // barrier: 320 of a step's 3500 cycles).  A split's partial sums differ from the x-only
+        // form by its first and last products; their total does not.
+        const u32x4h lft = shifted(c, prev_s);
+        const u32x4h a_sh = shifted(a, prev_d);
         mma(acc[0], av, lft);
         mma(acc[1], av, c);
-        mma(acc[2], av, rgt);
+        mma(acc[2], __builtin_bit_cast(ev8, a_sh), c);
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    WH_MARK(1);
     __syncthreads();
+    WH_MARK(2);
     if (has_next) store_lds();
+    WH_MARK(3);
     __syncthreads();
+    WH_MARK(4);
   }
 
   if (p.ws != nullptr) {
@@ -1603,6 +1671,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_h_kernel(const Wgrad1dArg
           unsafeAtomicAdd(p.dw + ((size_t)(kr * NT_ + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
       }
   }
+#if EMSA_WH_DBG
+  WH_MARK(6);
+  dbg_t[7] = dbg_prev - dbg_t0;
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 8; ++i) g_wh_dbg[(blockIdx.x * 4 + wave) * 8 + i] = dbg_t[i];
+#endif
   if (do_bias) {
     float* red = smem;   // [16 pixel groups][BCO]
     __syncthreads();     // (the K loop's LDS reads are done; red overlays dS)
@@ -1991,6 +2065,11 @@ int64_t wgrad_ws_bytes(const EmsaConvGeom* g, size_t esize) {
                                (int64_t)pl.w.n_co_tiles * 64) * (int64_t)sizeof(float);
 }
 }  // namespace
+#if EMSA_WH_DBG
+extern "C" int emsa_wgrad1d_h_dbg_read(long long* host, int n_entries) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wh_dbg), (size_t)n_entries * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 extern "C" int64_t emsa_conv_wgrad_ws_bytes(const EmsaConvGeom* g) {
   return wgrad_ws_bytes(g, sizeof(float));
 }
