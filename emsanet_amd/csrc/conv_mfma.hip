@@ -1341,22 +1341,23 @@ __global__ __launch_bounds__(256, XBN ? EMSA_W1DW_XBN_WPE : EMSA_W1DW_WPE) void 
 // rows they are loaded as.  Each loader thread owns 4 consecutive pixels x 4 channels of BOTH
 // tensors (four coalesced 8-byte loads each: 16 lanes cover one 128-byte pixel row), transposes the
 // 4x4 blocks in registers (8 v_perm_b32 each) and writes four 8-byte rows of the [channel][pixel]
-// LDS images.  One x image serves all three taps: the centre tap reads it with ds_read_b128, the
-// left / right taps are the same eight pixels shifted by one element -- rebuilt from the centre
-// registers and ONE extra dword with four v_alignbit_b32 each -- so LDS holds every element once
-// (the Winograd F(3,2) form stores four transformed copies of each and rounds them to bf16 once
-// more).  The pixel in front of the step and the one behind it share one halo dword per row.
+// LDS images.  One x image and one dy image serve all three taps: the left tap dy(p) x(p - 1) reads
+// x shifted by one pixel, the right tap is summed as dy(p - 1) x(p) -- the same set of products
+// over the padded enumeration -- and reads dy shifted by one pixel.  A shifted fragment is rebuilt
+// from the centre registers with four v_alignbit_b32 and the dword of its partner lane (the other
+// 8-pixel half of the row: v_permlane32_swap), so LDS holds every element once (the Winograd
+// F(3,2) form stores four transformed copies of each and rounds them to bf16 once more).  Both
+// shifts want the pixel in FRONT of a step: the last pixel of the previous step, written into the
+// rows' halo dword from the registers that step was loaded into (only a split's first step loads it).
 // Lines are enumerated with one virtual zero pixel behind every line (L = Lr + 1), so taps never
 // cross a line end and no masks exist.  64 pixels per K step: 12 MFMAs per wave between barriers.
 // Direct products of the stored bf16 values with fp32 accumulation: as exact as the fp32 kernel on
 // the same inputs.
-// Measured (bs=32 layer shapes, incl. the reduction pass): 42-48 us at EVERY channel count (the
-// Winograd bf16 kernel: 75-80): a launch moves ~157 MB through the CUs' vector memory path whatever
-// C is (HBM at C=64, L2 re-reads by the 64x64 tiles at C=512) with one K step (16 KB) in flight
-// per workgroup -- latency x occupancy bound at ~18 GB/s per CU.  A variant with 16-byte loads
-// (4 pixels x 8 channels per thread, waves 0-1 staging dy and waves 2-3 x) was SLOWER (51-57 us):
-// its eight-rows-apart LDS stores are 4-way bank conflicted whatever the row stride (rows are
-// 16-byte aligned), and the load width was never the limit.
+// Measured (bs=32 layer shapes, kernel trace): 32-36 us at EVERY channel count + 8 us of reduction
+// pass (the Winograd bf16 kernel: 75-80 in all): a launch moves ~157 MB through the CUs' vector
+// memory path whatever C is (HBM at C=64, L2 re-reads by the 64x64 tiles at C=512).  DESIGN.md 7
+// (round 4) has the ablations, counters and phase timings: no single resource bounds the K loop;
+// two K steps in flight, 128-pixel steps and (round 3) 16-byte loads were all measured no faster.
 // EMSA_WH_DBG=1 (tools/wgrad_phases.py builds only): lane 0 of every wave accumulates the shader-clock
 // time of each phase of its K loop; emsa_wgrad1d_h_dbg_read returns the table [wg][wave][8]
 #ifndef EMSA_WH_DBG
