@@ -1374,6 +1374,12 @@ __device__ long long g_wh_dbg[8 * 4 * 4096];
 #else
 #define WH_MARK(ph) do {} while (0)
 #endif
+// (the device pass only: the host pass does not know the feature)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EMSA_NO_LSOPT __attribute__((target("no-load-store-opt")))
+#else
+#define EMSA_NO_LSOPT
+#endif
 #ifndef EMSA_WH_PK
 #define EMSA_WH_PK 64
 #endif
@@ -1395,7 +1401,7 @@ constexpr int kWH_ROW = kWH_PK + 4; // LDS row (elements): the pixels + halo dwo
 // by one element, O(b-1)).  Round 2 ran modes 1 / 2 on the fp32-MFMA tap-group kernel with a
 // bf16 -> fp32 conversion at the LDS store (3.5 ms of the 51 ms bf16 step at 78-111 TFLOP/s).
 template <typename T, int MODE = 0>
-__global__ __launch_bounds__(256, 3) __attribute__((target("no-load-store-opt"))) void conv_wgrad1d_h_kernel(const Wgrad1dArgs p) {
+__global__ __launch_bounds__(256, 3) EMSA_NO_LSOPT void conv_wgrad1d_h_kernel(const Wgrad1dArgs p) {
   constexpr int BCO = 64, BCI = 64;
   constexpr uint32_t ES = sizeof(T);
   constexpr int NT_ = MODE == 1 ? 1 : 3;             // accumulator tiles (taps)
@@ -1787,6 +1793,63 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
   }
 }
 
+// The same pass for layers with many tiles and few splits (512 channels: 64 tiles x 12 splits): the
+// kernel above runs 12288 workgroups of 12 useful loads each and is bound by their dispatch (16 us
+// for the 37.7 MB that take 8 us at 64-256 channels; 3x3 512->512: 31).  Here a thread owns one
+// float4 of one (tile, co_l) row and sums all splits of all R x taps weight rows itself, in the
+// split order of the kernel above for <= 16 splits (bit-identical): 16 rows per workgroup.
+__global__ __launch_bounds__(256) void wgrad1d_reduce_rows_kernel(
+    const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
+    int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
+    float* __restrict__ dbias, int taps) {
+  const int tid = threadIdx.x;
+  const int tile_f = taps * 4096, nrt = R * taps;
+  const int weight_blocks = n_tiles * 4;
+  const int col = tid & 15, rw = tid >> 4;
+  if ((int)blockIdx.x < weight_blocks) {
+    const int tile = blockIdx.x >> 2, co_l = (blockIdx.x & 3) * 16 + rw;
+    const size_t sstride = (size_t)R * n_tiles * tile_f;
+    const int co = (tile / n_ci_tiles) * 64 + co_l;
+    const int ci = (tile % n_ci_tiles) * 64 + col * 4;
+    for (int rt = 0; rt < nrt; ++rt) {
+      const int kr = rt / taps, t = rt - kr * taps;
+      const float* src = ws + (size_t)(kr * n_tiles + tile) * tile_f + (t * 64 + co_l) * 64 + col * 4;
+      float4 a = emsa_zero4();
+      for (int sp = 0; sp < splits; sp += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = sp + u < splits ? emsa_ld4(src + (size_t)(sp + u) * sstride) : emsa_zero4();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+        }
+      }
+      if (co < n_ch) {
+        float* o = dw + ((size_t)co * k_ch + ci) * nrt + rt;     // [co][ci][kr][t], rt = kr * taps + t
+        if (ci + 0 < k_ch) o[0] = a.x;
+        if (ci + 1 < k_ch) o[nrt] = a.y;
+        if (ci + 2 < k_ch) o[2 * nrt] = a.z;
+        if (ci + 3 < k_ch) o[3 * nrt] = a.w;
+      }
+    }
+  } else if (dbias != nullptr && rw == 0) {
+    const int co_t = blockIdx.x - weight_blocks;
+    const float* src = ws_bias + (size_t)co_t * 64 + col * 4;
+    const size_t sstride = (size_t)n_co_tiles * 64;
+    float4 a = emsa_zero4();
+    for (int sp = 0; sp < splits; ++sp) {
+      const float4 v = emsa_ld4(src + (size_t)sp * sstride);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const int co = co_t * 64 + col * 4;
+    if (co + 0 < n_ch) dbias[co + 0] = a.x;
+    if (co + 1 < n_ch) dbias[co + 1] = a.y;
+    if (co + 2 < n_ch) dbias[co + 2] = a.z;
+    if (co + 3 < n_ch) dbias[co + 3] = a.w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -2165,7 +2228,15 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     else
       hipLaunchKernelGGL((conv_wgrad1d_kernel<BCO, BCI>), dim3(w.n_tiles * w.R * pl.ksplit),
                          dim3(256), lds, st, w);
-    if (ws != nullptr)
+    static const bool rows_on = [] {
+      const char* e = getenv("EMSA_WGRAD_REDUCE_ROWS");
+      return !(e && e[0] == '0');
+    }();
+    if (ws != nullptr && rows_on && pl.ksplit <= 16 && w.n_tiles >= 32)
+      hipLaunchKernelGGL(wgrad1d_reduce_rows_kernel, dim3(w.n_tiles * 4 + w.n_co_tiles),
+                         dim3(256), 0, st, ws, w.ws_bias, pl.ksplit, w.n_tiles, w.n_ci_tiles,
+                         w.n_co_tiles, w.n_ch, w.k_ch, w.R, dw, dbias, w.taps);
+    else if (ws != nullptr)
       hipLaunchKernelGGL(wgrad1d_reduce_kernel, dim3(w.n_tiles * w.R * w.taps * 64 + w.n_co_tiles),
                          dim3(256), 0, st, ws, w.ws_bias, pl.ksplit, w.n_tiles, w.n_ci_tiles,
                          w.n_co_tiles, w.n_ch, w.k_ch, w.R, dw, dbias, w.taps);

@@ -1,0 +1,4 @@
+#!/bin/bash
+timeout 900 python -m pytest tests/test_ops16_gpu.py tests/test_ops_gpu.py -x -q -k "wgrad" 2>&1 | tail -3
+bash tools/jobs/r04_wh3.sh base | tail -2
+EMSA_WGRAD_REDUCE_ROWS=0 bash tools/jobs/r04_wh3.sh base | tail -2
