@@ -321,6 +321,7 @@ def run(args):
         from emsanet_amd.graph import GraphedInference
         graphed = GraphedInference(model, batch)
     train_graph = None
+    graph_fallback = None
 
     def step(fresh=None):
         # `fresh`: a batch that was just staged from host memory (--h2d); default: the HBM-resident one
@@ -373,10 +374,18 @@ def run(args):
         del flat0
         args.no_kernel_timing = True
         cls = SegmentedGraphedTrainStep if segmented else GraphedTrainStep
+        # N > 1 (the default there is the segmented graph, which no multi-GPU node has run yet): a
+        # capture that RCCL / the runtime refuses must not cost the scaling run -- the object then
+        # replays its eager twin, the same complete step with the same collectives
+        kw = {'eager_fallback': True} if (segmented and world > 1 and not args.force_dist) else {}
         if crit is not None:
-            train_graph = cls(model, batch, buckets, opt, loss_fn=lambda out: crit(out, targets)[0])
+            train_graph = cls(model, batch, buckets, opt, loss_fn=lambda out: crit(out, targets)[0], **kw)
         else:
-            train_graph = cls(model, batch, buckets, opt, cotangents=cots)
+            train_graph = cls(model, batch, buckets, opt, cotangents=cots, **kw)
+        graph_fallback = getattr(train_graph, 'capture_error', None)
+        if graph_fallback:
+            print(f'[bench] rank {rank}: hipGraph capture failed ({graph_fallback}); eager segmented step',
+                  file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     buckets.reset_stats()
@@ -448,7 +457,8 @@ def run(args):
                 'grads_written_in_place': st['direct_tensors'] // steps_seen,
                 'grads_gathered_by_copy': st['gathered_tensors'] // steps_seen,
                 'bucket_bytes': [f.numel() * f.element_size() for f, _, _ in buckets.buckets],
-                'path': 'segmented-graph' if segmented else 'eager',
+                'path': ('segmented-graph' if not graph_fallback else
+                         f'segmented-eager (graph capture failed: {graph_fallback})') if segmented else 'eager',
                 'bucket_order': 'backward segments (graph per segment)' if segmented
                 else 'measured gradient-arrival order, last bucket <= 4 MiB'}
         if segmented and train_graph is not None:
@@ -698,6 +708,12 @@ def run(args):
         if step_gflop else None,
         'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         'comm': comm,
+        # nodes of the captured hipGraph(s) replayed per step (memset nodes replaced by fill kernels)
+        'hipgraph': ({'graphs': 1, 'nodes': [graphed.graph_info['nodes']]} if graphed is not None
+                     else {'graphs': len(getattr(train_graph, 'graph_info', None) or [1]),
+                           'nodes': [i['nodes'] for i in train_graph.graph_info]
+                           if isinstance(train_graph.graph_info, list)
+                           else [train_graph.graph_info['nodes']]} if train_graph is not None else None),
         'input': 'resident in HBM before the timed region',
         'h2d_staged': staged,
     }

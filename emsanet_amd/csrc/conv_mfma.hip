@@ -1703,6 +1703,221 @@ __global__ __launch_bounds__(256, 3) EMSA_NO_LSOPT void conv_wgrad1d_h_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The stride-1 3-tap weight gradient with hardware-transposed operand reads (round 4)
+// ------------------------------------------------------------------------------------------
+// Same tile (64 co x 64 ci x 3 taps, 4 waves of 32 x 32), same split-K workspace and reduction
+// pass as conv_wgrad1d_h_kernel MODE 0, but NOTHING is transposed or shifted by the VALU: the NHWC
+// rows go to LDS as they are loaded ([pixel][64 channels], 16-byte chunks: two
+// buffer_load_dwordx4 + two ds_write_b128 per thread and tensor instead of four 8-byte loads, 16
+// v_perm_b32 and four ds_write_b64), and ds_read_b64_tr_b16 delivers the K-contiguous MFMA
+// fragments: a 16-lane group hands in the addresses of a [4 pixels][16 channels] block, lane i
+// receives channel i of the four pixels.  A tap is a ROW offset of that read: the left tap reads x
+// one pixel row up, the right tap -- summed as dy(p - 1) x(p) -- reads dy one row up, so row 0 of
+// each image is the pixel in front of the step (kept from the previous step's registers).
+// conv_wgrad1d_h_kernel spends ~170 VALU instructions per wave and K step on offsets, register
+// transposes and v_alignbit shifts beside its 12 MFMAs; this form ~60.
+// Rows are 192 bytes apart (64 channels + 64 bytes of padding): the four pixel rows x 64 bytes of
+// a 32-lane half of a transposed read then cover the 64 banks once, and the 8 lanes of a
+// ds_write_b128 group (two pixel rows x 64 bytes) the 32 banks of the store rule once.
+constexpr int kWT_PK = 64;                          // pixels per K step
+constexpr int kWT_RS = 96;                          // LDS row stride (elements) = 192 B
+constexpr int kWT_IMG = (kWT_PK + 1) * kWT_RS;      // one image: the front row + 64 pixel rows
+template <typename T>
+__global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dArgs p) {
+  constexpr int BCO = 64, BCI = 64;
+  constexpr uint32_t ES = sizeof(T);
+  typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  T* const dS = reinterpret_cast<T*>(smem);          // [65][kWT_RS]: row 0 = pixel k0 - 1, row 1 + e = k0 + e
+  T* const xS = dS + kWT_IMG;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave & 1, wci = wave >> 1;
+#if EMSA_W1D_XCD
+  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+#else
+  const int wg = blockIdx.x;
+#endif
+  const int tile = wg % p.n_tiles, kr = (wg / p.n_tiles) % p.R;
+  const int ks = wg / (p.n_tiles * p.R);
+  const int dline = kr * p.dl_mul + p.dl_off;
+  const int ci_t = tile % p.n_ci_tiles, co_t = tile / p.n_ci_tiles;
+  const int co0 = co_t * BCO, ci0 = ci_t * BCI;
+  const int s_begin = ks * p.steps_per_split;
+  const int s_end = min(s_begin + p.steps_per_split, p.steps_total);
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(p.dout, p.dout_bytes);
+  // loader unit: quad tid >> 2 owns pixel (tid >> 2) of the step, its four lanes the 16-byte
+  // chunks (lane & 3) and 4 + (lane & 3) of the pixel's 128-byte row -- every lane decomposes its
+  // own pixel, nothing crosses lanes
+  const int lp = tid >> 2, ch0 = (lane & 3) * 8;
+  const bool do_bias = p.dbias != nullptr && ci_t == 0 && kr == 0;
+  uint32_t dadd[2], xadd[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    dadd[h] = co0 + ch0 + 32 * h < p.n_ch ? (uint32_t)(co0 + ch0 + 32 * h) * ES : kOOB;
+    xadd[h] = ci0 + ch0 + 32 * h < p.k_ch ? (uint32_t)(ci0 + ch0 + 32 * h) * ES : kOOB;
+  }
+  auto px_off = [&](int k, uint32_t& od, uint32_t& ox) {
+    const bool valid = k >= 0 && k < p.M;
+    const uint32_t ku = valid ? (uint32_t)k : 0u;
+    const uint32_t img = fast_div(ku, p.div_al);
+    const uint32_t line = fast_div(ku, p.div_l);                 // = img * A + a
+    const int b_ = (int)(ku - __umul24(line, (uint32_t)p.L));
+    const int a_ = (int)(line - __umul24(img, (uint32_t)p.A));
+    const int a2 = a_ * p.x_mul_a + dline;
+    const bool in_line = valid && b_ < p.Lr;                     // the virtual pixel reads zero
+    od = in_line ? (__umul24(img, (uint32_t)p.dy_simg) + __umul24((uint32_t)a_, (uint32_t)p.dy_sa) +
+                    __umul24((uint32_t)b_, (uint32_t)p.dy_sb)) * ES : kOOB;
+    ox = (in_line && a2 >= 0 && a2 < p.in_Ax)
+        ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa1) +
+           __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * ES : kOOB;
+  };
+  u32x4h rd[2], rx[2];
+  auto load_px = [&](int k, u32x4h (&d)[2], u32x4h (&x)[2]) {
+    uint32_t od, ox;
+    px_off(k, od, ox);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      d[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(od | dadd[h]) >= 0 ? (int)(od + dadd[h]) : (int)kOOB, 0, 0);
+      x[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(ox | xadd[h]) >= 0 ? (int)(ox + xadd[h]) : (int)kOOB, 0, 0);
+    }
+  };
+  float bsum[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[h][e] = 0.f;
+  // the pixel in front of the step: the registers of pixel 63 of the previous step (quad 63)
+  u32x4h sv_d[2], sv_x[2];
+  auto store_lds = [&]() {
+    if (do_bias) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x2w lo, hi;
+        lo.x = rd[h].x; lo.y = rd[h].y; hi.x = rd[h].z; hi.y = rd[h].w;
+        const float4 v0 = raw_f4(lo, (T*)nullptr), v1 = raw_f4(hi, (T*)nullptr);
+        bsum[h][0] += v0.x; bsum[h][1] += v0.y; bsum[h][2] += v0.z; bsum[h][3] += v0.w;
+        bsum[h][4] += v1.x; bsum[h][5] += v1.y; bsum[h][6] += v1.z; bsum[h][7] += v1.w;
+      }
+    }
+    if (lp == kWT_PK - 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<u32x4h*>(dS + ch0 + 32 * h) = sv_d[h];
+        *reinterpret_cast<u32x4h*>(xS + ch0 + 32 * h) = sv_x[h];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<u32x4h*>(dS + (1 + lp) * kWT_RS + ch0 + 32 * h) = rd[h];
+      *reinterpret_cast<u32x4h*>(xS + (1 + lp) * kWT_RS + ch0 + 32 * h) = rx[h];
+      sv_d[h] = rd[h]; sv_x[h] = rx[h];
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (s_begin < s_end) {
+    load_px(s_begin * kWT_PK - 1, sv_d, sv_x);
+    load_px(s_begin * kWT_PK + lp, rd, rx);
+    store_lds();
+  }
+  __syncthreads();
+
+  typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type E;
+  typedef E ev8 __attribute__((ext_vector_type(8)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto mma = [&](f32x16& c_, const s16x8& av, const s16x8& bv) {
+    if constexpr (std::is_same<T, emsa_f16>::value)
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ev8, av), __builtin_bit_cast(ev8, bv), c_, 0, 0, 0);
+    else
+      c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ev8, av), __builtin_bit_cast(ev8, bv), c_, 0, 0, 0);
+  };
+  // transposed fragment read: the 16-lane group lane >> 4 covers channel block (lane >> 4) & 1 of
+  // the wave's 32 channels and K half lane >> 5; lane i of it hands in pixel row (i >> 2), 8-byte
+  // piece (i & 3) and receives channel i of pixels 0..3 (first read) and 4..7 (second)
+  const int gi = lane & 15, g16 = lane >> 4;
+  const int frag_off = (8 * (g16 >> 1) + (gi >> 2)) * kWT_RS + ((g16 & 1) * 16 + 4 * (gi & 3));
+  const T* const dfr = dS + kWT_RS + frag_off + wco * 32;       // centre: pixel rows start at row 1
+  const T* const xfr = xS + kWT_RS + frag_off + wci * 32;
+  auto frag = [&](const T* base, int row) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s16x4*)(const_cast<T*>(base) + row * kWT_RS));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s16x4*)(const_cast<T*>(base) + (row + 4) * kWT_RS));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  };
+
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool has_next = s + 1 < s_end;
+    if (has_next) load_px((s + 1) * kWT_PK + lp, rd, rx);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k16 = 0; k16 < kWT_PK / 16; ++k16) {
+      const s16x8 a = frag(dfr, 16 * k16), a_up = frag(dfr, 16 * k16 - 1);
+      const s16x8 c = frag(xfr, 16 * k16), c_up = frag(xfr, 16 * k16 - 1);
+      mma(acc[0], a, c_up);        // dy(p) x(p - 1)
+      mma(acc[1], a, c);           // dy(p) x(p)
+      mma(acc[2], a_up, c);        // dy(p - 1) x(p) = the right tap's products
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    if (has_next) store_lds();
+    __syncthreads();
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (p.ws != nullptr) {
+    float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (3 * BCO * BCI);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        wt[(t * BCO + wco * 32 + row) * BCI + wci * 32 + l31] = acc[t][r];
+      }
+  } else {
+    const int ci = ci0 + wci * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int co = co0 + wco * 32 + row;
+        if (co < p.n_ch && ci < p.k_ch)
+          unsafeAtomicAdd(p.dw + ((size_t)(kr * 3 + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
+      }
+  }
+  if (do_bias) {
+    float* red = smem;   // [64 pixels][BCO]
+    __syncthreads();     // (the K loop's LDS reads are done; red overlays dS)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[lp * BCO + ch0 + 32 * h + e] = bsum[h][e];
+    __syncthreads();
+    if (tid < BCO) {
+      float a = 0.f;
+      for (int r = 0; r < kWT_PK; ++r) a += red[r * BCO + tid];
+      if (p.ws_bias != nullptr)
+        p.ws_bias[((size_t)ks * p.n_co_tiles + co_t) * BCO + tid] = a;
+      else if (co0 + tid < p.n_ch)
+        unsafeAtomicAdd(p.dbias + co0 + tid, a);
+    }
+  }
+}
+
 // second pass of the deterministic split-K: dw[co][ci][t] (OIHW of a 3-tap 1-D conv) =
 // sum over splits of ws[split][tile][t][co_l][ci_l]; dbias[co] = sum of ws_bias[split][co].
 // workgroup = one (tile, t, co_l) row of 64 ci (16 float4 columns) x 16 split groups; the
@@ -2116,6 +2331,15 @@ bool wgrad16_direct() {
   }();
   return v;
 }
+// EMSA_WGRAD16_TR=0: the stride-1 3-tap weight gradients on conv_wgrad1d_h_kernel (register
+// transposes) instead of conv_wgrad1d_tr_kernel (ds_read_b64_tr_b16)
+bool wgrad16_tr() {
+  static const bool v = [] {
+    const char* e = getenv("EMSA_WGRAD16_TR");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
 // geometry admits the direct 16-bit kernel (8-byte accesses: 4 channels; dout_is_aligned checks dy)
 bool direct16_geom(const EmsaConvGeom* g) { return wgrad16_direct() && !(g->k_ch & 3); }
 int64_t wgrad_ws_bytes(const EmsaConvGeom* g, size_t esize) {
@@ -2199,6 +2423,12 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
         else if (pl.mode == 2)
           hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 2>), grid, dim3(256),
                              (size_t)3 * 64 * kWH_ROW * sizeof(T), st, w);
+        else if (wgrad16_tr() && !(g->k_ch & 7) && !(g->n_ch & 7) && !(g->ld_out & 7) &&
+                 !(g->in_px_stride & 7) && !(g->in_row_stride & 7) && !(g->in_img_stride & 7) &&
+                 !((((uintptr_t)in) | ((uintptr_t)dout)) & 15))
+          // (16-byte chunks: every pixel row of both tensors starts on a 16-byte boundary)
+          hipLaunchKernelGGL((conv_wgrad1d_tr_kernel<T>), grid, dim3(256),
+                             (size_t)2 * kWT_IMG * sizeof(T), st, w);
         else
           hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 0>), grid, dim3(256),
                              (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);

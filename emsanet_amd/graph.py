@@ -307,7 +307,10 @@ class SegmentedGraphedTrainStep:
     the tests compare against and what the warm-up runs."""
 
     def __init__(self, model, example_batch, buckets, optimizer, loss_fn=None, cotangents=None,
-                 cut_stages=(2, 1), warmup=2, keep_warmup_updates=False):
+                 cut_stages=(2, 1), warmup=2, keep_warmup_updates=False, eager_fallback=False):
+        """eager_fallback: if the capture raises (a runtime / RCCL that refuses it), keep the object
+        and let replay() run the eager twin -- the same step, same collectives -- instead of
+        failing; `capture_error` then holds the reason (bench.py reports it).  Default: raise."""
         from .nn import CutPlan
         if not model.training:
             raise ValueError("SegmentedGraphedTrainStep captures the train-mode step")
@@ -349,9 +352,25 @@ class SegmentedGraphedTrainStep:
             self.graphs.append(g)
             keeps.append(kept)
         self._capturing = True
+        self.capture_error = None
         st0 = dict(buckets.stats)
         try:
             self.static_loss, self.static_out = self._run()
+        except Exception as e:                    # noqa: BLE001
+            if not eager_fallback:
+                raise
+            import warnings
+            self.capture_error = f'{type(e).__name__}: {e}'[:300]
+            warnings.warn(f"SegmentedGraphedTrainStep: capture failed ({self.capture_error}); "
+                          "replay() runs the eager segmented step", RuntimeWarning, stacklevel=2)
+            self._capturing = False
+            torch.cuda.synchronize()
+            for k, v in st0.items():
+                buckets.stats[k] = v
+            self.graphs, self.graph_info = None, []
+            self.replays = 0
+            self._ev = None
+            return
         finally:
             self._capturing = False
         # what one step gathers (host-side counters of the captured `gather` calls)
@@ -440,6 +459,9 @@ class SegmentedGraphedTrainStep:
 
     def replay(self, batch=None):
         """one training step on `batch` (same shapes as the example; None: the static inputs)"""
+        if self.graphs is None:                   # eager_fallback after a failed capture
+            self.replays += 1
+            return self.eager_step(batch)
         if batch is not None:
             for k, v in self.static_in.items():
                 v.copy_(batch[k], non_blocking=True)

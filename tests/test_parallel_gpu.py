@@ -302,6 +302,55 @@ def test_segmented_step_equals_plain_step_single_process(inst_fusion):
 
 
 @pytest.mark.gpu
+def test_segmented_step_falls_back_to_its_eager_twin_when_capture_fails(monkeypatch):
+    """a runtime that refuses the capture (simulated: graph creation raises) must not cost a
+    multi-GPU run: with eager_fallback=True the object survives, replay() runs the eager segmented
+    step -- same gradients -- and capture_error says why; without it the error propagates"""
+    sys.path.insert(0, ROOT)
+    from emsanet_amd import full_args, graph as G, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.optim import FusedSGD
+    from emsanet_amd.parallel import GradientBuckets
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = EMSANet(full_args(input_height=H, input_width=W), nyuv2_config()).to(dev).train()
+    model.dropout_seed = 5
+    batch = _batch(0, dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def loss_of(out):
+        return sum((t * t).mean() for t in _flatten(out))
+
+    loss_of(model(batch)).backward()
+    ref = [p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    model.dropout_step = 0
+
+    def refuse(*a, **k):
+        raise RuntimeError('capture refused (test)')
+    monkeypatch.setattr(G.torch.cuda, 'graph', refuse)
+    groups = G.segment_parameter_groups(model, (2, 1))
+    buckets = GradientBuckets(params, groups=groups, manual=True, tail_bytes=4 << 20)
+    opt = FusedSGD(buckets, lr=0.0, momentum=0.9, weight_decay=0.0)
+    with pytest.raises(RuntimeError, match='capture refused'):
+        G.SegmentedGraphedTrainStep(model, batch, buckets, opt, loss_fn=loss_of, cut_stages=(2, 1))
+    model.dropout_step = 0
+    with pytest.warns(RuntimeWarning, match='capture failed'):
+        step = G.SegmentedGraphedTrainStep(model, batch, buckets, opt, loss_fn=loss_of,
+                                           cut_stages=(2, 1), eager_fallback=True)
+    assert step.graphs is None and 'capture refused' in step.capture_error
+    model.dropout_step = 0
+    model._sync_dropout_state()
+    step.replay(batch)
+    torch.cuda.synchronize()
+    gmax = max(float(r.abs().max()) for r in ref)
+    for p, r in zip(params, ref):
+        assert float((p.grad - r).abs().max()) <= 2e-5 * gmax
+    assert step.replays == 1 and step.bucket_launch_ms_before_backward_end() is None
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_two_ranks_gloo():
     """`python bench.py --gpus 2` through its own launcher (torch.distributed.run on 127.0.0.1, the
     command line the driver uses), two ranks sharing this GPU over gloo (RCCL refuses two ranks on

@@ -43,6 +43,9 @@ python tools/stats_csv_to_md.py $(ls $O/prof_bf16_one_stream/*kernel_stats.csv |
 python tools/stats_csv_to_md.py $(ls $O/prof_eval_bs1_f16/*kernel_stats.csv | head -1) 110 "r04_z: rocprofv3 --kernel-trace --stats -- python bench.py --eval --graph --batch-size 1 --dtype f16 --steps 100 --warmup 10 (configs[4]: whole-model hipGraph, per forward)" > $O/eval_bs1_f16_kernel_stats.md
 timeout 600 python tools/conv_bench16.py all > $O/conv_bench16.txt 2>&1
 timeout 600 tools/bin/conv_rs_probe 32 time > $O/conv_rs_probe.txt 2>&1
+bash tools/jobs/r04_wh3.sh base > $O/wgrad16_kernel_trace.txt 2>&1
+EMSA_LIB=$PWD/tools/bin/whdbg/libemsanet_hip.so python tools/wgrad_phases.py "1x3 c128" 2>&1 | grep -v amdgpu.ids > $O/wgrad16_phases.txt
+EMSA_LIB=$PWD/tools/bin/whdbg/libemsanet_hip.so python tools/wgrad_phases.py "1x3 c512" 2>&1 | grep -v amdgpu.ids >> $O/wgrad16_phases.txt
 tools/pmc_traffic2.sh f32 > $O/pmc_f32.log 2>&1; python tools/pmc_traffic_json.py gpurun_out/pmc_f32/raw.json $O/r04_pmc_traffic.json r04 > $O/pmc_f32_json.log 2>&1; tail -8 $O/pmc_f32_json.log
 tools/pmc_traffic2.sh bf16 --dtype bf16 > $O/pmc_bf16.log 2>&1; EMSA_PMC_BENCH_ARGS="--dtype bf16" python tools/pmc_traffic_json.py gpurun_out/pmc_bf16/raw.json $O/r04_pmc_traffic_bf16.json r04 > $O/pmc_bf16_json.log 2>&1; tail -8 $O/pmc_bf16_json.log
 rm -rf gpurun_out/pmc_f32/FETCH_SIZE gpurun_out/pmc_f32/WRITE_SIZE gpurun_out/pmc_bf16/FETCH_SIZE gpurun_out/pmc_bf16/WRITE_SIZE $O/prof_*/
