@@ -1713,8 +1713,11 @@ __global__ __launch_bounds__(256, 3) EMSA_NO_LSOPT void conv_wgrad1d_h_kernel(co
 // v_perm_b32 and four ds_write_b64), and ds_read_b64_tr_b16 delivers the K-contiguous MFMA
 // fragments: a 16-lane group hands in the addresses of a [4 pixels][16 channels] block, lane i
 // receives channel i of the four pixels.  A tap is a ROW offset of that read: the left tap reads x
-// one pixel row up, the right tap -- summed as dy(p - 1) x(p) -- reads dy one row up, so row 0 of
-// each image is the pixel in front of the step (kept from the previous step's registers).
+// one pixel row up, the right tap -- summed as dy(p - 1) x(p) -- reads dy one row up; the pixel in
+// front of a step sits in one of two front rows of each image, stored there by the quad that
+// stored it as pixel 63 of the previous step (two rows: the current step still reads the other).
+// Measured no faster: fragments of K block k + 1 read under the MFMAs of block k (+20 VGPRs), two
+// steps of loads in flight (176 VGPRs: two workgroups per CU), 1024 workgroups.
 // conv_wgrad1d_h_kernel spends ~170 VALU instructions per wave and K step on offsets, register
 // transposes and v_alignbit shifts beside its 12 MFMAs; this form ~60.
 // Rows are 192 bytes apart (64 channels + 64 bytes of padding): the four pixel rows x 64 bytes of
@@ -1722,7 +1725,7 @@ __global__ __launch_bounds__(256, 3) EMSA_NO_LSOPT void conv_wgrad1d_h_kernel(co
 // ds_write_b128 group (two pixel rows x 64 bytes) the 32 banks of the store rule once.
 constexpr int kWT_PK = 64;                          // pixels per K step
 constexpr int kWT_RS = 96;                          // LDS row stride (elements) = 192 B
-constexpr int kWT_IMG = (kWT_PK + 1) * kWT_RS;      // one image: the front row + 64 pixel rows
+constexpr int kWT_IMG = (kWT_PK + 2) * kWT_RS;      // one image: two front rows + 64 pixel rows
 template <typename T>
 __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dArgs p) {
   constexpr int BCO = 64, BCI = 64;
@@ -1731,7 +1734,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  T* const dS = reinterpret_cast<T*>(smem);          // [65][kWT_RS]: row 0 = pixel k0 - 1, row 1 + e = k0 + e
+  // [66][kWT_RS]: row 2 + e = pixel k0 + e; the pixel in front of the step, k0 - 1, is in row
+  // (step & 1): the quad that stores pixel 63 of a step also stores it as the NEXT step's front row,
+  // which is not the one the current step reads
+  T* const dS = reinterpret_cast<T*>(smem);
   T* const xS = dS + kWT_IMG;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1786,14 +1792,16 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
       x[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(ox | xadd[h]) >= 0 ? (int)(ox + xadd[h]) : (int)kOOB, 0, 0);
     }
   };
+  // bias gradient (column sums of dy): 16 running sums per thread.  (Kept in LDS instead -- to
+  // free registers for a second set of loads in flight -- they cost 3 us per launch as read-add-
+  // write of the thread's own slots, and 190 us as ds_add_f32: ~64 cycles per wave instruction.)
   float bsum[2][8];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[h][e] = 0.f;
-  // the pixel in front of the step: the registers of pixel 63 of the previous step (quad 63)
-  u32x4h sv_d[2], sv_x[2];
-  auto store_lds = [&]() {
+  // st: the step being stored (its pixel 63 becomes the front row of step st + 1)
+  auto store_lds = [&](int st, const u32x4h (&rd)[2], const u32x4h (&rx)[2]) {
     if (do_bias) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1804,18 +1812,19 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
         bsum[h][4] += v1.x; bsum[h][5] += v1.y; bsum[h][6] += v1.z; bsum[h][7] += v1.w;
       }
     }
+    // quad 63 stores its pixel twice: lp_row = row 2 + 63 and the front row of the next step
+    const int fr = ((st + 1 - s_begin) & 1) * kWT_RS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<u32x4h*>(dS + (2 + lp) * kWT_RS + ch0 + 32 * h) = rd[h];
+      *reinterpret_cast<u32x4h*>(xS + (2 + lp) * kWT_RS + ch0 + 32 * h) = rx[h];
+    }
     if (lp == kWT_PK - 1) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        *reinterpret_cast<u32x4h*>(dS + ch0 + 32 * h) = sv_d[h];
-        *reinterpret_cast<u32x4h*>(xS + ch0 + 32 * h) = sv_x[h];
+        *reinterpret_cast<u32x4h*>(dS + fr + ch0 + 32 * h) = rd[h];
+        *reinterpret_cast<u32x4h*>(xS + fr + ch0 + 32 * h) = rx[h];
       }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *reinterpret_cast<u32x4h*>(dS + (1 + lp) * kWT_RS + ch0 + 32 * h) = rd[h];
-      *reinterpret_cast<u32x4h*>(xS + (1 + lp) * kWT_RS + ch0 + 32 * h) = rx[h];
-      sv_d[h] = rd[h]; sv_x[h] = rx[h];
     }
   };
 
@@ -1825,12 +1834,27 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+#if EMSA_WH_DBG
+  long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dbg_prev = (long long)__builtin_readcyclecounter();
+  const long long dbg_t0 = dbg_prev;
+#endif
   if (s_begin < s_end) {
-    load_px(s_begin * kWT_PK - 1, sv_d, sv_x);
+    // the pixel in front of the split: loaded by every quad, stored (as "pixel 63 of step
+    // s_begin - 1") by quad 63 into front row 0
+    load_px(s_begin * kWT_PK - 1, rd, rx);
+    if (lp == kWT_PK - 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<u32x4h*>(dS + ch0 + 32 * h) = rd[h];
+        *reinterpret_cast<u32x4h*>(xS + ch0 + 32 * h) = rx[h];
+      }
+    }
     load_px(s_begin * kWT_PK + lp, rd, rx);
-    store_lds();
+    store_lds(s_begin, rd, rx);
   }
   __syncthreads();
+  WH_MARK(5);
 
   typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type E;
   typedef E ev8 __attribute__((ext_vector_type(8)));
@@ -1846,38 +1870,65 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
   // piece (i & 3) and receives channel i of pixels 0..3 (first read) and 4..7 (second)
   const int gi = lane & 15, g16 = lane >> 4;
   const int frag_off = (8 * (g16 >> 1) + (gi >> 2)) * kWT_RS + ((g16 & 1) * 16 + 4 * (gi & 3));
-  const T* const dfr = dS + kWT_RS + frag_off + wco * 32;       // centre: pixel rows start at row 1
-  const T* const xfr = xS + kWT_RS + frag_off + wci * 32;
-  auto frag = [&](const T* base, int row) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_s16x4*)(const_cast<T*>(base) + row * kWT_RS));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_s16x4*)(const_cast<T*>(base) + (row + 4) * kWT_RS));
+  const T* const dfr = dS + 2 * kWT_RS + frag_off + wco * 32;   // pixel rows start at row 2
+  const T* const xfr = xS + 2 * kWT_RS + frag_off + wci * 32;
+  // the lanes whose "one row up" of the step's first K block is the front row (K half 0, row 0 of
+  // the 4-row block) reach it through an offset that alternates with the step: row (step & 1) is
+  // 2 - (step & 1) rows above pixel row 0, i.e. one more row up on even steps
+  const bool at_front = (g16 >> 1) == 0 && (gi >> 2) == 0;
+  auto tr4 = [&](const T* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)const_cast<T*>(ptr));
+  };
+  auto join = [&](const s16x4& lo, const s16x4& hi) {
     s16x8 v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
     v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
     return v;
   };
+  struct Frags { s16x8 a, a_up, c, c_up; };
+  auto read_frags = [&](int k16, int up0) {
+    // up0: element offset of the first "one row up" read of K block 0 (front row for some lanes)
+    Frags f;
+    const int r = 16 * k16 * kWT_RS;
+    f.a = join(tr4(dfr + r), tr4(dfr + r + 4 * kWT_RS));
+    f.c = join(tr4(xfr + r), tr4(xfr + r + 4 * kWT_RS));
+    const int u = k16 == 0 ? up0 : r - kWT_RS;
+    f.a_up = join(tr4(dfr + u), tr4(dfr + r + 3 * kWT_RS));
+    f.c_up = join(tr4(xfr + u), tr4(xfr + r + 3 * kWT_RS));
+    return f;
+  };
 
-  for (int s = s_begin; s < s_end; ++s) {
-    const bool has_next = s + 1 < s_end;
-    if (has_next) load_px((s + 1) * kWT_PK + lp, rd, rx);
+  auto compute = [&](int st) {
+    const int up0 = at_front ? -(2 - ((st - s_begin) & 1)) * kWT_RS : -kWT_RS;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k16 = 0; k16 < kWT_PK / 16; ++k16) {
-      const s16x8 a = frag(dfr, 16 * k16), a_up = frag(dfr, 16 * k16 - 1);
-      const s16x8 c = frag(xfr, 16 * k16), c_up = frag(xfr, 16 * k16 - 1);
-      mma(acc[0], a, c_up);        // dy(p) x(p - 1)
-      mma(acc[1], a, c);           // dy(p) x(p)
-      mma(acc[2], a_up, c);        // dy(p - 1) x(p) = the right tap's products
+      const Frags g = read_frags(k16, up0);
+      mma(acc[0], g.a, g.c_up);        // dy(p) x(p - 1)
+      mma(acc[1], g.a, g.c);           // dy(p) x(p)
+      mma(acc[2], g.a_up, g.c);        // dy(p - 1) x(p) = the right tap's products
     }
     __builtin_amdgcn_s_setprio(0);
+  };
+  for (int s = s_begin; s < s_end; ++s) {
+    const bool has_next = s + 1 < s_end;
+    if (has_next) load_px((s + 1) * kWT_PK + lp, rd, rx);
+    WH_MARK(0);
+    compute(s);
+    WH_MARK(1);
     __syncthreads();
-    if (has_next) store_lds();
+    WH_MARK(2);
+    if (has_next) store_lds(s + 1, rd, rx);
+    WH_MARK(3);
     __syncthreads();
+    WH_MARK(4);
   }
 
-  const int l31 = lane & 31, lh = lane >> 5;
+  // (the epilogue's lane / thread indices are rebuilt from v_mbcnt: carried over from the prologue
+  //  they would be live -- and spilled -- across the K loop)
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int tid_e = wave * 64 + lane_e;
+  const int l31 = lane_e & 31, lh = lane_e >> 5;
   if (p.ws != nullptr) {
     float* wt = p.ws + (((size_t)ks * p.R + kr) * p.n_tiles + tile) * (3 * BCO * BCI);
 #pragma unroll
@@ -1899,6 +1950,12 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
           unsafeAtomicAdd(p.dw + ((size_t)(kr * 3 + t) * p.n_ch + co) * p.k_ch + ci, acc[t][r]);
       }
   }
+#if EMSA_WH_DBG
+  WH_MARK(6);
+  dbg_t[7] = dbg_prev - dbg_t0;
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 8; ++i) g_wh_dbg[(blockIdx.x * 4 + wave) * 8 + i] = dbg_t[i];
+#endif
   if (do_bias) {
     float* red = smem;   // [64 pixels][BCO]
     __syncthreads();     // (the K loop's LDS reads are done; red overlays dS)
@@ -1907,13 +1964,13 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[lp * BCO + ch0 + 32 * h + e] = bsum[h][e];
     __syncthreads();
-    if (tid < BCO) {
+    if (tid_e < BCO) {
       float a = 0.f;
-      for (int r = 0; r < kWT_PK; ++r) a += red[r * BCO + tid];
+      for (int r = 0; r < kWT_PK; ++r) a += red[r * BCO + tid_e];
       if (p.ws_bias != nullptr)
-        p.ws_bias[((size_t)ks * p.n_co_tiles + co_t) * BCO + tid] = a;
-      else if (co0 + tid < p.n_ch)
-        unsafeAtomicAdd(p.dbias + co0 + tid, a);
+        p.ws_bias[((size_t)ks * p.n_co_tiles + co_t) * BCO + tid_e] = a;
+      else if (co0 + tid_e < p.n_ch)
+        unsafeAtomicAdd(p.dbias + co0 + tid_e, a);
     }
   }
 }

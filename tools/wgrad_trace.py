@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 per = 27                                             # conv_bench.timeit: 3 warm-up + 24 timed calls
-for pat in ("conv_wgrad1d_h_kernel", "wgrad1d_reduce"):
+for pat in ("conv_wgrad1d_", "wgrad1d_reduce"):
     sel = sorted((r for r in rows if pat in r['Kernel_Name']), key=lambda r: int(r['Start_Timestamp']))
     out = []
     for i in range(0, len(sel) - per + 1, per):
