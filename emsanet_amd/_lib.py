@@ -163,6 +163,7 @@ SIGNATURES = {
     'emsa_head_act_bwd_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_stem_pack_input_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_channel_mean_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
+    'emsa_se_pair_fwd_t': (c_int, [c_int32] + [_P] * 14 + [c_int32, c_int64, c_int32, c_int32, _P]),
     'emsa_se_scale_bwd_reduce_t': (c_int, [c_int32, _P, _P, _P, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_cast_channels': (c_int, [c_int32, _P, c_int32, c_int32, _P, c_int32, c_int64, c_int32, _P]),
     'emsa_conv_stats_rows_t': (c_int, [c_int32, _GP]),

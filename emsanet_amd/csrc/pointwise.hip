@@ -756,14 +756,20 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __res
 // stage 1: ws[n][split][c] = sum_{hw chunk} a*b (b may be NULL -> sum a); stage 2 sums the splits
 // in a fixed order -> bit-reproducible (no atomics: the SE weighting feeds every later layer, and
 // run-to-run noise there flips ReLU masks downstream)
+// nblk_a: the first nblk_a workgroups reduce `a`, the ones behind them `a2` (b == NULL): the two
+// squeeze inputs of an SE-add fusion in ONE launch (emsa_se_pair_fwd_t)
 template <typename T>
 __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                   float* __restrict__ ws, long hw, int cvn, int splits) {
+                                   float* __restrict__ ws, long hw, int cvn, int splits,
+                                   const T* __restrict__ a2 = nullptr, int nblk_a = 0x7fffffff) {
   // 16 bytes per lane in every storage type (8 channels of bf16 / fp16, 4 of fp32): block =
   // (cvn channel vectors) x (256 / cvn row lanes) over this split's pixels
   constexpr int V = VecIO<T>::V;
   extern __shared__ __attribute__((aligned(16))) float cred[];   // [lanes][c]
-  const int img = blockIdx.x / splits, sp = blockIdx.x % splits;
+  const bool second = (int)blockIdx.x >= nblk_a;
+  const int blk = second ? blockIdx.x - nblk_a : blockIdx.x;
+  if (second) a = a2;
+  const int img = blk / splits, sp = blk % splits;
   const long chunk = (hw + splits - 1) / splits;
   const long p0 = img * hw + sp * chunk, p1 = min(img * hw + (sp + 1) * chunk, (img + 1) * hw);
   const int lanes = kThreads / cvn, c = cvn * V;
@@ -836,6 +842,47 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ gap, const float* __
     float a = b2[i];
     for (int r = 0; r < cr; ++r) a += w2[(long)i * cr + r] * hsh[r];
     s[(long)img * c + i] = 1.f / (1.f + expf(-a));
+  }
+}
+
+// Both excitation MLPs of an SE-add fusion in one launch, fed by the split sums of
+// channel_dot_kernel directly (the channel_dot_finish pass in its loader, same summation order):
+// workgroup (img, m): gap[m][img][:] = scale * sum_sp ws[m][img][sp][:], then the MLP of modality
+// m.  7 launches per fusion -> 3 (the batch-1 inference graph is a chain of launches).
+__global__ void se_mlp_pair_fwd_kernel(const float* __restrict__ ws, int splits, float scale,
+                                       const float* __restrict__ w1a, const float* __restrict__ b1a,
+                                       const float* __restrict__ w2a, const float* __restrict__ b2a,
+                                       const float* __restrict__ w1b, const float* __restrict__ b1b,
+                                       const float* __restrict__ w2b, const float* __restrict__ b2b,
+                                       float* __restrict__ gap, float* __restrict__ hid,
+                                       float* __restrict__ s, int n, int c, int cr) {
+  extern __shared__ float sm[];   // [c] gap + [cr] hidden
+  float* g = sm;
+  float* hsh = sm + c;
+  const int img = blockIdx.x % n, m = blockIdx.x / n;
+  const float* w1 = m ? w1b : w1a; const float* b1 = m ? b1b : b1a;
+  const float* w2 = m ? w2b : w2a; const float* b2 = m ? b2b : b2a;
+  const long row = (long)m * n + img;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    float a = 0.f;
+    for (int sp = 0; sp < splits; ++sp) a += ws[(row * splits + sp) * c + i];
+    a *= scale;
+    g[i] = a;
+    gap[row * c + i] = a;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < cr; r += blockDim.x) {
+    float a = b1[r];
+    for (int k = 0; k < c; ++k) a += w1[(long)r * c + k] * g[k];
+    a = fmaxf(a, 0.f);
+    hsh[r] = a;
+    hid[row * cr + r] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    float a = b2[i];
+    for (int r = 0; r < cr; ++r) a += w2[(long)i * cr + r] * hsh[r];
+    s[row * c + i] = 1.f / (1.f + expf(-a));
   }
 }
 
@@ -2211,6 +2258,36 @@ extern "C" int emsa_se_mlp_fwd(const float* gap, const float* w1, const float* b
   hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(n), dim3(256), (size_t)(c + cr) * sizeof(float),
                      (hipStream_t)stream, gap, w1, b1, w2, b2, hid, s, c, cr);
   return emsa_launch_status();
+}
+template <typename T>
+static int se_pair_fwd(const T* xa, const T* xb, float* ws, const float* const* wts, float* gap,
+                       float* hid, float* s, int n, long hw, int c, int cr, hipStream_t st) {
+  if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
+  const int splits = channel_splits(hw);
+  const int cvn = c / VecIO<T>::V;
+  if (cvn > kThreads) return EMSA_E_SHAPE;
+  const int lanes = kThreads / cvn;
+  const size_t lds = (size_t)lanes * c * sizeof(float);
+  hipLaunchKernelGGL((channel_dot_kernel<T>), dim3(2 * n * splits), dim3(kThreads), lds, st, xa,
+                     (const T*)nullptr, ws, hw, cvn, splits, xb, n * splits);
+  hipLaunchKernelGGL(se_mlp_pair_fwd_kernel, dim3(2 * n), dim3(256),
+                     (size_t)(c + cr) * sizeof(float), st, ws, splits, 1.0f / (float)hw, wts[0],
+                     wts[1], wts[2], wts[3], wts[4], wts[5], wts[6], wts[7], gap, hid, s, n, c, cr);
+  return emsa_launch_status();
+}
+extern "C" int emsa_se_pair_fwd_t(int32_t dtype, const void* xa, const void* xb, float* ws,
+                                  const float* w1a, const float* b1a, const float* w2a,
+                                  const float* b2a, const float* w1b, const float* b1b,
+                                  const float* w2b, const float* b2b, float* gap, float* hid,
+                                  float* s, int32_t n, int64_t hw, int32_t c, int32_t cr,
+                                  void* stream) {
+  if (!xa || !xb || !ws || !w1a || !b1a || !w2a || !b2a || !w1b || !b1b || !w2b || !b2b || !gap ||
+      !hid || !s)
+    return EMSA_E_ARG;
+  const float* wts[8] = {w1a, b1a, w2a, b2a, w1b, b1b, w2b, b2b};
+  EMSA_DISPATCH_DTYPE(dtype, T, return se_pair_fwd<T>((const T*)xa, (const T*)xb, ws, wts, gap, hid,
+                                                      s, n, (long)hw, c, cr, (hipStream_t)stream));
+  return EMSA_E_ARG;
 }
 extern "C" int emsa_se_mlp_bwd(const float* gap, const float* w1, const float* w2,
                                const float* hid, const float* s, const float* ds, float* dgap,

@@ -913,6 +913,23 @@ def se_mlp_fwd(gap, w1, b1, w2, b2):
     return hid, s
 
 
+def se_pair_fwd(xa, xb, wa, wb):
+    """squeeze + excitation of both inputs of an SE-add fusion in two launches; wa / wb =
+    (w1 [cr][c], b1, w2 [c][cr], b2) of each.  -> (gap_a, gap_b, hid_a, hid_b, s_a, s_b), bit-identical
+    to channel_mean + se_mlp_fwd per input"""
+    n, c, h, w = xa.shape
+    assert xb.shape == xa.shape and xb.dtype == xa.dtype and ld_of(xa) == c and ld_of(xb) == c
+    cr = wa[0].shape[0]
+    dev = xa.device
+    gap, hid, s = _empty((2, n, c), dev), _empty((2, n, cr), dev), _empty((2, n, c), dev)
+    ws = _empty((2 * _lib.lib().emsa_channel_ws_floats(n, h * w, c),), dev)
+    check(_lib.lib().emsa_se_pair_fwd_t(dt(xa), _p(xa), _p(xb), _p(ws), _p(wa[0]), _p(wa[1]),
+                                        _p(wa[2]), _p(wa[3]), _p(wb[0]), _p(wb[1]), _p(wb[2]),
+                                        _p(wb[3]), _p(gap), _p(hid), _p(s), n, h * w, c, cr,
+                                        _stream()), 'emsa_se_pair_fwd_t')
+    return gap[0], gap[1], hid[0], hid[1], s[0], s[1]
+
+
 def se_mlp_bwd(gap, w1, w2, hid, s, ds):
     n, c = gap.shape
     cr = w1.shape[0]

@@ -941,6 +941,10 @@ class MaxPoolFunction(Function):
 # ---------------------------------------------------------------------------------------------
 # SE-add fusion
 # ---------------------------------------------------------------------------------------------
+# EMSA_SE_PAIR=0: the squeeze / excitation of the two inputs of an SE-add fusion as separate launches
+SE_PAIR = os.environ.get('EMSA_SE_PAIR', '1') != '0'
+
+
 def _se_params(se):
     f0, f2 = se.fc[0], se.fc[2]
     return [f0.weight, f0.bias, f2.weight, f2.bias]
@@ -959,9 +963,15 @@ class SEAddFunction(Function):
     def forward(ctx, rgb, depth, w1r, b1r, w2r, b2r, w1d, b1d, w2d, b2d):
         rgb, depth = Fn.as_act(rgb, dense=True), Fn.as_act(depth, dense=True)
         flat = lambda w: w.detach().reshape(w.shape[0], -1)   # noqa: E731
-        gr, gd = Fn.channel_mean(rgb), Fn.channel_mean(depth)
-        hr, sr = Fn.se_mlp_fwd(gr, flat(w1r), b1r.detach(), flat(w2r), b2r.detach())
-        hd, sd = Fn.se_mlp_fwd(gd, flat(w1d), b1d.detach(), flat(w2d), b2d.detach())
+        if SE_PAIR:
+            # both squeezes in one launch, both excitation MLPs in one (7 launches -> 3 per fusion)
+            gr, gd, hr, hd, sr, sd = Fn.se_pair_fwd(
+                rgb, depth, (flat(w1r), b1r.detach(), flat(w2r), b2r.detach()),
+                (flat(w1d), b1d.detach(), flat(w2d), b2d.detach()))
+        else:
+            gr, gd = Fn.channel_mean(rgb), Fn.channel_mean(depth)
+            hr, sr = Fn.se_mlp_fwd(gr, flat(w1r), b1r.detach(), flat(w2r), b2r.detach())
+            hd, sd = Fn.se_mlp_fwd(gd, flat(w1d), b1d.detach(), flat(w2d), b2d.detach())
         _trace_mask('se.rgb', hr)
         _trace_mask('se.depth', hd)
         out = Fn.se_scale_add(rgb, sr, depth, sd)

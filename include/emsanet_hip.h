@@ -628,6 +628,16 @@ int emsa_head_act_bwd_t(int32_t dtype, int32_t out_f32, const void* dy, const vo
     norm_off, int32_t n_norm, void* stream);
 int emsa_stem_pack_input_t(int32_t dtype, const float* x, void* xp, int32_t n, int32_t c,
     int32_t h, int32_t w, void* stream);
+/* The squeeze + excitation of BOTH inputs of an SE-add fusion (reference: emsanet/model.py
+ * fuse_rgb_depth -> nicr_segmentation SqueezeAndExciteFusionAdd: se_rgb(rgb) + se_depth(depth)) in
+ * two launches: channel sums of xa / xb, then both MLPs fed by the split sums.  Results are
+ * bit-identical to emsa_channel_mean_t + emsa_se_mlp_fwd per input.  ws: 2 *
+ * emsa_channel_ws_floats(n, hw, c) floats; gap / s: [2][n][c], hid: [2][n][cr] (index 0 = xa). */
+int emsa_se_pair_fwd_t(int32_t dtype, const void* xa, const void* xb, float* ws, const float* w1a,
+                       const float* b1a, const float* w2a, const float* b2a, const float* w1b,
+                       const float* b1b, const float* w2b, const float* b2b, float* gap,
+                       float* hid, float* s, int32_t n, int64_t hw, int32_t c, int32_t cr,
+                       void* stream);
 int emsa_channel_mean_t(int32_t dtype, const void* x, float* gap, float* ws, int32_t n, int64_t
     hw, int32_t c, void* stream);
 int emsa_se_scale_bwd_reduce_t(int32_t dtype, const void* dout, const void* x, float* ds, float*

@@ -312,6 +312,15 @@ def test_pool_se_upsample_ppm16(dtype):
     out = Fn.se_scale_add(act16(x, dtype), sa.to(DEV), act16(x2, dtype), sb.to(DEV))
     close(out, xq * sa.double()[:, :, None, None] + q(x2, dtype) * sb.double()[:, :, None, None],
           tol=TOL[dtype], what='se_scale_add16')
+    # both inputs of an SE-add fusion in two launches: bit-identical to the per-input launches
+    cr = 16
+    wa = [t.to(DEV) for t in (rnd(cr, c, seed=11, scale=0.2), rnd(cr, seed=12), rnd(c, cr, seed=13, scale=0.2), rnd(c, seed=14))]
+    wb = [t.to(DEV) for t in (rnd(cr, c, seed=15, scale=0.2), rnd(cr, seed=16), rnd(c, cr, seed=17, scale=0.2), rnd(c, seed=18))]
+    ga, gb, ha, hb, s_a, s_b = Fn.se_pair_fwd(act16(x, dtype), act16(x2, dtype), wa, wb)
+    for xin, wts, g_, h_, s_ in ((x, wa, ga, ha, s_a), (x2, wb, gb, hb, s_b)):
+        g1 = Fn.channel_mean(act16(xin, dtype))
+        h1, s1 = Fn.se_mlp_fwd(g1, *wts)
+        assert torch.equal(g_, g1) and torch.equal(h_, h1) and torch.equal(s_, s1)
     ds = Fn.se_scale_bwd_reduce(act16(x2, dtype), act16(x, dtype))
     close(ds, (q(x2, dtype) * xq).sum((2, 3)), tol=2e-4, what='se reduce16')
     dgap = rnd(n, c, seed=4)
