@@ -426,10 +426,20 @@ class LearnedUpsampling(nn.Module):
     def _padded(self):
         w, b = self.conv.weight, self.conv.bias
         if self.c_pad != self.c:
+            # without autograd (inference) the padded pair is cached per parameter state: four
+            # zero-fill / concat launches per head less in the batch-1 graph
+            key = None
+            if not torch.is_grad_enabled():
+                key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
+                hit = getattr(self, '_pad_cache', None)
+                if hit is not None and hit[0] == key:
+                    return hit[1], hit[2]
             # parameter-sized glue (a few hundred floats); autograd routes the slice back
             w = torch.cat([w, w.new_zeros(self.c_pad - self.c, 1, 3, 3)], 0)
             if b is not None:
                 b = torch.cat([b, b.new_zeros(self.c_pad - self.c)], 0)
+            if key is not None:
+                self._pad_cache = (key, w, b)
         return w, b
 
     def forward(self, x, skip=None, out_f32=False):
