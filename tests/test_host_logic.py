@@ -193,7 +193,7 @@ def test_dry_run_orchestration(fake_lib, train, monkeypatch):
     assert c['emsa_conv1d_wino_inbn'] == folded and c['emsa_conv_wgrad_inbn'] == folded
     assert c['emsa_conv1d_wino_bnb'] == folded and c['emsa_bn_bwd_apply_rows_t'] == folded
     assert wino >= 2 * (50 * 4 - 2 * 3 * 2) - 2
-    assert c['emsa_se_mlp_fwd'] == 10 and c['emsa_maxpool3x3s2_fwd'] == 2
+    assert c['emsa_se_pair_fwd_t'] == 5 and c['emsa_se_mlp_fwd'] == 0 and c['emsa_maxpool3x3s2_fwd'] == 2
     assert c['emsa_up2x_dw3x3_fwd'] == 2 * 3 + 2 * 2
     # merged dict variant (do_postprocessing=True), /root/reference/emsanet/model.py:230-231
     d = model(batch, do_postprocessing=True)
