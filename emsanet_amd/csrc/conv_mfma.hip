@@ -1593,9 +1593,14 @@ __global__ __launch_bounds__(256, 3) EMSA_NO_LSOPT void conv_wgrad1d_h_kernel(co
     // a fragment = two ds_read_b64 (2 LDS cycles each, 64-bank rule).  The kernel is compiled
     // without the load-store optimizer (target attribute): it would merge them into ds_read2_b64
     // (8 cycles, 32-bank rule) -- and the eight ds_write_b64 of the transposes into ds_write2_b64
+    // (and the second half through an offset the compiler cannot see through: the IR vectorizer
+    //  would turn the pair into one 16-byte load of 8-byte alignment, which is selected as
+    //  ds_read2_b64 again -- tools/check_wgrad16_isa.py)
+    int h4 = 4;
+    asm volatile("" : "+v"(h4));
     auto ld8 = [&](const T* row, int e) {
       const u32x2w a = *reinterpret_cast<const u32x2w*>(row + e);
-      const u32x2w b = *reinterpret_cast<const u32x2w*>(row + e + 4);
+      const u32x2w b = *reinterpret_cast<const u32x2w*>(row + e + h4);
       u32x4h v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
       return v;
     };

@@ -37,3 +37,15 @@ def test_conv_rs_has_no_vmcnt_wait_inside_its_mfma_sequence():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_rs_waits.py')],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'conv_rs wait check: ok' in r.stdout, r.stdout + r.stderr
+
+
+@needs_hipcc
+def test_wgrad16_kernels_use_the_lds_instructions_their_layouts_are_built_for():
+    """csrc/conv_mfma.hip: conv_wgrad1d_h_kernel's 136-byte rows are conflict-free for ds_read_b64 /
+    ds_write_b64 only -- fused into ds_read2_b64 / ds_write2_b64 (load-store optimizer, or the IR
+    vectorizer: it happened silently in round 4) they fall back to the 32-bank rule at four times
+    the cycles; conv_wgrad1d_tr_kernel must read its fragments with ds_read_b64_tr_b16 and carry no
+    register transposes or shifts"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_wgrad16_isa.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'wgrad16 isa check: ok' in r.stdout, r.stdout + r.stderr
