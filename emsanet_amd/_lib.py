@@ -174,10 +174,12 @@ SIGNATURES = {
     'emsa_pack_weight_t': (c_int, [c_int32, _P, _P, _P] + [c_int32] * 8 + [_P]),
     'emsa_conv_igemm_splitk_ws_bytes_t': (c_int64, [c_int32, _GP]),
     'emsa_conv_igemm_splitk_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P]),
+    'emsa_conv_igemm_pair_t': (c_int, [c_int32, _GP] + [_P] * 14 + [c_int32, c_int32, _P, _P, _P]),
     'emsa_conv1d_rs_supported': (c_int, [c_int32, _GP]),
     'emsa_conv1d_rs_stats_rows': (c_int, [c_int32, _GP]),
     'emsa_conv1d_rs_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,
                                  c_int32, _P]),
+    'emsa_conv1d_rs_pair_t': (c_int, [c_int32, _GP] + [_P] * 14 + [c_int32, c_int32, _P]),
     'emsa_conv1d_rs_bnb_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P,
                                      _P, _P, c_int32, _P]),
     'emsa_pack_weight_frag_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int32, _P]),

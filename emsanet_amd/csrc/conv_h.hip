@@ -107,6 +107,16 @@ struct ConvHArgs {
   int ksplit;
   uint32_t in_bytes, w_bytes;
   HFastDiv div_ohw, div_ow;
+  // twin launch (emsa_conv_igemm_pair_t, PAIR instantiations): the workgroups with blockIdx.y == 1
+  // run the SAME geometry on a second set of tensors
+  const void* in2;
+  const void* w2;
+  void* out2;
+  const float* bias2;
+  const float* scale2;
+  const float* shift2;
+  const void* residual2;
+  float* ws2;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t h_rsrc(const void* p, uint32_t bytes) {
@@ -143,11 +153,20 @@ __device__ __forceinline__ uint32_t h_gather(const HGather& q, int img_off, int 
 // shape (106 / 166 / 253 VGPRs instead of 74 / 98 / 157); kept as an A/B switch (EMSA_CONVH_PF=2).
 // BNB: the epilogue with the fused BatchNorm-backward sums (ConvHArgs::bnb_out) as its own
 // instantiation (its accumulators and channel vectors spilled in the common kernel).
-template <int BM, int BN, int WM, int WN, typename T, int PF, bool BNB = false, int HK = 64>
+template <int BM, int BN, int WM, int WN, typename T, int PF, bool BNB = false, int HK = 64,
+          bool PAIR = false>
 __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? ((PF == 2 || BNB) && BM * BN > 64 * 64 ? 3 : 4) : 2)
 void conv_h_kernel(
-    const ConvHArgs p) {
+    const ConvHArgs p_in) {
   static_assert(WM * WN == 4, "4 waves");
+  // PAIR: two independent convs of one geometry in one launch (grid.y = 2)
+  ConvHArgs p = p_in;
+  if constexpr (PAIR) {
+    if (blockIdx.y != 0) {
+      p.in = p_in.in2; p.w = p_in.w2; p.out = p_in.out2; p.bias = p_in.bias2;
+      p.scale = p_in.scale2; p.shift = p_in.shift2; p.residual = p_in.residual2; p.ws = p_in.ws2;
+    }
+  }
   static_assert(HK == 64 || HK == 32, "K step");
   constexpr int kHK = HK;               // channels per K step
   constexpr int kHLD = kHK + 8;         // padded LDS row of the register-staged variants (elements)
@@ -599,8 +618,17 @@ __global__ void conv_h_splitk_finish_kernel(const float* __restrict__ ws, int ks
                                             const float* __restrict__ scale,
                                             const float* __restrict__ shift,
                                             const T* __restrict__ residual, int ld_res, int act,
-                                            T* __restrict__ out) {
+                                            T* __restrict__ out,
+                                            const float* __restrict__ ws2 = nullptr,
+                                            const float* __restrict__ bias2 = nullptr,
+                                            const float* __restrict__ scale2 = nullptr,
+                                            const float* __restrict__ shift2 = nullptr,
+                                            const T* __restrict__ residual2 = nullptr,
+                                            T* __restrict__ out2 = nullptr) {
   typedef typename Vec8<T>::type V8;
+  if (blockIdx.y != 0) {          // second half of a twin launch
+    ws = ws2; bias = bias2; scale = scale2; shift = shift2; residual = residual2; out = out2;
+  }
   const int c8 = n_ch >> 3;
   const long total = M * c8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -719,6 +747,15 @@ int launch_h(const ConvHArgs& a_in, hipStream_t st) {
   const double bytes = (double)a.g.n_img * a.g.in_h * a.g.in_w * a.g.k_ch * 2.0 + px_out +
                        (double)a.g.kh * a.g.kw * a.g.n_ch * a.g.k_ch * 2.0 +
                        (a.residual ? px_out : 0.0) + (a.mask_src ? px_out : 0.0);
+  if (a.in2) {
+    // twin launch: the LDS-DMA forward kernel only (no statistics / mask / BatchNorm-backward form)
+    if (a.bnb_out || a.stats || a.mask_src || convh_pf() != 0) return EMSA_E_SHAPE;
+    const int ps2 = emsa_prof_begin(kProfClassConvH, 2.0 * flops, st, 2.0 * bytes);
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, HK, true>), dim3(grid, 2), dim3(256),
+                       lds, st, a);
+    emsa_prof_end(ps2, st);
+    return emsa_launch_status();
+  }
   const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
   if constexpr (HK == 32) {
     hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, 32>), dim3(grid), dim3(256), lds,
@@ -760,7 +797,7 @@ static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* i
                              int32_t ld_res, const void* mask_src, int32_t ld_mask,
                              int32_t act, const float* bnb_mean, const float* bnb_invstd,
                              float* bnb_out, int32_t bnb_rows_alloc, void* stream,
-                             float* ws = nullptr, int ksplit = 1) {
+                             float* ws = nullptr, int ksplit = 1, const ConvHArgs* twin = nullptr) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
   if (!h_geom_ok(g)) return EMSA_E_SHAPE;
   if (!in || !w || !out) return EMSA_E_ARG;
@@ -778,6 +815,13 @@ static int conv_igemm_h_impl(int32_t dtype, const EmsaConvGeom* g, const void* i
   a.bnb_mean = bnb_mean; a.bnb_invstd = bnb_invstd; a.bnb_out = bnb_out;
   a.bnb_rows_alloc = bnb_rows_alloc;
   a.ws = ws; a.ksplit = ksplit;
+  a.in2 = nullptr; a.w2 = nullptr; a.out2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr;
+  a.shift2 = nullptr; a.residual2 = nullptr; a.ws2 = nullptr;
+  if (twin) {
+    a.in2 = twin->in2; a.w2 = twin->w2; a.out2 = twin->out2; a.bias2 = twin->bias2;
+    a.scale2 = twin->scale2; a.shift2 = twin->shift2; a.residual2 = twin->residual2;
+    a.ws2 = twin->ws2;
+  }
   a.mapped = (g->out_pix_img || g->out_pix_row || g->out_pix_px || g->out_pix_off) ? 1 : 0;
   if (a.mapped && (stats || bnb_out)) return EMSA_E_ARG;    // (per-tile sums count one launch's rows)
   if (ksplit > 1 && (a.mapped || stats || bnb_out || mask_src || !ws)) return EMSA_E_ARG;
@@ -883,5 +927,59 @@ extern "C" int emsa_conv_igemm_splitk_t(int32_t dtype, const EmsaConvGeom* g, co
     hipLaunchKernelGGL(conv_h_splitk_finish_kernel<emsa_f16>, dim3(grid), dim3(256), 0, st, ws, ks, M,
                        g->n_ch, g->ld_out, bias, scale, shift, (const emsa_f16*)residual, ld_res, act,
                        (emsa_f16*)out);
+  return emsa_launch_status();
+}
+
+// Twin launch of emsa_conv_igemm_t / emsa_conv_igemm_splitk_t: the same geometry on two independent
+// sets of tensors in ONE launch (grid.y = 2) -- the strided convs and 1x1 skip convs of the rgb | depth
+// encoder blocks, the 3x3 and 1x1 skip-fusion convs of the semantic | instance decoder modules
+// (in0 may equal in1).  Forward epilogue only (bias, folded BatchNorm, residual, ReLU); each half ==
+// its own launch bit for bit.  ws0 / ws1: emsa_conv_igemm_splitk_ws_bytes_t(dtype, g) bytes each where
+// that is > 0 (the tap-split form is then used for both halves), else NULL.
+extern "C" int emsa_conv_igemm_pair_t(int32_t dtype, const EmsaConvGeom* g, const void* in0,
+                                      const void* in1, const void* w0, const void* w1, void* out0,
+                                      void* out1, const float* bias0, const float* bias1,
+                                      const float* scale0, const float* scale1, const float* shift0,
+                                      const float* shift1, const void* residual0,
+                                      const void* residual1, int32_t ld_res, int32_t act,
+                                      float* ws0, float* ws1, void* stream) {
+  if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_SHAPE;
+  if (!in1 || !w1 || !out1 || out0 == out1) return EMSA_E_ARG;
+  if ((bias0 == nullptr) != (bias1 == nullptr) || (scale0 == nullptr) != (scale1 == nullptr) ||
+      (shift0 == nullptr) != (shift1 == nullptr) || (residual0 == nullptr) != (residual1 == nullptr) ||
+      (scale1 == nullptr) != (shift1 == nullptr))
+    return EMSA_E_ARG;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!al16(in1) || !al16(w1) || !al16(out1) || !al16(bias1) || !al16(scale1) || !al16(shift1) ||
+      !al16(residual1) || !al16(ws0) || !al16(ws1))
+    return EMSA_E_SHAPE;
+  const int ks = splitk_plan(dtype, g);
+  ConvHArgs tw;
+  tw.in2 = in1; tw.w2 = w1; tw.out2 = out1; tw.bias2 = bias1; tw.scale2 = scale1; tw.shift2 = shift1;
+  tw.residual2 = residual1; tw.ws2 = ws1;
+  if (ks <= 1)
+    return conv_igemm_h_impl(dtype, g, in0, w0, out0, bias0, nullptr, scale0, shift0, residual0, ld_res,
+                             nullptr, 0, act, nullptr, nullptr, nullptr, 0, stream, nullptr, 1, &tw);
+  if (!ws0 || !ws1 || ws0 == ws1) return EMSA_E_ARG;
+  // tap-split: raw partial sums of both halves, then ONE finish launch for both
+  tw.bias2 = nullptr; tw.scale2 = nullptr; tw.shift2 = nullptr; tw.residual2 = nullptr;
+  int rc = conv_igemm_h_impl(dtype, g, in0, w0, out0, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                             nullptr, 0, EMSA_ACT_NONE, nullptr, nullptr, nullptr, 0, stream, ws0, ks, &tw);
+  if (rc != EMSA_OK) return rc;
+  const long M = (long)g->n_img * g->out_h * g->out_w;
+  const long total = M * (g->n_ch >> 3);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMSA_DT_BF16)
+    hipLaunchKernelGGL(conv_h_splitk_finish_kernel<emsa_bf16>, dim3(grid, 2), dim3(256), 0, st, ws0, ks, M,
+                       g->n_ch, g->ld_out, bias0, scale0, shift0, (const emsa_bf16*)residual0, ld_res, act,
+                       (emsa_bf16*)out0, ws1, bias1, scale1, shift1, (const emsa_bf16*)residual1,
+                       (emsa_bf16*)out1);
+  else
+    hipLaunchKernelGGL(conv_h_splitk_finish_kernel<emsa_f16>, dim3(grid, 2), dim3(256), 0, st, ws0, ks, M,
+                       g->n_ch, g->ld_out, bias0, scale0, shift0, (const emsa_f16*)residual0, ld_res, act,
+                       (emsa_f16*)out0, ws1, bias1, scale1, shift1, (const emsa_f16*)residual1,
+                       (emsa_f16*)out1);
   return emsa_launch_status();
 }

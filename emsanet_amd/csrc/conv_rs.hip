@@ -108,6 +108,15 @@ struct ConvRSArgs {
   int stat_rows;            // rows of the statistics / BatchNorm-backward partial buffers
   int bacc_off;             // LDS offset of the BNB accumulators [16][threads]
   RFastDiv div_w, div_tpi, div_tw;
+  // twin launch (emsa_conv1d_rs_pair_t, PAIR instantiations): the workgroups with blockIdx.y == 1 run
+  // the SAME geometry on a second set of tensors (the other encoder / decoder of the model)
+  const void* in2;
+  const void* wf2;
+  void* out2;
+  const float* bias2;
+  const float* scale2;
+  const float* shift2;
+  const void* residual2;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t r_rsrc(const void* p, uint32_t bytes) {
@@ -160,9 +169,19 @@ __device__ __forceinline__ int r_swz(int R) {
 #endif
 // EPI: the epilogue reads a residual and / or a mask tensor (as its own instantiation: the waits for
 // those loads would otherwise sit in every launch's output pass and drain the next tile's DMA).
-template <typename T, int KC, int TN, int WM, int WN, int WK, int TM, bool DIRH, bool BNB, bool EPI>
-__global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel(const ConvRSArgs p) {
+template <typename T, int KC, int TN, int WM, int WN, int WK, int TM, bool DIRH, bool BNB, bool EPI,
+          bool PAIR = false>
+__global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel(const ConvRSArgs p_in) {
   typedef typename RVec8<T>::type V8;
+  // PAIR: two independent convs of one geometry in one launch (grid.y = 2); everything below sees
+  // the tensors of its half through `p`
+  ConvRSArgs p = p_in;
+  if constexpr (PAIR) {
+    if (blockIdx.y != 0) {
+      p.in = p_in.in2; p.wf = p_in.wf2; p.out = p_in.out2; p.bias = p_in.bias2;
+      p.scale = p_in.scale2; p.shift = p_in.shift2; p.residual = p_in.residual2;
+    }
+  }
   constexpr int NWV = WM * WN * WK, NT = 64 * NWV;
   constexpr int KS = KC / 16, KSW = KS / WK;          // k16 steps: all / per wave
   constexpr int RB = KC * 2, CPR = KC / 8, RPI = 64 / CPR;
@@ -744,23 +763,36 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
 
 template <typename T, int KC, int TN, int WM, int WN, int WK, int TM>
 int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
-  const dim3 grid(8 * pl.gx * pl.nslice), block(64 * WM * WN * WK);
+  const bool pair = a.in2 != nullptr;
+  const dim3 grid(8 * pl.gx * pl.nslice, pair ? 2 : 1), block(64 * WM * WN * WK);
   const bool epi = a.residual != nullptr || a.mask_src != nullptr;
   auto go = [&](void (*kern)(const ConvRSArgs)) {
     // more than 64 KB of dynamic LDS has to be asked for, once per kernel
-    static const void* seen[96];
+    static const void* seen[160];
     static int n_seen = 0;
     bool known = false;
     for (int i = 0; i < n_seen; ++i) known = known || seen[i] == (const void*)kern;
     if (!known) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (n_seen < 96) seen[n_seen++] = (const void*)kern;
+      if (n_seen < 160) seen[n_seen++] = (const void*)kern;
     }
     hipLaunchKernelGGL(kern, grid, block, pl.lds, st, a);
   };
   // (the fused BatchNorm-backward form exists for bf16 only: fp16 is an inference storage type)
   constexpr bool kTrain = sizeof(T) == 2 && !__is_same(T, emsa_f16);
   if (bnb && !kTrain) return EMSA_E_ARG;
+  if (pair) {
+    // twin launch: forward epilogues only (bias, folded BatchNorm, residual, ReLU)
+    if (bnb || a.mask_src || a.stats) return EMSA_E_ARG;
+    if (pl.dirh) {
+      if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, true, true>);
+      else go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, false, true>);
+    } else {
+      if (epi) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, true, true>);
+      else go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, false, false, false, true>);
+    }
+    return emsa_launch_status();
+  }
   if (pl.dirh) {
     if (bnb) {
       if constexpr (kTrain) go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, true, true>);
@@ -791,10 +823,18 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
                  const float* bias, float* stats, const float* scale, const float* shift,
                  const void* residual, int32_t ld_res, const void* mask_src, int32_t ld_mask,
                  int32_t act, const float* bnb_mean, const float* bnb_invstd, float* bnb_out,
-                 int32_t bnb_rows_alloc, void* stream) {
+                 int32_t bnb_rows_alloc, void* stream, const ConvRSArgs* twin = nullptr) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
   RSPlan pl;
   if (!rs_plan(g, pl)) return EMSA_E_SHAPE;
+  if (twin) {
+    // both halves resident at once: half the persistent workgroups per half where the full grid
+    // would not fit twice
+    const int per_cu = (pl.nwv == 8 || 2 * pl.lds > 160 * 1024) ? 1 : 2;
+    int gx2 = rs_cu_count() * per_cu / (16 * pl.nslice);
+    if (gx2 < 1) gx2 = 1;
+    if (pl.gx > gx2) pl.gx = gx2;
+  }
   if (!in || !wf || !out) return EMSA_E_ARG;
   if ((scale == nullptr) != (shift == nullptr)) return EMSA_E_ARG;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
@@ -826,6 +866,12 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
   a.tiles = pl.tiles; a.tiles_w = pl.tiles_w > 0 ? pl.tiles_w : 1; a.twl = pl.twl; a.th = pl.th;
   a.gx = pl.gx; a.nslice = pl.nslice; a.ni = pl.ni; a.abuf = pl.abuf; a.stat_rows = 8 * pl.gx;
   a.bacc_off = pl.bacc_off;
+  a.in2 = nullptr; a.wf2 = nullptr; a.out2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr;
+  a.shift2 = nullptr; a.residual2 = nullptr;
+  if (twin) {
+    a.in2 = twin->in2; a.wf2 = twin->wf2; a.out2 = twin->out2; a.bias2 = twin->bias2;
+    a.scale2 = twin->scale2; a.shift2 = twin->shift2; a.residual2 = twin->residual2;
+  }
   a.div_w = r_make_fastdiv((uint32_t)g->out_w);
   const int tpi = pl.dirh ? pl.tiles / g->n_img : 1;
   a.div_tpi = r_make_fastdiv((uint32_t)(tpi > 0 ? tpi : 1));
@@ -834,7 +880,7 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
   const double flops = 2.0 * M * g->k_ch * g->n_ch * 3.0;
   const double px = (double)M * g->n_ch * 2.0;
   const double bytes = 2.0 * px + 3.0 * g->n_ch * g->k_ch * 2.0 + (residual ? px : 0.0) + (mask_src ? px : 0.0);
-  const int ps = emsa_prof_begin(kProfClassConvRS, flops, st, bytes);
+  const int ps = emsa_prof_begin(kProfClassConvRS, twin ? 2.0 * flops : flops, st, twin ? 2.0 * bytes : bytes);
   const int rc = dtype == EMSA_DT_BF16 ? rs_dispatch<emsa_bf16>(a, pl, bnb, st)
                                        : rs_dispatch<emsa_f16>(a, pl, bnb, st);
   emsa_prof_end(ps, st);
@@ -896,6 +942,35 @@ extern "C" int emsa_conv1d_rs_t(int32_t dtype, const EmsaConvGeom* g, const void
                                 void* stream) {
   return conv_rs_impl(dtype, g, in, wfrag, out, bias, stats, scale, shift, residual, ld_res,
                       mask_src, ld_mask, act, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Twin launch: the same conv geometry on two independent sets of tensors (the rgb | depth encoder
+// blocks and the semantic | instance decoder blocks of the model have identical shapes) in ONE
+// launch -- grid.y = 2, the second half of the workgroups reads the "1" operands.  Forward epilogue
+// only (bias, folded BatchNorm scale / shift, residual, ReLU); each half's result is bit-identical
+// to its own emsa_conv1d_rs_t launch.  bias / scale+shift / residual: given for both halves or neither.
+extern "C" int emsa_conv1d_rs_pair_t(int32_t dtype, const EmsaConvGeom* g, const void* in0,
+                                     const void* in1, const void* wfrag0, const void* wfrag1,
+                                     void* out0, void* out1, const float* bias0, const float* bias1,
+                                     const float* scale0, const float* scale1, const float* shift0,
+                                     const float* shift1, const void* residual0,
+                                     const void* residual1, int32_t ld_res, int32_t act,
+                                     void* stream) {
+  if (!in1 || !wfrag1 || !out1) return EMSA_E_ARG;
+  if ((bias0 == nullptr) != (bias1 == nullptr) || (scale0 == nullptr) != (scale1 == nullptr) ||
+      (shift0 == nullptr) != (shift1 == nullptr) || (residual0 == nullptr) != (residual1 == nullptr))
+    return EMSA_E_ARG;
+  if ((scale1 == nullptr) != (shift1 == nullptr)) return EMSA_E_ARG;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!al16(in1) || !al16(wfrag1) || !al16(out1) || !al16(bias1) || !al16(scale1) || !al16(shift1) ||
+      !al16(residual1))
+    return EMSA_E_SHAPE;
+  if (out0 == out1) return EMSA_E_ARG;
+  ConvRSArgs tw;
+  tw.in2 = in1; tw.wf2 = wfrag1; tw.out2 = out1; tw.bias2 = bias1; tw.scale2 = scale1;
+  tw.shift2 = shift1; tw.residual2 = residual1;
+  return conv_rs_impl(dtype, g, in0, wfrag0, out0, bias0, nullptr, scale0, shift0, residual0, ld_res,
+                      nullptr, 0, act, nullptr, nullptr, nullptr, 0, stream, &tw);
 }
 
 extern "C" int emsa_conv1d_rs_bnb_t(int32_t dtype, const EmsaConvGeom* g, const void* dy,

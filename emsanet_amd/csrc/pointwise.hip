@@ -820,6 +820,28 @@ __global__ void channel_dot_finish_kernel(const float* __restrict__ ws, float* _
   out[i] = a * scale;
 }
 
+// hidden layer of the excitation MLP: hsh[r] = relu(b1[r] + w1[r][:] . g[:]) with one WAVE per hidden
+// unit (lanes stride the channels: coalesced rows of w1, a fixed butterfly for the wave sum) -- one
+// THREAD per unit walked its row alone: c dependent loads, 7-18 us of a batch-1 graph whose other
+// nodes take 5.  Same order in every caller (single / paired forward): bit-identical results.
+__device__ __forceinline__ void se_hidden_layer(const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* g,
+                                                float* hsh, float* __restrict__ hid_row, int c,
+                                                int cr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < cr; r += nw) {
+    float a = 0.f;
+    for (int k = lane; k < c; k += 64) a += w1[(long)r * c + k] * g[k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+      a = fmaxf(a + b1[r], 0.f);
+      hsh[r] = a;
+      hid_row[r] = a;
+    }
+  }
+}
+
 __global__ void se_mlp_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                   const float* __restrict__ b2, float* __restrict__ hid,
@@ -830,13 +852,7 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ gap, const float* __
   const int img = blockIdx.x;
   for (int i = threadIdx.x; i < c; i += blockDim.x) g[i] = gap[(long)img * c + i];
   __syncthreads();
-  for (int r = threadIdx.x; r < cr; r += blockDim.x) {
-    float a = b1[r];
-    for (int k = 0; k < c; ++k) a += w1[(long)r * c + k] * g[k];
-    a = fmaxf(a, 0.f);
-    hsh[r] = a;
-    hid[(long)img * cr + r] = a;
-  }
+  se_hidden_layer(w1, b1, g, hsh, hid + (long)img * cr, c, cr);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     float a = b2[i];
@@ -871,13 +887,7 @@ __global__ void se_mlp_pair_fwd_kernel(const float* __restrict__ ws, int splits,
     gap[row * c + i] = a;
   }
   __syncthreads();
-  for (int r = threadIdx.x; r < cr; r += blockDim.x) {
-    float a = b1[r];
-    for (int k = 0; k < c; ++k) a += w1[(long)r * c + k] * g[k];
-    a = fmaxf(a, 0.f);
-    hsh[r] = a;
-    hid[row * cr + r] = a;
-  }
+  se_hidden_layer(w1, b1, g, hsh, hid + row * cr, c, cr);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     float a = b2[i];
@@ -2195,8 +2205,12 @@ extern "C" int emsa_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const int8
   }
 }
 
-static int channel_splits(long hw) {
+// pixel chunks per image: 512 pixels per workgroup -- unless that leaves the launch with a handful of
+// workgroups each walking its chunk a few rows at a time (batch-1 inference: 300 pixels x 512
+// channels = ONE workgroup of 4 row lanes x 75 dependent steps, 26 us): then 64-pixel chunks
+static int channel_splits(long hw, int n) {
   int splits = (int)((hw + 511) / 512);
+  if ((long)n * splits < 64) splits = (int)((hw + 63) / 64);
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
   return splits;
@@ -2206,7 +2220,7 @@ template <typename T>
 static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, long hw,
                        int c, float scale, hipStream_t st) {
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
-  const int splits = channel_splits(hw);
+  const int splits = channel_splits(hw, n);
   const int cvn = c / VecIO<T>::V;
   // one thread column per channel vector: wider tensors (> 1024 fp32 / 2048 16-bit channels) would
   // leave `lanes` = 0 and every sum silently zero -- refuse them
@@ -2221,7 +2235,7 @@ static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, lon
 }
 
 extern "C" int emsa_channel_ws_floats(int32_t n, int64_t hw, int32_t c) {
-  return n * channel_splits((long)hw) * c;
+  return n * channel_splits((long)hw, n) * c;
 }
 extern "C" int emsa_channel_mean(const float* x, float* gap, float* ws, int32_t n, int64_t hw,
                                  int32_t c, void* stream) {
@@ -2263,7 +2277,7 @@ template <typename T>
 static int se_pair_fwd(const T* xa, const T* xb, float* ws, const float* const* wts, float* gap,
                        float* hid, float* s, int n, long hw, int c, int cr, hipStream_t st) {
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
-  const int splits = channel_splits(hw);
+  const int splits = channel_splits(hw, n);
   const int cvn = c / VecIO<T>::V;
   if (cvn > kThreads) return EMSA_E_SHAPE;
   const int lanes = kThreads / cvn;

@@ -98,23 +98,77 @@ class DecoderBody(nn.Module):
         self.fusion_downsamplings = tuple(fusion_downsamplings)
         self.side_output_downscales = (32, 16, 8)
         self.postprocessing = None
+        self._pre = None             # (x, sides) of this forward pass when a twin launch made it
+
+    def _skip(self, skips, ds):
+        sk = skips[str(ds)]
+        if self.fusion.startswith('add-'):
+            return sk[self.fusion[4:]]              # 'add-rgb' (default), 'add-depth', 'add-rgbd'
+        # 'add' (single-modality models, /root/reference/emsanet/tests/test_interface_model.py:32):
+        # the only encoder stream there is
+        if len(sk) != 1:
+            raise NotImplementedError("encoder-decoder fusion 'add' with two modalities")
+        return next(iter(sk.values()))
 
     def body(self, x, skips):
+        if self._pre is not None:
+            # computed in lockstep with a twin decoder (twin_bodies below) for THIS forward pass
+            r, self._pre = self._pre, None
+            return r
         sides = []
         for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
                             self.fusion_downsamplings):
-            sk = skips[str(ds)]
-            if self.fusion.startswith('add-'):
-                skip = sk[self.fusion[4:]]          # 'add-rgb' (default), 'add-depth', 'add-rgbd'
-            else:
-                # 'add' (single-modality models, /root/reference/emsanet/tests/
-                # test_interface_model.py:32): the only encoder stream there is
-                if len(sk) != 1:
-                    raise NotImplementedError("encoder-decoder fusion 'add' with two modalities")
-                skip = next(iter(sk.values()))
-            x, s = m(x, skip, h)
+            x, s = m(x, self._skip(skips, ds), h)
             sides.append(s)
         return x, tuple(sides)
+
+
+def twin_bodies_ok(da, db, x):
+    """two dense decoders of one layout in the 16-bit eval fast path: their NBt1D blocks can run as
+    twin launches"""
+    from .nn import _fast_eval, twin_launches
+    # (x = the context module's output at 1/32 of the input)
+    if not (Fn.CONV_RS and _fast_eval(da) and _fast_eval(db)):
+        return False
+    from . import nn as enn
+    if enn.TWIN is None and enn._TWIN_ENV is None:
+        if x.shape[0] * x.shape[2] * x.shape[3] * 32 * 32 > enn.TWIN_MAX_PIXELS:
+            return False
+    elif not twin_launches():
+        return False
+    if x.dtype == torch.float32 or len(da.decoder_modules) != len(db.decoder_modules) or \
+            da.fusion_downsamplings != db.fusion_downsamplings:
+        return False
+    for ma, mb in zip(da.decoder_modules, db.decoder_modules):
+        if len(ma.blocks) != len(mb.blocks) or \
+                ma.conv3x3.conv.out_channels != mb.conv3x3.conv.out_channels:
+            return False
+    return True
+
+
+def twin_bodies(da, db, x, skips):
+    """DecoderBody.body of two decoders (semantic | instance, /root/reference/emsanet/decoder.py:63-139:
+    same channels, blocks and resolutions) in lockstep on one stream: the 3x3 convs, the NBt1D blocks
+    and the 1x1 skip-fusion convs of a module pair run as twin launches (ops.conv_bn_act_eval_pair,
+    ops.nbt1d_eval_pair).  Results == the two bodies run one after the other."""
+    xa = xb = x
+    for ma, mb, ds in zip(da.decoder_modules, db.decoder_modules, da.fusion_downsamplings):
+        ska, skb = da._skip(skips, ds), db._skip(skips, ds)
+        xa, xb = ops.conv_bn_act_eval_pair(Fn.as_act(xa), Fn.as_act(xb), ma.conv3x3, mb.conv3x3)
+        xa, xb = Fn.as_act(xa, dense=True), Fn.as_act(xb, dense=True)
+        for ba, bb in zip(ma.blocks, mb.blocks):
+            xa, xb = ops.nbt1d_eval_pair(xa, xb, ba._rt, bb._rt)
+        if ma.skip_fusion is not None and mb.skip_fusion is not None:
+            ska, skb = ops.conv_bn_act_eval_pair(Fn.as_act(ska), Fn.as_act(skb), ma.skip_fusion,
+                                                 mb.skip_fusion)
+        else:
+            if ma.skip_fusion is not None:
+                ska = ma.skip_fusion(ska)
+            if mb.skip_fusion is not None:
+                skb = mb.skip_fusion(skb)
+        xa, xb = ma.upsampling(xa, ska), mb.upsampling(xb, skb)
+    n = len(da.decoder_modules)
+    return (xa, (None,) * n), (xb, (None,) * n)
 
 
 class SemanticHead(nn.Module):

@@ -393,6 +393,76 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
     return (res, bits) if want_relu_bits else res
 
 
+def conv_fwd_pair(xs, wfrags, spec, biases=(None, None), scales=(None, None), shifts=(None, None),
+                  residuals=(None, None), act=ACT_NONE):
+    """two forward convs of ONE geometry (the rgb | depth encoders, the semantic | instance decoders)
+    in one launch of the register-stationary kernel (emsa_conv1d_rs_pair_t, grid.y = 2); returns
+    (out0, out1), or None where that kernel does not take the pair (other dtype / geometry / strides)
+    -- the caller then launches the two convs one by one.  Each result is bit-identical to its own
+    conv_fwd(..., wfrag=...) launch."""
+    x0, x1 = xs
+    if wfrags[0] is None or wfrags[1] is None or x0.dtype != x1.dtype or x0.shape != x1.shape:
+        return None
+    code = dt(x0)
+    if code == 0 or wfrags[0].dtype != x0.dtype or wfrags[1].dtype != x0.dtype:
+        return None
+    n, c, h, w = x0.shape
+    if ld_of(x0) != ld_of(x1):
+        return None
+    r0, r1 = residuals
+    if (r0 is None) != (r1 is None) or (r0 is not None and ld_of(r0) != ld_of(r1)):
+        return None
+    for pr in (biases, scales, shifts):
+        if (pr[0] is None) != (pr[1] is None):
+            return None
+    oh, ow = spec.out_hw(h, w)
+    g = spec.geom_fwd(n, h, w, ld_of(x0), spec.cout)
+    if not rs_supported(code, g):
+        return None
+    out0 = act_empty(n, spec.cout, oh, ow, x0.device, dtype=x0.dtype)
+    out1 = act_empty(n, spec.cout, oh, ow, x0.device, dtype=x0.dtype)
+    lr = ld_of(r0) if r0 is not None else 0
+    check(_lib.lib().emsa_conv1d_rs_pair_t(
+        code, g, _p(x0), _p(x1), _p(wfrags[0]), _p(wfrags[1]), _p(out0), _p(out1), _p(biases[0]),
+        _p(biases[1]), _p(scales[0]), _p(scales[1]), _p(shifts[0]), _p(shifts[1]), _p(r0), _p(r1),
+        lr, act, _stream()), 'emsa_conv1d_rs_pair_t')
+    return out0, out1
+
+
+def conv_igemm_pair(xs, wps, spec, biases=(None, None), scales=(None, None), shifts=(None, None),
+                    residuals=(None, None), act=ACT_NONE):
+    """conv_fwd_pair for the convs the implicit GEMM runs (strided, 1x1, 3x3; 16-bit storage):
+    emsa_conv_igemm_pair_t, tap-split where the single launch would be.  (out0, out1) or None"""
+    x0, x1 = xs
+    if wps[0] is None or wps[1] is None or x0.dtype != x1.dtype or x0.shape != x1.shape:
+        return None
+    code = dt(x0)
+    if code == 0 or wps[0].dtype != x0.dtype or wps[1].dtype != x0.dtype or ld_of(x0) != ld_of(x1):
+        return None
+    r0, r1 = residuals
+    if (r0 is None) != (r1 is None) or (r0 is not None and ld_of(r0) != ld_of(r1)):
+        return None
+    for pr in (biases, scales, shifts):
+        if (pr[0] is None) != (pr[1] is None):
+            return None
+    if os.environ.get('EMSA_CONVH_PF', '0') not in ('', '0'):
+        return None
+    n, c, h, w = x0.shape
+    oh, ow = spec.out_hw(h, w)
+    g = spec.geom_fwd(n, h, w, ld_of(x0), spec.cout)
+    out0 = act_empty(n, spec.cout, oh, ow, x0.device, dtype=x0.dtype)
+    out1 = act_empty(n, spec.cout, oh, ow, x0.device, dtype=x0.dtype)
+    wsb = _splitk_ws_bytes(code, g)
+    ws0 = _empty((wsb // 4,), x0.device) if wsb > 0 else None
+    ws1 = _empty((wsb // 4,), x0.device) if wsb > 0 else None
+    lr = ld_of(r0) if r0 is not None else 0
+    check(_lib.lib().emsa_conv_igemm_pair_t(
+        code, g, _p(x0), _p(x1), _p(wps[0]), _p(wps[1]), _p(out0), _p(out1), _p(biases[0]),
+        _p(biases[1]), _p(scales[0]), _p(scales[1]), _p(shifts[0]), _p(shifts[1]), _p(r0), _p(r1),
+        lr, act, _p(ws0), _p(ws1), _stream()), 'emsa_conv_igemm_pair_t')
+    return out0, out1
+
+
 # Strided data gradients by output phase (one dense stride-1 launch per parity class instead of ONE
 # launch that visits every tap for every output pixel, half of them structurally zero at stride 2).
 # Measured per training step: fp32 +1.2 % (the matrix-bound implicit GEMM does half the MACs: 12

@@ -197,10 +197,22 @@ class EMSANet(nn.Module):
         """the decoders in `self.decoders` order; with two dense decoders (semantic, instance) the
         second one runs on a second HIP stream: same inputs, independent work, and the launches of
         their /32 and /16 modules are too small to fill 256 CUs alone (nn._dual_stream)"""
-        from .decoder import DecoderBody
+        from .decoder import DecoderBody, PanopticHelper, twin_bodies, twin_bodies_ok
         from .nn import _dual_stream
         decs = list(self.decoders.values())
         dense = [d for d in decs if isinstance(d, DecoderBody)]
+        # 16-bit inference: the first two dense decoders (also inside a PanopticHelper) walk their
+        # modules in lockstep, block pairs as twin launches, everything on one stream
+        bodies = []
+        for d in decs:
+            bodies += [d.semantic_decoder, d.instance_decoder] if isinstance(d, PanopticHelper) else \
+                ([d] if isinstance(d, DecoderBody) else [])
+        if len(bodies) >= 2 and twin_bodies_ok(bodies[0], bodies[1], x[0]):
+            bodies[0]._pre, bodies[1]._pre = twin_bodies(bodies[0], bodies[1], x[0], skips)
+            try:
+                return [d(x, skips, batch, do_postprocessing=do_postprocessing) for d in decs]
+            finally:
+                bodies[0]._pre = bodies[1]._pre = None
         if len(dense) < 2 or not _dual_stream(x[0]):
             return [d(x, skips, batch, do_postprocessing=do_postprocessing) for d in decs]
         cur = torch.cuda.current_stream()

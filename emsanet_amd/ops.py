@@ -80,6 +80,10 @@ class ConvRT:
         self.rs = Fn.rs_eligible(self.spec)
         self._hf = {}             # fragment-ordered 16-bit packs: dtype -> [key, fwd, key_d, dgrad]
 
+    def spec_key(self):
+        s = self.spec
+        return (s.cin, s.cout, s.kh, s.kw, s.sh, s.sw, s.ph, s.pw)
+
     def _wino_weights(self):
         w = self.conv.weight
         key = (w._version, w.data_ptr())
@@ -630,6 +634,58 @@ def nbt1d_eval(x, rt):
         idn = x
     s2, t2 = rt.bn2.folded()
     return rt.c13_2.forward(y3, bias=b(rt.c13_2), scale=s2, shift=t2, residual=idn, act=ACT_RELU)
+
+
+def _conv_pair(xa, xb, ca, cb, **kw):
+    """the same conv layer of two twin modules on their two inputs: one twin launch -- of the
+    register-stationary kernel where it takes the geometry (Fn.conv_fwd_pair), else of the implicit
+    GEMM (Fn.conv_igemm_pair) -- or two launches (fp32 storage).
+    kw: per-operand pairs (bias=, scale=, shift=, residual=) and act="""
+    act = kw.pop('act', ACT_NONE)
+    pr = {k: kw.get(k, (None, None)) for k in ('bias', 'scale', 'shift', 'residual')}
+    if ca.spec_key() == cb.spec_key():
+        r = Fn.conv_fwd_pair((xa, xb), (ca.frag(xa.dtype), cb.frag(xb.dtype)), ca.spec,
+                             biases=pr['bias'], scales=pr['scale'], shifts=pr['shift'],
+                             residuals=pr['residual'], act=act)
+        if r is None and xa.dtype != torch.float32:
+            r = Fn.conv_igemm_pair((xa, xb), (ca.packed(xa.dtype), cb.packed(xb.dtype)), ca.spec,
+                                   biases=pr['bias'], scales=pr['scale'], shifts=pr['shift'],
+                                   residuals=pr['residual'], act=act)
+        if r is not None:
+            return r
+    one = lambda i, x, c: c.forward(x, act=act, **{k: v[i] for k, v in pr.items() if v[i] is not None})  # noqa: E731
+    return one(0, xa, ca), one(1, xb, cb)
+
+
+def conv_bn_act_eval_pair(xa, xb, ma, mb):
+    """conv_bn_act_eval of the same ConvNormAct layer of two twin modules (nn.ConvNormAct: `_crt`,
+    `_brt`, `act`) as one twin launch; xa may be xb (the skip both decoders read)"""
+    if ma.act != mb.act:
+        raise _lib.EmsaError("twin ConvNormAct layers differ in their activation")
+    (sa, ta), (sb, tb) = ma._brt.folded(), mb._brt.folded()
+    return _conv_pair(xa, xb, ma._crt, mb._crt, scale=(sa, sb), shift=(ta, tb), act=ma.act)
+
+
+def nbt1d_eval_pair(xa, xb, ra, rb):
+    """nbt1d_eval of the SAME block of two twin networks (rgb | depth encoder, semantic | instance
+    decoder) in lockstep: every conv both blocks share a geometry for is one twin launch (4 instead
+    of 8 launches per block pair; at batch 1 a launch is its fixed cost).  Results == nbt1d_eval."""
+    b = lambda c: c.conv.bias.detach()   # noqa: E731
+    y1a, y1b = _conv_pair(xa, xb, ra.c31_1, rb.c31_1, bias=(b(ra.c31_1), b(rb.c31_1)), act=ACT_RELU)
+    (s1a, t1a), (s1b, t1b) = ra.bn1.folded(), rb.bn1.folded()
+    a2a, a2b = _conv_pair(y1a, y1b, ra.c13_1, rb.c13_1, bias=(b(ra.c13_1), b(rb.c13_1)),
+                          scale=(s1a, s1b), shift=(t1a, t1b), act=ACT_RELU)
+    y3a, y3b = _conv_pair(a2a, a2b, ra.c31_2, rb.c31_2, bias=(b(ra.c31_2), b(rb.c31_2)), act=ACT_RELU)
+    if (ra.cds is None) != (rb.cds is None):
+        raise _lib.EmsaError("twin NBt1D blocks differ in their skip path")
+    if ra.cds is not None:
+        (sda, tda), (sdb, tdb) = ra.bnds.folded(), rb.bnds.folded()
+        ida, idb = _conv_pair(xa, xb, ra.cds, rb.cds, scale=(sda, sdb), shift=(tda, tdb))
+    else:
+        ida, idb = xa, xb
+    (s2a, t2a), (s2b, t2b) = ra.bn2.folded(), rb.bn2.folded()
+    return _conv_pair(y3a, y3b, ra.c13_2, rb.c13_2, bias=(b(ra.c13_2), b(rb.c13_2)),
+                      scale=(s2a, s2b), shift=(t2a, t2b), residual=(ida, idb), act=ACT_RELU)
 
 
 # ---------------------------------------------------------------------------------------------

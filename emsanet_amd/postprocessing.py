@@ -25,19 +25,25 @@ def softmax_argmax(logits):
     if logits.dim() == 2:
         n, c = logits.shape
         cp = Fn.pad4(c)
+        # rows of `cp` floats, one "pixel" per sample (the row stride is passed as such: with ONE
+        # sample no stride of a (1, C, 1, 1) view says what it is -- batch-1 inference)
         x = torch.cat([logits, logits.new_zeros(n, cp - c)], 1) if cp != c else logits.contiguous()
-        x4 = x.view(n, 1, 1, cp).permute(0, 3, 1, 2)[:, :c]
-        s, i = softmax_argmax(x4)
-        return s.view(n), i.view(n)
+        score = Fn._empty((n,), x.device)
+        idx = torch.empty((n,), device=x.device, dtype=torch.int64)
+        check(_lib.lib().emsa_softmax_argmax(Fn._p(x), cp, c, n, Fn._p(score), idx.data_ptr(),
+                                             Fn._stream()), 'emsa_softmax_argmax')
+        return score, idx
     x = Fn.as_act(logits)
     n, c, h, w = x.shape
-    if Fn.ld_of(x) % 4:          # rows must be 16-byte aligned: re-lay out with a padded stride
-        xp = Fn.act_empty(n, Fn.pad4(c), h, w, x.device)
+    ld = Fn.ld_of(x)
+    if ld % 4:                   # rows must be 16-byte aligned: re-lay out with a padded stride
+        ld = Fn.pad4(c)
+        xp = Fn.act_empty(n, ld, h, w, x.device)
         xp[:, :c].copy_(x)
         x = xp[:, :c]
     score = Fn._empty((n, h, w), x.device)
     idx = torch.empty((n, h, w), device=x.device, dtype=torch.int64)
-    check(_lib.lib().emsa_softmax_argmax(Fn._p(x), Fn.ld_of(x), c, n * h * w, Fn._p(score),
+    check(_lib.lib().emsa_softmax_argmax(Fn._p(x), ld, c, n * h * w, Fn._p(score),
                                          idx.data_ptr(), Fn._stream()), 'emsa_softmax_argmax')
     return score, idx
 

@@ -522,6 +522,19 @@ int emsa_conv_igemm_splitk_t(int32_t dtype, const EmsaConvGeom* g, const void* i
                              void* out, const float* bias, const float* scale, const float* shift,
                              const void* residual, int32_t ld_res, int32_t act, float* ws,
                              void* stream);
+/* Twin launch of emsa_conv_igemm_t / emsa_conv_igemm_splitk_t (16-bit storage): ONE launch (grid.y = 2)
+ * runs the same geometry on two independent sets of tensors -- the strided / 1x1 convs of the
+ * rgb | depth encoder blocks and the 3x3 / skip-fusion convs of the semantic | instance decoder modules
+ * (/root/reference/emsanet/model.py:95-160, decoder.py:63-139); in0 may equal in1.  Forward epilogue
+ * only; each half == its own launch bit for bit.  ws0 / ws1: emsa_conv_igemm_splitk_ws_bytes_t(dtype, g)
+ * bytes each where that is > 0 (tap-split form, one finish launch for both halves), else NULL.
+ * EMSA_E_SHAPE: not a 16-bit launch the twin form exists for (the caller launches twice). */
+int emsa_conv_igemm_pair_t(int32_t dtype, const EmsaConvGeom* g, const void* in0, const void* in1,
+                           const void* w0, const void* w1, void* out0, void* out1,
+                           const float* bias0, const float* bias1, const float* scale0,
+                           const float* scale1, const float* shift0, const float* shift1,
+                           const void* residual0, const void* residual1, int32_t ld_res,
+                           int32_t act, float* ws0, float* ws1, void* stream);
 /* 16-bit twin of emsa_conv1d_wino_bnb (tiles: emsa_conv_stats_rows_t(dtype, g)) and the BatchNorm
  * backward that consumes its output: g = the masked gradient stored by the conv, partial =
  * float[2][rows + 16][c] with rows [0, rows) filled; dtype EMSA_DT_F32 pairs with the Winograd
@@ -567,6 +580,17 @@ int emsa_conv1d_rs_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const
                      void* out, const float* bias, float* stats, const float* scale,
                      const float* shift, const void* residual, int32_t ld_res,
                      const void* mask_src, int32_t ld_mask, int32_t act, void* stream);
+/* Twin launch of the kernel above: ONE launch (grid.y = 2) runs the same geometry on two independent
+ * sets of tensors -- the rgb | depth encoder blocks and the semantic | instance decoder blocks of
+ * /root/reference/emsanet/model.py:95-160 have identical shapes, and at batch 1 (BASELINE configs[4])
+ * a launch is its fixed cost.  Forward epilogue only; each half == its own emsa_conv1d_rs_t launch bit
+ * for bit.  bias / scale + shift / residual: for both halves or for neither; one ld_res. */
+int emsa_conv1d_rs_pair_t(int32_t dtype, const EmsaConvGeom* g, const void* in0, const void* in1,
+                          const void* wfrag0, const void* wfrag1, void* out0, void* out1,
+                          const float* bias0, const float* bias1, const float* scale0,
+                          const float* scale1, const float* shift0, const float* shift1,
+                          const void* residual0, const void* residual1, int32_t ld_res,
+                          int32_t act, void* stream);
 int emsa_conv1d_rs_bnb_t(int32_t dtype, const EmsaConvGeom* g, const void* dy, const void* wfrag,
                          void* out, const void* residual, int32_t ld_res, const void* t,
                          int32_t ld_t, const float* bn_scale, const float* bn_shift,

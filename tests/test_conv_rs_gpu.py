@@ -271,3 +271,107 @@ def test_conv_rs_switch(monkeypatch):
     monkeypatch.setattr(Fn, 'CONV_RS', False)
     spec = _spec(Fn, 64, (1, 3))
     assert not Fn.rs_supported(1, spec.geom_fwd(2, 40, 48, 64, 64))
+
+
+# batch-32 maps (every persistent workgroup busy in both halves) next to the ragged small ones
+PAIR_CONVS = RS_CONVS + [(64, (1, 3), 8, 120, 160), (128, (3, 1), 8, 60, 80), (512, (1, 3), 32, 15, 20)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', PAIR_CONVS)
+def test_conv_rs_pair_is_two_launches(cfg, dtype):
+    """emsa_conv1d_rs_pair_t (twin launch, grid.y = 2: the rgb | depth encoder blocks and the
+    semantic | instance decoder blocks of /root/reference/emsanet/model.py:95-160): each half is
+    bit-identical to its own emsa_conv1d_rs_t launch, for the three epilogues of an eval-mode
+    NBt1D block (bias+ReLU, bias+folded BN+ReLU, bias+folded BN+residual+ReLU) and the plain one"""
+    Fn = _fn()
+    c, k, n, h, w = cfg
+    spec = _spec(Fn, c, k)
+    xs = [act16(rnd(n, c, h, w, seed=11 + i), dtype) for i in range(2)]
+    wts = [rnd(c, c, *k, seed=21 + i, scale=0.1).to(DEV) for i in range(2)]
+    wfs = [Fn.pack_weight_frag_t(wt, dtype, fwd=True)[0] for wt in wts]
+    wps = [Fn.pack_weight_t(wt, dtype, fwd=True)[0] for wt in wts]
+    bs = [rnd(c, seed=31 + i).to(DEV) for i in range(2)]
+    scs = [rnd(c, seed=41 + i).to(DEV) for i in range(2)]
+    shs = [rnd(c, seed=51 + i).to(DEV) for i in range(2)]
+    rs = [act16(rnd(n, c, h, w, seed=61 + i), dtype) for i in range(2)]
+    N2 = (None, None)
+    cases = [dict(), dict(biases=bs, act=Fn.ACT_RELU),
+             dict(biases=bs, scales=scs, shifts=shs, act=Fn.ACT_RELU),
+             dict(biases=bs, scales=scs, shifts=shs, residuals=rs, act=Fn.ACT_RELU)]
+    for kw in cases:
+        pair = Fn.conv_fwd_pair(xs, wfs, spec, **kw)
+        assert pair is not None, "the twin launch must take this case"
+        torch.cuda.synchronize()
+        for i in range(2):
+            one = Fn.conv_fwd(xs[i], wps[i], spec, bias=kw.get('biases', N2)[i],
+                              scale=kw.get('scales', N2)[i], shift=kw.get('shifts', N2)[i],
+                              residual=kw.get('residuals', N2)[i], act=kw.get('act', Fn.ACT_NONE),
+                              wfrag=wfs[i])
+            assert torch.equal(pair[i], one), f"half {i} of the twin launch, case {sorted(kw)}"
+    # operands given for one half only / other geometry: refused (the caller launches twice)
+    assert Fn.conv_fwd_pair(xs, wfs, spec, biases=(bs[0], None)) is None
+    assert Fn.conv_fwd_pair(xs, (wfs[0], None), spec) is None
+    rc = _lib_rc_pair_bad_args(Fn, xs, wfs, spec)
+    assert rc != 0
+
+
+def _lib_rc_pair_bad_args(Fn, xs, wfs, spec):
+    """the C entry point itself refuses a residual for one half only"""
+    from emsanet_amd import _lib
+    n, c, h, w = xs[0].shape
+    g = spec.geom_fwd(n, h, w, c, c)
+    out = [torch.empty_like(x) for x in xs]
+    p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    return _lib.lib().emsa_conv1d_rs_pair_t(Fn.dt(xs[0]), g, p(xs[0]), p(xs[1]), p(wfs[0]), p(wfs[1]),
+                                            p(out[0]), p(out[1]), None, None, None, None, None, None,
+                                            p(xs[0]), None, c, 0, torch.cuda.current_stream().cuda_stream)
+
+
+# cin, cout, kernel, stride, padding, n, h, w -- the convs of the twin eval path that the implicit GEMM
+# runs: the strided 3x1 / 1x3 and 1x1 down-sampling convs of the first block of an encoder stage, the
+# 3x3 and 1x1 skip-fusion convs of the decoder modules (batch 1: tap-split form at 512 -> 512)
+IGEMM_PAIRS = [
+    (64, 128, (3, 1), (2, 1), (1, 0), 1, 120, 160),
+    (128, 128, (1, 3), (1, 2), (0, 1), 1, 60, 160),
+    (64, 128, (1, 1), (2, 2), (0, 0), 1, 120, 160),
+    (512, 512, (3, 3), (1, 1), (1, 1), 1, 15, 20),
+    (512, 256, (3, 3), (1, 1), (1, 1), 1, 30, 40),
+    (256, 512, (1, 1), (1, 1), (0, 0), 2, 30, 40),
+    (256, 128, (3, 3), (1, 1), (1, 1), 3, 23, 31),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', IGEMM_PAIRS)
+def test_conv_igemm_pair_is_two_launches(cfg, dtype):
+    """emsa_conv_igemm_pair_t: each half of the twin launch == its own emsa_conv_igemm_t /
+    emsa_conv_igemm_splitk_t launch bit for bit (folded BatchNorm + ReLU, + residual, plain; shared
+    input as the decoders' skip-fusion convs have it)"""
+    Fn = _fn()
+    cin, cout, k, st, pad, n, h, w = cfg
+    spec = Fn.ConvSpec(cin, cout, k, st, pad)
+    xs = [act16(rnd(n, cin, h, w, seed=11 + i), dtype) for i in range(2)]
+    wps = [Fn.pack_weight_t(rnd(cout, cin, *k, seed=21 + i, scale=0.1).to(DEV), dtype, fwd=True)[0]
+           for i in range(2)]
+    oh, ow = spec.out_hw(h, w)
+    bs = [rnd(cout, seed=31 + i).to(DEV) for i in range(2)]
+    scs = [rnd(cout, seed=41 + i).to(DEV) for i in range(2)]
+    shs = [rnd(cout, seed=51 + i).to(DEV) for i in range(2)]
+    rs = [act16(rnd(n, cout, oh, ow, seed=61 + i), dtype) for i in range(2)]
+    N2 = (None, None)
+    cases = [(xs, dict()), (xs, dict(scales=scs, shifts=shs, act=Fn.ACT_RELU)),
+             (xs, dict(biases=bs, scales=scs, shifts=shs, residuals=rs, act=Fn.ACT_RELU)),
+             ([xs[0], xs[0]], dict(scales=scs, shifts=shs, act=Fn.ACT_RELU))]
+    for xin, kw in cases:
+        pair = Fn.conv_igemm_pair(xin, wps, spec, **kw)
+        assert pair is not None, "the twin launch must take this case"
+        torch.cuda.synchronize()
+        for i in range(2):
+            one = Fn.conv_fwd(xin[i], wps[i], spec, bias=kw.get('biases', N2)[i],
+                              scale=kw.get('scales', N2)[i], shift=kw.get('shifts', N2)[i],
+                              residual=kw.get('residuals', N2)[i], act=kw.get('act', Fn.ACT_NONE))
+            assert torch.equal(pair[i], one), f"half {i} of the twin launch, case {sorted(kw)}"
+    assert Fn.conv_igemm_pair(xs, wps, spec, scales=(scs[0], None), shifts=(shs[0], None)) is None
+    x32 = [x.float() for x in xs]
+    assert Fn.conv_igemm_pair(x32, wps, spec) is None          # fp32 storage: two launches

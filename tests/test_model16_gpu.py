@@ -510,3 +510,75 @@ def test_full_size_bf16_batch_consistency_and_determinism():
             outs.append([t.clone() for t in _flatten(model({'rgb': rgb, 'depth': depth}))])
     for a, b in zip(*outs):
         assert torch.equal(a, b), 'bf16 train-mode forward is not bit-reproducible'
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(1, 480, 640), (3, 96, 128)])
+def test_twin_launches_match_separate_launches(dtype, shape, monkeypatch):
+    """16-bit eval fast path: the rgb | depth encoder blocks and the semantic | instance decoder
+    blocks run in lockstep with one twin launch per conv pair (emsa_conv1d_rs_pair_t;
+    nn.FusedEncoder._forward_twin_eval, decoder.twin_bodies).  Every output is bit-identical to the
+    forward with one launch per conv (EMSA_TWIN=0), and the twin path really is the one that ran"""
+    from emsanet_amd import _lib, full_args, nn as enn, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import synthetic_batch
+    model = EMSANet(full_args(compute_dtype='bfloat16' if dtype == torch.bfloat16 else 'float16'),
+                    nyuv2_config()).to(DEV).eval()
+    b = {k: v.to(DEV) for k, v in synthetic_batch(*shape, seed=3).items()}
+    calls = {'pair': 0, 'one': 0, 'igemm_pair': 0}
+    L = _lib.lib()
+    pair_fn, one_fn, ig_fn = L.emsa_conv1d_rs_pair_t, L.emsa_conv1d_rs_t, L.emsa_conv_igemm_pair_t
+
+    class Counting:
+        def __getattr__(self, name):
+            if name == 'emsa_conv1d_rs_pair_t':
+                def f(*a):
+                    calls['pair'] += 1
+                    return pair_fn(*a)
+                return f
+            if name == 'emsa_conv_igemm_pair_t':
+                def f(*a):
+                    calls['igemm_pair'] += 1
+                    return ig_fn(*a)
+                return f
+            if name == 'emsa_conv1d_rs_t':
+                def f(*a):
+                    calls['one'] += 1
+                    return one_fn(*a)
+                return f
+            return getattr(L, name)
+    monkeypatch.setattr(_lib, 'lib', lambda: Counting())
+    with torch.no_grad():
+        monkeypatch.setattr(enn, 'TWIN', False)
+        ref = [t.clone() for t in _flatten(model(b))]
+        n_one = calls['one']
+        assert calls['pair'] == 0 and n_one > 0
+        calls['one'] = 0
+        monkeypatch.setattr(enn, 'TWIN', True)
+        got = [t.clone() for t in _flatten(model(b))]
+    torch.cuda.synchronize()
+    # ResNet-34: 16 blocks x 4 convs per encoder minus the 2 strided convs of 3 blocks = 58 pairs;
+    # decoders: 3 modules x 3 blocks x 4 convs = 36 pairs
+    assert calls['pair'] == 58 + 36, calls
+    # + the implicit-GEMM pairs: 3 strided blocks x (conv3x1 s2, conv1x3 s2, 1x1 s2) of the encoders,
+    # the 3x3 conv and the 1x1 skip-fusion conv of the 3 decoder modules
+    assert calls['igemm_pair'] >= 9 + 3, calls
+    assert calls['one'] == n_one - 2 * (58 + 36), (calls, n_one)
+    assert len(got) == len(ref)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    # merged post-processing dict with the PanopticHelper around the two decoders
+    args = full_args(compute_dtype='bfloat16' if dtype == torch.bfloat16 else 'float16',
+                     enable_panoptic=True)
+    pm = EMSANet(args, nyuv2_config()).to(DEV).eval()
+    with torch.no_grad():
+        monkeypatch.setattr(enn, 'TWIN', False)
+        r0 = pm(b, do_postprocessing=True)
+        monkeypatch.setattr(enn, 'TWIN', True)
+        calls['pair'] = 0
+        r1 = pm(b, do_postprocessing=True)
+    assert calls['pair'] == 58 + 36
+    keys = [k for k, v in r0.items() if torch.is_tensor(v)]
+    assert 'semantic_output' in keys and 'instance_centers' in keys
+    for k in keys:
+        assert torch.equal(r0[k], r1[k]), k

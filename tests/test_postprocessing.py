@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.mark.parametrize('c,shape', [(40, (2, 30, 41)), (10, (3, 1, 1)), (8, (1, 7, 5))])
+# (10, (1, 1, 1)): the scene head at batch 1 -- ONE row of 10 logits, no stride says what the padded row is
+@pytest.mark.parametrize('c,shape', [(40, (2, 30, 41)), (10, (3, 1, 1)), (8, (1, 7, 5)), (10, (1, 1, 1))])
 def test_softmax_argmax(c, shape):
     from emsanet_amd.postprocessing import softmax_argmax
     from oracle.postprocessing_oracle import softmax_argmax as ref_fn
