@@ -816,25 +816,34 @@ __global__ void channel_dot_finish_kernel(const float* __restrict__ ws, float* _
   if (i >= n * c) return;
   const int img = i / c, ch = i % c;
   float a = 0.f;
+#pragma unroll 8
   for (int sp = 0; sp < splits; ++sp) a += ws[((long)img * splits + sp) * c + ch];
   out[i] = a * scale;
 }
 
-// hidden layer of the excitation MLP: hsh[r] = relu(b1[r] + w1[r][:] . g[:]) with one WAVE per hidden
-// unit (lanes stride the channels: coalesced rows of w1, a fixed butterfly for the wave sum) -- one
-// THREAD per unit walked its row alone: c dependent loads, 7-18 us of a batch-1 graph whose other
-// nodes take 5.  Same order in every caller (single / paired forward): bit-identical results.
+// hidden layer of the excitation MLP: hsh[r] = relu(b1[r] + w1[r][:] . g[:]), all hidden units at once:
+// G = 256 / cr (<= 64) neighbouring lanes share a unit, lane j of a group sums the channels j, j + G, ...
+// (coalesced pieces of the row of w1), then a fixed butterfly over the group -- one THREAD per unit
+// walked its row alone (c dependent steps: 7-18 us of a batch-1 graph whose other nodes take 5).
+// Same order in every caller (single / paired forward): bit-identical results.  blockDim.x = 256.
 __device__ __forceinline__ void se_hidden_layer(const float* __restrict__ w1,
                                                 const float* __restrict__ b1, const float* g,
                                                 float* hsh, float* __restrict__ hid_row, int c,
                                                 int cr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int r = wave; r < cr; r += nw) {
+  int G = 64;
+  while (G > 1 && G * cr > 256) G >>= 1;          // lanes per hidden unit (power of two)
+  const int per_pass = 256 / G;
+  const int j = threadIdx.x % G, u = threadIdx.x / G;
+  for (int r0 = 0; r0 < cr; r0 += per_pass) {
+    const int r = r0 + u;
     float a = 0.f;
-    for (int k = lane; k < c; k += 64) a += w1[(long)r * c + k] * g[k];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0) {
+    if (r < cr) {
+      const float* row = w1 + (long)r * c;
+#pragma unroll 8
+      for (int k = j; k < c; k += G) a += row[k] * g[k];
+    }
+    for (int o = G >> 1; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    if (j == 0 && r < cr) {
       a = fmaxf(a + b1[r], 0.f);
       hsh[r] = a;
       hid_row[r] = a;
@@ -856,6 +865,7 @@ __global__ void se_mlp_fwd_kernel(const float* __restrict__ gap, const float* __
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     float a = b2[i];
+#pragma unroll 4
     for (int r = 0; r < cr; ++r) a += w2[(long)i * cr + r] * hsh[r];
     s[(long)img * c + i] = 1.f / (1.f + expf(-a));
   }
@@ -881,6 +891,7 @@ __global__ void se_mlp_pair_fwd_kernel(const float* __restrict__ ws, int splits,
   const long row = (long)m * n + img;
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     float a = 0.f;
+#pragma unroll 8
     for (int sp = 0; sp < splits; ++sp) a += ws[(row * splits + sp) * c + i];
     a *= scale;
     g[i] = a;
@@ -891,6 +902,7 @@ __global__ void se_mlp_pair_fwd_kernel(const float* __restrict__ ws, int splits,
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
     float a = b2[i];
+#pragma unroll 4
     for (int r = 0; r < cr; ++r) a += w2[(long)i * cr + r] * hsh[r];
     s[row * c + i] = 1.f / (1.f + expf(-a));
   }
@@ -1107,7 +1119,17 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 template <typename T, typename TO, bool NT = false>
 __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const T* __restrict__ skip,
-                                   TO* __restrict__ y, int n, int h, int w, int c4n) {
+                                   TO* __restrict__ y, int n, int h, int w, int c4n,
+                                   const T* __restrict__ x2 = nullptr,
+                                   const float* __restrict__ wdw2 = nullptr,
+                                   const float* __restrict__ bias2 = nullptr,
+                                   const T* __restrict__ skip2 = nullptr,
+                                   TO* __restrict__ y2 = nullptr) {
+  // twin launch (emsa_up2x_dw3x3_fwd_pair_t, grid.y = 2): the second half of the workgroups runs the
+  // same shape on the "2" tensors (the other decoder of the model)
+  if (blockIdx.y != 0) {
+    x = x2; wdw = wdw2; bias = bias2; skip = skip2; y = y2;
+  }
   // the depth-wise weights [c][9], transposed to [9][c] in LDS once per workgroup: 9 ds_read_b128
   // per thread instead of 36 strided scalar global loads (the kernel was load-instruction bound)
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -2392,6 +2414,38 @@ static int up2x_dw3x3_fwd_impl(const T* x, const float* wdw, const float* bias, 
                        (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
                        h, w, c / 4);
   return emsa_launch_status();
+}
+// Twin launch of emsa_up2x_dw3x3_fwd_t (16-bit storage in, same type out): the learned x2 up-sampling
+// (+ skip) of the semantic | instance decoder modules in ONE launch; each half == its own launch.
+template <typename T>
+static int up2x_pair_impl(const T* x0, const T* x1, const float* w0, const float* w1, const float* b0,
+                          const float* b1, const T* s0, const T* s1, T* y0, T* y1, int n, int h,
+                          int w, int c, hipStream_t st) {
+  const long total = (long)n * 4 * h * w * (c / 4);
+  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T>), dim3(grid_for(total), 2), dim3(kThreads),
+                     (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w, c / 4, x1, w1, b1,
+                     s1, y1);
+  return emsa_launch_status();
+}
+extern "C" int emsa_up2x_dw3x3_fwd_pair_t(int32_t dtype, const void* x0, const void* x1,
+                                          const float* wdw0, const float* wdw1, const float* bias0,
+                                          const float* bias1, const void* skip0, const void* skip1,
+                                          void* y0, void* y1, int32_t n, int32_t h, int32_t w,
+                                          int32_t c, void* stream) {
+  if (!x0 || !x1 || !wdw0 || !wdw1 || !y0 || !y1 || y0 == y1) return EMSA_E_ARG;
+  if ((bias0 == nullptr) != (bias1 == nullptr) || (skip0 == nullptr) != (skip1 == nullptr))
+    return EMSA_E_ARG;
+  if (!c4_ok(c)) return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EMSA_DT_BF16)
+    return up2x_pair_impl<emsa_bf16>((const emsa_bf16*)x0, (const emsa_bf16*)x1, wdw0, wdw1, bias0, bias1,
+                                     (const emsa_bf16*)skip0, (const emsa_bf16*)skip1, (emsa_bf16*)y0,
+                                     (emsa_bf16*)y1, n, h, w, c, st);
+  if (dtype == EMSA_DT_F16)
+    return up2x_pair_impl<emsa_f16>((const emsa_f16*)x0, (const emsa_f16*)x1, wdw0, wdw1, bias0, bias1,
+                                    (const emsa_f16*)skip0, (const emsa_f16*)skip1, (emsa_f16*)y0,
+                                    (emsa_f16*)y1, n, h, w, c, st);
+  return EMSA_E_SHAPE;
 }
 extern "C" int emsa_up2x_dw3x3_fwd(const float* x, const float* wdw, const float* bias, const float* skip, float* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
   return up2x_dw3x3_fwd_impl<float, float>(x, wdw, bias, skip, y, n, h, w, c, stream);

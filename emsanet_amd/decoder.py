@@ -166,7 +166,7 @@ def twin_bodies(da, db, x, skips):
                 ska = ma.skip_fusion(ska)
             if mb.skip_fusion is not None:
                 skb = mb.skip_fusion(skb)
-        xa, xb = ma.upsampling(xa, ska), mb.upsampling(xb, skb)
+        xa, xb = LearnedUpsampling.eval_pair(ma.upsampling, mb.upsampling, xa, xb, ska, skb)
     n = len(da.decoder_modules)
     return (xa, (None,) * n), (xb, (None,) * n)
 

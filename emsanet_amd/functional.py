@@ -1066,6 +1066,26 @@ def up2x_dw_fwd(x, wdw, bias, skip=None, out_f32=False):
 UP2X_FUSED_BWD = os.environ.get('EMSA_UP2X_FUSED', '1') != '0'
 
 
+def up2x_dw_fwd_pair(xs, wdws, biases, skips):
+    """up2x_dw_fwd of two twin modules in one launch (emsa_up2x_dw3x3_fwd_pair_t: 16-bit features,
+    same shapes); (y0, y1) or None where there is no twin form"""
+    x0, x1 = xs
+    if x0.dtype == torch.float32 or x0.dtype != x1.dtype or x0.shape != x1.shape:
+        return None
+    if (biases[0] is None) != (biases[1] is None) or (skips[0] is None) != (skips[1] is None):
+        return None
+    n, c, h, w = x0.shape
+    for t in (x0, x1) + tuple(k for k in skips if k is not None):
+        if ld_of(t) != c or t.dtype != x0.dtype:
+            return None
+    y0 = act_empty(n, c, 2 * h, 2 * w, x0.device, dtype=x0.dtype)
+    y1 = act_empty(n, c, 2 * h, 2 * w, x0.device, dtype=x0.dtype)
+    check(_lib.lib().emsa_up2x_dw3x3_fwd_pair_t(
+        dt(x0), _p(x0), _p(x1), _p(wdws[0]), _p(wdws[1]), _p(biases[0]), _p(biases[1]), _p(skips[0]),
+        _p(skips[1]), _p(y0), _p(y1), n, h, w, c, _stream()), 'emsa_up2x_dw3x3_fwd_pair_t')
+    return y0, y1
+
+
 def up2x_dw_bwd(dy, x, wdw, need_dx=True):
     n, c, h, w = x.shape
     assert ld_of(dy) == c

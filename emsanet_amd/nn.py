@@ -503,6 +503,18 @@ class LearnedUpsampling(nn.Module):
         w, b = self._padded()
         return ops.UpsampleDWFunction.apply(x, w, b, skip, out_f32)
 
+    @staticmethod
+    def eval_pair(ma, mb, xa, xb, ska, skb):
+        """forward of two twin up-sampling modules (no autograd) as one twin launch, else one by one"""
+        (wa, ba), (wb, bb) = ma._padded(), mb._padded()
+        xa, xb = Fn.as_act(xa, dense=True), Fn.as_act(xb, dense=True)
+        if ska is not None and skb is not None:
+            ska, skb = Fn.as_act(ska, dense=True), Fn.as_act(skb, dense=True)
+        det = lambda t: None if t is None else t.detach()      # noqa: E731
+        r = Fn.up2x_dw_fwd_pair((xa, xb), (wa.detach().contiguous(), wb.detach().contiguous()),
+                                (det(ba), det(bb)), (ska, skb)) if wa.shape == wb.shape else None
+        return r if r is not None else (ma(xa, ska), mb(xb, skb))
+
 
 def make_plain_conv_rt(conv):
     """runtime for an nn.Conv2d (+bias) evaluated by the MFMA kernel with its output channels

@@ -630,6 +630,14 @@ int emsa_se_scale_bwd_apply_t(int32_t dtype, const void* dout, const float* s, c
 int emsa_up2x_dw3x3_fwd_t(int32_t dtype, int32_t out_f32, const void* x, const float* wdw, const
     float* bias, const void* skip, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void*
     stream);
+/* Twin launch of emsa_up2x_dw3x3_fwd_t (16-bit features in, the same type out): the learned x2
+ * up-sampling + skip addition of the semantic | instance decoder modules
+ * (/root/reference/emsanet/decoder.py:63-139, args.py:290-298) in ONE launch, grid.y = 2; each half ==
+ * its own launch bit for bit.  bias / skip: for both halves or for neither. */
+int emsa_up2x_dw3x3_fwd_pair_t(int32_t dtype, const void* x0, const void* x1, const float* wdw0,
+                               const float* wdw1, const float* bias0, const float* bias1,
+                               const void* skip0, const void* skip1, void* y0, void* y1, int32_t n,
+                               int32_t h, int32_t w, int32_t c, void* stream);
 int emsa_up2x_dw3x3_bwd_data_t(int32_t dtype, int32_t out_f32, const void* dy, const float* wdw,
     void* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int emsa_up2x_dw3x3_bwd_weight_t(int32_t dtype, int32_t out_f32, const void* dy, const void* x,

@@ -375,3 +375,25 @@ def test_conv_igemm_pair_is_two_launches(cfg, dtype):
     assert Fn.conv_igemm_pair(xs, wps, spec, scales=(scs[0], None), shifts=(shs[0], None)) is None
     x32 = [x.float() for x in xs]
     assert Fn.conv_igemm_pair(x32, wps, spec) is None          # fp32 storage: two launches
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(512, 1, 15, 20), (256, 1, 30, 40), (128, 2, 23, 31), (64, 3, 7, 5)])
+def test_up2x_pair_is_two_launches(cfg, dtype):
+    """emsa_up2x_dw3x3_fwd_pair_t: the learned x2 up-sampling (+ skip) of the two decoders in one
+    launch, each half == emsa_up2x_dw3x3_fwd_t bit for bit"""
+    Fn = _fn()
+    c, n, h, w = cfg
+    xs = [act16(rnd(n, c, h, w, seed=71 + i), dtype) for i in range(2)]
+    sk = [act16(rnd(n, c, 2 * h, 2 * w, seed=73 + i), dtype) for i in range(2)]
+    ws = [rnd(c, 1, 3, 3, seed=75 + i).to(DEV).contiguous() for i in range(2)]
+    bs = [rnd(c, seed=77 + i).to(DEV) for i in range(2)]
+    for biases, skips in (((None, None), (None, None)), (bs, sk), ((None, None), sk)):
+        pair = Fn.up2x_dw_fwd_pair(xs, ws, biases, skips)
+        assert pair is not None
+        torch.cuda.synchronize()
+        for i in range(2):
+            one = Fn.up2x_dw_fwd(xs[i], ws[i], biases[i], skips[i])
+            assert torch.equal(pair[i], one)
+    assert Fn.up2x_dw_fwd_pair(xs, ws, (bs[0], None), (None, None)) is None
+    assert Fn.up2x_dw_fwd_pair([x.float() for x in xs], ws, (None, None), (None, None)) is None

@@ -578,7 +578,11 @@ def test_twin_launches_match_separate_launches(dtype, shape, monkeypatch):
         calls['pair'] = 0
         r1 = pm(b, do_postprocessing=True)
     assert calls['pair'] == 58 + 36
-    keys = [k for k, v in r0.items() if torch.is_tensor(v)]
-    assert 'semantic_output' in keys and 'instance_centers' in keys
+    # (the raw network outputs and the class maps; the centre lists behind the NMS come out of an
+    #  atomic compaction whose ORDER is not reproducible between two runs of the same input)
+    keys = [k for k, v in r0.items() if torch.is_tensor(v) and
+            (k.endswith('_output') or k.endswith('_idx') or k in ('instance_centers', 'instance_offsets',
+                                                                  'instance_orientation'))]
+    assert 'semantic_output' in keys and 'instance_centers' in keys and 'scene_output' in keys
     for k in keys:
         assert torch.equal(r0[k], r1[k]), k
