@@ -502,7 +502,33 @@ def run(args):
         return kernels
 
     kernels = read_kernels() if timing else []
-    # The timed region runs the two independent halves of the network on TWO HIP streams (rgb |
+    # whole-step roofline position: the algorithmic bytes of ONE step -- every
+    # tensor operand of every launch counted once per launch (emsanet_amd.functional._p), summed over
+    # an eager pass of the same step (a graph replay issues the same launches) -- against the step
+    # time of the timed region and the 8 TB/s HBM roofline, next to the step's FLOPs against the
+    # MFMA peak of the arithmetic
+    whole_step = None
+    if world == 1 and not args.h2d:
+        cnt = [0]
+        Fn.BYTES = cnt
+        try:
+            if train_graph is not None:
+                (train_graph.eager_step(None) if hasattr(train_graph, 'eager_step') else train_graph._step())
+            elif args.eval:
+                with torch.no_grad():
+                    model(batch)
+            else:
+                step()
+        finally:
+            Fn.BYTES = None
+        torch.cuda.synchronize()
+        step_s = dt / args.steps
+        whole_step = {'algo_gb_per_step': round(cnt[0] / 1e9, 3),
+                      'hbm_frac': round(cnt[0] / step_s / 8e12, 4),
+                      'note': 'sum over all launches of one step of the bytes of every tensor operand, '
+                              'each once per launch (weights, workspaces and statistics rows included; '
+                              'the table-driven weight-pack launch excluded) / ms_per_step / 8 TB/s'}
+ of the network on TWO HIP streams (rgb |
     # depth encoder stage, semantic | instance decoder): launches overlap there, and the duration of
     # an overlapped launch is not its own -- two kernels share the CUs.  The kernel's own rate is
     # therefore measured live in `roofline_steps` more steps of the same workload with the second
@@ -700,6 +726,7 @@ def run(args):
                    'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval
                    else ('train+losses' if args.losses else 'train') + ('-hipgraph' if args.graph else '')},
         'roofline': roofline,
+        'whole_step': whole_step,
         'roofline_by_class': by_class,
         'conv_kernels': kernels,
         'conv_mfma_time_share': round(conv_ms / (dt_roof * 1e3), 4) if kernels else None,

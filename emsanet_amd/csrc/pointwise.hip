@@ -2232,8 +2232,13 @@ extern "C" int emsa_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const int8
 // channels = ONE workgroup of 4 row lanes x 75 dependent steps, 26 us): then 64-pixel chunks
 static int channel_splits(long hw, int n) {
   int splits = (int)((hw + 511) / 512);
-  if ((long)n * splits < 64) splits = (int)((hw + 63) / 64);
   if (splits > 64) splits = 64;
+  if ((long)n * splits <= 64) {
+    // (up to 256 chunks: the /2 map of a batch-1 forward, 76,800 pixels x 64 channels for both
+    //  encoders, took 15.7 us on 128 workgroups)
+    splits = (int)((hw + 63) / 64);
+    if (splits > 256) splits = 256;
+  }
   if (splits < 1) splits = 1;
   return splits;
 }

@@ -113,8 +113,18 @@ def as_act(t, dense=False):
     return to_nhwc(t)
 
 
+# bench.py: a one-element list while it counts the ALGORITHMIC bytes of one eager step -- every tensor
+# operand of every launch once (sum over fused kernels of input + output + weight
+# bytes); None otherwise
+BYTES = None
+
+
 def _p(t):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if BYTES is not None:
+        BYTES[0] += t.numel() * t.element_size()
+    return t.data_ptr()
 
 
 # bench.py sets this while it samples kernel times: convs that run on zero-padded channel counts
