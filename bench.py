@@ -528,7 +528,7 @@ def run(args):
                       'note': 'sum over all launches of one step of the bytes of every tensor operand, '
                               'each once per launch (weights, workspaces and statistics rows included; '
                               'the table-driven weight-pack launch excluded) / ms_per_step / 8 TB/s'}
- of the network on TWO HIP streams (rgb |
+    # The timed region runs the two independent halves of the network on TWO HIP streams (rgb |
     # depth encoder stage, semantic | instance decoder): launches overlap there, and the duration of
     # an overlapped launch is not its own -- two kernels share the CUs.  The kernel's own rate is
     # therefore measured live in `roofline_steps` more steps of the same workload with the second

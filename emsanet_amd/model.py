@@ -8,6 +8,8 @@ tuples, or one merged dict), same attributes callers touch (`encoder`, `context_
 """
 from typing import Any, Dict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -207,13 +209,21 @@ class EMSANet(nn.Module):
         for d in decs:
             bodies += [d.semantic_decoder, d.instance_decoder] if isinstance(d, PanopticHelper) else \
                 ([d] if isinstance(d, DecoderBody) else [])
-        if len(bodies) >= 2 and twin_bodies_ok(bodies[0], bodies[1], x[0]):
+        twin = len(bodies) >= 2 and twin_bodies_ok(bodies[0], bodies[1], x[0])
+        if twin:
             bodies[0]._pre, bodies[1]._pre = twin_bodies(bodies[0], bodies[1], x[0], skips)
-            try:
-                return [d(x, skips, batch, do_postprocessing=do_postprocessing) for d in decs]
-            finally:
+        try:
+            return self._run_decoder_heads(decs, dense, twin, x, skips, batch, do_postprocessing)
+        finally:
+            if twin:
                 bodies[0]._pre = bodies[1]._pre = None
-        if len(dense) < 2 or not _dual_stream(x[0]):
+
+    def _run_decoder_heads(self, decs, dense, twin, x, skips, batch, do_postprocessing):
+        from .nn import _dual_stream
+        # (behind twin bodies only the two heads are left: they share the calling stream unless
+        #  EMSA_TWIN_HEADS_DUAL=1 -- A/B switch)
+        if len(dense) < 2 or not _dual_stream(x[0]) or \
+                (twin and os.environ.get('EMSA_TWIN_HEADS_DUAL') != '1'):
             return [d(x, skips, batch, do_postprocessing=do_postprocessing) for d in decs]
         cur = torch.cuda.current_stream()
         if self._side_stream is None:
