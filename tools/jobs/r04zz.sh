@@ -27,6 +27,7 @@ run bench_bf16_graph --dtype bf16 --graph --steps 20 --warmup 5 --no-cpu-baselin
 for dt in f16 bf16 f32; do
   run config4_eval_graph_bs1_$dt --dtype $dt --eval --graph --batch-size 1 --steps 300 --warmup 30 --no-cpu-baseline
 done
+EMSA_TWIN_HEADS_DUAL=1 run config4_eval_graph_bs1_f16_heads_dual --dtype f16 --eval --graph --batch-size 1 --steps 300 --warmup 30 --no-cpu-baseline
 EMSA_TWIN=0 run config4_eval_graph_bs1_f16_twin_off --dtype f16 --eval --graph --batch-size 1 --steps 300 --warmup 30 --no-cpu-baseline
 run eval_bs32_f32 --eval --steps 20 --warmup 5 --no-cpu-baseline
 run eval_bs32_bf16 --dtype bf16 --eval --steps 20 --warmup 5 --no-cpu-baseline
