@@ -235,6 +235,47 @@ def test_dry_run_fast_eval_uses_folded_kernels(fake_lib, monkeypatch):
     assert c['emsa_bn_act_fwd'] == 0
 
 
+@pytest.mark.parametrize('panoptic', [False, True])
+def test_dry_run_twin_launch_orchestration(fake_lib, monkeypatch, panoptic):
+    """16-bit eval fast path on the stubbed C-ABI: the rgb | depth encoder blocks and the semantic |
+    instance decoder modules (also inside a PanopticHelper) issue ONE twin launch per conv pair and per
+    up-sampling pair (the stub takes no geometry on the register-stationary kernel, so every pair goes
+    to emsa_conv_igemm_pair_t); EMSA_TWIN=0 / fp32 storage / a batch beyond nn.TWIN_MAX_PIXELS launch
+    per module as before"""
+    import emsanet_amd.model as M
+    from emsanet_amd import full_args, nn as enn
+    from oracle.emsanet_oracle import synthetic_batch
+    model = _model(full_args(input_height=64, input_width=96, compute_dtype='bfloat16',
+                             enable_panoptic=panoptic)).eval()
+    monkeypatch.setattr(M.EMSANet, 'forward', _bypass_device_check(model))
+    c = fake_lib.calls
+    with torch.no_grad():
+        model(synthetic_batch(1, 64, 96))
+    # encoders: 16 blocks x 4 convs + 3 down-sampling convs; decoders: 3 x (3x3 + 3 blocks x 4 + skip 1x1)
+    n_pairs = c['emsa_conv_igemm_pair_t']
+    assert n_pairs == (16 * 4 + 3) + 3 * (1 + 12 + 1), n_pairs
+    assert c['emsa_up2x_dw3x3_fwd_pair_t'] == 3
+    assert c['emsa_conv1d_rs_pair_t'] == 0 and c['emsa_conv1d_rs_t'] == 0
+    singles = c['emsa_conv_igemm_t'] + c['emsa_conv_igemm_splitk_t']
+    for key in ('emsa_conv_igemm_pair_t', 'emsa_up2x_dw3x3_fwd_pair_t'):
+        c[key] = 0
+    monkeypatch.setattr(enn, 'TWIN', False)
+    before = c['emsa_conv_igemm_t'] + c['emsa_conv_igemm_splitk_t']
+    with torch.no_grad():
+        model(synthetic_batch(1, 64, 96))
+    assert c['emsa_conv_igemm_pair_t'] == 0 and c['emsa_up2x_dw3x3_fwd_pair_t'] == 0
+    assert c['emsa_conv_igemm_t'] + c['emsa_conv_igemm_splitk_t'] - before == singles + 2 * n_pairs
+    # default rule: a batch with more input pixels than nn.TWIN_MAX_PIXELS keeps one launch per module
+    monkeypatch.setattr(enn, 'TWIN', None)
+    monkeypatch.setattr(enn, 'TWIN_MAX_PIXELS', 64 * 96)
+    with torch.no_grad():
+        model(synthetic_batch(2, 64, 96))
+    assert c['emsa_conv_igemm_pair_t'] == 0
+    with torch.no_grad():
+        model(synthetic_batch(1, 64, 96))
+    assert c['emsa_conv_igemm_pair_t'] == n_pairs
+
+
 def test_dry_run_training_losses(fake_lib, monkeypatch):
     """TrainingLosses on the engine's raw training outputs: every supervised scale reaches its
     loss kernel, the weighted total back-propagates into every parameter (stubbed C-ABI)"""
