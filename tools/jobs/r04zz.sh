@@ -14,7 +14,7 @@ except Exception as e:
 PY
 }
 if [ "$1" != "notests" ]; then
-timeout 3300 python -m pytest tests -m gpu -x -q > $O/tests_gpu.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests_gpu.log
+timeout 3300 python -m pytest tests -m gpu -q > $O/tests_gpu.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests_gpu.log
 fi
 timeout 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 tools/pmc_traffic2.sh f32 > $O/pmc_f32.log 2>&1; python tools/pmc_traffic_json.py gpurun_out/pmc_f32/raw.json $O/r04_pmc_traffic.json r04 > $O/pmc_f32_json.log 2>&1; tail -4 $O/pmc_f32_json.log
