@@ -262,8 +262,10 @@ TWIN = None                 # bench.py / tests: True / False overrides (None: on
 # network-input pixels per batch up to which the twin launches are used by default (one box, fp16,
 # whole-model graph, twin vs two streams): batch 1 (640x480) 1.24 vs 1.73 ms (158 vs 271 nodes),
 # batch 2 1.57 vs 1.74, batch 4 2.25 vs 2.06, batch 8 3.29 vs 3.11; batch 32 eager bf16 3,497 vs
-# 3,623 images/s -- from batch 4 on two independent launches on two streams are the faster form
-TWIN_MAX_PIXELS = 2 * 640 * 480
+# 3,623 images/s -- from batch 4 on two independent launches on two streams are the faster form.
+# Second box (tools/jobs/r04_th.sh): batch 3 1.73 vs 1.82 ms; ResNet-101 encoders at 960x736 batch 1
+# (706,560 pixels) 2.27 vs 2.69 ms, batch 2 (1.41 M pixels) 2.96 vs 2.84
+TWIN_MAX_PIXELS = 3 * 640 * 480
 
 
 def twin_launches(t=None):
