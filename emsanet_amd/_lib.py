@@ -128,6 +128,7 @@ SIGNATURES = {
                                      _P, c_int32, _P]),
     'emsa_softmax_argmax': (c_int, [_P, c_int32, c_int32, c_int64, _P, _P, _P]),
     'emsa_center_candidates_max': (c_int, []),
+    'emsa_center_ws_entries': (c_int64, [c_int32, c_int32, c_int32]),
     'emsa_instance_centers': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                       c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'emsa_instance_assign': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _P,

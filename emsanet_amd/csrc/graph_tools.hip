@@ -80,11 +80,15 @@ extern "C" int emsa_graph_replace_memsets(void* graph, int32_t* replaced) {
   std::vector<hipGraphNode_t> nodes(n);
   if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return EMSA_E_LAUNCH;
   // pass 1: collect and validate every memset node (nothing is modified if one is unsupported:
-  // a half-rewritten graph must never be instantiated -- ADVICE r3)
+  // a half-rewritten graph must never be instantiated -- ADVICE r3).  Only the node's own
+  // parameters are read here: its edges are queried in pass 2, right before the node is rewritten,
+  // because rewriting a memset changes the edges of a memset chained behind it (memset1 -> memset2,
+  // two `zero_()` calls in a row: a dependency list taken now would still name the destroyed
+  // memset1 when memset2's turn comes, and the replacement of memset1 would lose its edge to
+  // memset2 -- ADVICE r4).
   struct Job {
     hipGraphNode_t node;
     hipMemsetParams mp;
-    std::vector<hipGraphNode_t> deps, outs;
   };
   std::vector<Job> jobs;
   for (size_t i = 0; i < n; ++i) {
@@ -95,22 +99,22 @@ extern "C" int emsa_graph_replace_memsets(void* graph, int32_t* replaced) {
     jb.node = nodes[i];
     if (hipGraphMemsetNodeGetParams(nodes[i], &jb.mp) != hipSuccess) return EMSA_E_LAUNCH;
     if (jb.mp.elementSize != 1 && jb.mp.elementSize != 2 && jb.mp.elementSize != 4) return EMSA_E_SHAPE;
-    size_t nd = 0, nn = 0;
-    if (hipGraphNodeGetDependencies(nodes[i], nullptr, &nd) != hipSuccess) return EMSA_E_LAUNCH;
-    jb.deps.resize(nd);
-    if (nd && hipGraphNodeGetDependencies(nodes[i], jb.deps.data(), &nd) != hipSuccess)
-      return EMSA_E_LAUNCH;
-    if (hipGraphNodeGetDependentNodes(nodes[i], nullptr, &nn) != hipSuccess) return EMSA_E_LAUNCH;
-    jb.outs.resize(nn);
-    if (nn && hipGraphNodeGetDependentNodes(nodes[i], jb.outs.data(), &nn) != hipSuccess)
-      return EMSA_E_LAUNCH;
-    jobs.push_back(std::move(jb));
+    jobs.push_back(jb);
   }
   // pass 2: rewrite
   int done = 0;
   for (Job& jb : jobs) {
     const hipMemsetParams& mp = jb.mp;
-    const size_t nd = jb.deps.size(), nn = jb.outs.size();
+    // the node's edges as they are NOW (an earlier job may have put a fill kernel in front of it)
+    size_t nd = 0, nn = 0;
+    if (hipGraphNodeGetDependencies(jb.node, nullptr, &nd) != hipSuccess) return EMSA_E_LAUNCH;
+    std::vector<hipGraphNode_t> deps(nd);
+    if (nd && hipGraphNodeGetDependencies(jb.node, deps.data(), &nd) != hipSuccess)
+      return EMSA_E_LAUNCH;
+    if (hipGraphNodeGetDependentNodes(jb.node, nullptr, &nn) != hipSuccess) return EMSA_E_LAUNCH;
+    std::vector<hipGraphNode_t> outs(nn);
+    if (nn && hipGraphNodeGetDependentNodes(jb.node, outs.data(), &nn) != hipSuccess)
+      return EMSA_E_LAUNCH;
     unsigned char* dst = (unsigned char*)mp.dst;
     unsigned int value = mp.value, esize = mp.elementSize;
     size_t width = mp.width, height = mp.height ? mp.height : 1;
@@ -143,10 +147,10 @@ extern "C" int emsa_graph_replace_memsets(void* graph, int32_t* replaced) {
       kp.kernelParams = args;
     }
     hipGraphNode_t kn;
-    if (hipGraphAddKernelNode(&kn, g, nd ? jb.deps.data() : nullptr, nd, &kp) != hipSuccess)
+    if (hipGraphAddKernelNode(&kn, g, nd ? deps.data() : nullptr, nd, &kp) != hipSuccess)
       return EMSA_E_LAUNCH;
     for (size_t k = 0; k < nn; ++k)
-      if (hipGraphAddDependencies(g, &kn, &jb.outs[k], 1) != hipSuccess) return EMSA_E_LAUNCH;
+      if (hipGraphAddDependencies(g, &kn, &outs[k], 1) != hipSuccess) return EMSA_E_LAUNCH;
     if (hipGraphDestroyNode(jb.node) != hipSuccess) return EMSA_E_LAUNCH;   // drops its edges too
     ++done;
   }

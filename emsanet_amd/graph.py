@@ -14,6 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .ops import mark_bn_stats_written
 
 
 def _flatten(out):
@@ -253,6 +254,8 @@ class GraphedTrainStep:
         m._seed_dev_host = (m.dropout_seed & 0xFFFFFFFF, m.dropout_step & 0xFFFFFFFF)
         for bn, inc in self._bn_inc:
             bn._emsa_pending += inc
+            if inc:
+                mark_bn_stats_written(bn)   # (the graph rewrote the running statistics)
         self.opt.after_replay()     # version counters of the parameters, first-step flag
         return self.static_loss, self.static_out
 
@@ -354,6 +357,7 @@ class SegmentedGraphedTrainStep:
         self._capturing = True
         self.capture_error = None
         st0 = dict(buckets.stats)
+        ds0, first0 = model.dropout_step, optimizer._first
         try:
             self.static_loss, self.static_out = self._run()
         except Exception as e:                    # noqa: BLE001
@@ -367,6 +371,16 @@ class SegmentedGraphedTrainStep:
             torch.cuda.synchronize()
             for k, v in st0.items():
                 buckets.stats[k] = v
+            # host-side state the aborted capture pass advanced (nothing of it ran on the device):
+            # the fallback must start where a successful capture would have
+            for m in self._bns:
+                m._emsa_pending = pend[id(m)]
+            model.dropout_step = ds0
+            model._seed_dev_host = None
+            model._sync_dropout_state()
+            optimizer._first = first0
+            optimizer._upload_hyper()
+            self._bn_inc = []
             self.graphs, self.graph_info = None, []
             self.replays = 0
             self._ev = None
@@ -491,6 +505,8 @@ class SegmentedGraphedTrainStep:
         m._seed_dev_host = (m.dropout_seed & 0xFFFFFFFF, m.dropout_step & 0xFFFFFFFF)
         for bn, inc in self._bn_inc:
             bn._emsa_pending += inc
+            if inc:
+                mark_bn_stats_written(bn)   # (the graph rewrote the running statistics)
         self.opt.after_replay()
         return self.static_loss, self.static_out
 

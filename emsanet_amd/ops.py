@@ -367,6 +367,18 @@ def _bn_load_hook(module, state_dict, prefix, *unused):
     module._emsa_pending = 0
 
 
+def mark_bn_stats_written(bn):
+    """the running statistics of `bn` were (or are about to be) rewritten through raw pointers --
+    `emsa_bn_finalize`, a replayed hipGraph -- which does not move their tensor version counters.
+    Everything that caches a function of them keys on `_version` (BNRT._frozen_fold, the
+    inference graph's `_weights_key`): bump it here, or the next eval silently runs on the folded
+    statistics of an older state (eval -> train-mode forward under no_grad, frozen
+    affine parameters -> eval)."""
+    if bn.running_mean is not None:
+        torch.autograd.graph.increment_version(bn.running_mean)
+        torch.autograd.graph.increment_version(bn.running_var)
+
+
 def flush_bn_counters(root):
     """add the host-side training-step counts of every BatchNorm below `root` to the
     `num_batches_tracked` buffers.  (`state_dict()` of the model or of any sub-module does this
@@ -416,6 +428,8 @@ class BNRT:
                 # nn.BatchNorm2d.forward is never called: keep its step counter like torch does
                 # (checkpoints carry it); counted on the host, flushed by `flush_bn_counters`
                 self.pending_batches += 1
+            if rm is not None:
+                mark_bn_stats_written(bn)
             return Fn.bn_finalize(stats, count, g, b, bn.eps, mom, rm, rv)
         scale, shift, invstd = self._frozen_fold()
         return scale, shift, bn.running_mean, invstd

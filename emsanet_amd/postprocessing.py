@@ -52,17 +52,23 @@ def _u8(m):
     return None if m is None else m.reshape(-1).to(torch.uint8).contiguous()
 
 
-def instance_centers(heatmap, threshold=0.1, nms_kernel_size=17, top_k=64, foreground=None):
+def instance_centers(heatmap, threshold=0.1, nms_kernel_size=17, top_k=64, foreground=None,
+                     return_survivors=False):
     """heatmap (N,1,H,W) -> centers (N,top_k,2) float (y, x; -1 padded), scores (N,top_k),
-    n_centers (N,) int32 (defaults: /root/reference/emsanet/args.py:469-504)"""
+    n_centers (N,) int32 (defaults: /root/reference/emsanet/args.py:469-504).  The top-k is exact
+    over ALL pixels that survive the NMS (ref decoder.py:95-104), also on saturated plateaus with
+    tens of thousands of survivors; return_survivors: also that count per image (N,) int32"""
     x = Fn.as_act(heatmap)
     n, _, h, w = x.shape
     L = _lib.lib()
-    cmax = L.emsa_center_candidates_max()
+    cap = L.emsa_center_ws_entries(h, w, top_k)
+    if cap <= 0 or top_k > L.emsa_center_candidates_max() // 2:
+        raise _lib.EmsaError(f"instance_centers: top_k={top_k} outside [1, "
+                             f"{L.emsa_center_candidates_max() // 2}]")
     dev = x.device
-    ws_count = torch.empty(n, device=dev, dtype=torch.int32)
-    ws_score = Fn._empty((n * cmax,), dev)
-    ws_pos = torch.empty(n * cmax, device=dev, dtype=torch.int32)
+    ws_count = torch.empty(2 * n, device=dev, dtype=torch.int32)
+    ws_score = Fn._empty((n * cap,), dev)
+    ws_pos = torch.empty(n * cap, device=dev, dtype=torch.int32)
     centers = Fn._empty((n, top_k, 2), dev)
     scores = Fn._empty((n, top_k), dev)
     n_centers = torch.empty(n, device=dev, dtype=torch.int32)
@@ -71,6 +77,8 @@ def instance_centers(heatmap, threshold=0.1, nms_kernel_size=17, top_k=64, foreg
                                   top_k, Fn._p(fg), ws_count.data_ptr(), Fn._p(ws_score),
                                   ws_pos.data_ptr(), Fn._p(centers), Fn._p(scores),
                                   n_centers.data_ptr(), Fn._stream()), 'emsa_instance_centers')
+    if return_survivors:
+        return centers, scores, n_centers, ws_count[n:]
     return centers, scores, n_centers
 
 

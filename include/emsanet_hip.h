@@ -442,8 +442,12 @@ int emsa_instance_loss_bwd(const float* center, int32_t ld_c, const float* offse
  *                           (`semantic_segmentation_idx|score`, `scene_class_idx|score`)
  *   emsa_instance_centers   heat >= threshold  ->  k x k max-pool NMS  ->  top_k by score
  *                           (args.py:468-504); centers float[n][top_k][2] = (y, x) or -1,
- *                           scores float[n][top_k], n_centers int[n]; ws_* = scratch: count
- *                           int[n], score float[n * emsa_center_candidates_max()], pos alike;
+ *                           scores float[n][top_k], n_centers int[n].  The top-k is EXACT over all
+ *                           NMS survivors (ref decoder.py:95-104), however many a saturated
+ *                           heat-map has: per-chunk top-k, then a merge in rounds; top_k <=
+ *                           emsa_center_candidates_max() / 2.  ws_* = scratch: ws_count int[2n]
+ *                           ([n, 2n) returns the number of NMS survivors per image), ws_score
+ *                           float[n * emsa_center_ws_entries(h, w, top_k)], ws_pos int32 alike;
  *                           fg (may be NULL): uint8 foreground applied to the heatmap first
  *   emsa_instance_assign    ids[p] = 1 + argmin_k |(y + off_y*scale_y, x + off_x*scale_x) - c_k|,
  *                           0 outside fg / without centres / beyond max_distance (<= 0: off)
@@ -453,6 +457,7 @@ int emsa_instance_loss_bwd(const float* center, int32_t ld_c, const float* offse
 int emsa_softmax_argmax(const float* logits, int32_t ld, int32_t n_classes, int64_t pixels,
                         float* score, int64_t* idx, void* stream);
 int emsa_center_candidates_max(void);
+int64_t emsa_center_ws_entries(int32_t h, int32_t w, int32_t top_k);
 int emsa_instance_centers(const float* heat, int32_t ld, int32_t n, int32_t h, int32_t w,
                           int32_t nms_kernel, float threshold, int32_t top_k, const uint8_t* fg,
                           int32_t* ws_count, float* ws_score, int32_t* ws_pos, float* centers,

@@ -984,3 +984,77 @@ def test_hipgraph_inference_with_postprocessing(panoptic):
     for (k, a), (_, b) in zip(o1 + o2, e1 + e2):
         assert a.shape == b.shape and torch.equal(a, b), k
     assert any(not torch.equal(a, b) for (_, a), (_, b) in zip(o1, o2))
+
+
+def test_graph_memset_repair_handles_chained_memsets():
+    """two (three) zero-fills back to back on one stream are memset -> memset chains in the captured
+    graph: the repair must re-read a node's edges when its turn comes (with edges taken up
+    front, the second memset's dependency list named the already destroyed first one and the
+    ordering kernel -> memset2 -> kernel was lost).  Replays must reproduce the eager result."""
+    from emsanet_amd.graph import _new_graph, _repair_and_instantiate, _CAPTURE_MODE
+    a = torch.ones(1 << 16, device=DEV)
+    b = torch.ones(1 << 16, device=DEV)
+    src = torch.arange(1 << 16, device=DEV, dtype=torch.float32)
+    out = torch.empty(1 << 16, device=DEV)
+
+    def work():
+        a.add_(src)                 # kernel in front of the chain
+        a.zero_()                   # memset 1
+        b.zero_()                   # memset 2, chained behind memset 1
+        a.zero_()                   # memset 3, same buffer again
+        b.add_(src)                 # kernels behind the chain
+        torch.add(a, b, out=out)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        work()
+    torch.cuda.current_stream().wait_stream(side)
+    g, kept = _new_graph()
+    if not kept:
+        pytest.skip("this torch has no CUDAGraph(keep_graph=True)")
+    with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+        work()
+    info = _repair_and_instantiate(g, kept)
+    assert info['memset_nodes'] >= 3 and info['replaced'] == info['memset_nodes'], info
+    for _ in range(3):
+        a.fill_(7.0)
+        b.fill_(9.0)
+        out.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, src) and torch.equal(b, src) and float(a.abs().max()) == 0.0
+
+
+def test_eval_after_stats_only_train_forward_sees_new_running_stats():
+    """eval -> train-mode forward under no_grad (BatchNorm recalibration: no parameter changes, the
+    running statistics are rewritten through raw pointers by emsa_bn_finalize) -> eval: the cached
+    frozen-BatchNorm fold must be re-derived (the cache was keyed on tensor version
+    counters that raw-pointer writes do not move).  Oracle: the same three calls in plain PyTorch."""
+    from emsanet_amd.nn import NonBottleneck1D
+    from oracle import emsanet_oracle as O
+    torch.manual_seed(0)
+    ref = O.NonBottleneck1D(64, 64, 1, 0.0)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.momentum = 0.5
+    blk = NonBottleneck1D(64, 64, 1, 0.0)
+    blk.load_state_dict(ref.state_dict())
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.5
+    blk.to(DEV)
+    x0, x1 = rnd(2, 64, 12, 16, seed=1), rnd(2, 64, 12, 16, seed=2, scale=3.0) + 1.0
+    with torch.no_grad():
+        ref.eval(), blk.eval()
+        close(blk(to_act(x0)), ref(x0), tol=2e-4, what='eval before')
+        before = blk(to_act(x0)).clone()
+        ref.train(), blk.train()
+        ref(x1), blk(to_act(x1))                       # statistics only
+        ref.eval(), blk.eval()
+        after = blk(to_act(x0))
+        close(after, ref(x0), tol=2e-4, what='eval after recalibration')
+        assert float((after - before).abs().max()) > 1e-2      # (the statistics did move)
