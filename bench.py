@@ -72,9 +72,12 @@ def parse():
                     help='storage type of the activations: f32 = the reference arithmetic and the '
                          'headline metric (BASELINE configs[1]); bf16 = configs[2] mixed precision '
                          '(fp32 master weights, statistics, accumulation, outputs); f16: --eval only')
-    ap.add_argument('--grad-dtype', default='f32', choices=('f32', 'bf16'),
+    ap.add_argument('--grad-dtype', default=None, choices=('f32', 'bf16'),
                     help='dtype of the gradient all-reduce buckets on the wire (bf16: half the xGMI '
-                         'bytes, SURVEY 8e)')
+                         'bytes, SURVEY 8e).  Default: the storage type of the run -- f32 for --dtype '
+                         'f32, bf16 for --dtype bf16 (mixed precision: the gradients were computed '
+                         'from bf16 activations anyway; the fp32 master copy and the optimizer state '
+                         'stay fp32)')
     ap.add_argument('--h2d', action='store_true',
                     help='also time the same steps with every batch staged from pinned host memory '
                          '(raw uint8/uint16 frames, overlapped copy, on-device normalisation); '
@@ -85,6 +88,14 @@ def parse():
     ap.add_argument('--graph', action='store_true',
                     help='replay the step from a hipGraph: with --eval the whole-model forward '
                          '(BASELINE config 5 shape), otherwise the whole training step')
+    ap.add_argument('--protocol', default='resident', choices=('resident', 'reference'),
+                    help='--eval only.  resident (default): inputs in HBM before the timed region, '
+                         'K forward passes between two synchronisations.  reference: the timing '
+                         'protocol of /root/reference/inference_time_whole_model.py:297-347 -- per run '
+                         'one event pair around {host->device copy of the inputs, forward, '
+                         'device->host copy of every main output}, synchronised per run, '
+                         '--warmup (reference: 20) + --steps (80) runs, FPS = mean(1/t) +- std; '
+                         'reported as `reference_protocol` beside the resident value')
     ap.add_argument('--eager', action='store_true',
                     help='N > 1 only: keep the hook-driven eager step (default for N > 1 is the '
                          'segmented-hipGraph step: the eager 16-bit step is host-bound)')
@@ -187,6 +198,90 @@ def cpu_baseline(args):
                       f'{cores} threads, after {n_warm} warm-up iteration(s) ({warm:.1f}s)'}
 
 
+def reference_protocol(args, model, graphed, bs, dev):
+    """/root/reference/inference_time_whole_model.py:297-347 (`time_inference_pytorch`), run for run:
+    start event; inputs host -> device; forward; every main output (side outputs ignored, eval mode
+    has none) device -> host; end event; synchronise; t = elapsed.  Inputs are the reference's
+    random frames (`:519-545`): --warmup + --steps DIFFERENT samples, fps = mean(1 / t) +- std
+    (`:592`; `inference_time.bash:15-18` uses 20 + 80).  Two forms:
+      as_reference   pageable float32 NCHW host tensors (normalised on the host, as the reference's
+                     `.to(device)` sees them) and pageable `.cpu()` outputs -- the reference's loop
+                     with this engine's forward in the middle;
+      pinned_raw     what a deployment of this engine does: raw uint8 / uint16 frames in pinned host
+                     memory (1/4 .. 1/2 of the bytes), normalisation as device kernels, outputs into
+                     pinned host buffers.
+    The forward is the whole-model hipGraph when --graph is given, else the eager forward."""
+    from emsanet_amd.postprocessing import normalize_depth, normalize_rgb
+    n_warm, n_runs = args.warmup, args.steps
+    h, w = args.height, args.width
+    rng = np.random.default_rng(4242)
+
+    def main_outputs(out):
+        flat = []
+        for o, _ in out:
+            for t in (o if isinstance(o, tuple) else (o,)):
+                flat += list(t) if isinstance(t, tuple) else [t]
+        return flat
+
+    def forward(b):
+        if graphed is not None:
+            return graphed(b)
+        with torch.no_grad():
+            return model(b)
+
+    def run(kind):
+        frames = []
+        for _ in range(n_warm + n_runs):
+            rgb = rng.integers(0, 255, (bs, h, w, 3), dtype=np.uint8)
+            depth = rng.integers(0, 40000, (bs, h, w), dtype=np.uint16)
+            if kind == 'as_reference':
+                frames.append({'rgb': torch.from_numpy(np.ascontiguousarray(
+                    (rgb / 255).astype('float32').transpose(0, 3, 1, 2))),
+                    'depth': torch.from_numpy((depth.astype('float32') / 20000)[:, None].copy())})
+            else:
+                frames.append({'rgb': torch.from_numpy(rgb).pin_memory(),
+                               'depth': torch.from_numpy(depth).pin_memory()})
+        host_out = None
+        times, nbytes_in, nbytes_out = [], 0, 0
+        for i, f in enumerate(frames):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if kind == 'as_reference':
+                # (the graph's static input buffers are the destination of the host -> device copy)
+                b = f if graphed is not None else {k: v.to(dev) for k, v in f.items()}
+            else:
+                b = {'rgb': normalize_rgb(f['rgb'].to(dev, non_blocking=True),
+                                          mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)),
+                     'depth': normalize_depth(f['depth'].to(dev, non_blocking=True), 0.0, 20000.0,
+                                              keep_invalid_zero=False)}
+            outs = main_outputs(forward(b))
+            if kind == 'as_reference':
+                cpu = [t.cpu() for t in outs]
+            else:
+                if host_out is None:
+                    host_out = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in outs]
+                for d, t in zip(host_out, outs):
+                    d.copy_(t, non_blocking=True)
+                cpu = host_out
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= n_warm:
+                times.append(e0.elapsed_time(e1) / 1e3)
+            nbytes_in = sum(v.numel() * v.element_size() for v in f.values())
+            nbytes_out = sum(t.numel() * t.element_size() for t in cpu)
+        t = np.array(times)
+        return {'fps_mean': round(float(np.mean(1 / t)) * bs, 2), 'fps_std': round(float(np.std(1 / t)) * bs, 2),
+                'ms_mean': round(float(t.mean()) * 1e3, 4), 'ms_min': round(float(t.min()) * 1e3, 4),
+                'host_to_device_bytes': nbytes_in, 'device_to_host_bytes': nbytes_out}
+    res = {'protocol': 'ref inference_time_whole_model.py:297-347: per run {H2D inputs, forward, D2H main '
+                       f'outputs}} inside one event pair, synchronised per run; {n_warm} warm-up + {n_runs} '
+                       'timed runs on different random frames; fps = mean(1/t) +- std (x batch size)',
+           'forward': 'whole-model hipGraph replay' if graphed is not None else 'eager forward',
+           'as_reference': run('as_reference')}
+    res['pinned_raw'] = run('pinned_raw')
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher around it: become the launcher -- one process
     per GPU through torch.distributed.run on 127.0.0.1 (the same command line the driver uses),
@@ -267,6 +362,8 @@ def run(args):
         model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     # FusedSGD folds the 1/world averaging into its update kernel; torch's optimizer needs it done
+    if args.grad_dtype is None:
+        args.grad_dtype = 'bf16' if args.dtype == 'bf16' else 'f32'
     comm_dtype = {'f32': None, 'bf16': torch.bfloat16}[args.grad_dtype]
     dist_on = dist.is_initialized() and (world > 1 or args.force_dist)
     # several ranks: the default is the segmented-hipGraph step (one graph per backward segment,
@@ -435,6 +532,9 @@ def run(args):
                   'input': 'raw uint8 RGB + uint16 depth frames in pinned host memory, H2D on a copy '
                            'stream overlapped with the previous step, NormalizeRGB/NormalizeDepth + '
                            'HWC->CHW as device kernels'}
+    ref_protocol = None
+    if args.eval and args.protocol == 'reference' and world == 1:
+        ref_protocol = reference_protocol(args, model, graphed, bs, dev)
     comm = None
     if dist.is_initialized():
         # evidence that the ranks really ran and exchanged: every rank reports (rank, device index,
@@ -454,6 +554,8 @@ def run(args):
                 'allreduce_bytes_per_step': st['bytes'] // steps_seen,
                 'collectives_per_step': st['collectives'] // steps_seen,
                 'bucket_dtype': args.grad_dtype,
+                'rccl_env': __import__('emsanet_amd.parallel', fromlist=['rccl_env']).rccl_env(),
+                'conv_rs_cu_budget': getattr(buckets, 'rs_cu_budget', None),
                 'grads_written_in_place': st['direct_tensors'] // steps_seen,
                 'grads_gathered_by_copy': st['gathered_tensors'] // steps_seen,
                 'bucket_bytes': [f.numel() * f.element_size() for f, _, _ in buckets.buckets],
@@ -587,8 +689,8 @@ def run(args):
     roofline = None
     traffic, traffic_src = None, None
     pmc, pmc_file = None, None
-    pmc_names = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json') \
-        if args.dtype == 'f32' else (f'r04_pmc_traffic_{args.dtype}.json', f'r03_pmc_traffic_{args.dtype}.json')
+    pmc_names = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json') \
+        if args.dtype == 'f32' else (f'r05_pmc_traffic_{args.dtype}.json', f'r04_pmc_traffic_{args.dtype}.json')
     pmc_stale = None
     for name in pmc_names:                                             # newest measurement first
         try:
@@ -694,22 +796,43 @@ def run(args):
     head = (f'full EMSANet RGB-D ({args.backbone}-NBt1D x2, SE-add fusion, PPM, '
             f'semantic+instance+orientation+scene heads), {args.width}x{args.height}, bs={bs}/GPU, '
             f'{args.dtype}')
+    # which BASELINE.json config this run is (or that it is none of them)
+    at_640 = (args.height, args.width) == (480, 640)
+    if args.backbone == 'resnet101':
+        cfg = ('BASELINE.json configs[3] (ResNet-101-NBt1D dual encoder, 960x720 rounded up to the '
+               'next multiple of 32 rows, bs=16/GPU)' if (args.width, bs) == (960, 16) and args.height in (720, 736)
+               else 'ResNet-101-NBt1D variant (not a BASELINE.json config)')
+    elif args.eval and bs == 1 and at_640:
+        cfg = 'BASELINE.json configs[4] (inference, bs=1' + (', fp16' if args.dtype == 'f16' else
+                                                             f'; {args.dtype} instead of fp16') + ')'
+    elif at_640 and bs == 32 and args.backbone == 'resnet34':
+        cfg = f'BASELINE.json configs[{1 if args.dtype == "f32" else 2}]' + (' shape, inference' if args.eval else '')
+    else:
+        cfg = 'not a BASELINE.json config (other size / batch / backbone)'
     if args.eval:
-        # not the headline metric: configs[4] is the reference's bs=1 inference case, other batch
-        # sizes are the eval pass of the training configuration
-        workload = (f'BASELINE.json configs[{4 if bs == 1 else (1 if args.dtype == "f32" else 2)}] '
-                    f'shape, inference: {head}, eval mode (BatchNorm folded into the convolutions), '
+        workload = (f'{cfg}: {head}, eval mode (BatchNorm folded into the convolutions), '
                     'step = one forward pass' + (' replayed from a hipGraph' if args.graph else ''))
     else:
-        workload = (f'BASELINE.json configs[{1 if args.dtype == "f32" else 2}]: {head}, train mode '
+        workload = (f'{cfg}: {head}, train mode '
                     '(BN batch stats, Dropout2d), step = fwd + bwd ('
                     + ('all task losses on device' if args.losses else 'fixed output cotangents')
                     + ') + grad all-reduce + SGD-nesterov update'
                     + (' replayed from a hipGraph' if args.graph else ''))
+    if roofline is None and whole_step is not None and (args.eval or args.graph):
+        # no per-launch brackets (graph replay) or no dominant MFMA class (inference): the roofline
+        # position of the WHOLE step -- algorithmic bytes of all its launches / step time / 8 TB/s
+        gbps = whole_step['algo_gb_per_step'] / (dt / args.steps)
+        roofline = {'bound': 'hbm', 'kernel': 'whole step (every launch of one '
+                    + ('forward pass' if args.eval else 'training step') + ')',
+                    'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': round(gbps / HBM_PEAK_GBPS, 4), 'traffic': None,
+                    'algo_mb_per_step': round(whole_step['algo_gb_per_step'] * 1e3, 2),
+                    'launches': (graphed.graph_info['nodes'] if graphed is not None else None),
+                    'measured_over': 'the timed region (wall clock between two synchronisations)'}
 
     out = {
-        'metric': 'images/sec (640x480 RGB-D, bs=32/GPU) ' + ('forward (inference)' if args.eval
-                                                               else 'fwd+bwd'),
+        'metric': f'images/sec ({args.width}x{args.height} RGB-D, bs={bs}/GPU) '
+                  + ('forward (inference)' if args.eval else 'fwd+bwd'),
         'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -724,7 +847,9 @@ def run(args):
                    'global_batch': bs * world, 'parallelism': f'dp{world}',
                    'weights': 'random init (deterministic)',
                    'mode': ('eval-fwd-hipgraph' if args.graph else 'eval-fwd') if args.eval
-                   else ('train+losses' if args.losses else 'train') + ('-hipgraph' if args.graph else '')},
+                   else ('train+losses' if args.losses else 'train')
+                   + ('-hipgraph' if args.graph and not graph_fallback else '')
+                   + ('-eager-after-failed-capture' if graph_fallback else '')},
         'roofline': roofline,
         'whole_step': whole_step,
         'roofline_by_class': by_class,
@@ -736,13 +861,15 @@ def run(args):
         'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         'comm': comm,
         # nodes of the captured hipGraph(s) replayed per step (memset nodes replaced by fill kernels)
-        'hipgraph': ({'graphs': 1, 'nodes': [graphed.graph_info['nodes']]} if graphed is not None
+        'hipgraph': ({'graphs': 1, 'nodes': [graphed.graph_info['nodes']],
+                      'memset_nodes_replaced_by_kernels': graphed.graph_info['replaced']} if graphed is not None
                      else {'graphs': len(getattr(train_graph, 'graph_info', None) or [1]),
                            'nodes': [i['nodes'] for i in train_graph.graph_info]
                            if isinstance(train_graph.graph_info, list)
                            else [train_graph.graph_info['nodes']]} if train_graph is not None else None),
         'input': 'resident in HBM before the timed region',
         'h2d_staged': staged,
+        'reference_protocol': ref_protocol,
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args)

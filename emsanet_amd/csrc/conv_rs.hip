@@ -23,7 +23,11 @@
 //     residual, ReLU, ReLU-backward mask, fused BatchNorm-backward sums), taken from fp32 values in
 //     an LDS stage so that every global access is 16 bytes per lane / full 128-byte lines.
 // HBM traffic = input + output once; L2 -> LDS traffic = input x (C_out / channels per workgroup).
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "common.h"
 #include "prof.h"
@@ -651,15 +655,36 @@ struct RSPlan {
   int ni = 0, abuf = 0, lds = 0, bacc_off = 0, gx = 0, nslice = 0, sign = 1;
 };
 
+// CUs the persistent grid is planned for: the current device's count (cached per device; several
+// devices / threads in one process are fine -- ADVICE r4), capped by the CU budget (EMSA_RS_CUS or
+// emsa_conv_rs_set_cu_budget: room for co-resident collective kernels, see functional.py)
+constexpr int kMaxDev = 64;
+std::atomic<int> g_dev_cus[kMaxDev];
+std::atomic<int> g_cu_budget{-1};       // -1: not initialised (EMSA_RS_CUS read on first use), 0: none
+
+int rs_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  return dev;
+}
+
 int rs_cu_count() {
-  static int cus = 0;
+  const int dev = rs_device();
+  int cus = g_dev_cus[dev].load(std::memory_order_relaxed);
   if (!cus) {
-    int dev = 0;
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
-      cus = pr.multiProcessorCount;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
     if (cus <= 0) cus = 256;
+    g_dev_cus[dev].store(cus, std::memory_order_relaxed);
   }
+  int budget = g_cu_budget.load(std::memory_order_relaxed);
+  if (budget < 0) {
+    const char* e = getenv("EMSA_RS_CUS");
+    budget = e ? atoi(e) : 0;
+    if (budget < 0) budget = 0;
+    g_cu_budget.store(budget, std::memory_order_relaxed);
+  }
+  if (budget > 0 && budget < cus) cus = budget < 8 ? 8 : budget;
   return cus;
 }
 
@@ -767,14 +792,15 @@ int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
   const dim3 grid(8 * pl.gx * pl.nslice, pair ? 2 : 1), block(64 * WM * WN * WK);
   const bool epi = a.residual != nullptr || a.mask_src != nullptr;
   auto go = [&](void (*kern)(const ConvRSArgs)) {
-    // more than 64 KB of dynamic LDS has to be asked for, once per kernel
-    static const void* seen[160];
-    static int n_seen = 0;
-    bool known = false;
-    for (int i = 0; i < n_seen; ++i) known = known || seen[i] == (const void*)kern;
-    if (!known) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (n_seen < 160) seen[n_seen++] = (const void*)kern;
+    // more than 64 KB of dynamic LDS has to be asked for, once per kernel AND device (the
+    // cache was process-wide and unguarded -- a second GPU or thread could launch without it)
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> seen;
+    const std::pair<int, const void*> key(rs_device(), (const void*)kern);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (seen.insert(key).second)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     hipLaunchKernelGGL(kern, grid, block, pl.lds, st, a);
   };
@@ -921,6 +947,13 @@ extern "C" int emsa_conv1d_rs_dbg_read(long long* host, int n_entries) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rs_dbg), (size_t)n_entries * 8) == hipSuccess ? 0 : -3;
 }
 #endif
+
+// cus <= 0: no budget (all CUs of the device).  Returns the CU count conv_rs now plans with.  The
+// statistics-row count of a launch depends on it: re-query emsa_conv1d_rs_stats_rows afterwards.
+extern "C" int emsa_conv_rs_set_cu_budget(int32_t cus) {
+  g_cu_budget.store(cus > 0 ? cus : 0, std::memory_order_relaxed);
+  return rs_cu_count();
+}
 
 extern "C" int emsa_conv1d_rs_supported(int32_t dtype, const EmsaConvGeom* g) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return 0;

@@ -2231,10 +2231,17 @@ extern "C" int emsa_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const int8
 // with a handful of workgroups each walking its chunk a few rows at a time (batch-1 inference: 300
 // pixels x 512 channels was ONE workgroup of 4 row lanes x 75 dependent steps, 26 us in a graph whose
 // other nodes take 5; the /2 map 15.7 us on 128 workgroups): then 64-pixel chunks, at most 256.
-// (A rule of the map size alone -- every sample summed in the same order whatever its batch -- was
-//  tried: it re-partitions the sums of the training shapes too, and the bf16 train-mode gates of
-//  tests/test_model16_gpu.py, which sit on one draw of a chaotic system, moved: an SE hidden unit
-//  flipped against the oracle's.  The training partitions therefore stay what they were.)
+// The rule depends on the BATCH (n * splits <= 64), so the order in which one sample's pixels are
+// summed differs between batch sizes wherever the coarse partition leaves <= 64 workgroups: batch-1
+// inference at every stage, and also the /32 maps of a batch-32 step (300 pixels: 1 chunk coarse,
+// 32 workgroups -> 5 chunks of 64).  Per-sample results therefore depend on the batch size at fp32
+// rounding level: measured 1.0e-4 of the tensor magnitude on the tanh offset map between batch 1 and
+// batch 32 (<= 4e-5 on the other outputs; tests/test_model_gpu.py::
+// test_full_size_batch_consistency_and_determinism gates 2e-4).  (A rule of the map size alone --
+// every sample summed in the same order whatever its batch -- was tried: it re-partitions the /4 ..
+// /16 sums of the training shapes too, and the bf16 train-mode gates of tests/test_model16_gpu.py,
+// which sit on one draw of a chaotic system, moved: an SE hidden unit flipped against the oracle's.
+// Those partitions stay what they were)
 static int channel_splits(long hw, int n) {
   int splits = (int)((hw + 511) / 512);
   if (splits > 64) splits = 64;

@@ -225,11 +225,28 @@ def rs_supported(code, g):
     if not CONV_RS or code == 0:
         return False
     r = getattr(g, '_rs', None)
-    if r is None or r[0] != code:
+    if r is None or r[0] != code or r[3] != RS_EPOCH:
         ok = _lib.lib().emsa_conv1d_rs_supported(code, g) == 1
-        r = (code, ok, _lib.lib().emsa_conv1d_rs_stats_rows(code, g) if ok else 0)
+        r = (code, ok, _lib.lib().emsa_conv1d_rs_stats_rows(code, g) if ok else 0, RS_EPOCH)
         g._rs = r
     return r[1]
+
+
+# The persistent grid of conv_rs is sized to the CUs of the device; a CU budget below that leaves
+# room for kernels that must be co-resident for the whole step -- RCCL's all-reduce workgroups when
+# several ranks train (a collective's channels must not queue behind a
+# 2-workgroups-per-CU persistent grid whose static tile partition waits for its last workgroup).
+# EMSA_RS_CUS=n fixes it by hand; parallel.GradientBuckets sets it when the world has > 1 rank.  The
+# plans (statistics rows per launch) are cached per geometry: RS_EPOCH invalidates them.
+RS_EPOCH = 0
+
+
+def set_rs_cu_budget(cus):
+    """cus <= 0: all CUs.  -> the number of CUs conv_rs now plans with"""
+    global RS_EPOCH
+    got = _lib.lib().emsa_conv_rs_set_cu_budget(int(cus))
+    RS_EPOCH += 1
+    return got
 
 
 def _splitk_ws_bytes(code, g):

@@ -29,6 +29,18 @@ TRACE = None
 MASK_TRACE = None
 
 
+# tools/actgrad_compare.py: set to a dict to record, per convolution module (key: id(module)), the
+# gradient w.r.t. that convolution's OUTPUT as its backward kernels receive it -- the quantity a
+# tensor hook on the conv output gives in plain PyTorch -- to localise where activation gradients
+# of engine and oracle part
+GRAD_TRACE = None
+
+
+def _trace_grad(module, dy):
+    if GRAD_TRACE is not None:
+        GRAD_TRACE[id(module)] = dy.detach().float().cpu()
+
+
 def _trace_mask(tag, t):
     if MASK_TRACE is not None:
         MASK_TRACE.append((tag, t > 0))
@@ -488,6 +500,7 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=
     already carries that ReLU's mask (ConvRT.dgrad_bnb).  in_affine: the forward folded that
     BatchNorm + ReLU into the conv's loader (x = the BatchNorm's INPUT)"""
     conv = crt.conv
+    _trace_grad(conv, dy)
     # the gradients go straight into their flat all-reduce / optimizer bucket views when
     # GradientBuckets manages the parameters (no gather copy later)
     tw = grad_target(conv.weight)
@@ -904,6 +917,9 @@ class MultiConvFunction(Function):
         dy = Fn.as_act(dy)
         s = rt.spec
         Fn.prof_flops(rt.real_flops(x))
+        if GRAD_TRACE is not None:
+            for m, co, _ in rt.placements:            # (merged convs: each module's own channels)
+                _trace_grad(m, dy[:, co:co + m.weight.shape[0]])
         dwp, db, _ = Fn.conv_wgrad(x, dy, s, rt.has_bias)
         grads = []
         for m, co, ci in rt.placements:
@@ -974,6 +990,7 @@ class StemFunction(Function):
         dout = Fn.as_act(dout, dense=True)
         dy, _, dg, db = Fn.bn_bwd(dout, mask, y, rt.brt.bn.weight.detach(), mean, invstd, None,
                                   ACT_RELU, ctx.bn_train, want_dres=False, **_bn_targets(rt.brt))
+        _trace_grad(rt.conv, dy)
         res = Fn.stem_wgrad(xp, dy, rt.spec, n, h, w, rt.conv.weight,
                             out=grad_target(rt.conv.weight), want_bias=ctx.has_bias)
         dw, dbias = res if ctx.has_bias else (res, None)

@@ -45,6 +45,42 @@ def _join_engine_streams():
             cur.wait_stream(s)
 
 
+# CUs left free of the persistent conv_rs grid while several ranks train: RCCL's all-reduce kernel
+# lives through a whole collective on up to this many workgroups (one per channel), and a
+# 2-workgroups-per-CU persistent grid with a static tile partition would make either side queue
+# behind the other.  EMSA_RS_CUS (total CUs for conv_rs) overrides;
+# EMSA_RCCL_CUS sets the reserve (default 32: RCCL's channel count on a 7-link xGMI ring is <= 32).
+def reserve_cus_for_collectives():
+    """-> the CU count conv_rs now plans with (None: left alone)"""
+    import os
+    from . import functional as Fn
+    if os.environ.get('EMSA_RS_CUS'):
+        return int(os.environ['EMSA_RS_CUS'])
+    reserve = int(os.environ.get('EMSA_RCCL_CUS', '32'))
+    if reserve <= 0:
+        return None
+    total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return Fn.set_rs_cu_budget(max(8, total - reserve))
+
+
+def rccl_env():
+    """the RCCL / HSA settings that shape a multi-rank run, for the benchmark's JSON line"""
+    import os
+    keys = ('NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'NCCL_PROTO', 'NCCL_ALGO', 'NCCL_BUFFSIZE',
+            'NCCL_NTHREADS', 'NCCL_P2P_LEVEL', 'NCCL_IB_DISABLE', 'NCCL_DEBUG', 'RCCL_MSCCL_ENABLE',
+            'RCCL_MSCCLPP_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY', 'HSA_ENABLE_SDMA',
+            'HSA_FORCE_FINE_GRAIN_PCIE', 'GPU_MAX_HW_QUEUES', 'EMSA_RS_CUS', 'EMSA_RCCL_CUS',
+            'EMSA_DIST_BACKEND', 'OMP_NUM_THREADS')
+    env = {k: os.environ[k] for k in keys if k in os.environ}
+    ver = None
+    try:
+        v = torch.cuda.nccl.version()
+        ver = '.'.join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:       # noqa: BLE001
+        pass
+    return {'set': env, 'unset_means_library_default': True, 'rccl_version': ver}
+
+
 def grad_target(p):
     """The flat-bucket view this parameter's gradient should be written into by the backward
     kernel that produces it (so that neither the all-reduce nor the fused optimizer needs a
@@ -143,6 +179,9 @@ class GradientBuckets:
                 p._emsa_grad_slot = (v, self)
                 if self.active and not manual:
                     p.register_post_accumulate_grad_hook(self._hook)
+        self.rs_cu_budget = None
+        if self.world > 1 and params and params[0].is_cuda:
+            self.rs_cu_budget = reserve_cus_for_collectives()
         self.reset()
 
     ALIGN = 4        # elements: every tensor starts on a 16-byte boundary (float4 kernels read

@@ -578,7 +578,12 @@ int emsa_stem_pack_weight_t(int32_t dtype, const float* w, void* wp, int32_t cou
  *          of a channel slice; the rows carry (sum, M2, count) like emsa_conv_igemm's).
  * emsa_conv1d_rs_supported: 1 when this kernel takes the geometry (and EMSA_CONV_RS != 0), else 0 --
  * callers fall back to emsa_conv_igemm_t with the [tap][n][k] operand.
+ * emsa_conv_rs_set_cu_budget(cus): plan the persistent grid for `cus` CUs instead of all of them
+ * (<= 0: all; also EMSA_RS_CUS) so that long-lived co-resident kernels -- RCCL's all-reduce
+ * channels of a multi-rank step -- find free CU slots; returns the CU count now in use.  Changes
+ * emsa_conv1d_rs_stats_rows: query it again afterwards.
  * ------------------------------------------------------------------------------------------ */
+int emsa_conv_rs_set_cu_budget(int32_t cus);
 int emsa_conv1d_rs_supported(int32_t dtype, const EmsaConvGeom* g);
 int emsa_conv1d_rs_stats_rows(int32_t dtype, const EmsaConvGeom* g);
 int emsa_conv1d_rs_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* wfrag,

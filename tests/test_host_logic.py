@@ -22,8 +22,11 @@ class _FakeLib:
             if name in ('emsa_conv_stats_rows', 'emsa_conv1d_wino_stats_rows', 'emsa_bn_bwd_rows'):
                 return 3
             if name in ('emsa_channel_ws_floats', 'emsa_bn_finalize_ws_bytes',
-                        'emsa_ce_semantic_blocks', 'emsa_instance_loss_blocks'):
+                        'emsa_ce_semantic_blocks', 'emsa_instance_loss_blocks',
+                        'emsa_center_ws_entries'):
                 return 64
+            if name == 'emsa_center_candidates_max':
+                return 1024
             return 0
         return fn
 
