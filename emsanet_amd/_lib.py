@@ -71,6 +71,9 @@ SIGNATURES = {
                                c_int64, c_int64, _P]),
     'emsa_conv1d_wino_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P]),
     'emsa_conv_wgrad_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'emsa_conv_wgrad_multi_ws_bytes': (c_int64, [c_int32, c_int32, _GP]),
+    'emsa_conv_wgrad_multi_t': (c_int, [c_int32, c_int32, _GP, POINTER(c_void_p), POINTER(c_void_p),
+                                        POINTER(c_void_p), POINTER(c_void_p), _P, _P]),
     'emsa_pack_wino': (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
     'emsa_pack_batch': (c_int, [_P, c_int32, c_int32, _P]),
     'emsa_pack_wino_packed': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),

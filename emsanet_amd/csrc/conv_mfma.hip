@@ -1731,8 +1731,20 @@ __global__ __launch_bounds__(256, 3) EMSA_NO_LSOPT void conv_wgrad1d_h_kernel(co
 constexpr int kWT_PK = 64;                          // pixels per K step
 constexpr int kWT_RS = 96;                          // LDS row stride (elements) = 192 B
 constexpr int kWT_IMG = (kWT_PK + 2) * kWT_RS;      // one image: two front rows + 64 pixel rows
+// up to kWgradMultiMax independent weight gradients in ONE launch (grid.y = job): the four convs of
+// an NBt1D block (same channel count, same pixel count; ref emsanet/model.py:47-58).  A single launch
+// at the /16 and /32 stages is 64-256 output tiles split ~12x along K to fill the chip: every
+// workgroup then runs ~10 K steps between a cold prologue and a 48 KB partial-tile epilogue, and the
+// launch ends in a half-empty round.  Four jobs share the split budget (768 workgroups in total, not
+// per job): a quarter of the splits = a quarter of the partial-tile traffic and of the reduction
+// pass, four times the K steps per workgroup, one tail round instead of four.
+constexpr int kWgradMultiMax = 4;
+struct WgradMulti {
+  Wgrad1dArgs j[kWgradMultiMax];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dArgs p) {
+__device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int bid, const int nblk) {
   constexpr int BCO = 64, BCI = 64;
   constexpr uint32_t ES = sizeof(T);
   typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
@@ -1748,9 +1760,9 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave & 1, wci = wave >> 1;
 #if EMSA_W1D_XCD
-  const int wg = emsa_xcd_remap(blockIdx.x, gridDim.x);
+  const int wg = emsa_xcd_remap(bid, nblk);
 #else
-  const int wg = blockIdx.x;
+  const int wg = bid;
 #endif
   const int tile = wg % p.n_tiles, kr = (wg / p.n_tiles) % p.R;
   const int ks = wg / (p.n_tiles * p.R);
@@ -1980,23 +1992,32 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dAr
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dArgs p) {
+  wgrad1d_tr_body<T>(p, blockIdx.x, gridDim.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_multi_kernel(const WgradMulti m) {
+  wgrad1d_tr_body<T>(m.j[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
 // second pass of the deterministic split-K: dw[co][ci][t] (OIHW of a 3-tap 1-D conv) =
 // sum over splits of ws[split][tile][t][co_l][ci_l]; dbias[co] = sum of ws_bias[split][co].
 // workgroup = one (tile, t, co_l) row of 64 ci (16 float4 columns) x 16 split groups; the
 // workgroups behind the weight rows reduce the bias.  (A finer 8 x 32 split with 4 loads in
 // flight was slower on every layer shape: most split groups idle when there are few splits.)
-__global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
+__device__ __forceinline__ void wgrad1d_reduce_body(
     const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
     int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
-    float* __restrict__ dbias, int taps) {
+    float* __restrict__ dbias, int taps, const int bid) {
   // taps: 3 (1-D / 3x3 row taps) or 1 (1x1 convs of the 16-bit direct kernel)
   __shared__ float4 red[16][16];
   const int tid = threadIdx.x;
   const int rows = taps * 64, tile_f = taps * 4096;
   const int weight_blocks = n_tiles * R * rows;
-  if ((int)blockIdx.x < weight_blocks) {
+  if (bid < weight_blocks) {
     // workgroup = (kernel row kr, tile, row = t*64 + co_l); ws[split][kr][tile][t][co_l][ci_l]
-    const int kt = blockIdx.x / rows, row = blockIdx.x % rows;
+    const int kt = bid / rows, row = bid % rows;
     const int kr = kt / n_tiles, tile = kt % n_tiles;
     const int col = tid & 15, sg = tid >> 4;
     const float* src = ws + (size_t)kt * tile_f + row * 64 + col * 4;
@@ -2038,7 +2059,7 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
     // bias: 16 lanes x float4 = the tile's 64 channels, 16 split groups, 8 loads in flight (a
     // plain loop over the splits was the critical path of the whole pass for 64-channel layers:
     // 192 dependent round trips)
-    const int co_t = blockIdx.x - weight_blocks;
+    const int co_t = bid - weight_blocks;
     const int col = tid & 15, sg = tid >> 4;
     const float* src = ws_bias + (size_t)co_t * 64 + col * 4;
     const size_t sstride = (size_t)n_co_tiles * 64;
@@ -2075,16 +2096,16 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
 // for the 37.7 MB that take 8 us at 64-256 channels; 3x3 512->512: 31).  Here a thread owns one
 // float4 of one (tile, co_l) row and sums all splits of all R x taps weight rows itself, in the
 // split order of the kernel above for <= 16 splits (bit-identical): 16 rows per workgroup.
-__global__ __launch_bounds__(256) void wgrad1d_reduce_rows_kernel(
+__device__ __forceinline__ void wgrad1d_reduce_rows_body(
     const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
     int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
-    float* __restrict__ dbias, int taps) {
+    float* __restrict__ dbias, int taps, const int bid) {
   const int tid = threadIdx.x;
   const int tile_f = taps * 4096, nrt = R * taps;
   const int weight_blocks = n_tiles * 4;
   const int col = tid & 15, rw = tid >> 4;
-  if ((int)blockIdx.x < weight_blocks) {
-    const int tile = blockIdx.x >> 2, co_l = (blockIdx.x & 3) * 16 + rw;
+  if (bid < weight_blocks) {
+    const int tile = bid >> 2, co_l = (bid & 3) * 16 + rw;
     const size_t sstride = (size_t)R * n_tiles * tile_f;
     const int co = (tile / n_ci_tiles) * 64 + co_l;
     const int ci = (tile % n_ci_tiles) * 64 + col * 4;
@@ -2111,7 +2132,7 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_rows_kernel(
       }
     }
   } else if (dbias != nullptr && rw == 0) {
-    const int co_t = blockIdx.x - weight_blocks;
+    const int co_t = bid - weight_blocks;
     const float* src = ws_bias + (size_t)co_t * 64 + col * 4;
     const size_t sstride = (size_t)n_co_tiles * 64;
     float4 a = emsa_zero4();
@@ -2125,6 +2146,39 @@ __global__ __launch_bounds__(256) void wgrad1d_reduce_rows_kernel(
     if (co + 2 < n_ch) dbias[co + 2] = a.z;
     if (co + 3 < n_ch) dbias[co + 3] = a.w;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad1d_reduce_kernel(
+    const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
+    int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
+    float* __restrict__ dbias, int taps) {
+  wgrad1d_reduce_body(ws, ws_bias, splits, n_tiles, n_ci_tiles, n_co_tiles, n_ch, k_ch, R, dw, dbias,
+                      taps, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void wgrad1d_reduce_rows_kernel(
+    const float* __restrict__ ws, const float* __restrict__ ws_bias, int splits, int n_tiles,
+    int n_ci_tiles, int n_co_tiles, int n_ch, int k_ch, int R, float* __restrict__ dw,
+    float* __restrict__ dbias, int taps) {
+  wgrad1d_reduce_rows_body(ws, ws_bias, splits, n_tiles, n_ci_tiles, n_co_tiles, n_ch, k_ch, R, dw,
+                           dbias, taps, (int)blockIdx.x);
+}
+// the second pass of a multi-job launch: grid.y = job, everything but the four pointers is shared
+struct ReduceMulti {
+  const float* ws[kWgradMultiMax];
+  const float* ws_bias[kWgradMultiMax];
+  float* dw[kWgradMultiMax];
+  float* dbias[kWgradMultiMax];
+  int splits, n_tiles, n_ci_tiles, n_co_tiles, n_ch, k_ch, R, taps;
+};
+template <bool ROWS>
+__global__ __launch_bounds__(256) void wgrad1d_reduce_multi_kernel(const ReduceMulti m) {
+  const int j = blockIdx.y;
+  if constexpr (ROWS)
+    wgrad1d_reduce_rows_body(m.ws[j], m.ws_bias[j], m.splits, m.n_tiles, m.n_ci_tiles, m.n_co_tiles,
+                             m.n_ch, m.k_ch, m.R, m.dw[j], m.dbias[j], m.taps, (int)blockIdx.x);
+  else
+    wgrad1d_reduce_body(m.ws[j], m.ws_bias[j], m.splits, m.n_tiles, m.n_ci_tiles, m.n_co_tiles,
+                        m.n_ch, m.k_ch, m.R, m.dw[j], m.dbias[j], m.taps, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2573,6 +2627,116 @@ extern "C" int emsa_conv_wgrad_t(int32_t dtype, const EmsaConvGeom* g, const voi
     return conv_wgrad_impl<emsa_bf16>(g, (const emsa_bf16*)in, (const emsa_bf16*)dout, dw, dbias,
                                       ws, stream);
   return EMSA_E_ARG;
+}
+
+// ---- several weight gradients in one launch (16-bit storage, conv_wgrad1d_tr_kernel) ----------
+namespace {
+// all jobs: stride-1 3-tap 1-D (or 3x3) convs the transposing-read kernel takes, same channel counts
+// and kernel rows; common split count from ONE budget of 768 workgroups
+bool plan_wgrad_multi(int n_jobs, const EmsaConvGeom* geoms, Wgrad1dPlan* pls, int& ksplit) {
+  if (n_jobs < 2 || n_jobs > kWgradMultiMax || !wgrad16_tr()) return false;
+  for (int j = 0; j < n_jobs; ++j) {
+    const EmsaConvGeom* g = geoms + j;
+    if (!geom_ok(g) || geom_mapped(g) || g->div_h != 1 || g->div_w != 1) return false;
+    if (!direct16_geom(g) || !plan_wgrad1d(g, dout_is_aligned(g, nullptr), pls[j], 2, true)) return false;
+    if (pls[j].mode != 0) return false;
+    if ((g->k_ch & 7) || (g->n_ch & 7) || (g->ld_out & 7) || (g->in_px_stride & 7) ||
+        (g->in_row_stride & 7) || (g->in_img_stride & 7))
+      return false;
+    if (pls[j].w.n_tiles != pls[0].w.n_tiles || pls[j].w.R != pls[0].w.R ||
+        pls[j].w.n_ch != pls[0].w.n_ch || pls[j].w.k_ch != pls[0].w.k_ch)
+      return false;
+  }
+  const Wgrad1dArgs& w0 = pls[0].w;
+  int ks = 768 / (n_jobs * w0.n_tiles * w0.R);
+  for (int j = 0; j < n_jobs; ++j) {
+    const int max_split = (pls[j].w.steps_total + 3) / 4;
+    if (ks > max_split) ks = max_split;
+  }
+  if (ks < 1) ks = 1;
+  // every job gets the same number of splits (grid.x is shared): the LONGEST job fixes it
+  int n_split = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    Wgrad1dArgs& w = pls[j].w;
+    w.steps_per_split = (w.steps_total + ks - 1) / ks;
+    const int need = (w.steps_total + w.steps_per_split - 1) / w.steps_per_split;
+    if (need > n_split) n_split = need;
+  }
+  ksplit = n_split;           // (a job with fewer steps leaves its last split(s) empty: zero tiles)
+  for (int j = 0; j < n_jobs; ++j) pls[j].ksplit = n_split;
+  return true;
+}
+int64_t wgrad_multi_job_floats(const Wgrad1dPlan& pl) {
+  return (int64_t)pl.ksplit * ((int64_t)pl.w.n_tiles * pl.w.R * pl.w.taps * 4096 + (int64_t)pl.w.n_co_tiles * 64);
+}
+}  // namespace
+
+// workspace bytes of emsa_conv_wgrad_multi_t for these jobs; 0: this set of jobs has no multi-job
+// form (run them one by one through emsa_conv_wgrad_t)
+extern "C" int64_t emsa_conv_wgrad_multi_ws_bytes(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms) {
+  if (dtype != EMSA_DT_BF16 || !geoms) return 0;
+  Wgrad1dPlan pls[kWgradMultiMax];
+  int ks = 0;
+  if (!plan_wgrad_multi(n_jobs, geoms, pls, ks)) return 0;
+  int64_t fl = 0;
+  for (int j = 0; j < n_jobs; ++j) fl += wgrad_multi_job_floats(pls[j]);
+  return fl * (int64_t)sizeof(float);
+}
+
+// n_jobs (2 .. 4) weight (+ bias) gradients of convs with the same channel counts in one launch +
+// one reduction launch: in / dout / dw / dbias are arrays of n_jobs pointers (dbias[j] may be NULL),
+// geoms an array of n_jobs geometries, ws = emsa_conv_wgrad_multi_ws_bytes bytes.  Results are
+// written in the OIHW parameter layout like emsa_conv_wgrad_t's two-pass form (deterministic).
+extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
+                                       const void* const* in, const void* const* dout,
+                                       float* const* dw, float* const* dbias, float* ws,
+                                       void* stream) {
+  if (dtype != EMSA_DT_BF16) return EMSA_E_ARG;
+  if (!geoms || !in || !dout || !dw || !dbias || !ws) return EMSA_E_ARG;
+  Wgrad1dPlan pls[kWgradMultiMax];
+  int ks = 0;
+  if (!plan_wgrad_multi(n_jobs, geoms, pls, ks)) return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  WgradMulti m;
+  ReduceMulti r;
+  float* wsp = ws;
+  double flops = 0.0, bytes = 0.0;
+  for (int j = 0; j < kWgradMultiMax; ++j) {
+    const int k = j < n_jobs ? j : 0;             // (unused slots repeat job 0; never indexed)
+    if (j < n_jobs) {
+      const EmsaConvGeom* g = geoms + j;
+      if (!in[j] || !dout[j] || !dw[j]) return EMSA_E_ARG;
+      if ((((uintptr_t)in[j]) | ((uintptr_t)dout[j])) & 15) return EMSA_E_SHAPE;
+      Wgrad1dArgs& w = pls[j].w;
+      w.in = reinterpret_cast<const float*>(in[j]);
+      w.dout = reinterpret_cast<const float*>(dout[j]);
+      w.dw = dw[j];
+      w.dbias = dbias[j];
+      w.ws = wsp;
+      w.ws_bias = wsp + (size_t)ks * w.n_tiles * w.R * w.taps * 4096;
+      w.in_scale = w.in_shift = nullptr;
+      wsp += wgrad_multi_job_floats(pls[j]);
+      flops += algo_flops(*g);
+      bytes += (double)g->n_img * g->in_h * g->in_w * g->k_ch * 2.0 +
+               (double)g->n_img * g->out_h * g->out_w * g->n_ch * 2.0 + (double)g->kh * g->kw * g->n_ch * g->k_ch * 4.0;
+    }
+    m.j[j] = pls[k].w;
+    r.ws[j] = pls[k].w.ws; r.ws_bias[j] = pls[k].w.ws_bias; r.dw[j] = pls[k].w.dw; r.dbias[j] = pls[k].w.dbias;
+  }
+  const Wgrad1dArgs& w0 = pls[0].w;
+  r.splits = ks; r.n_tiles = w0.n_tiles; r.n_ci_tiles = w0.n_ci_tiles; r.n_co_tiles = w0.n_co_tiles;
+  r.n_ch = w0.n_ch; r.k_ch = w0.k_ch; r.R = w0.R; r.taps = w0.taps;
+  const int ps = prof_begin(kProfClassWgradH, flops, st, bytes);
+  hipLaunchKernelGGL((conv_wgrad1d_tr_multi_kernel<emsa_bf16>), dim3(w0.n_tiles * w0.R * ks, n_jobs),
+                     dim3(256), (size_t)2 * kWT_IMG * sizeof(emsa_bf16), st, m);
+  if (ks <= 16 && w0.n_tiles >= 32)
+    hipLaunchKernelGGL((wgrad1d_reduce_multi_kernel<true>), dim3(w0.n_tiles * 4 + w0.n_co_tiles, n_jobs),
+                       dim3(256), 0, st, r);
+  else
+    hipLaunchKernelGGL((wgrad1d_reduce_multi_kernel<false>),
+                       dim3(w0.n_tiles * w0.R * w0.taps * 64 + w0.n_co_tiles, n_jobs), dim3(256), 0, st, r);
+  prof_end(ps, st);
+  return emsa_launch_status();
 }
 
 // ---- profiling C-ABI -------------------------------------------------------------------------

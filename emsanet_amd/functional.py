@@ -7,6 +7,7 @@ NHWC (torch "channels_last"), possibly a channel slice of a wider NHWC buffer (p
 `ld` >= C).  torch is used here for device memory and the current stream only; every byte of
 arithmetic happens in the HIP kernels.
 """
+import ctypes
 import os
 
 import torch
@@ -757,6 +758,60 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db
     if ws is not None:
         return dw.view(like.shape), db, False
     return dw, db, True
+
+
+# Weight gradients of one NBt1D block in ONE launch (bf16 storage; csrc/conv_mfma.hip
+# emsa_conv_wgrad_multi_t): the block's four convs have the same channel count and pixel count, their
+# weight gradients are off the critical path of the backward pass (nothing waits for them but the
+# optimizer) and each alone is a launch of 64-256 output tiles split ~12x along K.  EMSA_WGRAD_MULTI=0
+# keeps one launch per conv.
+WGRAD_MULTI = os.environ.get('EMSA_WGRAD_MULTI', '1') != '0'
+WGRAD_MULTI_MAX = 4
+
+
+def wgrad_multi_eligible(x, spec):
+    return (WGRAD_MULTI and x.dtype == torch.bfloat16 and deterministic_wgrad() and spec.sh == 1 and
+            spec.sw == 1 and (spec.kh, spec.kw, spec.ph, spec.pw) in ((3, 1, 1, 0), (1, 3, 0, 1)) and
+            spec.cin % 8 == 0 and spec.cout % 8 == 0)
+
+
+def conv_wgrad_multi(jobs):
+    """jobs: [(x, dy, spec, like, dw_out, db_out, want_bias)] of `wgrad_multi_eligible` convs with the
+    same channel counts -> [(dw (parameter layout), dbias or None)] per job, or None when the library
+    has no multi-job form for this set (caller: one conv_wgrad per job)"""
+    n_jobs = len(jobs)
+    if n_jobs < 2 or n_jobs > WGRAD_MULTI_MAX:
+        return None
+    L = _lib.lib()
+    geoms = (_lib.EmsaConvGeom * n_jobs)()
+    for j, (x, dy, spec, *_rest) in enumerate(jobs):
+        n, c, h, w = x.shape
+        if x.dtype != dy.dtype:
+            raise _lib.EmsaError(f"weight gradient of {x.dtype} activations with a {dy.dtype} gradient")
+        g = spec.geom_fwd(n, h, w, ld_of(x), ld_of(dy))
+        ctypes.memmove(ctypes.byref(geoms[j]), ctypes.byref(g), ctypes.sizeof(_lib.EmsaConvGeom))
+    code = dt(jobs[0][0])
+    ws_bytes = L.emsa_conv_wgrad_multi_ws_bytes(code, n_jobs, geoms)
+    if ws_bytes <= 0:
+        return None
+    dev = jobs[0][0].device
+    ws = _empty((ws_bytes // 4,), dev)
+    arr = lambda: (ctypes.c_void_p * n_jobs)()          # noqa: E731
+    a_in, a_dy, a_dw, a_db = arr(), arr(), arr(), arr()
+    outs = []
+    for j, (x, dy, spec, like, dw_out, db_out, want_bias) in enumerate(jobs):
+        nw = spec.kh * spec.kw * spec.cout * spec.cin
+        if dw_out is not None and (db_out is not None or not want_bias):
+            dw, db = dw_out.view(-1), db_out
+        else:
+            buf = _empty((nw + (spec.cout if want_bias else 0),), dev)
+            dw = buf[:nw]
+            db = buf[nw:] if want_bias else None
+        a_in[j], a_dy[j], a_dw[j], a_db[j] = _p(x), _p(dy), _p(dw), _p(db)
+        outs.append((dw.view(like.shape), db))
+    check(L.emsa_conv_wgrad_multi_t(code, n_jobs, geoms, a_in, a_dy, a_dw, a_db, _p(ws), _stream()),
+          'emsa_conv_wgrad_multi_t')
+    return outs
 
 
 # ---------------------------------------------------------------------------------------------

@@ -493,24 +493,134 @@ def _bn_targets(brt):
     return {'dg_out': tg, 'db_out': tb} if tg is not None and tb is not None else {}
 
 
-def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None, bnb=None,
-                   in_affine=None):
-    """-> dx (or None), dw (OIHW), dbias (or None); with bnb = (t, (scale, shift), mean, invstd) of
-    the BatchNorm+ReLU in front of the conv: -> dx, dw, dbias, (partial, rows) or None -- dx then
-    already carries that ReLU's mask (ConvRT.dgrad_bnb).  in_affine: the forward folded that
-    BatchNorm + ReLU into the conv's loader (x = the BatchNorm's INPUT)"""
+# EMSA_WGRAD_STREAM=1 / 2: the (deferred) weight gradients of the NBt1D blocks run on a side stream of
+# LOW (1) / default (2) priority that joins the issuing stream when the backward pass ends.  The idea
+# (round 5): the backward critical path alternates matrix-bound data gradients with HBM-bound
+# BatchNorm passes; weight gradients are matrix-bound and nothing but the optimizer waits for them,
+# so at low queue priority they can take the CU slots the HBM-bound passes leave idle instead of
+# extending the critical path.  (Rounds 2 / 3 measured a plain second stream at default priority,
+# joined per block, SLOWER: the weight gradients then displace their own block's data gradients.)
+WGRAD_STREAM = int(os.environ.get('EMSA_WGRAD_STREAM', '0'))
+_wgrad_sides = {}          # id of the issuing stream -> side stream
+_wgrad_pending = []        # side streams with work of the current backward pass
+
+
+def _wgrad_side(cur):
+    key = (cur.device.index, cur.cuda_stream)
+    side = _wgrad_sides.get(key)
+    if side is None:
+        lo, hi = 0, 0
+        try:
+            # (torch: smaller number = higher priority; ROCm exposes low = +1 where the runtime has it)
+            side = torch.cuda.Stream(device=cur.device, priority=1 if WGRAD_STREAM == 1 else 0)
+        except Exception:                       # noqa: BLE001
+            side = torch.cuda.Stream(device=cur.device)
+        _wgrad_sides[key] = side
+        from .parallel import register_stream
+        register_stream(side)
+    return side
+
+
+def _join_wgrad_streams():
+    cur = torch.cuda.current_stream()
+    while _wgrad_pending:
+        cur.wait_stream(_wgrad_pending.pop())
+
+
+class _Deferred:
+    """placeholder of a weight / bias gradient whose launch was deferred (`_flush_wgrads`)"""
+
+    def __init__(self, index, which):
+        self.index, self.which = index, which
+
+
+_in_side = False
+
+
+class _SideGuard:
+    def __enter__(self):
+        global _in_side
+        _in_side = True
+
+    def __exit__(self, *exc):
+        global _in_side
+        _in_side = False
+
+
+def _wgrad_now(x, dy, crt, tw, tb, in_affine=None):
     conv = crt.conv
-    _trace_grad(conv, dy)
-    # the gradients go straight into their flat all-reduce / optimizer bucket views when
-    # GradientBuckets manages the parameters (no gather copy later)
-    tw = grad_target(conv.weight)
-    tb = grad_target(conv.bias) if conv.bias is not None else None
     dw, db, packed = Fn.conv_wgrad(x, dy, crt.spec, conv.bias is not None, like=conv.weight,
                                    dw_out=tw, db_out=tb, in_affine=in_affine)
     if packed:
         dw = Fn.unpack_wgrad(dw, conv.weight, out=tw)
     elif tw is not None and dw.data_ptr() == tw.data_ptr():
         dw = tw
+    return dw, db
+
+
+def _flush_wgrads(defer, grads):
+    """launch the deferred weight gradients -- convs of equal channel counts together in one
+    multi-job launch (Fn.conv_wgrad_multi; the four convs of an NBt1D block), the rest one by one --
+    and put the results in the places their `_Deferred` placeholders hold in `grads`"""
+    if not defer:
+        return grads
+    if WGRAD_STREAM and defer[0][0].is_cuda and not _in_side:
+        cur = torch.cuda.current_stream()
+        side = _wgrad_side(cur)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), _SideGuard():
+            out = _flush_wgrads(defer, grads)
+        for x, dy, *_ in defer:                 # (the caching allocator must not recycle them early)
+            x.record_stream(side)
+            dy.record_stream(side)
+        if not _wgrad_pending:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad_streams)
+        if side not in _wgrad_pending:
+            _wgrad_pending.append(side)
+        return out
+    res = [None] * len(defer)
+    groups = {}
+    for i, job in enumerate(defer):
+        ok = job[5] is None and Fn.wgrad_multi_eligible(job[0], job[2].spec)
+        groups.setdefault((job[2].spec.cin, job[2].spec.cout) if ok else ('single', i), []).append(i)
+    for idx in groups.values():
+        for k in range(0, len(idx), Fn.WGRAD_MULTI_MAX):
+            part = idx[k:k + Fn.WGRAD_MULTI_MAX]
+            out = None
+            if len(part) >= 2:
+                out = Fn.conv_wgrad_multi([(defer[i][0], defer[i][1], defer[i][2].spec,
+                                            defer[i][2].conv.weight, defer[i][3], defer[i][4],
+                                            defer[i][2].conv.bias is not None) for i in part])
+            if out is None:
+                for i in part:
+                    x, dy, crt, tw, tb, aff = defer[i]
+                    res[i] = _wgrad_now(x, dy, crt, tw, tb, aff)
+            else:
+                for i, (dw, db) in zip(part, out):
+                    tw = defer[i][3]
+                    res[i] = (tw if tw is not None and dw.data_ptr() == tw.data_ptr() else dw, db)
+    return [res[g.index][g.which] if isinstance(g, _Deferred) else g for g in grads]
+
+
+def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=None, bnb=None,
+                   in_affine=None, defer=None):
+    """-> dx (or None), dw (OIHW), dbias (or None); with bnb = (t, (scale, shift), mean, invstd) of
+    the BatchNorm+ReLU in front of the conv: -> dx, dw, dbias, (partial, rows) or None -- dx then
+    already carries that ReLU's mask (ConvRT.dgrad_bnb).  in_affine: the forward folded that
+    BatchNorm + ReLU into the conv's loader (x = the BatchNorm's INPUT).  defer: a list -- the
+    weight gradient is not launched here but queued (`_flush_wgrads`), dw / dbias are placeholders"""
+    conv = crt.conv
+    _trace_grad(conv, dy)
+    # the gradients go straight into their flat all-reduce / optimizer bucket views when
+    # GradientBuckets manages the parameters (no gather copy later)
+    tw = grad_target(conv.weight)
+    tb = grad_target(conv.bias) if conv.bias is not None else None
+    if defer is not None and (WGRAD_STREAM or (in_affine is None and
+                                               Fn.wgrad_multi_eligible(x, crt.spec))):
+        defer.append((x, dy, crt, tw, tb, in_affine))
+        dw, db = _Deferred(len(defer) - 1, 0), _Deferred(len(defer) - 1, 1)
+    else:
+        dw, db = _wgrad_now(x, dy, crt, tw, tb, in_affine)
     dx = None
     if bnb is not None:
         t, affine, mean, invstd = bnb
@@ -608,12 +718,14 @@ class NBt1DFunction(Function):
         dout = Fn.as_act(dout, dense=True)
         t1, t2, tds = ctx.bn_train
         need_dx = ctx.needs_input_grad[0]
+        defer = []           # the block's weight gradients: launched together at the end
 
         # out = relu(bn2(y4)*drop + idn)
         dy4, dres, dg2, db2 = Fn.bn_bwd(dout, k2, y4, rt.bn2.bn.weight.detach(), m2, is2, drop,
                                         ACT_RELU, t2, want_dres=True, **_bn_targets(rt.bn2))
         # conv1x3_2 (input y3 = relu(.)): ReLU mask fused into the dgrad epilogue
-        dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3, mask_bits=q3)
+        dz3, dw4, dbias4 = _conv_backward(y3, dy4, rt.c13_2, True, mask_src=y3, mask_bits=q3,
+                                          defer=defer)
         # conv3x1_2 (input a2 = relu(bn1(y2)))
         # the data gradient's epilogue applies bn1's ReLU mask and emits bn1's backward sums (one
         # pass over da2 and y2 less); falls back to the separate reduction pass
@@ -623,27 +735,29 @@ class NBt1DFunction(Function):
                                                      bnb=(y2, aff1, m1, is1), in_affine=aff1)
         else:
             da2, dw3, dbias3, fused = _conv_backward(a2, dz3, rt.c31_2, True,
-                                                     bnb=(y2, aff1, m1, is1))
+                                                     bnb=(y2, aff1, m1, is1), defer=defer)
         if fused is not None:
             dy2, dg1, db1 = Fn.bn_bwd_from_rows(da2, y2, rt.bn1.bn.weight.detach(), m1, is1,
                                                 fused[0], fused[1], t1, **_bn_targets(rt.bn1))
         else:
             dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
                                          ACT_RELU, t1, want_dres=False, **_bn_targets(rt.bn1))
-        dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1, mask_bits=q1)
+        dz1, dw2, dbias2 = _conv_backward(y1, dy2, rt.c13_1, True, mask_src=y1, mask_bits=q1,
+                                          defer=defer)
         grads = []
         if rt.cds is None:
             # identity skip: dx = dgrad(conv3x1_1) + dres, add fused into the epilogue
-            dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dres)
+            dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dres, defer=defer)
         else:
             dyd, _, dgd, dbd = Fn.bn_bwd(dres, None, yd, rt.bnds.bn.weight.detach(), md, isd,
                                          None, ACT_NONE, tds, want_dres=False,
                                          **_bn_targets(rt.bnds))
             dxd, dwd, _ = _conv_backward(x, dyd, rt.cds, need_dx)
-            dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dxd)
+            dx, dw1, dbias1 = _conv_backward(x, dz1, rt.c31_1, need_dx, residual=dxd, defer=defer)
         grads = [dw1, dbias1, dw2, dbias2, dg1, db1, dw3, dbias3, dw4, dbias4, dg2, db2]
         if rt.cds is not None:
             grads += [dwd, dgd, dbd]
+        grads = _flush_wgrads(defer, grads)
         return (dx, None, None) + tuple(grads)
 
 

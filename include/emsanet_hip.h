@@ -556,6 +556,17 @@ int emsa_bn_bwd_apply_rows_t(int32_t dtype, const void* g, const void* x, const 
 int64_t emsa_conv_wgrad_ws_bytes_t(int32_t dtype, const EmsaConvGeom* g);
 int emsa_conv_wgrad_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* dout,
                       float* dw, float* dbias, float* ws, void* stream);
+/* Several independent weight gradients in ONE launch + one reduction launch (bf16 activations):
+ * n_jobs = 2..4 stride-1 3-tap 1-D (or 3x3) convs with the same channel counts -- the four convs of
+ * an NBt1D block, /root/reference/emsanet/model.py:47-58 -- share one split-K budget (grid.y = job).
+ * geoms: array of n_jobs geometries; in / dout / dw / dbias: arrays of n_jobs pointers (dbias[j]
+ * may be NULL); ws: emsa_conv_wgrad_multi_ws_bytes bytes (0 = no multi-job form for these jobs: run
+ * them through emsa_conv_wgrad_t).  Every job's result is what emsa_conv_wgrad_t's deterministic
+ * two-pass form gives up to the fp32 summation order of the splits. */
+int64_t emsa_conv_wgrad_multi_ws_bytes(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms);
+int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
+                            const void* const* in, const void* const* dout, float* const* dw,
+                            float* const* dbias, float* ws, void* stream);
 int emsa_pack_weight_t(int32_t dtype, const float* w, void* wp_fwd, void* wp_dgrad, int32_t cout,
                        int32_t cin, int32_t kh, int32_t kw, int32_t cout_total, int32_t cout_off,
                        int32_t cin_total, int32_t cin_off, void* stream);

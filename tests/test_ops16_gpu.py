@@ -220,6 +220,56 @@ def test_conv16_wgrad(cfg):
         close(db, b.grad, tol=2e-4, what='dbias16')
 
 
+@pytest.mark.parametrize('c,n,h,w,n_jobs', [(64, 2, 24, 40, 4), (128, 2, 13, 21, 4), (256, 3, 15, 20, 4),
+                                            (512, 2, 15, 20, 4), (512, 1, 8, 9, 3), (64, 1, 3, 5, 2),
+                                            (256, 32, 30, 40, 4)])
+def test_conv16_wgrad_multi(c, n, h, w, n_jobs):
+    """the weight gradients of an NBt1D block's convs in ONE launch (emsa_conv_wgrad_multi_t: grid.y =
+    job, one split-K budget; ref emsanet/model.py:47-58 -- conv3x1, conv1x3, conv3x1, conv1x3 of the
+    same channel count) against the fp64 reference of every job, written straight into `dw_out` /
+    `db_out` views like the flat gradient buckets hand out; odd lines, a job without a bias"""
+    Fn = _fn()
+    dtype = torch.bfloat16
+    kinds = [((3, 1), (1, 0)), ((1, 3), (0, 1)), ((3, 1), (1, 0)), ((1, 3), (0, 1))][:n_jobs]
+    jobs, refs = [], []
+    for j, (k, p) in enumerate(kinds):
+        x = rnd(n, c, h, w, seed=10 + j)
+        dy = rnd(n, c, h, w, seed=20 + j)
+        wt = torch.zeros(c, c, *k, dtype=torch.float64, requires_grad=True)
+        b = torch.zeros(c, dtype=torch.float64, requires_grad=True)
+        F.conv2d(q(x, dtype), wt, b, padding=p).backward(q(dy, dtype))
+        spec = Fn.ConvSpec(c, c, k, (1, 1), p)
+        like = torch.empty(c, c, *k, device=DEV)
+        want_bias = j != 2
+        flat = torch.full((like.numel() + c + 8,), float('nan'), device=DEV)
+        dw_out = flat[:like.numel()].view_as(like) if j != 1 else None       # (job 1: own buffers)
+        db_out = flat[like.numel() + 4:like.numel() + 4 + c] if (want_bias and j != 1) else None
+        jobs.append((act16(x, dtype), act16(dy, dtype), spec, like, dw_out, db_out, want_bias))
+        refs.append((wt.grad, b.grad if want_bias else None, flat, dw_out))
+    out = Fn.conv_wgrad_multi(jobs)
+    torch.cuda.synchronize()
+    assert out is not None and len(out) == n_jobs
+    for j, ((dw, db), (rw, rb, flat, dw_out)) in enumerate(zip(out, refs)):
+        close(dw, rw, tol=2e-4, what=f'multi wgrad job {j}')
+        if rb is not None:
+            close(db, rb, tol=2e-4, what=f'multi dbias job {j}')
+        else:
+            assert db is None
+        if dw_out is not None:
+            assert dw.data_ptr() == dw_out.data_ptr()
+            assert bool(torch.isnan(flat[-4:]).all())                       # nothing written past the views
+        # and what one launch per job gives (different split counts: fp32 summation order only)
+        x, dy, spec, like, _, _, wb = jobs[j]
+        dw1, db1, packed = Fn.conv_wgrad(x, dy, spec, wb, like=like, two_pass=True)
+        assert not packed
+        close(dw, dw1.double().cpu(), tol=2e-5, what=f'multi vs single job {j}')
+    # a set the library has no multi-job form for (channel counts differ): the caller falls back
+    a = jobs[0]
+    spec2 = Fn.ConvSpec(c, c * 2, (1, 3), (1, 1), (0, 1))
+    assert Fn.conv_wgrad_multi([a, (a[0], act16(rnd(n, c * 2, h, w, seed=5), dtype), spec2,
+                                    torch.empty(c * 2, c, 1, 3, device=DEV), None, None, True)]) is None
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_stem16(dtype):
     """7x7/2 stem on the fp32 NCHW network input: packed to 16-bit NHWC4, conv_h kernel, BN stats"""
