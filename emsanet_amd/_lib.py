@@ -64,6 +64,7 @@ SIGNATURES = {
                                          c_int32, c_int32, _P, _P, _P, _P]),
     'emsa_conv1d_wino': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P,
                                  _P, _P]),
+    'emsa_memset_async': (c_int, [_P, c_int32, c_int64, _P]),
     'emsa_graph_count_nodes': (c_int, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     'emsa_graph_replace_memsets': (c_int, [_P, POINTER(c_int32)]),
     'emsa_dropout2d_mask_batch': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_uint32, _P, _P]),

@@ -47,6 +47,15 @@ __global__ void emsa_graph_fill16_kernel(uint4* dst, unsigned int pattern, size_
 
 }  // namespace
 
+// hipMemsetAsync on `stream` (what torch issues for reduction semaphores / scratch: under stream
+// capture it becomes a MEMSET node -- tests use it to build memset chains for
+// emsa_graph_replace_memsets; the engine's own zero-fills are kernels, common.h emsa_zero_async)
+extern "C" int emsa_memset_async(void* dst, int32_t value, int64_t bytes, void* stream) {
+  if (!dst || bytes < 0) return EMSA_E_ARG;
+  return hipMemsetAsync(dst, value, (size_t)bytes, (hipStream_t)stream) == hipSuccess ? EMSA_OK
+                                                                                    : EMSA_E_LAUNCH;
+}
+
 // Counts the nodes of `graph` (a hipGraph_t) by kind.  n_nodes / n_memset / n_kernel may be NULL.
 extern "C" int emsa_graph_count_nodes(void* graph, int32_t* n_nodes, int32_t* n_memset,
                                       int32_t* n_kernel) {

@@ -714,6 +714,7 @@ int emsa_to_nhwc_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t c, 
  * and gradient buffers) as a fill KERNEL node with the same edges: captured memset nodes were
  * found to corrupt replays when eager memsets run in between (ROCm 7.2).
  * ------------------------------------------------------------------------------------------ */
+int emsa_memset_async(void* dst, int32_t value, int64_t bytes, void* stream);
 int emsa_graph_count_nodes(void* graph, int32_t* n_nodes, int32_t* n_memset, int32_t* n_kernel);
 int emsa_graph_replace_memsets(void* graph, int32_t* replaced);
 

@@ -997,11 +997,18 @@ def test_graph_memset_repair_handles_chained_memsets():
     src = torch.arange(1 << 16, device=DEV, dtype=torch.float32)
     out = torch.empty(1 << 16, device=DEV)
 
+    from emsanet_amd import _lib
+    L = _lib.lib()
+
+    def memset(t):          # (torch's own zero_() is a fill KERNEL; hipMemsetAsync captures as a MEMSET node)
+        _lib.check(L.emsa_memset_async(t.data_ptr(), 0, t.numel() * t.element_size(),
+                                       torch.cuda.current_stream().cuda_stream), 'emsa_memset_async')
+
     def work():
         a.add_(src)                 # kernel in front of the chain
-        a.zero_()                   # memset 1
-        b.zero_()                   # memset 2, chained behind memset 1
-        a.zero_()                   # memset 3, same buffer again
+        memset(a)                   # memset 1
+        memset(b)                   # memset 2, chained behind memset 1
+        memset(a)                   # memset 3, same buffer again
         b.add_(src)                 # kernels behind the chain
         torch.add(a, b, out=out)
     side = torch.cuda.Stream()
