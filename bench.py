@@ -174,6 +174,20 @@ def cpu_baseline(args):
             p.grad = None
         flat = flatten_outputs(o(batch))
         torch.autograd.backward(flat, [torch.full_like(t, 1e-3) for t in flat])
+    # thread count: torch's default (all host cores) is the WORST choice for this workload on a
+    # many-core box -- 128 threads on the ~300 small convolutions of a step take 14x longer than 16
+    # (profiles/r05_oracle_threads.txt) -- so the baseline is timed with the fastest of a short
+    # sweep, two steps each (the first one of the sweep also warms allocator / oneDNN caches)
+    all_cores = os.cpu_count() or cores
+    sweep = {}
+    for nt in sorted({t for t in (8, 16, 32) if t <= all_cores} | ({all_cores} if all_cores <= 32 else set())):
+        torch.set_num_threads(nt)
+        step()
+        t1 = time.time()
+        step()
+        sweep[nt] = time.time() - t1
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     # 3 warm-up + 10 timed iterations; bounded so that the default run stays within
     # minutes on a slow host (warm-up: at most 30 s after the first iteration, timed: at least
     # 3 iterations, then until --cpu-seconds)
@@ -195,7 +209,9 @@ def cpu_baseline(args):
             'best_iteration_value': round(bs / min(times), 4),
             'sample': f'{n} timed fwd+bwd iteration(s) of the PyTorch-CPU oracle, bs={bs}, '
                       f'{args.width}x{args.height} RGB-D, all heads, train mode, fp32 oneDNN, '
-                      f'{cores} threads, after {n_warm} warm-up iteration(s) ({warm:.1f}s)'}
+                      f'{cores} threads (fastest of a sweep over '
+                      + ', '.join(f'{k}: {v:.2f} s/step' for k, v in sweep.items())
+                      + f'; the host has {all_cores} cores), after {n_warm} warm-up iteration(s) ({warm:.1f}s)'}
 
 
 def reference_protocol(args, model, graphed, bs, dev):

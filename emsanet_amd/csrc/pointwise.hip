@@ -246,7 +246,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int slices, in
 // One launch instead of two when the statistics arrive in few rows (<= 512: conv_rs.hip writes one
 // row per persistent workgroup; the /32 stage of the fp32 kernels; small images): level 1 and level 2 of the merge above in the same
 // workgroup, same fp64 arithmetic, same summation order per row group.
-__global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int rows, int c,
+template <int RG>
+__global__ __launch_bounds__(4 * RG) void bn_finalize_rows_kernel(const float* __restrict__ stats, int rows, int c,
                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                         float eps, float momentum, float* running_mean,
                                         float* running_var, float* __restrict__ scale,
@@ -255,13 +256,15 @@ __global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int row
   // 4 channels x 64 row groups per workgroup (grid = c / 4: 16 ... 128 workgroups), branch-free and
   // unrolled: <= 8 row iterations per thread, all loads of a thread in flight together.  (32 x 8
   // with a branch around empty rows ran 64 dependent L2 round trips: 21 us; 16 x 16 still 13-19.)
-  __shared__ double sh[3][64][4];
+  // RG = 64 row groups (<= 512 rows) or 256 (1024 threads; round 5: the fp32 kernels' 513 ... 4800
+  // per-tile rows too -- one launch of ~8 us instead of bn_partial + bn_finalize, 9 + 5 us)
+  __shared__ double sh[3][RG][4];
   const int cl = threadIdx.x & 3, rg = threadIdx.x >> 2;
   const int ch = blockIdx.x * 4 + cl;
   const int chc = ch < c ? ch : c - 1;
   double n = 0.0, s1 = 0.0, q = 0.0;
 #pragma unroll 8
-  for (int r = rg; r < rows; r += 64) {
+  for (int r = rg; r < rows; r += RG) {
     const float nbf = stats[((long)2 * rows + r) * c + chc];
     const float sbf = stats[((long)0 * rows + r) * c + chc];
     const float m2f = stats[((long)1 * rows + r) * c + chc];
@@ -273,9 +276,20 @@ __global__ void bn_finalize_rows_kernel(const float* __restrict__ stats, int row
   }
   sh[0][rg][cl] = n; sh[1][rg][cl] = s1; sh[2][rg][cl] = q;
   __syncthreads();
+  if constexpr (RG > 64) {
+    // second level in two steps: 16 threads per channel sum RG / 16 groups each, one thread the 16
+    // (a 256-step serial sum by one thread would be the tail of the wide form)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (rg < 16)
+      for (int k = rg; k < RG; k += 16) { a0 += sh[0][k][cl]; a1 += sh[1][k][cl]; a2 += sh[2][k][cl]; }
+    __syncthreads();
+    if (rg < 16) { sh[0][rg][cl] = a0; sh[1][rg][cl] = a1; sh[2][rg][cl] = a2; }
+    __syncthreads();
+  }
   if (rg != 0 || ch >= c) return;
   n = s1 = q = 0.0;
-  for (int k = 0; k < 64; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
+  constexpr int kLast = RG > 64 ? 16 : RG;
+  for (int k = 0; k < kLast; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
   const double mean = n > 0.0 ? s1 / n : 0.0;
   double m2 = q - s1 * mean;
   if (m2 < 0.0) m2 = 0.0;
@@ -2009,8 +2023,19 @@ extern "C" int emsa_bn_finalize(const float* stats, int32_t rows, int32_t c, int
   if (slices < 1) slices = 1;
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 512) {
-    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3((c + 3) / 4), dim3(256), 0, st, stats, rows, c,
+    hipLaunchKernelGGL(bn_finalize_rows_kernel<64>, dim3((c + 3) / 4), dim3(256), 0, st, stats, rows, c,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
+                       save_mean, save_invstd);
+    return emsa_launch_status();
+  }
+  // EMSA_BN_FINALIZE_WIDE=0: the two-launch form for > 512 rows (A/B)
+  static const bool wide = [] {
+    const char* e = getenv("EMSA_BN_FINALIZE_WIDE");
+    return !(e && e[0] == '0');
+  }();
+  if (wide && rows <= 8192) {
+    hipLaunchKernelGGL(bn_finalize_rows_kernel<256>, dim3((c + 3) / 4), dim3(1024), 0, st, stats, rows,
+                       c, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
                        save_mean, save_invstd);
     return emsa_launch_status();
   }

@@ -36,6 +36,8 @@ EMU_TOL = {torch.bfloat16: 2e-2, torch.float16: 3e-3}
 # train-mode model level (BatchNorm batch statistics renormalise the storage noise at every layer):
 # provisional gates, see the measured values printed by the test
 TRAIN_OUT_TOL, TRAIN_COS = 0.5, 0.95
+# frozen-BatchNorm (eval) gradients at 640x480: provisional until measured (the test prints them)
+EVAL_GRAD_OUT_TOL, EVAL_GRAD_COS_MEDIAN, EVAL_GRAD_COS_MIN = 0.1, 0.98, 0.8
 
 
 def _flatten(outs):
@@ -263,10 +265,108 @@ def test_train_bf16_pinned_gradients(shape, monkeypatch):
     # tensor has to clear both bounds, and 97 % of them the tight ratio band.
     worst = int(cos.argmin())
     assert cos.min().item() >= 0.9, (names[worst], cos.min().item())
+    # The norm ratio is NOT centred on 1: it climbs from 1.00 at the heads through every train-mode
+    # BatchNorm of the decoders to ~1.09 on every encoder tensor.  That is a
+    # property of the comparison, not of the kernels -- the oracle runs on the ENGINE's ReLU branch,
+    # where its pinned "ReLU" x * m is no rectifier of its own pre-activation (smaller mean, larger
+    # variance), and every batch-statistics BatchNorm returns that variance excess as a smaller
+    # gradient (profiles/r05_actgrad_*, r05_bn_stats_*).  The yardstick is the
+    # SAME experiment without any engine (tools/pin_artifact.py): an independent bf16-storage
+    # implementation (the emulating oracle in float32, on its own branch) against the fp64
+    # emulating oracle pinned to ITS decisions -- measured 1.1016 on the encoder tensors where the
+    # engine shows 1.0954, and 1.032 / 1.052 / 1.065 / 1.097 / 1.118 along the decoder where the
+    # engine shows 1.033 / 1.056 / 1.062 / 1.093 / 1.111.  Gate: the engine's gain follows the
+    # control's, at the encoder plateau and at the check points along the backward path.
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from pin_artifact import CHECKPOINTS, run_pair
+    ctrl = {k: r for k, r, _ in run_pair('emul32', 'emul64', hh, ww, bs, seed=321)[0]}
+    eng = dict(zip(names, ratio.tolist()))
+    enc = [k for k in names if k.startswith('encoder') and k in ctrl]
+    med_e = torch.tensor([eng[k] for k in enc]).median().item()
+    med_c = torch.tensor([ctrl[k] for k in enc]).median().item()
+    print("gradient-norm gain on %d encoder tensors: engine / pinned oracle median %.4f; two-oracle "
+          "control (no engine) %.4f; check points engine | control: %s" % (
+              len(enc), med_e, med_c,
+              ' '.join('%.3f|%.3f' % (eng[k], ctrl[k]) for k in CHECKPOINTS if k in eng and k in ctrl)))
+    assert abs(med_e - med_c) <= 0.04, (med_e, med_c)
+    for k in CHECKPOINTS:
+        if k in eng and k in ctrl:
+            assert abs(eng[k] - ctrl[k]) <= 0.04, (k, eng[k], ctrl[k])
     lo, hi = int(ratio.argmin()), int(ratio.argmax())
     assert ratio.min().item() >= 0.6 and ratio.max().item() <= 1.4, \
         (names[lo], ratio.min().item(), names[hi], ratio.max().item())
     assert ((ratio - 1.0).abs() <= 0.15).float().mean().item() >= 0.97
+
+
+def test_eval_bn_bf16_pinned_gradients_baseline_resolution(monkeypatch):
+    """bf16 engine with FROZEN BatchNorm statistics (model.eval(), gradients on: the `eval_grad` path)
+    at the BASELINE resolution 640x480 (bs 2: the conv_rs plans, patch tilings and launch set of
+    configs[2]) against the storage-emulating fp64 oracle on the engine's ReLU branch.  Without
+    batch statistics nothing renormalises the divergence of two bf16 roundings, so -- unlike the
+    train-mode case above, whose norm ratios carry the pinning artefact -- per-tensor gates can be
+    tight here: gradient-norm ratio centred on 1, cosine near 1."""
+    import torch.nn.functional as F
+    from emsanet_amd import full_args, ops
+    from oracle import emsanet_oracle as O
+    from test_model_gpu import _PinnedRelu
+    bs, hh, ww = 2, 480, 640
+    args = full_args(input_height=hh, input_width=ww)
+    model, oracle = _pair(args)
+    oracle = oracle.double()
+    model.set_compute_dtype(torch.bfloat16)
+    model.eval()
+    oracle.eval()
+    batch = O.synthetic_batch(bs, hh, ww)
+    ops.MASK_TRACE = []
+    try:
+        out = _flatten(model({k: v.to(DEV) for k, v in batch.items()}))
+        trace = ops.MASK_TRACE
+    finally:
+        ops.MASK_TRACE = None
+    pinned = _PinnedRelu(trace)
+    monkeypatch.setattr(F, 'relu', pinned)
+    monkeypatch.setattr(O.Spec, 'STORAGE', torch.bfloat16)
+    ref = _flatten(oracle({k: v.double() for k, v in batch.items()}))
+    assert pinned.i == len(trace)
+    eo = [_rel_l2(a, b) for a, b in zip(out, ref)]
+    cots = [rnd(*t.shape, seed=100 + i, scale=1e-1) for i, t in enumerate(ref)]
+    torch.autograd.backward(out, [c.to(DEV) for c in cots])
+    torch.autograd.backward(ref, [c.double() for c in cots])
+    monkeypatch.undo()
+    pr, mp = dict(oracle.named_parameters()), dict(model.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in pr.values() if p.grad is not None)
+    names, ratio, cos = [], [], []
+    for k, p in mp.items():
+        r = pr[k].grad
+        if p.grad is None or r is None or r.abs().max().item() < 1e-9 * gmax:
+            continue
+        assert torch.isfinite(p.grad).all(), k
+        g = p.grad.detach().cpu().double().flatten()
+        names.append(k)
+        ratio.append(g.norm().item() / r.norm().item())
+        cos.append(torch.dot(g, r.flatten()).item() / (g.norm().item() * r.norm().item()))
+    ratio, cos = torch.tensor(ratio), torch.tensor(cos)
+    enc = torch.tensor([k.startswith('encoder') for k in names])
+    print("bf16 eval-BN 640x480: outputs rel-L2 vs emulating oracle %s; %d gradients: norm ratio median "
+          "%.4f (encoder %.4f) p1 %.4f p99 %.4f min %.4f max %.4f; cosine median %.4f p1 %.4f min %.4f; "
+          "%d of %d ReLU decisions differ from the oracle's own" % (
+              ' '.join(f'{e:.1e}' for e in eo), len(names), ratio.median(), ratio[enc].median(),
+              ratio.quantile(0.01), ratio.quantile(0.99), ratio.min(), ratio.max(), cos.median(),
+              cos.quantile(0.01), cos.min(), pinned.flips, pinned.total))
+    import os
+    if os.path.isdir('gpurun_out'):
+        with open('gpurun_out/grad_ratio_bf16_evalbn_480x640.txt', 'w') as f:
+            for k, r_, c_ in zip(names, ratio.tolist(), cos.tolist()):
+                f.write(f"{r_:.4f} {c_:.4f} {k}\n")
+    assert max(eo) <= EVAL_GRAD_OUT_TOL, eo
+    assert abs(ratio.median().item() - 1.0) <= 0.02 and abs(ratio[enc].median().item() - 1.0) <= 0.02
+    assert cos.median().item() >= EVAL_GRAD_COS_MEDIAN
+    lo, hi, wc = int(ratio.argmin()), int(ratio.argmax()), int(cos.argmin())
+    assert ((ratio - 1.0).abs() <= 0.05).float().mean().item() >= 0.97, \
+        (names[lo], ratio.min().item(), names[hi], ratio.max().item())
+    assert cos.min().item() >= EVAL_GRAD_COS_MIN, (names[wc], cos.min().item())
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
