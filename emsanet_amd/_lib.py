@@ -182,6 +182,12 @@ SIGNATURES = {
     'emsa_up2x_dw3x3_fwd_pair_t': (c_int, [c_int32] + [_P] * 10 + [c_int32] * 4 + [_P]),
     'emsa_conv_igemm_pair_t': (c_int, [c_int32, _GP] + [_P] * 14 + [c_int32, c_int32, _P, _P, _P]),
     'emsa_conv_rs_set_cu_budget': (c_int, [c_int32]),
+    'emsa_nbt_half_block_supported': (c_int, [c_int32, c_int32, c_int32]),
+    'emsa_nbt_half_block_t': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                      POINTER(c_void_p), c_int32, POINTER(c_void_p), POINTER(c_void_p),
+                                      POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                      POINTER(c_void_p), POINTER(c_void_p), c_int32, POINTER(c_void_p),
+                                      c_int32, c_int32, _P]),
     'emsa_conv1d_rs_supported': (c_int, [c_int32, _GP]),
     'emsa_conv1d_rs_stats_rows': (c_int, [c_int32, _GP]),
     'emsa_conv1d_rs_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32,

@@ -421,6 +421,59 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
     return (res, bits) if want_relu_bits else res
 
 
+# Fused NBt1D half-block (csrc/conv_hb.hip): conv3x1 + ReLU -> conv1x3 + folded BatchNorm (+ residual)
+# + ReLU as ONE launch, for the small-batch 16-bit eval fast path where a launch is its fixed cost.
+# EMSA_HALF_BLOCK=0 / 1 forces it off / on at every size; default: up to HALF_BLOCK_MAX_PIXELS pixels
+# per map (bs * h * w at the block's resolution): beyond that the persistent conv_rs kernel is faster.
+_HALF_BLOCK_ENV = os.environ.get('EMSA_HALF_BLOCK')
+HALF_BLOCK = None                    # tests: True / False overrides
+HALF_BLOCK_MAX_PIXELS = 3 * 120 * 160
+
+
+def half_block_ok(x, c):
+    """this map (N, c, H, W) takes the fused half-block kernel"""
+    if x.dtype == torch.float32 or c not in (64, 128) or ld_of(x) != c:
+        return False
+    on = HALF_BLOCK if HALF_BLOCK is not None else (
+        _HALF_BLOCK_ENV != '0' if _HALF_BLOCK_ENV is not None else None)
+    if on is False:
+        return False
+    n, _, h, w = x.shape
+    if on is None and n * h * w > HALF_BLOCK_MAX_PIXELS:
+        return False
+    return _lib.lib().emsa_nbt_half_block_supported(dt(x), c, w) == 1
+
+
+def nbt_half_block(xs, wfa, bias_a, wfb, bias_b, scales, shifts, residuals, act=ACT_RELU):
+    """xs: 1 or 2 dense maps of the same shape (the twin modules); every other argument a sequence of
+    the same length (entries of bias / scale+shift / residual may be None) -> tuple of outputs"""
+    k = len(xs)
+    x0 = xs[0]
+    n, c, h, w = x0.shape
+    code = dt(x0)
+    for x in xs:
+        if x.shape != x0.shape or x.dtype != x0.dtype or ld_of(x) != c:
+            raise _lib.EmsaError("nbt_half_block: the tensor sets differ in shape / dtype / layout")
+    rs = [r for r in residuals if r is not None]
+    if rs and (len(rs) != k or any(ld_of(r) != ld_of(rs[0]) or r.dtype != x0.dtype for r in rs)):
+        raise _lib.EmsaError("nbt_half_block: residual operands differ between the tensor sets")
+    outs = [act_empty(n, c, h, w, x0.device, dtype=x0.dtype) for _ in range(k)]
+
+    def arr(ts):
+        a = (ctypes.c_void_p * k)()
+        for j, t in enumerate(ts):
+            a[j] = _p(t)
+        return a
+    for wf in list(wfa) + list(wfb):
+        if wf is None or wf.dtype != x0.dtype:
+            raise _lib.EmsaError("nbt_half_block: fragment-ordered weights missing for this dtype")
+    check(_lib.lib().emsa_nbt_half_block_t(
+        code, k, n, h, w, c, arr(xs), c, arr(wfa), arr(bias_a), arr(wfb), arr(bias_b), arr(scales),
+        arr(shifts), arr(residuals), ld_of(rs[0]) if rs else 0, arr(outs), c, act, _stream()),
+        'emsa_nbt_half_block_t')
+    return tuple(outs)
+
+
 def conv_fwd_pair(xs, wfrags, spec, biases=(None, None), scales=(None, None), shifts=(None, None),
                   residuals=(None, None), act=ACT_NONE):
     """two forward convs of ONE geometry (the rgb | depth encoders, the semantic | instance decoders)

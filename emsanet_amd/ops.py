@@ -761,18 +761,45 @@ class NBt1DFunction(Function):
         return (dx, None, None) + tuple(grads)
 
 
+def _half_block_specs(rt):
+    """the block's two half-blocks are conv3x1 -> conv1x3 pairs the fused kernel takes (stride 1, equal
+    channel counts); the first half of a down-sampling block is not"""
+    def ok(ca, cb):
+        sa, sb = ca.spec, cb.spec
+        return (Fn.rs_eligible(sa) and Fn.rs_eligible(sb) and (sa.kh, sa.kw) == (3, 1) and
+                (sb.kh, sb.kw) == (1, 3) and sa.cout == sb.cin)
+    return ok(rt.c31_1, rt.c13_1), ok(rt.c31_2, rt.c13_2)
+
+
+def _half(xs, cas, cbs, bns, residuals):
+    """one fused half-block launch over 1 or 2 tensor sets (Fn.nbt_half_block)"""
+    b = lambda c: c.conv.bias.detach() if c.conv.bias is not None else None   # noqa: E731
+    folds = [bn.folded() for bn in bns]
+    dtype = xs[0].dtype
+    return Fn.nbt_half_block(xs, [c.frag(dtype) for c in cas], [b(c) for c in cas],
+                             [c.frag(dtype) for c in cbs], [b(c) for c in cbs],
+                             [f[0] for f in folds], [f[1] for f in folds], residuals, ACT_RELU)
+
+
 def nbt1d_eval(x, rt):
-    """no-grad / eval fast path: both BatchNorms folded into the conv epilogues (4 launches)."""
+    """no-grad / eval fast path: both BatchNorms folded into the conv epilogues (4 launches; 2 where
+    the fused half-block kernel takes the map: small-batch 16-bit inference at C = 64 / 128)."""
     b = lambda c: c.conv.bias.detach()   # noqa: E731
-    y1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU)
-    s1, t1 = rt.bn1.folded()
-    a2 = rt.c13_1.forward(y1, bias=b(rt.c13_1), scale=s1, shift=t1, act=ACT_RELU)
-    y3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU)
+    h1, h2 = _half_block_specs(rt)
+    if h1 and Fn.half_block_ok(x, rt.c31_1.spec.cin):
+        (a2,) = _half([x], [rt.c31_1], [rt.c13_1], [rt.bn1], [None])
+    else:
+        y1 = rt.c31_1.forward(x, bias=b(rt.c31_1), act=ACT_RELU)
+        s1, t1 = rt.bn1.folded()
+        a2 = rt.c13_1.forward(y1, bias=b(rt.c13_1), scale=s1, shift=t1, act=ACT_RELU)
     if rt.cds is not None:
         sd, td = rt.bnds.folded()
         idn = rt.cds.forward(x, scale=sd, shift=td)
     else:
         idn = x
+    if h2 and Fn.half_block_ok(a2, rt.c31_2.spec.cin) and Fn.ld_of(idn) == idn.shape[1]:
+        return _half([a2], [rt.c31_2], [rt.c13_2], [rt.bn2], [idn])[0]
+    y3 = rt.c31_2.forward(a2, bias=b(rt.c31_2), act=ACT_RELU)
     s2, t2 = rt.bn2.folded()
     return rt.c13_2.forward(y3, bias=b(rt.c13_2), scale=s2, shift=t2, residual=idn, act=ACT_RELU)
 
@@ -812,18 +839,34 @@ def nbt1d_eval_pair(xa, xb, ra, rb):
     decoder) in lockstep: every conv both blocks share a geometry for is one twin launch (4 instead
     of 8 launches per block pair; at batch 1 a launch is its fixed cost).  Results == nbt1d_eval."""
     b = lambda c: c.conv.bias.detach()   # noqa: E731
-    y1a, y1b = _conv_pair(xa, xb, ra.c31_1, rb.c31_1, bias=(b(ra.c31_1), b(rb.c31_1)), act=ACT_RELU)
-    (s1a, t1a), (s1b, t1b) = ra.bn1.folded(), rb.bn1.folded()
-    a2a, a2b = _conv_pair(y1a, y1b, ra.c13_1, rb.c13_1, bias=(b(ra.c13_1), b(rb.c13_1)),
-                          scale=(s1a, s1b), shift=(t1a, t1b), act=ACT_RELU)
-    y3a, y3b = _conv_pair(a2a, a2b, ra.c31_2, rb.c31_2, bias=(b(ra.c31_2), b(rb.c31_2)), act=ACT_RELU)
     if (ra.cds is None) != (rb.cds is None):
         raise _lib.EmsaError("twin NBt1D blocks differ in their skip path")
+    h1a, h2a = _half_block_specs(ra)
+    h1b, h2b = _half_block_specs(rb)
+    same1 = ra.c31_1.spec_key() == rb.c31_1.spec_key() and ra.c13_1.spec_key() == rb.c13_1.spec_key()
+    same2 = ra.c31_2.spec_key() == rb.c31_2.spec_key() and ra.c13_2.spec_key() == rb.c13_2.spec_key()
+    twin_ok = xa.shape == xb.shape and xa.dtype == xb.dtype
+    if twin_ok and h1a and h1b and same1 and Fn.half_block_ok(xa, ra.c31_1.spec.cin) and \
+            Fn.half_block_ok(xb, rb.c31_1.spec.cin):
+        # one launch for both twins' first half-block (fused conv3x1 -> conv1x3, csrc/conv_hb.hip)
+        a2a, a2b = _half([xa, xb], [ra.c31_1, rb.c31_1], [ra.c13_1, rb.c13_1], [ra.bn1, rb.bn1],
+                         [None, None])
+    else:
+        y1a, y1b = _conv_pair(xa, xb, ra.c31_1, rb.c31_1, bias=(b(ra.c31_1), b(rb.c31_1)), act=ACT_RELU)
+        (s1a, t1a), (s1b, t1b) = ra.bn1.folded(), rb.bn1.folded()
+        a2a, a2b = _conv_pair(y1a, y1b, ra.c13_1, rb.c13_1, bias=(b(ra.c13_1), b(rb.c13_1)),
+                              scale=(s1a, s1b), shift=(t1a, t1b), act=ACT_RELU)
     if ra.cds is not None:
         (sda, tda), (sdb, tdb) = ra.bnds.folded(), rb.bnds.folded()
         ida, idb = _conv_pair(xa, xb, ra.cds, rb.cds, scale=(sda, sdb), shift=(tda, tdb))
     else:
         ida, idb = xa, xb
+    if h2a and h2b and same2 and a2a.shape == a2b.shape and Fn.half_block_ok(a2a, ra.c31_2.spec.cin) and \
+            Fn.half_block_ok(a2b, rb.c31_2.spec.cin) and Fn.ld_of(ida) == ida.shape[1] and \
+            Fn.ld_of(idb) == idb.shape[1]:
+        return _half([a2a, a2b], [ra.c31_2, rb.c31_2], [ra.c13_2, rb.c13_2], [ra.bn2, rb.bn2],
+                     [ida, idb])
+    y3a, y3b = _conv_pair(a2a, a2b, ra.c31_2, rb.c31_2, bias=(b(ra.c31_2), b(rb.c31_2)), act=ACT_RELU)
     (s2a, t2a), (s2b, t2b) = ra.bn2.folded(), rb.bn2.folded()
     return _conv_pair(y3a, y3b, ra.c13_2, rb.c13_2, bias=(b(ra.c13_2), b(rb.c13_2)),
                       scale=(s2a, s2b), shift=(t2a, t2b), residual=(ida, idb), act=ACT_RELU)

@@ -594,6 +594,21 @@ int emsa_stem_pack_weight_t(int32_t dtype, const float* w, void* wp, int32_t cou
  * channels of a multi-rank step -- find free CU slots; returns the CU count now in use.  Changes
  * emsa_conv1d_rs_stats_rows: query it again afterwards.
  * ------------------------------------------------------------------------------------------ */
+/* Fused NBt1D half-block for small-batch 16-bit inference (csrc/conv_hb.hip; the block is composed at
+ * /root/reference/emsanet/model.py:47-58, args.py:158-164):
+ *   out = act((conv1x3(relu(conv3x1(in) + bias_a)) + bias_b) * scale + shift + residual)
+ * as ONE launch for c = 64 / 128 -- the intermediate row stays in LDS.  n_sets = 1 or 2 independent
+ * tensor sets of the same shape (the twin modules: rgb | depth, semantic | instance); every pointer
+ * argument is an ARRAY of n_sets pointers (bias_*[k], scale[k] + shift[k], residual[k] may be NULL).
+ * wfa / wfb: fragment-ordered forward weights (emsa_pack_weight_frag_t).  Bit-identical to
+ * emsa_conv1d_rs_t on the 3x1 conv followed by emsa_conv1d_rs_t on the 1x3 conv. */
+int emsa_nbt_half_block_supported(int32_t dtype, int32_t c, int32_t w);
+int emsa_nbt_half_block_t(int32_t dtype, int32_t n_sets, int32_t n_img, int32_t h, int32_t w,
+                          int32_t c, const void* const* in, int32_t ld_in, const void* const* wfa,
+                          const float* const* bias_a, const void* const* wfb,
+                          const float* const* bias_b, const float* const* scale,
+                          const float* const* shift, const void* const* residual, int32_t ld_res,
+                          void* const* out, int32_t ld_out, int32_t act, void* stream);
 int emsa_conv_rs_set_cu_budget(int32_t cus);
 int emsa_conv1d_rs_supported(int32_t dtype, const EmsaConvGeom* g);
 int emsa_conv1d_rs_stats_rows(int32_t dtype, const EmsaConvGeom* g);

@@ -397,3 +397,77 @@ def test_up2x_pair_is_two_launches(cfg, dtype):
             assert torch.equal(pair[i], one)
     assert Fn.up2x_dw_fwd_pair(xs, ws, (bs[0], None), (None, None)) is None
     assert Fn.up2x_dw_fwd_pair([x.float() for x in xs], ws, (None, None), (None, None)) is None
+
+
+# channels, n, h, w: the /4 and /8 maps of the batch-1 forward (120 x 160, 60 x 80), widths off the
+# 32-pixel blocks, one-row and one-column maps, a second image
+HALF_BLOCKS = [(64, 1, 120, 160), (128, 1, 60, 80), (64, 2, 7, 33), (128, 3, 5, 30), (64, 1, 1, 9),
+               (128, 1, 9, 1), (64, 1, 23, 240)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('twin', [False, True])
+@pytest.mark.parametrize('cfg', HALF_BLOCKS)
+def test_nbt_half_block_is_two_launches(cfg, twin, dtype):
+    """the fused half-block (csrc/conv_hb.hip: conv3x1 + ReLU -> conv1x3 + folded BatchNorm (+ residual)
+    + ReLU, /root/reference/emsanet/model.py:47-58) == the two emsa_conv1d_rs_t launches it replaces,
+    bit for bit, with and without the residual / the affine, for one tensor set and for a twin pair;
+    and both against the fp64 reference that rounds the intermediate tensor like the engine stores it"""
+    Fn = _fn()
+    c, n, h, w = cfg
+    sa, sb = _spec(Fn, c, (3, 1)), _spec(Fn, c, (1, 3))
+    assert Fn._lib.lib().emsa_nbt_half_block_supported(Fn.DT[dtype], c, w) == 1
+    sets = []
+    for s in range(2 if twin else 1):
+        x = rnd(n, c, h, w, seed=10 + s)
+        wa, wb = rnd(c, c, 3, 1, seed=20 + s, scale=0.1), rnd(c, c, 1, 3, seed=30 + s, scale=0.1)
+        ba, bb = rnd(c, seed=40 + s), rnd(c, seed=50 + s)
+        sc, sh = rnd(c, seed=60 + s).abs() + 0.5, rnd(c, seed=70 + s)
+        res = rnd(n, c, h, w, seed=80 + s)
+        sets.append(dict(x=x, wa=wa, wb=wb, ba=ba, bb=bb, sc=sc, sh=sh, res=res,
+                         xa=act16(x, dtype), ra=act16(res, dtype),
+                         wfa=Fn.pack_weight_frag_t(wa.to(DEV), dtype, fwd=True)[0],
+                         wfb=Fn.pack_weight_frag_t(wb.to(DEV), dtype, fwd=True)[0],
+                         wpa=Fn.pack_weight_t(wa.to(DEV), dtype, fwd=True)[0],
+                         wpb=Fn.pack_weight_t(wb.to(DEV), dtype, fwd=True)[0]))
+    # (maps conv_rs refuses -- fewer pixels than its smallest plan -- run the two-launch twin on the
+    #  implicit GEMM, whose accumulation order differs: storage tolerance instead of bit equality)
+    code = Fn.dt(sets[0]['xa'])
+    bitwise = Fn.rs_supported(code, sa.geom_fwd(n, h, w, c, c)) and Fn.rs_supported(code, sb.geom_fwd(n, h, w, c, c))
+    for with_res, with_affine in ((True, True), (False, True), (False, False)):
+        outs = Fn.nbt_half_block(
+            [s['xa'] for s in sets], [s['wfa'] for s in sets], [s['ba'].to(DEV) for s in sets],
+            [s['wfb'] for s in sets], [s['bb'].to(DEV) for s in sets],
+            [s['sc'].to(DEV) if with_affine else None for s in sets],
+            [s['sh'].to(DEV) if with_affine else None for s in sets],
+            [s['ra'] if with_res else None for s in sets], Fn.ACT_RELU)
+        torch.cuda.synchronize()
+        for s, out in zip(sets, outs):
+            y1 = Fn.conv_fwd(s['xa'], s['wpa'], sa, bias=s['ba'].to(DEV), act=Fn.ACT_RELU, wfrag=s['wfa'])
+            two = Fn.conv_fwd(y1, s['wpb'], sb, bias=s['bb'].to(DEV),
+                              scale=s['sc'].to(DEV) if with_affine else None,
+                              shift=s['sh'].to(DEV) if with_affine else None,
+                              residual=s['ra'] if with_res else None, act=Fn.ACT_RELU, wfrag=s['wfb'])
+            torch.cuda.synchronize()
+            assert out.dtype == dtype
+            if bitwise:
+                assert torch.equal(out, two), (cfg, with_res, with_affine)
+            else:
+                close(out, two.double().cpu(), tol=TOL[dtype], what=f'half-block vs two launches {cfg}')
+            mid = F.relu(F.conv2d(q(s['x'], dtype), q(s['wa'], dtype), s['ba'].double(), padding=(1, 0)))
+            ref = F.conv2d(q(mid, dtype), q(s['wb'], dtype), s['bb'].double(), padding=(0, 1))
+            if with_affine:
+                ref = ref * s['sc'].double().view(1, -1, 1, 1) + s['sh'].double().view(1, -1, 1, 1)
+            if with_res:
+                ref = ref + q(s['res'], dtype)
+            close(out, F.relu(ref), tol=TOL[dtype], what=f'half-block {cfg}')
+
+
+def test_nbt_half_block_refusals():
+    Fn = _fn()
+    L = Fn._lib.lib()
+    assert L.emsa_nbt_half_block_supported(Fn.DT[torch.bfloat16], 256, 40) == 0      # channels
+    assert L.emsa_nbt_half_block_supported(Fn.DT[torch.bfloat16], 64, 4000) == 0     # row does not fit LDS
+    assert L.emsa_nbt_half_block_supported(0, 64, 40) == 0                           # fp32 storage
+    x = act16(rnd(1, 64, 4, 8, seed=1), torch.bfloat16)
+    assert not Fn.half_block_ok(x.float(), 64)

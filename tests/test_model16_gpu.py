@@ -613,15 +613,65 @@ def test_full_size_bf16_batch_consistency_and_determinism():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('twin', [True, False])
+def test_half_blocks_match_separate_launches(dtype, twin, monkeypatch):
+    """BASELINE configs[4] (640x480, batch 1, 16-bit): the NBt1D half-blocks at C = 64 / 128 -- encoder
+    layer1 / layer2, decoder module 2 -- run as ONE launch each (emsa_nbt_half_block_t, csrc/
+    conv_hb.hip: conv3x1 + ReLU -> conv1x3 + folded BatchNorm (+ residual) + ReLU, the intermediate row
+    in LDS; ref emsanet/model.py:47-58).  Every model output is bit-identical to the forward with one
+    launch per conv, on the twin path (19 fused launches: 6 + 7 in the encoders, 6 in the decoders)
+    and without twin launches (2 x 19)."""
+    from emsanet_amd import _lib, full_args, functional as Fn, nn as enn, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import synthetic_batch
+    model = EMSANet(full_args(compute_dtype='bfloat16' if dtype == torch.bfloat16 else 'float16'),
+                    nyuv2_config()).to(DEV).eval()
+    b = {k: v.to(DEV) for k, v in synthetic_batch(1, 480, 640, seed=3).items()}
+    monkeypatch.setattr(enn, 'TWIN', twin)
+    calls = {'hb': 0}
+    L = _lib.lib()
+    hb_fn = L.emsa_nbt_half_block_t
+
+    class Counting:
+        def __getattr__(self, name):
+            if name == 'emsa_nbt_half_block_t':
+                def f(*a):
+                    calls['hb'] += 1
+                    return hb_fn(*a)
+                return f
+            return getattr(L, name)
+    monkeypatch.setattr(_lib, 'lib', lambda: Counting())
+    with torch.no_grad():
+        monkeypatch.setattr(Fn, 'HALF_BLOCK', False)
+        ref = [t.clone() for t in _flatten(model(b))]
+        assert calls['hb'] == 0
+        monkeypatch.setattr(Fn, 'HALF_BLOCK', None)           # the default rule: on at this size
+        got = [t.clone() for t in _flatten(model(b))]
+    torch.cuda.synchronize()
+    assert calls['hb'] == (19 if twin else 38), calls
+    assert len(got) == len(ref)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    # batch 32 is beyond HALF_BLOCK_MAX_PIXELS: the persistent conv_rs launches stay
+    calls['hb'] = 0
+    b32 = {k: v.to(DEV) for k, v in synthetic_batch(8, 480, 640, seed=4).items()}
+    with torch.no_grad():
+        model(b32)
+    assert calls['hb'] == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(1, 480, 640), (3, 96, 128)])
 def test_twin_launches_match_separate_launches(dtype, shape, monkeypatch):
     """16-bit eval fast path: the rgb | depth encoder blocks and the semantic | instance decoder
     blocks run in lockstep with one twin launch per conv pair (emsa_conv1d_rs_pair_t;
     nn.FusedEncoder._forward_twin_eval, decoder.twin_bodies).  Every output is bit-identical to the
     forward with one launch per conv (EMSA_TWIN=0), and the twin path really is the one that ran"""
-    from emsanet_amd import _lib, full_args, nn as enn, nyuv2_config
+    from emsanet_amd import _lib, full_args, functional as Fn, nn as enn, nyuv2_config
     from emsanet_amd.model import EMSANet
     from oracle.emsanet_oracle import synthetic_batch
+    # (the fused half-blocks of round 5 would take the C = 64 / 128 pairs: their own test below)
+    monkeypatch.setattr(Fn, 'HALF_BLOCK', False)
     model = EMSANet(full_args(compute_dtype='bfloat16' if dtype == torch.bfloat16 else 'float16'),
                     nyuv2_config()).to(DEV).eval()
     b = {k: v.to(DEV) for k, v in synthetic_batch(*shape, seed=3).items()}

@@ -15,7 +15,7 @@ Printed in backward order (the order the gradient travels): norm ratio engine / 
 and the same two numbers for the per-channel pixel sums (what a bias gradient sees: rounding noise
 averages out of it, a systematic scale does not).
 
-  python tools/actgrad_compare.py [bf16|f32] [H W BS] [--plain] [--out FILE]
+  python tools/actgrad_compare.py [bf16|f32] [H W BS] [--plain] [--eval] [--out FILE]
     bf16 (default): engine in bf16 storage vs the fp64 oracle in storage-emulation mode, both on
                     the engine's ReLU branch; --plain: against the oracle WITHOUT storage emulation
     f32:            control -- fp32 engine vs fp64 oracle (ratios must be 1.000)
@@ -81,7 +81,7 @@ def main():
     if mode == 'bf16':
         model.set_compute_dtype(torch.bfloat16)
     for m in (model, oracle):
-        m.train()
+        m.train('--eval' not in sys.argv)      # --eval: frozen BatchNorm statistics, gradients on
         m.dropout_seed = 321
     batch = O.synthetic_batch(bs, h, w)
 
