@@ -61,19 +61,30 @@ struct HalfBlockArgs {
   int xp;                      // pixels per LDS row of X = 32 * ceil((W + 2) / 32)
 };
 
+// Everything a workgroup reads from global memory is requested in its first instructions -- both weight
+// sets, the residual row, the three input rows -- so that ONE memory round trip is paid, not one per
+// phase: a workgroup is alone on its CU (one output row each: 120-240 workgroups per launch), nothing
+// else hides latency.  (The first version loaded the 1x3 conv's weights behind the 3x1 conv and the
+// residual element by element inside the epilogue: 18.7 us per launch, slower than the two launches
+// it replaced.)
 template <typename T, int C>
 __global__ __launch_bounds__(256) void nbt_half_block_kernel(const HalfBlockArgs p) {
   typedef typename HVec8<T>::type V8;
+  typedef float hf32x8 __attribute__((ext_vector_type(8)));
   constexpr int C8 = C / 8;                // 16-byte chunks per pixel
   constexpr int PS = C + 8;                // LDS pixel stride (elements): conflict-free ds_read_b128
   constexpr int KS = C / 16;               // k16 steps per tap
   constexpr int NB = C / 32;               // 32-channel output blocks
   constexpr int WN = NB < 4 ? NB : 4;      // waves along the channels
   constexpr int WM = 4 / WN;               // waves along the pixels
+  constexpr int SLD = C + 4;               // fp32 stage row (floats)
+  constexpr int XB = 8;                    // input chunks per thread and batch
+  constexpr int RCH = 8;                   // residual / output chunks per thread (W * C8 <= 256 * RCH)
   static_assert(NB == WN, "one 32-channel block per wave column");
   extern __shared__ __attribute__((aligned(16))) unsigned char hb_smem[];
   T* const X = reinterpret_cast<T*>(hb_smem);                 // [3][xp][PS]
   T* const Y = X + (size_t)3 * p.xp * PS;                       // [xp + 2][PS]
+  float* const stage = reinterpret_cast<float*>(hb_smem);     // [32 * MBb][SLD], overlays X behind conv3x1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -84,27 +95,61 @@ __global__ __launch_bounds__(256) void nbt_half_block_kernel(const HalfBlockArgs
   const T* const in = static_cast<const T*>(p.in[set]);
   const V8* const wfa = static_cast<const V8*>(p.wfa[set]);
   const V8* const wfb = static_cast<const V8*>(p.wfb[set]);
+  const T* const res = static_cast<const T*>(p.res[set]);
+  const size_t pix0 = (size_t)(img * p.H + r) * W;
+  const hu32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  // ---- weights of the 3x1 conv: this wave's 32 output channels, all taps and K steps ------------
-  // fragment image [tap][n / 32][k / 16][lane][8]: one coalesced 1 KB load per fragment
-  V8 bf[3][KS];
+  // ---- all global reads of the workgroup, issued back to back ------------------------------------
+  // weights: this wave's 32 output channels of both convs, fragment image [tap][n / 32][k / 16][lane][8]
+  V8 bfa[3][KS], bfb[3][KS];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) bf[t][kk] = wfa[((t * NB + wn) * KS + kk) * 64 + lane];
-
-  // ---- input rows r - 1, r, r + 1 -> X (pixel i of a row = image column i - 1) ------------------
-  const hu32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int kk = 0; kk < KS; ++kk) bfa[t][kk] = wfa[((t * NB + wn) * KS + kk) * 64 + lane];
+  // per-channel epilogue operands: this lane's channel of both biases; the 8 channels of this
+  // thread's output chunks (q % C8 is the same for all of a thread's chunks: 256 % C8 == 0)
+  const int n = wn * 32 + l31;
+  const int oc0 = (tid % C8) * 8;
+  const bool affine = p.scale[set] != nullptr;
+  const float ba = p.bias_a[set] ? p.bias_a[set][n] : 0.f;
+  const float bb = p.bias_b[set] ? p.bias_b[set][n] : 0.f;
+  float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sc1 = sc0, sh0 = emsa_zero4(), sh1 = sh0;
+  if (affine) {
+    sc0 = emsa_ld4(p.scale[set] + oc0); sc1 = emsa_ld4(p.scale[set] + oc0 + 4);
+    sh0 = emsa_ld4(p.shift[set] + oc0); sh1 = emsa_ld4(p.shift[set] + oc0 + 4);
+  }
+  // residual row: chunk q = (pixel, 16-byte piece) as the output pass will need it
+  hu32x4 rres[RCH];
+#pragma unroll
+  for (int u = 0; u < RCH; ++u) {
+    const int q = tid + 256 * u;
+    rres[u] = zero4;
+    if (res && q < W * C8)
+      rres[u] = *reinterpret_cast<const hu32x4*>(res + (pix0 + q / C8) * p.ld_res + (q % C8) * 8);
+  }
+  // input rows r - 1, r, r + 1 -> X (pixel i of a row = image column i - 1), XB loads in flight
   {
-    const int per_row = W * C8;
-    for (int q = tid; q < 3 * per_row; q += 256) {
-      const int t = q / per_row, rem = q - t * per_row;
-      const int px = rem / C8, c8 = rem - px * C8;
-      const int rr = r - 1 + t;
-      hu32x4 v = zero4;
-      if (rr >= 0 && rr < p.H)
-        v = *reinterpret_cast<const hu32x4*>(in + ((size_t)(img * p.H + rr) * W + px) * p.ld_in + c8 * 8);
-      *reinterpret_cast<hu32x4*>(X + ((size_t)t * XP + px + 1) * PS + c8 * 8) = v;
+    const int per_row = W * C8, total = 3 * per_row;
+    for (int q0 = tid; q0 < total; q0 += 256 * XB) {
+      hu32x4 v[XB];
+      int dst[XB];
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int q = q0 + 256 * u;
+        v[u] = zero4;
+        dst[u] = -1;
+        if (q < total) {
+          const int t = q / per_row, rem = q - t * per_row;
+          const int px = rem / C8, c8 = rem - px * C8;
+          const int rr = r - 1 + t;
+          dst[u] = (t * XP + px + 1) * PS + c8 * 8;
+          if (rr >= 0 && rr < p.H)
+            v[u] = *reinterpret_cast<const hu32x4*>(in + ((size_t)(img * p.H + rr) * W + px) * p.ld_in + c8 * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < XB; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<hu32x4*>(X + dst[u]) = v[u];
     }
     // zero pad pixels: i = 0 and i in (W, XP) of every row; Y[XP], Y[XP + 1]
     const int npad = XP - W;                      // pixels per row: 1 in front + (XP - W - 1) behind
@@ -117,13 +162,18 @@ __global__ __launch_bounds__(256) void nbt_half_block_kernel(const HalfBlockArgs
     for (int q = tid; q < 2 * C8; q += 256)
       *reinterpret_cast<hu32x4*>(Y + (size_t)(XP + q / C8) * PS + (q % C8) * 8) = zero4;
   }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) bfb[t][kk] = wfb[((t * NB + wn) * KS + kk) * 64 + lane];
   __syncthreads();
 
-  const int n = wn * 32 + l31;                    // this lane's output channel
   const int MBa = XP / 32;                        // pixel blocks of the intermediate row
   // ---- conv3x1 + bias + ReLU -> Y ----------------------------------------------------------------
+  // (Measured and dropped: the wave's pixel blocks interleaved on separate accumulators -- the
+  //  dependent MFMA chain of one block at a time is not what bounds the launch: 13.4-18.6 us instead of
+  //  11-15.6 us, the extra accumulators go through AGPR copies at this register budget.)
   {
-    const float ba = p.bias_a[set] ? p.bias_a[set][n] : 0.f;
     for (int mb = wm; mb < MBa; mb += WM) {
       f32x16 acc;
 #pragma unroll
@@ -133,7 +183,7 @@ __global__ __launch_bounds__(256) void nbt_half_block_kernel(const HalfBlockArgs
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          acc = hmfma(*reinterpret_cast<const V8*>(a0 + (size_t)t * XP * PS + kk * 16), bf[t][kk], acc);
+          acc = hmfma(*reinterpret_cast<const V8*>(a0 + (size_t)t * XP * PS + kk * 16), bfa[t][kk], acc);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int i = 32 * mb + (q & 3) + 8 * (q >> 2) + 4 * lh;
@@ -143,22 +193,11 @@ __global__ __launch_bounds__(256) void nbt_half_block_kernel(const HalfBlockArgs
       }
     }
   }
-  // ---- weights of the 1x3 conv (the loads fly across the barrier) --------------------------------
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) bf[t][kk] = wfb[((t * NB + wn) * KS + kk) * 64 + lane];
-  __syncthreads();
+  __syncthreads();                                // (Y complete; X is free: the stage overlays it)
 
-  // ---- conv1x3 + bias, scale / shift, residual, activation -> out --------------------------------
+  // ---- conv1x3 + bias -> fp32 stage ---------------------------------------------------------------
+  const int MBb = (W + 31) / 32;
   {
-    const float bb = p.bias_b[set] ? p.bias_b[set][n] : 0.f;
-    const bool affine = p.scale[set] != nullptr;
-    const float sc = affine ? p.scale[set][n] : 1.f, sh = affine ? p.shift[set][n] : 0.f;
-    const T* const res = static_cast<const T*>(p.res[set]);
-    T* const out = static_cast<T*>(p.out[set]);
-    const size_t pix0 = (size_t)(img * p.H + r) * W;
-    const int MBb = (W + 31) / 32;
     for (int mb = wm; mb < MBb; mb += WM) {
       f32x16 acc;
 #pragma unroll
@@ -168,17 +207,38 @@ __global__ __launch_bounds__(256) void nbt_half_block_kernel(const HalfBlockArgs
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          acc = hmfma(*reinterpret_cast<const V8*>(a0 + (size_t)t * PS + kk * 16), bf[t][kk], acc);
+          acc = hmfma(*reinterpret_cast<const V8*>(a0 + (size_t)t * PS + kk * 16), bfb[t][kk], acc);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int j = 32 * mb + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        if (j < W) {
-          float v = acc[q] + bb;
-          if (affine) v = v * sc + sh;
-          if (res) v += (float)res[(pix0 + j) * p.ld_res + n];
-          if (p.act == EMSA_ACT_RELU) v = fmaxf(v, 0.f);
-          out[(pix0 + j) * p.ld_out + n] = (T)v;
+        stage[(size_t)j * SLD + n] = acc[q] + bb;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- output pass: scale / shift, residual, activation; 8 channels = 16 bytes per access --------
+  {
+    T* const out = static_cast<T*>(p.out[set]);
+#pragma unroll
+    for (int u = 0; u < RCH; ++u) {
+      const int q = tid + 256 * u;
+      if (q < W * C8) {
+        const int j = q / C8, c0 = oc0;
+        const float4 v0 = emsa_ld4(stage + (size_t)j * SLD + c0), v1 = emsa_ld4(stage + (size_t)j * SLD + c0 + 4);
+        hf32x8 x = hf32x8{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (affine) {
+          x = hf32x8{x[0] * sc0.x + sh0.x, x[1] * sc0.y + sh0.y, x[2] * sc0.z + sh0.z,
+                     x[3] * sc0.w + sh0.w, x[4] * sc1.x + sh1.x, x[5] * sc1.y + sh1.y,
+                     x[6] * sc1.z + sh1.z, x[7] * sc1.w + sh1.w};
         }
+        if (res) x += __builtin_convertvector(__builtin_bit_cast(V8, rres[u]), hf32x8);
+        if (p.act == EMSA_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        const V8 o = __builtin_convertvector(x, V8);
+        *reinterpret_cast<hu32x4*>(out + (pix0 + j) * p.ld_out + c0) = __builtin_bit_cast(hu32x4, o);
       }
     }
   }
@@ -218,6 +278,9 @@ extern "C" int emsa_nbt_half_block_supported(int32_t dtype, int32_t c, int32_t w
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return 0;
   if (c != 64 && c != 128) return 0;
   if (w < 1 || hb_lds_bytes(c, w) > 160 * 1024) return 0;
+  if ((long)w * (c / 8) > 256 * 8) return 0;                       // output chunks per thread (RCH)
+  const long xp = (w + 2 + 31) / 32 * 32;
+  if ((long)((w + 31) / 32 * 32) * (c + 4) * 4 > 3 * xp * (c + 8) * 2) return 0;   // stage inside X
   return 1;
 }
 
@@ -246,7 +309,9 @@ extern "C" int emsa_nbt_half_block_t(int32_t dtype, int32_t n_sets, int32_t n_im
     if (!in[s] || !wfa[s] || !wfb[s] || !out[s]) return EMSA_E_ARG;
     if ((scale[s] == nullptr) != (shift[s] == nullptr)) return EMSA_E_ARG;
     if ((((uintptr_t)in[s]) | ((uintptr_t)wfa[s]) | ((uintptr_t)wfb[s])) & 15) return EMSA_E_SHAPE;
-    if (residual[s] && ld_res < c) return EMSA_E_SHAPE;
+    if (residual[s] && (ld_res < c || (ld_res & 7) || (((uintptr_t)residual[s]) & 15))) return EMSA_E_SHAPE;
+    if ((((uintptr_t)out[s]) & 15) || (scale[s] && ((((uintptr_t)scale[s]) | ((uintptr_t)shift[s])) & 15)))
+      return EMSA_E_SHAPE;
     a.in[k] = in[s]; a.out[k] = out[s]; a.res[k] = residual[s]; a.wfa[k] = wfa[s]; a.wfb[k] = wfb[s];
     a.bias_a[k] = bias_a[s]; a.bias_b[k] = bias_b[s]; a.scale[k] = scale[s]; a.shift[k] = shift[s];
   }

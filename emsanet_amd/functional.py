@@ -423,8 +423,11 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
 
 # Fused NBt1D half-block (csrc/conv_hb.hip): conv3x1 + ReLU -> conv1x3 + folded BatchNorm (+ residual)
 # + ReLU as ONE launch, for the small-batch 16-bit eval fast path where a launch is its fixed cost.
-# EMSA_HALF_BLOCK=0 / 1 forces it off / on at every size; default: up to HALF_BLOCK_MAX_PIXELS pixels
-# per map (bs * h * w at the block's resolution): beyond that the persistent conv_rs kernel is faster.
+# OPT-IN (EMSA_HALF_BLOCK=1): bit-identical to the two launches it replaces and 19 graph nodes fewer at
+# batch 1 (155 -> 136), but not faster -- one fused launch takes 11-13 us at C = 64 and 14-16 us at
+# C = 128 where the two twin conv_rs launches take 2 x 5.5-6.5 (profiles/r05_e_*: 1.16 vs 1.14-1.15 ms
+# per forward).  With it on, maps above HALF_BLOCK_MAX_PIXELS pixels (bs * h * w at the
+# block's resolution) still take the persistent conv_rs kernel.
 _HALF_BLOCK_ENV = os.environ.get('EMSA_HALF_BLOCK')
 HALF_BLOCK = None                    # tests: True / False overrides
 HALF_BLOCK_MAX_PIXELS = 3 * 120 * 160
@@ -434,12 +437,11 @@ def half_block_ok(x, c):
     """this map (N, c, H, W) takes the fused half-block kernel"""
     if x.dtype == torch.float32 or c not in (64, 128) or ld_of(x) != c:
         return False
-    on = HALF_BLOCK if HALF_BLOCK is not None else (
-        _HALF_BLOCK_ENV != '0' if _HALF_BLOCK_ENV is not None else None)
-    if on is False:
+    on = HALF_BLOCK if HALF_BLOCK is not None else (_HALF_BLOCK_ENV == '1')
+    if not on:
         return False
     n, _, h, w = x.shape
-    if on is None and n * h * w > HALF_BLOCK_MAX_PIXELS:
+    if n * h * w > HALF_BLOCK_MAX_PIXELS:
         return False
     return _lib.lib().emsa_nbt_half_block_supported(dt(x), c, w) == 1
 

@@ -36,8 +36,14 @@ EMU_TOL = {torch.bfloat16: 2e-2, torch.float16: 3e-3}
 # train-mode model level (BatchNorm batch statistics renormalise the storage noise at every layer):
 # provisional gates, see the measured values printed by the test
 TRAIN_OUT_TOL, TRAIN_COS = 0.5, 0.95
-# frozen-BatchNorm (eval) gradients at 640x480: provisional until measured (the test prints them)
-EVAL_GRAD_OUT_TOL, EVAL_GRAD_COS_MEDIAN, EVAL_GRAD_COS_MIN = 0.1, 0.98, 0.8
+# frozen-BatchNorm (eval) gradients at 640x480, measured (three runs, two boxes): outputs rel-L2 1.0e-2 ..
+# 6.2e-2; norm ratio median 0.9992 (encoder tensors 0.9981), p1 .. p99 0.986 .. 1.015; cosine median 0.9999,
+# p1 0.9985, min 0.9856.  Ten of the 742 tensors leave the +-5 % band: SE fc.0 of the first two fusions
+# (0.949 / 1.038), and the instance head's centre / offset task convs and up-sampling weights (0.95 .. 1.12;
+# the one-element centre bias 1.54 at cosine +1) -- the gradient through sigmoid / tanh scales like
+# exp(-|x|), so the 4-6 % forward deviation of these outputs becomes 10 % in their derivative; the
+# orientation conv beside them (no saturating activation) sits at 0.9975 / 1.0000.
+EVAL_GRAD_OUT_TOL, EVAL_GRAD_COS_MEDIAN, EVAL_GRAD_COS_MIN = 0.1, 0.999, 0.95
 
 
 def _flatten(outs):
@@ -314,11 +320,31 @@ def test_eval_bn_bf16_pinned_gradients_baseline_resolution(monkeypatch):
     bs, hh, ww = 2, 480, 640
     args = full_args(input_height=hh, input_width=ww)
     model, oracle = _pair(args)
+    batch = O.synthetic_batch(bs, hh, ww)
+    # frozen statistics OF THIS NETWORK: the deterministic state dict draws running_mean / running_var
+    # at random, and an eval-mode forward through statistics that do not belong to the weights is not
+    # normalised -- its head logits reach |x| > 15, where the fp32 sigmoid / tanh derivatives
+    # y (1 - y), 1 - y^2 (the reference's own arithmetic, torch's formula) are quantisation noise
+    # against the fp64 oracle (first run of this test: centre / offset task convs at cosine 0.90 /
+    # 0.99 with the orientation conv beside them at 1.0000).  One train-mode pass of the fp32 oracle
+    # with momentum 1 puts the batch statistics into the buffers of both sides (BatchNorm
+    # recalibration), then both are frozen.
+    with torch.no_grad():
+        moms = {}
+        for m in oracle.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                moms[m] = m.momentum
+                m.momentum = 1.0
+        oracle.train()
+        oracle.dropout_seed = 321
+        oracle(batch)
+        for m, mom in moms.items():
+            m.momentum = mom
+    model.load_state_dict(oracle.state_dict())
     oracle = oracle.double()
     model.set_compute_dtype(torch.bfloat16)
     model.eval()
     oracle.eval()
-    batch = O.synthetic_batch(bs, hh, ww)
     ops.MASK_TRACE = []
     try:
         out = _flatten(model({k: v.to(DEV) for k, v in batch.items()}))
@@ -620,7 +646,8 @@ def test_half_blocks_match_separate_launches(dtype, twin, monkeypatch):
     conv_hb.hip: conv3x1 + ReLU -> conv1x3 + folded BatchNorm (+ residual) + ReLU, the intermediate row
     in LDS; ref emsanet/model.py:47-58).  Every model output is bit-identical to the forward with one
     launch per conv, on the twin path (19 fused launches: 6 + 7 in the encoders, 6 in the decoders)
-    and without twin launches (2 x 19)."""
+    and without twin launches (2 x 19).  The kernel is opt-in (not faster than the launches it
+    replaces); this test keeps it correct."""
     from emsanet_amd import _lib, full_args, functional as Fn, nn as enn, nyuv2_config
     from emsanet_amd.model import EMSANet
     from oracle.emsanet_oracle import synthetic_batch
@@ -645,16 +672,16 @@ def test_half_blocks_match_separate_launches(dtype, twin, monkeypatch):
         monkeypatch.setattr(Fn, 'HALF_BLOCK', False)
         ref = [t.clone() for t in _flatten(model(b))]
         assert calls['hb'] == 0
-        monkeypatch.setattr(Fn, 'HALF_BLOCK', None)           # the default rule: on at this size
+        monkeypatch.setattr(Fn, 'HALF_BLOCK', True)           # (opt-in: EMSA_HALF_BLOCK=1)
         got = [t.clone() for t in _flatten(model(b))]
     torch.cuda.synchronize()
     assert calls['hb'] == (19 if twin else 38), calls
     assert len(got) == len(ref)
     for a, r in zip(got, ref):
         assert torch.equal(a, r)
-    # batch 32 is beyond HALF_BLOCK_MAX_PIXELS: the persistent conv_rs launches stay
+    # batch 16 is beyond HALF_BLOCK_MAX_PIXELS at both resolutions: the persistent conv_rs launches stay
     calls['hb'] = 0
-    b32 = {k: v.to(DEV) for k, v in synthetic_batch(8, 480, 640, seed=4).items()}
+    b32 = {k: v.to(DEV) for k, v in synthetic_batch(16, 480, 640, seed=4).items()}
     with torch.no_grad():
         model(b32)
     assert calls['hb'] == 0
@@ -670,8 +697,7 @@ def test_twin_launches_match_separate_launches(dtype, shape, monkeypatch):
     from emsanet_amd import _lib, full_args, functional as Fn, nn as enn, nyuv2_config
     from emsanet_amd.model import EMSANet
     from oracle.emsanet_oracle import synthetic_batch
-    # (the fused half-blocks of round 5 would take the C = 64 / 128 pairs: their own test below)
-    monkeypatch.setattr(Fn, 'HALF_BLOCK', False)
+    monkeypatch.setattr(Fn, 'HALF_BLOCK', False)     # (the opt-in fused half-blocks: their own test above)
     model = EMSANet(full_args(compute_dtype='bfloat16' if dtype == torch.bfloat16 else 'float16'),
                     nyuv2_config()).to(DEV).eval()
     b = {k: v.to(DEV) for k, v in synthetic_batch(*shape, seed=3).items()}
