@@ -170,7 +170,7 @@ def test_eval_16bit_vs_storage_emulating_oracle(dtype, monkeypatch):
     assert max(errs) <= EMU_TOL[dtype]
 
 
-@pytest.mark.parametrize('shape', [(8, 256, 320), (2, 480, 640)])
+@pytest.mark.parametrize('shape', [(8, 256, 320), (2, 480, 640), (8, 480, 640)])
 def test_train_bf16_pinned_gradients(shape, monkeypatch):
     """configs[2] arithmetic on one rank: bf16 train step (BatchNorm batch statistics, Dropout2d),
     fwd + bwd at 256x320 with bs 8 and AT THE BASELINE RESOLUTION 640x480 with bs 2 (the kernels'
