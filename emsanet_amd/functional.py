@@ -657,18 +657,28 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
     return out
 
 
-# BatchNorm-backward reduction inside the data gradient in front of it (conv_dgrad_bnb).  Measured
-# per training step at bs=32: 16-bit storage -0.4 ms (+0.8 %); fp32 +-0 (the Winograd data gradient
-# of the 64/128-channel stages is not purely matrix-bound, the extra epilogue reads cost what the
-# saved pass gains: 124.3 vs 121.7 us average per launch) -> on for 16-bit, off for fp32.
-# EMSA_BN_FUSE=0 / 1 forces it off / on for every storage type.
+# BatchNorm-backward reduction inside the data gradient in front of it (conv_dgrad_bnb): OFF by
+# default in both storage types since round 5.  History: with the implicit GEMM (round 3) it gained
+# 0.4 ms per bf16 step and was the 16-bit default; fp32 measured +-0 (the Winograd data gradient of
+# the 64 / 128-channel stages is not purely matrix-bound: 124.3 vs 121.7 us per launch).  Since the
+# 16-bit 1-D convs run on conv_rs.hip (round 4) the fused epilogue costs +48 / +25 / +10 / +8 us per
+# launch at 64 / 128 / 256 / 512 channels (profiles/r05_z_bf16_one_stream_kernel_stats.md: 84.8 vs
+# 36.3, 50.8 vs 26.6, 35.8 vs 26.8, 32.9 vs 25.6 us) where the separate reduction pass it replaces
+# costs ~36 / 21 / 13 / 9 us.  A/B on one box, bf16 step replayed from a hipGraph, two runs each
+# (profiles/r05_f_*): fused everywhere 855.1 / 852.7, at >= 128 channels 856.0 / 856.2, at >= 256
+# 861.0 / 861.8, nowhere **863.3 / 864.3** images/s.
+# EMSA_BN_FUSE=0 / 1 forces it off / on for every storage type; EMSA_BN_FUSE_MIN_C=n switches it on
+# for 16-bit convs of >= n channels.
 _BN_FUSE_ENV = os.environ.get('EMSA_BN_FUSE')
+_BN_FUSE_MIN_C = int(os.environ.get('EMSA_BN_FUSE_MIN_C', '0'))
 
 
-def bn_fused_reduce(dtype):
+def bn_fused_reduce(dtype, c=None):
     if _BN_FUSE_ENV is not None:
         return _BN_FUSE_ENV != '0'
-    return dtype != torch.float32
+    if dtype == torch.float32 or _BN_FUSE_MIN_C <= 0:
+        return False
+    return c is None or c >= _BN_FUSE_MIN_C
 
 
 # The NBt1D block's bn1 without a forward pass of its own (fp32 training): conv3x1_2 and its weight

@@ -136,7 +136,7 @@ class ConvRT:
         (Fn.conv_dgrad_bnb), or None when this conv's kernel has no such epilogue (fp32 without
         the Winograd form).  force: the caller has no other way (the forward folded the BatchNorm
         into this conv's loader: no ReLU bit mask exists)"""
-        if affine is None or not (force or Fn.bn_fused_reduce(dy.dtype)):
+        if affine is None or not (force or Fn.bn_fused_reduce(dy.dtype, self.spec.cin)):
             return None
         scale, shift = affine
         if dy.dtype != torch.float32:
