@@ -165,6 +165,9 @@ SIGNATURES = {
     'emsa_bilinear_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_bilinear_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_head_act_fwd_t': (c_int, [c_int32, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_head_act_bwd_gather_t': (c_int, [c_int32, _P, c_int32, c_int32, _P, c_int32, c_int32, _P, c_int32,
+                                           c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                           c_int32, _P]),
     'emsa_head_act_bwd_t': (c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_stem_pack_input_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_channel_mean_t': (c_int, [c_int32, _P, _P, _P, c_int32, c_int64, c_int32, _P]),

@@ -1712,6 +1712,36 @@ __global__ void head_act_fwd_kernel(const T* __restrict__ x, TO* __restrict__ y,
   }
 }
 
+// the same for the 8-channel (padded) instance head with fp32 outputs, one thread per PIXEL: 16 / 32
+// bytes in, 32 bytes out per thread instead of one element (the map is 315 MB of fp32 at bs 32)
+template <typename T>
+__global__ void head_act_fwd8_kernel(const T* __restrict__ x, float* __restrict__ y, long pixels,
+                                     int n_sig, int n_tanh, int norm_off, int n_norm) {
+  constexpr int C = 8, V = VecIO<T>::V;
+  const int ot = n_sig + n_tanh;
+  for (long px = blockIdx.x * (long)blockDim.x + threadIdx.x; px < pixels;
+       px += (long)gridDim.x * blockDim.x) {
+    float v[C], part[V];
+#pragma unroll
+    for (int h = 0; h < C / V; ++h) {
+      VecIO<T>::load(x + px * C + h * V, part);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[h * V + k] = part[k];
+    }
+    float r[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      r[ch] = ch < n_sig ? 1.f / (1.f + expf(-v[ch])) : ch < ot ? tanhf(v[ch]) : v[ch];
+      if (ch >= norm_off && ch < norm_off + n_norm) {
+        const float u = ch == norm_off ? v[ch + 1 < C ? ch + 1 : ch] : v[ch > 0 ? ch - 1 : 0];
+        r[ch] = v[ch] / fmaxf(sqrtf(v[ch] * v[ch] + u * u), 1e-12f);
+      }
+    }
+    emsa_st4(y + px * C, make_float4(r[0], r[1], r[2], r[3]));
+    emsa_st4(y + px * C + 4, make_float4(r[4], r[5], r[6], r[7]));
+  }
+}
+
 template <typename T, typename TO>
 __global__ void head_act_bwd_kernel(const TO* __restrict__ dy, const TO* __restrict__ y,
                                     const T* __restrict__ x, T* __restrict__ dx,
@@ -1731,6 +1761,67 @@ __global__ void head_act_bwd_kernel(const TO* __restrict__ dy, const TO* __restr
       r = nrm > 1e-12f ? (g - v * (v * g + emsa_ld1(y + j) * emsa_ld1(dy + j))) / nrm : g / 1e-12f;
     }
     emsa_st1(dx + i, r);
+  }
+}
+
+// head_act_bwd with the GATHER of the task gradients in front of it: the instance head hands out
+// channel-slice views of one activated 8-channel tensor (centre | offset | orientation | padding), and
+// its backward pass used to copy the three incoming fp32 gradients into a padded 8-channel tensor
+// (three strided copies + a fill of the padding channels: 315 MB written and read again per step at
+// bs 32) before this kernel ran.  Here one thread owns one PIXEL: it reads its gradient channels from
+// up to three sources (channel count cs[k], pixel stride ld[k]; a NULL source = zero gradient), the
+// pixel's 8 outputs y, and writes the pixel's 8 input gradients (padding channels: 0) in one piece.
+struct HeadGatherArgs {
+  const float* g[3];
+  int cs[3], ld[3];
+};
+template <typename T>
+__global__ void head_act_bwd_gather_kernel(const HeadGatherArgs a, const float* __restrict__ y,
+                                           const T* __restrict__ x, T* __restrict__ dx,
+                                           long pixels, int n_sig, int n_tanh, int norm_off,
+                                           int n_norm) {
+  constexpr int C = 8;
+  const int ot = n_sig + n_tanh;
+  for (long px = blockIdx.x * (long)blockDim.x + threadIdx.x; px < pixels;
+       px += (long)gridDim.x * blockDim.x) {
+    // (every register index below is a compile-time constant: which source a channel comes from is
+    //  decided per channel, not by walking the sources -- a run-time index into g[] would put it in
+    //  scratch memory)
+    const int o1 = a.cs[0], o2 = o1 + a.cs[1], o3 = o2 + a.cs[2];
+    float g[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      const float* src = ch < o1 ? a.g[0] : ch < o2 ? a.g[1] : ch < o3 ? a.g[2] : nullptr;
+      const int ld = ch < o1 ? a.ld[0] : ch < o2 ? a.ld[1] : a.ld[2];
+      const int k = ch < o1 ? ch : ch < o2 ? ch - o1 : ch - o2;
+      g[ch] = src ? src[px * ld + k] : 0.f;
+    }
+    const float4 y0 = emsa_ld4(y + px * C), y1 = emsa_ld4(y + px * C + 4);
+    const float v[C] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+    float r[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch)
+      r[ch] = ch < n_sig ? g[ch] * v[ch] * (1.f - v[ch]) : ch < ot ? g[ch] * (1.f - v[ch] * v[ch]) : g[ch];
+    if (n_norm) {
+      // y = x / max(|x|, eps):  dx = (g - y (y . g)) / |x|   (|x| > eps), g / eps otherwise
+      const float xa = emsa_ld1(x + px * C + norm_off), xb = emsa_ld1(x + px * C + norm_off + 1);
+      const float nrm = sqrtf(xa * xa + xb * xb);
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch)
+        if (ch == norm_off || ch == norm_off + 1) {
+          const bool first = ch == norm_off;
+          const float vj = first ? v[ch + 1 < C ? ch + 1 : ch] : v[ch > 0 ? ch - 1 : 0];
+          const float gj = first ? g[ch + 1 < C ? ch + 1 : ch] : g[ch > 0 ? ch - 1 : 0];
+          r[ch] = nrm > 1e-12f ? (g[ch] - v[ch] * (v[ch] * g[ch] + vj * gj)) / nrm : g[ch] / 1e-12f;
+        }
+    }
+    float rr[VecIO<T>::V];
+#pragma unroll
+    for (int h = 0; h < C / VecIO<T>::V; ++h) {
+#pragma unroll
+      for (int k = 0; k < VecIO<T>::V; ++k) rr[k] = r[h * VecIO<T>::V + k];
+      VecIO<T>::store(dx + px * C + h * VecIO<T>::V, rr);
+    }
   }
 }
 
@@ -2716,6 +2807,13 @@ static int head_act_fwd_impl(const T* x, TO* y, int64_t pixels, int32_t c, int32
       (n_norm && (norm_off < n_sig + n_tanh || norm_off + n_norm > c)))
     return EMSA_E_SHAPE;
   const long total = (long)pixels * c;
+  if constexpr (std::is_same<TO, float>::value) {
+    if (c == 8 && !((((uintptr_t)x) | ((uintptr_t)y)) & 15) && norm_off + n_norm <= 8 && norm_off >= 1) {
+      hipLaunchKernelGGL((head_act_fwd8_kernel<T>), dim3(grid_for((long)pixels)), dim3(kThreads), 0,
+                         (hipStream_t)stream, x, y, (long)pixels, n_sig, n_tanh, norm_off, n_norm);
+      return emsa_launch_status();
+    }
+  }
   hipLaunchKernelGGL((head_act_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, total, c, n_sig, n_tanh, norm_off, n_norm);
   return emsa_launch_status();
@@ -2740,6 +2838,46 @@ static int head_act_bwd_impl(const TO* dy, const TO* y, const T* x, T* dx, int64
   const long total = (long)pixels * c;
   hipLaunchKernelGGL((head_act_bwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, dy, y, x, dx, total, c, n_sig, n_tanh, norm_off, n_norm);
+  return emsa_launch_status();
+}
+// head_act_bwd over an 8-channel (padded) head with the task gradients gathered on the fly: g0 / g1 /
+// g2 = fp32 gradients of the leading c0 / c1 / c2 channels (NHWC, pixel strides ld0..2; NULL = no
+// gradient for that task), y fp32 [pixels][8], x (only for n_norm) and dx in `dtype` [pixels][8];
+// channels behind c0 + c1 + c2 are padding and get a zero gradient.
+extern "C" int emsa_head_act_bwd_gather_t(int32_t dtype, const float* g0, int32_t ld0, int32_t c0,
+                                          const float* g1, int32_t ld1, int32_t c1, const float* g2,
+                                          int32_t ld2, int32_t c2, const float* y, const void* x,
+                                          void* dx, int64_t pixels, int32_t c, int32_t n_sig,
+                                          int32_t n_tanh, int32_t norm_off, int32_t n_norm,
+                                          void* stream) {
+  if (!y || !dx || (n_norm && !x)) return EMSA_E_ARG;
+  if (c != 8 || c0 < 0 || c1 < 0 || c2 < 0 || c0 + c1 + c2 > c || pixels < 1) return EMSA_E_SHAPE;
+  if ((g0 && ld0 < c0) || (g1 && ld1 < c1) || (g2 && ld2 < c2)) return EMSA_E_SHAPE;
+  if ((n_norm != 0 && n_norm != 2) || n_sig < 0 || n_tanh < 0 || n_sig + n_tanh > c ||
+      (n_norm && (norm_off < n_sig + n_tanh || norm_off + n_norm > c)))
+    return EMSA_E_SHAPE;
+  if ((((uintptr_t)y) | ((uintptr_t)dx)) & 15) return EMSA_E_SHAPE;
+  HeadGatherArgs a;
+  a.g[0] = g0; a.g[1] = g1; a.g[2] = g2;
+  a.cs[0] = c0; a.cs[1] = c1; a.cs[2] = c2;
+  a.ld[0] = ld0; a.ld[1] = ld1; a.ld[2] = ld2;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(grid_for((long)pixels)), block(kThreads);
+  switch (dtype) {
+    case EMSA_DT_F32:
+      hipLaunchKernelGGL(head_act_bwd_gather_kernel<float>, grid, block, 0, st, a, y, (const float*)x,
+                         (float*)dx, (long)pixels, n_sig, n_tanh, norm_off, n_norm);
+      break;
+    case EMSA_DT_BF16:
+      hipLaunchKernelGGL(head_act_bwd_gather_kernel<emsa_bf16>, grid, block, 0, st, a, y,
+                         (const emsa_bf16*)x, (emsa_bf16*)dx, (long)pixels, n_sig, n_tanh, norm_off, n_norm);
+      break;
+    case EMSA_DT_F16:
+      hipLaunchKernelGGL(head_act_bwd_gather_kernel<emsa_f16>, grid, block, 0, st, a, y,
+                         (const emsa_f16*)x, (emsa_f16*)dx, (long)pixels, n_sig, n_tanh, norm_off, n_norm);
+      break;
+    default: return EMSA_E_ARG;
+  }
   return emsa_launch_status();
 }
 extern "C" int emsa_head_act_bwd(const float* dy, const float* y, const float* x, float* dx, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream) {

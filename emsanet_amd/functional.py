@@ -1315,6 +1315,39 @@ def head_act_bwd(dy, y, n_sig, n_tanh, n_norm=0, x=None, norm_off=3, dtype=torch
     return dx
 
 
+# EMSA_HEAD_GATHER=0: the instance head's backward as padded copy + emsa_head_act_bwd_t (A/B)
+HEAD_GATHER = os.environ.get('EMSA_HEAD_GATHER', '1') != '0'
+
+
+def head_act_bwd_gather(grads, sizes, y, n_sig, n_tanh, n_norm=0, x=None, norm_off=3,
+                        dtype=torch.float32):
+    """head_act_bwd with the task gradients gathered inside the kernel: grads[k] (or None) is the fp32
+    gradient of the sizes[k] channels behind the previous tasks' (<= 3 tasks, 8-channel head) -> dx in
+    `dtype`, or None when the kernel does not take the case (caller: copy + head_act_bwd)"""
+    n, c, h, w = y.shape
+    if c != 8 or len(sizes) > 3 or y.dtype != torch.float32 or ld_of(y) != c or not HEAD_GATHER:
+        return None
+    gs = []
+    for g_ in grads:
+        if g_ is None:
+            gs.append(None)
+            continue
+        g_ = as_act(g_ if g_.dtype == torch.float32 else g_.float())
+        if tuple(g_.shape[2:]) != (h, w):
+            return None
+        gs.append(g_)
+    gs += [None] * (3 - len(gs))
+    cs = list(sizes) + [0] * (3 - len(sizes))
+    dx = act_empty(n, c, h, w, y.device, dtype=dtype)
+    args = []
+    for g_, ck in zip(gs, cs):
+        args += [_p(g_), ld_of(g_) if g_ is not None else 0, ck]
+    check(_lib.lib().emsa_head_act_bwd_gather_t(DT[dtype], *args, _p(y), _p(x), _p(dx), n * h * w, c,
+                                                n_sig, n_tanh, norm_off, n_norm, _stream()),
+          'emsa_head_act_bwd_gather_t')
+    return dx
+
+
 def copy_channels(src, dst):
     """copy an activation (possibly a channel slice) into another (possibly a slice); the storage
     types may differ (conversion on the fly)."""

@@ -691,6 +691,14 @@ int emsa_bilinear_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int
     iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream);
 int emsa_head_act_fwd_t(int32_t dtype, int32_t out_f32, const void* x, void* y, int64_t pixels,
     int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream);
+/* emsa_head_act_bwd over the 8-channel (padded) instance head with the three task gradients (centre,
+ * offset, orientation: fp32, NHWC, own pixel strides; NULL = zero) gathered on the fly instead of
+ * copied into a padded tensor first; y fp32, x / dx in `dtype` */
+int emsa_head_act_bwd_gather_t(int32_t dtype, const float* g0, int32_t ld0, int32_t c0, const float* g1,
+                               int32_t ld1, int32_t c1, const float* g2, int32_t ld2, int32_t c2,
+                               const float* y, const void* x, void* dx, int64_t pixels, int32_t c,
+                               int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm,
+                               void* stream);
 int emsa_head_act_bwd_t(int32_t dtype, int32_t out_f32, const void* dy, const void* y, const
     void* x, void* dx, int64_t pixels, int32_t c, int32_t n_sig, int32_t n_tanh, int32_t
     norm_off, int32_t n_norm, void* stream);

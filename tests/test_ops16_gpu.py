@@ -435,3 +435,31 @@ def test_head_act_and_casts16(dtype):
     assert f.dtype == torch.float32 and torch.equal(f.cpu().double(), q(x, dtype))
     f.backward(torch.ones_like(f))
     assert t.grad.dtype == dtype and float(t.grad.float().min()) == 1.0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n_norm', [0, 2])
+def test_head_act_bwd_gather_is_copy_plus_bwd(dtype, n_norm):
+    """emsa_head_act_bwd_gather_t (the three task gradients read inside the backward kernel) == the
+    padded copy + emsa_head_act_bwd_t it replaces, bit for bit: channels-last and NCHW-contiguous
+    gradients, a missing task gradient, the L2-normalised orientation pair, odd sizes"""
+    Fn = _fn()
+    n, h, w = 2, 7, 9
+    x = rnd(n, 8, h, w, seed=1)
+    xg = act16(x, dtype) if dtype != torch.float32 else x.to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = Fn.head_act_fwd(xg, 1, 2, n_norm)
+    sizes = (1, 2, 2)
+    gs = [rnd(n, s, h, w, seed=5 + k).to(DEV) for k, s in enumerate(sizes)]
+    gs[1] = gs[1].contiguous(memory_format=torch.channels_last)
+    for drop in (None, 2):
+        grads = [g if k != drop else None for k, g in enumerate(gs)]
+        dy = Fn.act_zeros(n, 8, h, w, DEV)
+        o = 0
+        for s, g in zip(sizes, grads):
+            if g is not None:
+                Fn.copy_channels(Fn.as_act(g), dy[:, o:o + s])
+            o += s
+        ref = Fn.head_act_bwd(dy, y, 1, 2, n_norm, x=xg if n_norm else None, dtype=dtype)
+        got = Fn.head_act_bwd_gather(grads, sizes, y, 1, 2, n_norm, x=xg if n_norm else None, dtype=dtype)
+        torch.cuda.synchronize()
+        assert got is not None and got.dtype == dtype and torch.equal(got, ref), (dtype, n_norm, drop)
