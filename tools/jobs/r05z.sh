@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round evidence on the final sources: tests, smoke, PMC traffic (+ calibration), bench lines of
 # every BASELINE config, rocprofv3 tables
-O=gpurun_out/r05z; mkdir -p $O
+O=gpurun_out/r05z; mkdir -p $O   # (run three times this round: the last run is what profiles/r05_z_* hold)
 R=$GRAFT_REPO_ROOT
 run() { name=$1; shift; timeout 900 python bench.py "$@" > $O/$name.json 2> $O/$name.err; python - <<PY
 import json
