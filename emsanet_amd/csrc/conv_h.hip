@@ -720,11 +720,18 @@ bool convh_short_k() {
   return !(e && e[0] == '0');
 }
 
+// EMSA_CONVH_STEM32=0: the 7-tap stem on 64-channel K steps as before round 5 (A/B)
+bool convh_stem32() {
+  const char* e = getenv("EMSA_CONVH_STEM32");
+  return !(e && e[0] == '0');
+}
+
 template <int BM, int BN, int WM, int WN, typename T, int HK = 64>
 int launch_h(const ConvHArgs& a_in, hipStream_t st) {
   if constexpr (HK == 64) {
     const int steps64 = a_in.g.kh * a_in.g.kw * ((a_in.g.k_ch + 63) / 64);
-    if (!a_in.bnb_out && convh_pf() == 0 && steps64 <= kShortK && convh_short_k())
+    // (k_ch <= 32 -- the 7-tap stem over the packed NHWC4 input: 7 steps of 64 would be half padding)
+    if (!a_in.bnb_out && convh_pf() == 0 && (steps64 <= kShortK || (a_in.g.k_ch <= 32 && convh_stem32())) && convh_short_k())
       return launch_h<BM, BN, WM, WN, T, 32>(a_in, st);
   }
   ConvHArgs a = a_in;
