@@ -394,7 +394,7 @@ def run(args):
         if args.torch_optimizer:
             raise SystemExit("--graph with several ranks uses the fused optimizer")
         from emsanet_amd.graph import segment_parameter_groups
-        buckets = GradientBuckets(params, groups=segment_parameter_groups(model, (2, 1)),
+        buckets = GradientBuckets(params, groups=segment_parameter_groups(model, (2, 1), decoder_cut=True),
                                   manual=True, force_collectives=args.force_dist, average=False,
                                   comm_dtype=comm_dtype, tail_bytes=4 << 20)
     elif dist_on and not args.eval:
@@ -491,6 +491,8 @@ def run(args):
         # capture that RCCL / the runtime refuses must not cost the scaling run -- the object then
         # replays its eager twin, the same complete step with the same collectives
         kw = {'eager_fallback': True} if (segmented and world > 1 and not args.force_dist) else {}
+        if segmented:
+            kw['decoder_cut'] = True       # the decoder segment's buckets leave in two steps (nn.CutPlan)
         if crit is not None:
             train_graph = cls(model, batch, buckets, opt, loss_fn=lambda out: crit(out, targets)[0], **kw)
         else:
@@ -577,7 +579,7 @@ def run(args):
                 'bucket_bytes': [f.numel() * f.element_size() for f, _, _ in buckets.buckets],
                 'path': ('segmented-graph' if not graph_fallback else
                          f'segmented-eager (graph capture failed: {graph_fallback})') if segmented else 'eager',
-                'bucket_order': 'backward segments (graph per segment)' if segmented
+                'bucket_order': 'backward segments (graph per segment; the decoder segment cut in two)' if segmented
                 else 'measured gradient-arrival order, last bucket <= 4 MiB'}
         if segmented and train_graph is not None:
             # per bucket: issued this long before the device finished the backward pass

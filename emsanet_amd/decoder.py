@@ -116,10 +116,14 @@ class DecoderBody(nn.Module):
             r, self._pre = self._pre, None
             return r
         sides = []
-        for m, h, ds in zip(self.decoder_modules, self.side_output_heads,
-                            self.fusion_downsamplings):
+        plan = getattr(self, '_cut_plan', None)
+        for i, (m, h, ds) in enumerate(zip(self.decoder_modules, self.side_output_heads,
+                                           self.fusion_downsamplings)):
             x, s = m(x, self._skip(skips, ds), h)
             sides.append(s)
+            if i == 0 and plan is not None and plan.decoder_cut and len(self.decoder_modules) > 1:
+                # segmented backward (nn.CutPlan): the later modules and the head run on a leaf
+                x = plan.cut(x, None, plan.DECODER_MID)
         return x, tuple(sides)
 
 

@@ -260,15 +260,31 @@ class GraphedTrainStep:
         return self.static_loss, self.static_out
 
 
-def segment_parameter_groups(model, cut_stages=(2, 1)):
+def segment_parameter_groups(model, cut_stages=(2, 1), decoder_cut=False):
     """Parameters of `model` grouped by the backward SEGMENT that produces their gradients, in
     backward order: [context module + decoders], [encoder stages behind the last cut], ...,
     [encoder stages up to the first cut].  Pass as `GradientBuckets(params, groups=...,
-    manual=True)`: no bucket then straddles two segments (= two captured graphs)."""
+    manual=True)`: no bucket then straddles two segments (= two captured graphs).
+    decoder_cut (nn.CutPlan): the first group is two -- [heads + decoder modules 1.. of the dense
+    decoders], [their first modules + first side heads, context module, the other decoders]."""
+    from .decoder import DecoderBody
     from .nn import CutPlan
-    plan = CutPlan(cut_stages)
+    plan = CutPlan(cut_stages, decoder_cut)
     enc = model.encoder
-    groups = [list(reversed(list(model.context_module.parameters()) + list(model.decoders.parameters())))]
+    dec_all = list(model.context_module.parameters()) + list(model.decoders.parameters())
+    if decoder_cut:
+        bodies = [m for m in model.decoders.modules() if isinstance(m, DecoderBody)
+                  and len(m.decoder_modules) > 1]
+        dense = {id(p) for b_ in bodies for p in b_.parameters()}
+        # (a PanopticHelper wraps two bodies and has no parameters of its own; what is not inside a
+        #  dense body -- the scene head -- hangs on the context module: second segment)
+        first = {id(p) for b_ in bodies
+                 for p in list(b_.decoder_modules[0].parameters()) + list(b_.side_output_heads[0].parameters())}
+        seg_a = [p for p in dec_all if id(p) in dense and id(p) not in first]
+        seg_b = [p for p in dec_all if id(p) not in dense or id(p) in first]
+        groups = [list(reversed(seg_a)), list(reversed(seg_b))]
+    else:
+        groups = [list(reversed(dec_all))]
     hi = 4
     for c in plan.stages:                         # descending
         ps = []
@@ -310,7 +326,8 @@ class SegmentedGraphedTrainStep:
     the tests compare against and what the warm-up runs."""
 
     def __init__(self, model, example_batch, buckets, optimizer, loss_fn=None, cotangents=None,
-                 cut_stages=(2, 1), warmup=2, keep_warmup_updates=False, eager_fallback=False):
+                 cut_stages=(2, 1), warmup=2, keep_warmup_updates=False, eager_fallback=False,
+                 decoder_cut=False):
         """eager_fallback: if the capture raises (a runtime / RCCL that refuses it), keep the object
         and let replay() run the eager twin -- the same step, same collectives -- instead of
         failing; `capture_error` then holds the reason (bench.py reports it).  Default: raise."""
@@ -323,8 +340,8 @@ class SegmentedGraphedTrainStep:
             raise ValueError("GradientBuckets(manual=True, groups=segment_parameter_groups(...))")
         self.model, self.buckets, self.opt = model, buckets, optimizer
         self.loss_fn, self.cots = loss_fn, cotangents
-        self.plan = CutPlan(cut_stages)
-        self.n_seg = len(self.plan.stages) + 2
+        self.plan = CutPlan(cut_stages, decoder_cut)
+        self.n_seg = len(self.plan.stages) + 2 + (1 if decoder_cut else 0)
         if len(buckets.group_buckets) != self.n_seg:
             raise ValueError(f"buckets have {len(buckets.group_buckets)} parameter groups, the cut "
                              f"plan {self.n_seg} backward segments")
@@ -422,29 +439,53 @@ class SegmentedGraphedTrainStep:
         model, plan, b = self.model, self.plan, self.buckets
         model._cut_plan = plan
         try:
+            D, DM = plan.DECODERS, plan.DECODER_MID
             with self._segment(0):
                 b.reset()
                 out = model({**self.static_in, **self.extra})
                 flat = _flatten(out)
-                leaves = [c for _, c, _, g in plan.records if g == plan.DECODERS]
+                recs = plan.records
+                if plan.decoder_cut:
+                    # first decoder segment: heads + later modules; its leaves are the cuts behind
+                    # the first modules and the skips the LATER modules add
+                    leaves = [c for _, c, st, g in recs
+                              if g == DM or (g == D and st not in plan.late_stages)]
+                else:
+                    leaves = [c for _, c, _, g in recs if g == D]
                 if self.loss_fn is not None:
                     loss = self.loss_fn(out)
-                    torch.autograd.backward([loss], inputs=leaves + self.seg_params[0])
+                    roots, grads = [loss], [None]
                 else:
                     loss = None
-                    torch.autograd.backward(flat, self.cots, inputs=leaves + self.seg_params[0])
+                    roots, grads = list(flat), list(self.cots)
+                # (decoder_cut: the second segment starts from the same roots again -- the first side
+                #  outputs and the scene logits reach the first modules / the context module without
+                #  passing a cut -- so this pass keeps the graph)
+                torch.autograd.backward(roots, grads, inputs=leaves + self.seg_params[0],
+                                        retain_graph=plan.decoder_cut)
                 for bi in b.group_buckets[0]:
                     b.gather(bi)
             self._reduce(0)
-            pending = [(o, c.grad, st) for o, c, st, g in plan.records
-                       if g == plan.DECODERS and c.grad is not None]
+            k0 = 1
+            if plan.decoder_cut:
+                with self._segment(1):
+                    mid = [(o, c.grad) for o, c, _, g in recs if g == DM and c.grad is not None]
+                    leaves = [c for _, c, st, g in recs if g == D and st in plan.late_stages]
+                    torch.autograd.backward(roots + [o for o, _ in mid], grads + [g for _, g in mid],
+                                            inputs=leaves + self.seg_params[1])
+                    for bi in b.group_buckets[1]:
+                        b.gather(bi)
+                self._reduce(1)
+                k0 = 2
+            pending = [(o, c.grad, st) for o, c, st, g in recs
+                       if g == D and c.grad is not None]
             bounds = list(plan.stages) + [-1]
-            for k, cstage in enumerate(bounds, start=1):
+            for k, cstage in enumerate(bounds, start=k0):
                 with self._segment(k):
-                    roots = [(o, g) for o, g, st in pending if st > cstage]
+                    roots_k = [(o, g) for o, g, st in pending if st > cstage]
                     pending = [(o, g, st) for o, g, st in pending if st <= cstage]
                     merged = {}
-                    for o, g in roots:        # one tensor may have been cut twice (skip + encoder cut)
+                    for o, g in roots_k:      # one tensor may have been cut twice (skip + encoder cut)
                         merged[id(o)] = (o, g if id(o) not in merged else merged[id(o)][1] + g)
                     leaves = [c for _, c, _, g in plan.records if g == cstage]
                     torch.autograd.backward([o for o, _ in merged.values()],

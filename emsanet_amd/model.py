@@ -209,6 +209,9 @@ class EMSANet(nn.Module):
         for d in decs:
             bodies += [d.semantic_decoder, d.instance_decoder] if isinstance(d, PanopticHelper) else \
                 ([d] if isinstance(d, DecoderBody) else [])
+        plan = self._cut_plan if self.training else None
+        for bdy in bodies:
+            bdy._cut_plan = plan
         twin = len(bodies) >= 2 and twin_bodies_ok(bodies[0], bodies[1], x[0])
         if twin:
             bodies[0]._pre, bodies[1]._pre = twin_bodies(bodies[0], bodies[1], x[0], skips)
@@ -333,12 +336,18 @@ class EMSANet(nn.Module):
             # encoder / decoder boundary: everything the context module and the decoders read is a
             # detached leaf; the originals become roots of the encoder's backward segments
             D = plan.DECODERS
+            deep_raw = deep
             deep = {k: plan.cut(v, st, D) for k, (v, st) in deep.items()}
             # every skip stream a decoder READS ('add-rgb' by default; 'add-depth' / 'add-rgbd' per
             # decoder, emsanet/decoder.py:63-91) is cut into a leaf whose gradient flows back into
             # its encoder segment; a stream no decoder reads is just detached (its gradient comes
             # through the fusion modules only)
             read = self._skip_streams_read()
+            # (which of these leaves belong to the SECOND decoder segment of a decoder_cut plan: the
+            #  deep features and the skip the first decoder modules add, the one of the largest ds)
+            first_ds = str(max(int(ds) for ds in skips)) if skips else None
+            plan.late_stages = {st for _, (_, st) in deep_raw.items()} | \
+                ({st for _, (_, st) in skips[first_ds].items()} if first_ds is not None else set())
             skips = {ds: {k: (plan.cut(v, st, D) if k in read or len(sk) == 1 else v.detach())
                           for k, (v, st) in sk.items()} for ds, sk in skips.items()}
         # the context module sees the fused rgb stream, or the only stream there is

@@ -289,12 +289,21 @@ class CutPlan:
     the encoder / decoder boundary is always a cut."""
 
     DECODERS = 99          # `stage` of the encoder/decoder boundary group
+    DECODER_MID = 98       # group of the cut INSIDE the dense decoders (decoder_cut)
 
-    def __init__(self, stages=(2, 1)):
+    def __init__(self, stages=(2, 1), decoder_cut=False):
+        """decoder_cut: also cut every dense decoder behind its FIRST module (the 512-channel one:
+        three quarters of the decoders' parameters).  The decoder segment then runs as two backward
+        segments -- heads + later modules first, the first modules + context module + scene head
+        second -- so that its gradient buckets leave in two steps instead of all at the segment's
+        end."""
         self.stages = tuple(sorted(set(int(s) for s in stages), reverse=True))
         if any(s < 0 or s > 3 for s in self.stages):
             raise ValueError("CutPlan: encoder cuts go after stage 0..3")
+        self.decoder_cut = bool(decoder_cut)
         self.records = []      # (original, cut copy, producing stage, group)
+        self.late_stages = set()   # producing stages of the boundary tensors the FIRST decoder modules
+        #                            (and the context module) read: leaves of the second decoder segment
 
     def begin(self):
         self.records = []

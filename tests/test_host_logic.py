@@ -495,6 +495,18 @@ def test_segment_parameter_groups_partition_the_model():
     assert b2.buckets[-1][0].numel() * 4 <= 2 << 20
     with pytest.raises(ValueError):
         GradientBuckets(params, groups=groups[:-1])
+    # decoder_cut: the decoder group in two -- later modules + heads | first modules, first side heads,
+    # context module, scene head -- still a partition
+    g5 = segment_parameter_groups(model, (2, 1), decoder_cut=True)
+    assert len(g5) == 5 and [id(p) for g in g5[2:] for p in g] == [id(p) for g in groups[1:] for p in g]
+    assert {id(p) for p in g5[0]} | {id(p) for p in g5[1]} == {id(p) for p in groups[0]}
+    assert not ({id(p) for p in g5[0]} & {id(p) for p in g5[1]})
+    n0, n1 = [names[id(p)] for p in g5[0]], [names[id(p)] for p in g5[1]]
+    assert all('decoder_modules.0.' not in n and 'side_output_heads.0.' not in n and
+               not n.startswith(('context_module.', 'decoders.scene_decoder.')) for n in n0)
+    assert any(n.startswith('context_module.') for n in n1) and any('decoder_modules.0.' in n for n in n1)
+    assert any(n.startswith('decoders.scene_decoder.') for n in n1)
+    assert any('.head.' in n for n in n0) and any('decoder_modules.2.' in n for n in n0)
 
 
 def test_cut_plan_dry_run(fake_lib, monkeypatch):
@@ -523,3 +535,11 @@ def test_cut_plan_dry_run(fake_lib, monkeypatch):
     assert got and all(n.startswith(('decoders.', 'context_module.')) for n in got)
     with pytest.raises(ValueError):
         CutPlan((4,))
+    # decoder_cut: one more leaf per dense decoder behind its first module; the deep features and
+    # the /16 skip (what the first modules and the context module read) are marked "late"
+    plan = CutPlan((2, 1), decoder_cut=True)
+    model._cut_plan = plan
+    model(synthetic_batch(2, 64, 96))
+    model._cut_plan = None
+    assert [g for _, _, _, g in plan.records].count(CutPlan.DECODER_MID) == 2
+    assert plan.late_stages == {3, 4}

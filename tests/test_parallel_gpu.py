@@ -197,11 +197,12 @@ def _seg_worker(rank, world, port, ret):
         expect.append(t / world)
     gmax = max(e.abs().max().item() for e in expect)
 
-    groups = segment_parameter_groups(model, (2, 1))
+    groups = segment_parameter_groups(model, (2, 1), decoder_cut=True)
     buckets = GradientBuckets(params, bucket_bytes=8 << 20, groups=groups, manual=True,
                               average=False, tail_bytes=4 << 20)
     opt = FusedSGD(buckets, lr=0.0, momentum=0.9, weight_decay=0.0)
-    step = SegmentedGraphedTrainStep(model, batch, buckets, opt, cotangents=cots, cut_stages=(2, 1))
+    step = SegmentedGraphedTrainStep(model, batch, buckets, opt, cotangents=cots, cut_stages=(2, 1),
+                                     decoder_cut=True)
     assert model.dropout_step == 0              # the warm-up was taken back
     step.replay(batch)
     torch.cuda.synchronize()
@@ -220,7 +221,8 @@ def _seg_worker(rank, world, port, ret):
     both = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(both, digest)
     if rank == 0:
-        ret.update(worst=max(errs), n_buckets=len(buckets.buckets), early=early, lead=lead,
+        seg_lead = [max(lead[bi] for bi in g) for g in buckets.group_buckets]
+        ret.update(worst=max(errs), n_buckets=len(buckets.buckets), early=early, lead=lead, seg_lead=seg_lead,
                    n_last=len(last_seg), tail_bytes=tail_bytes,
                    same=bool((both[0] == both[1]).all().item()),
                    graphs=[i['nodes'] for i in step.graph_info])
@@ -242,16 +244,23 @@ def test_two_rank_segmented_graph_step_on_one_gpu():
     # the last segment (stem + layer1: the only gradients that cannot overlap) is small
     assert ret['early'] == ret['n_buckets'] - ret['n_last'] and ret['early'] >= ret['n_buckets'] - 1
     assert ret['tail_bytes'] <= 4 << 20
+    # decoder_cut: five backward segments (decoder heads + later modules | first decoder modules +
+    # context module | encoder stages 4-3 | stage 2 | stages 1-0), their buckets leave one segment
+    # after the other: strictly decreasing lead times
+    sl = ret['seg_lead']
+    assert len(sl) == 5 and all(a > b for a, b in zip(sl, sl[1:])), sl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('decoder_cut', [False, True])
 @pytest.mark.parametrize('inst_fusion', ['add-rgb', 'add-depth'])
-def test_segmented_step_equals_plain_step_single_process(inst_fusion):
+def test_segmented_step_equals_plain_step_single_process(inst_fusion, decoder_cut):
     """one process, no collectives: the segmented backward (cuts at the decoder boundary and
     behind encoder stages 2 and 1) gives the gradients of the ordinary backward pass, eagerly and
     replayed from its graphs; a second replay draws fresh Dropout2d masks.  'add-depth' for the
     instance decoder (emsanet/decoder.py:94-139 takes the fusion per decoder): the depth skips are
-    cut too, so the decoder's skip gradients reach the depth encoder"""
+    cut too, so the decoder's skip gradients reach the depth encoder.  decoder_cut: a
+    further cut behind the first module of both dense decoders, the loss is a root of two segments"""
     sys.path.insert(0, ROOT)
     from emsanet_amd import full_args, nyuv2_config
     from emsanet_amd.graph import SegmentedGraphedTrainStep, segment_parameter_groups
@@ -280,11 +289,12 @@ def test_segmented_step_equals_plain_step_single_process(inst_fusion):
     for p in params:
         p.grad = None
     model.dropout_step = 0
-    groups = segment_parameter_groups(model, (2, 1))
-    assert sum(len(g) for g in groups) == len(params) and len(groups) == 4
+    groups = segment_parameter_groups(model, (2, 1), decoder_cut=decoder_cut)
+    assert sum(len(g) for g in groups) == len(params) and len(groups) == 4 + decoder_cut
     buckets = GradientBuckets(params, groups=groups, manual=True, tail_bytes=4 << 20)
     opt = FusedSGD(buckets, lr=0.0, momentum=0.9, weight_decay=0.0)
-    step = SegmentedGraphedTrainStep(model, batch, buckets, opt, loss_fn=loss_of, cut_stages=(2, 1))
+    step = SegmentedGraphedTrainStep(model, batch, buckets, opt, loss_fn=loss_of, cut_stages=(2, 1),
+                                     decoder_cut=decoder_cut)
     gmax = max(float(r.abs().max()) for r in ref)
     loss_e, _ = step.eager_step(batch)
     for p, r in zip(params, ref):
