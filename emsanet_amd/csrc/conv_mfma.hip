@@ -2648,7 +2648,13 @@ bool plan_wgrad_multi(int n_jobs, const EmsaConvGeom* geoms, Wgrad1dPlan* pls, i
       return false;
   }
   const Wgrad1dArgs& w0 = pls[0].w;
-  int ks = 768 / (n_jobs * w0.n_tiles * w0.R);
+  // (EMSA_WGRAD_MULTI_WGS: the shared workgroup budget, tuning runs only)
+  static const int budget = [] {
+    const char* e = getenv("EMSA_WGRAD_MULTI_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 64 ? v : 768;
+  }();
+  int ks = budget / (n_jobs * w0.n_tiles * w0.R);
   for (int j = 0; j < n_jobs; ++j) {
     const int max_split = (pls[j].w.steps_total + 3) / 4;
     if (ks > max_split) ks = max_split;

@@ -320,6 +320,32 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
   }
 }
 
+// ---- the arithmetic of the BatchNorm passes, spelled out ----------------------------------------
+// One fma / mul / add per step, none left to the compiler's contraction heuristics: the general and
+// the fast form of a pass (below) must round alike, and what clang fuses depends on the code around
+// an expression (a product hoisted out of a loop is no longer fused into the sum behind it).
+__device__ __forceinline__ float bn_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float bn_add(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+// y = x * scale + shift
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+// one term of sum g * xhat:  acc + (g * (x - mean)) * invstd
+__device__ __forceinline__ float bn_acc_xhat(float acc, float g, float x, float mu, float is) {
+  return __builtin_fmaf(bn_mul(g, bn_add(x, -mu)), is, acc);
+}
+// dx = gamma * invstd * (g - sum_g / N - xhat * sum_gxhat / N), gi = gamma * invstd (bn_mul)
+__device__ __forceinline__ float bn_dx_train(float g, float x, float mu, float is, float gi, float db,
+                                             float dg, float inv_count) {
+  const float xh = bn_mul(bn_add(x, -mu), is);
+  const float t = __builtin_fmaf(-db, inv_count, g);
+  return bn_mul(gi, __builtin_fmaf(-bn_mul(xh, dg), inv_count, t));
+}
+
 // ---- vector access per lane: 16 bytes = 4 fp32 or 8 16-bit channels ---------------------------
 // (the first 16-bit versions of the three BatchNorm passes moved 4 channels = 8 bytes per lane and
 //  ran at the SAME time as their fp32 twins on half the bytes: 35 vs 43, 35 vs 34, 23 vs 32 us)
@@ -330,6 +356,15 @@ template <typename T> struct VecIO {
   typedef float fv __attribute__((ext_vector_type(8)));
   static __device__ __forceinline__ void load(const T* p, float (&v)[8]) {
     const fv f = __builtin_convertvector(*reinterpret_cast<const ev*>(p), fv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f[k];
+  }
+  // the 16 bytes as they are (the fast BatchNorm passes issue all loads of an iteration first and
+  // convert where the values are used)
+  typedef ev raw;
+  static __device__ __forceinline__ raw load_raw(const T* p) { return *reinterpret_cast<const ev*>(p); }
+  static __device__ __forceinline__ void cvt(const raw& r, float (&v)[8]) {
+    const fv f = __builtin_convertvector(r, fv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = f[k];
   }
@@ -344,6 +379,11 @@ template <> struct VecIO<float> {
   static constexpr int V = 4;
   static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
     const float4 f = emsa_ld4(p);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  }
+  typedef float4 raw;
+  static __device__ __forceinline__ raw load_raw(const float* p) { return emsa_ld4(p); }
+  static __device__ __forceinline__ void cvt(const raw& f, float (&v)[4]) {
     v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
   }
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
@@ -379,18 +419,18 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
     ldf<V>(scale + cv * V, sc);
     ldf<V>(shift + cv * V, sh);
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = v[k] * sc[k] + sh[k];
+    for (int k = 0; k < V; ++k) v[k] = bn_affine(v[k], sc[k], sh[k]);
     if (drop) {
       float d[V];
       ldf<V>(drop + (pix / hw) * (long)cvn * V + cv * V, d);
 #pragma unroll
-      for (int k = 0; k < V; ++k) v[k] *= d[k];
+      for (int k = 0; k < V; ++k) v[k] = bn_mul(v[k], d[k]);
     }
     if (residual) {
       float r[V];
       VecIO<T>::load(residual + i * V, r);
 #pragma unroll
-      for (int k = 0; k < V; ++k) v[k] += r[k];
+      for (int k = 0; k < V; ++k) v[k] = bn_add(v[k], r[k]);
     }
     if (act == EMSA_ACT_RELU) {
 #pragma unroll
@@ -406,6 +446,98 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 #pragma unroll
         for (int k = 0; k < V; ++k) m[k] = b[k];
       }
+    }
+  }
+}
+
+// ---- fast forms of the three BatchNorm passes (round 5) ------------------------------------------
+// The loops above cost the bf16 step 2.4-3.8 TB/s of algorithmic bytes where a streaming kernel
+// reaches 5 (profiles/r05_l_pointwise_bench16*.txt): per iteration two 64-bit divisions (i % cvn,
+// pix / hw: ~200 instructions), the per-channel vectors re-loaded from global memory, and the
+// tensor loads SERIALISED -- x, wait, drop (its address depends on the division), wait, residual,
+// wait: three memory round trips where one is needed.  The fast forms, taken when the channel-vector
+// count is a power of two <= 256 (every BatchNorm of the model) and the tensor has < 2^31 vectors:
+//   * 32-bit indices; the grid stride is a multiple of cvn, so a thread's channel vector never
+//     changes: scale / shift / gamma / mean / invstd are loaded ONCE into registers;
+//   * optional operands are template parameters -- no control flow between a load and its use, all
+//     loads of an iteration (two elements per iteration) are issued before the first is consumed;
+//   * the same arithmetic in the same order (bn_affine / bn_mul / bn_dx_train ...: every fma spelled
+//     out): results are bit-identical to the loops above, which stay as the general form
+//     (EMSA_BN_FAST=0 selects them for A/B runs; tests/test_ops16_gpu.py compares the two).
+template <typename T, bool DROP, bool RES>
+__global__ __launch_bounds__(kThreads) void bn_act_fwd_fast_kernel(
+    const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ drop, const T* __restrict__ residual,
+    uint32_t hw, int cvn_log2, uint32_t totalv, int act, uint64_t* __restrict__ mask_bits) {
+  constexpr int V = VecIO<T>::V;
+  typedef typename VecIO<T>::raw Raw;
+  const uint32_t stride = gridDim.x * kThreads;
+  uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t cvn = 1u << cvn_log2, cv = i & (cvn - 1);
+  const uint32_t dpix = stride >> cvn_log2;
+  uint32_t pix = i >> cvn_log2;
+  float sc[V], sh[V];
+  ldf<V>(scale + cv * V, sc);
+  ldf<V>(shift + cv * V, sh);
+  auto finish = [&](uint32_t idx, const Raw& rx, const Raw& rr, const float (&d)[V]) {
+    float v[V];
+    VecIO<T>::cvt(rx, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = bn_affine(v[k], sc[k], sh[k]);
+    if constexpr (DROP) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = bn_mul(v[k], d[k]);
+    }
+    if constexpr (RES) {
+      float r[V];
+      VecIO<T>::cvt(rr, r);
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = bn_add(v[k], r[k]);
+    }
+    if (act == EMSA_ACT_RELU) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    VecIO<T>::store(y + (size_t)idx * V, v);
+    if (mask_bits) {
+      uint64_t b[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) b[k] = __ballot(v[k] > 0.f);
+      if ((idx & 63) == 0) {
+        uint64_t* m = mask_bits + (size_t)(idx >> 6) * V;
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = b[k];
+      }
+    }
+  };
+  auto ld_drop = [&](uint32_t px, float (&d)[V]) {
+    if constexpr (DROP) ldf<V>(drop + ((size_t)(px / hw) * cvn + cv) * V, d);
+  };
+  // wave-uniform loop bounds (the ballots want whole waves): iw = the wave's first index
+  uint32_t iw = i & ~63u;
+  for (; iw + stride + 64 <= totalv; iw += 2 * stride, i += 2 * stride, pix += 2 * dpix) {
+    const uint32_t i1 = i + stride;
+    const Raw x0 = VecIO<T>::load_raw(x + (size_t)i * V);
+    const Raw x1 = VecIO<T>::load_raw(x + (size_t)i1 * V);
+    Raw r0 = x0, r1 = x1;
+    if constexpr (RES) {
+      r0 = VecIO<T>::load_raw(residual + (size_t)i * V);
+      r1 = VecIO<T>::load_raw(residual + (size_t)i1 * V);
+    }
+    float d0[V], d1[V];
+    ld_drop(pix, d0);
+    ld_drop(pix + dpix, d1);
+    finish(i, x0, r0, d0);
+    finish(i1, x1, r1, d1);
+  }
+  for (; iw < totalv; iw += stride, i += stride, pix += dpix) {
+    if (i < totalv) {
+      const Raw x0 = VecIO<T>::load_raw(x + (size_t)i * V);
+      Raw r0 = x0;
+      if constexpr (RES) r0 = VecIO<T>::load_raw(residual + (size_t)i * V);
+      float d0[V];
+      ld_drop(pix, d0);
+      finish(i, x0, r0, d0);
     }
   }
 }
@@ -480,7 +612,7 @@ __device__ __forceinline__ void bn_bwd_load(const T* __restrict__ dy, const T* _
     float d[V];
     ldf<V>(drop + ((pix / hw) * cvn + cv) * V, d);
 #pragma unroll
-    for (int k = 0; k < V; ++k) g[k] *= d[k];
+    for (int k = 0; k < V; ++k) g[k] = bn_mul(g[k], d[k]);
   }
 }
 
@@ -514,8 +646,8 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
       VecIO<T>::load(x + i * V, xx);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        a1[k] += g[k];
-        a2[k] += g[k] * (xx[k] - mu[k]) * is[k];
+        a1[k] = bn_add(a1[k], g[k]);
+        a2[k] = bn_acc_xhat(a2[k], g[k], xx[k], mu[k], is[k]);
       }
     }
 #pragma unroll
@@ -615,12 +747,200 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
       ldf<V>(dgamma + cv * V, dg);
 #pragma unroll
       for (int k = 0; k < V; ++k)
-        o[k] = ga[k] * is[k] * (g[k] - db[k] * inv_count - (xx[k] - mu[k]) * is[k] * dg[k] * inv_count);
+        o[k] = bn_dx_train(g[k], xx[k], mu[k], is[k], bn_mul(ga[k], is[k]), db[k], dg[k], inv_count);
     } else {
 #pragma unroll
-      for (int k = 0; k < V; ++k) o[k] = g[k] * ga[k] * is[k];
+      for (int k = 0; k < V; ++k) o[k] = bn_mul(bn_mul(g[k], ga[k]), is[k]);
     }
     VecIO<T>::store(dx + i * V, o);
+  }
+}
+
+// fast form of bn_bwd_reduce_kernel (see bn_act_fwd_fast_kernel): same thread -> (pixel lane,
+// channel vector) mapping and the same summation order, i.e. bit-identical partial rows; MASK = 0
+// none / 1 the bit mask / 2 the activation output y
+template <typename T, int MASK, bool DROP>
+struct BnBwdElem {
+  typename VecIO<T>::raw g, x, y;
+  ulonglong2 w[VecIO<T>::V / 2];
+  float d[VecIO<T>::V];
+};
+template <typename T, int MASK, bool DROP>
+__device__ __forceinline__ void bn_bwd_issue(BnBwdElem<T, MASK, DROP>& e, const T* __restrict__ dy,
+                                             const T* __restrict__ y,
+                                             const uint64_t* __restrict__ mask_bits,
+                                             const T* __restrict__ x, const float* __restrict__ drop,
+                                             uint32_t i, uint32_t pix, uint32_t hw, uint32_t cvn,
+                                             uint32_t cv, bool want_x) {
+  constexpr int V = VecIO<T>::V;
+  e.g = VecIO<T>::load_raw(dy + (size_t)i * V);
+  if (want_x) e.x = VecIO<T>::load_raw(x + (size_t)i * V);
+  if constexpr (MASK == 1) {
+    const ulonglong2* w = reinterpret_cast<const ulonglong2*>(mask_bits + (size_t)(i >> 6) * V);
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) e.w[k] = w[k];
+  }
+  if constexpr (MASK == 2) e.y = VecIO<T>::load_raw(y + (size_t)i * V);
+  if constexpr (DROP) ldf<V>(drop + ((size_t)(pix / hw) * cvn + cv) * V, e.d);
+}
+// -> g (masked, dropped), gres (masked): the values bn_bwd_load produces
+template <typename T, int MASK, bool DROP>
+__device__ __forceinline__ void bn_bwd_grad(const BnBwdElem<T, MASK, DROP>& e, uint32_t i,
+                                            float (&g)[VecIO<T>::V], float (&gres)[VecIO<T>::V]) {
+  constexpr int V = VecIO<T>::V;
+  VecIO<T>::cvt(e.g, g);
+  if constexpr (MASK == 1) {
+    const int sh = (int)(i & 63);
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) {
+      g[2 * k] = ((e.w[k].x >> sh) & 1ull) ? g[2 * k] : 0.f;
+      g[2 * k + 1] = ((e.w[k].y >> sh) & 1ull) ? g[2 * k + 1] : 0.f;
+    }
+  }
+  if constexpr (MASK == 2) {
+    float yy[V];
+    VecIO<T>::cvt(e.y, yy);
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) gres[k] = g[k];
+  if constexpr (DROP) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = bn_mul(g[k], e.d[k]);
+  }
+}
+
+template <typename T, int MASK, bool DROP>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_fast_kernel(
+    const T* __restrict__ dy, const T* __restrict__ y, const uint64_t* __restrict__ mask_bits,
+    const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ drop, uint32_t pixels, uint32_t hw, int cvn, int rows_alloc,
+    float* __restrict__ partial) {
+  constexpr int V = VecIO<T>::V;
+  typedef BnBwdElem<T, MASK, DROP> Elem;
+  extern __shared__ __attribute__((aligned(16))) float cred[];   // [2][lanes][c]
+  const uint32_t rows = gridDim.x;
+  const uint32_t chunk = (pixels + rows - 1) / rows;
+  const uint32_t p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
+  const int lanes = kThreads / cvn, c = cvn * V;
+  const int cv = threadIdx.x % cvn, rl = threadIdx.x / cvn;
+  float a1[V], a2[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) a1[k] = a2[k] = 0.f;
+  if (rl < lanes) {
+    float mu[V], is[V];
+    ldf<V>(mean + cv * V, mu);
+    ldf<V>(invstd + cv * V, is);
+    auto use = [&](const Elem& e, uint32_t i) {
+      float g[V], gres[V], xx[V];
+      bn_bwd_grad<T, MASK, DROP>(e, i, g, gres);
+      VecIO<T>::cvt(e.x, xx);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        a1[k] = bn_add(a1[k], g[k]);
+        a2[k] = bn_acc_xhat(a2[k], g[k], xx[k], mu[k], is[k]);
+      }
+    };
+    uint32_t p = p0 + rl;
+    for (; p + lanes < p1; p += 2 * lanes) {
+      Elem e0, e1;
+      const uint32_t i0 = p * cvn + cv, i1 = (p + lanes) * cvn + cv;
+      bn_bwd_issue<T, MASK, DROP>(e0, dy, y, mask_bits, x, drop, i0, p, hw, cvn, cv, true);
+      bn_bwd_issue<T, MASK, DROP>(e1, dy, y, mask_bits, x, drop, i1, p + lanes, hw, cvn, cv, true);
+      use(e0, i0);
+      use(e1, i1);
+    }
+    if (p < p1) {
+      Elem e0;
+      const uint32_t i0 = p * cvn + cv;
+      bn_bwd_issue<T, MASK, DROP>(e0, dy, y, mask_bits, x, drop, i0, p, hw, cvn, cv, true);
+      use(e0, i0);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      cred[(0 * lanes + rl) * c + cv * V + k] = a1[k];
+      cred[(1 * lanes + rl) * c + cv * V + k] = a2[k];
+    }
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < 2 * c; ch += blockDim.x) {
+    const int which = ch / c, cc = ch % c;
+    float a = 0.f;
+    for (int k = 0; k < lanes; ++k) a += cred[(which * lanes + k) * c + cc];
+    partial[((long)which * rows_alloc + blockIdx.x) * c + cc] = a;
+  }
+}
+
+// fast form of bn_bwd_apply_kernel: a thread's channel vector is fixed (grid stride = a multiple of
+// cvn), its gamma / invstd / mean / sums live in registers
+template <typename T, int MASK, bool DROP, bool TRAIN>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_fast_kernel(
+    const T* __restrict__ dy, const T* __restrict__ y, const uint64_t* __restrict__ mask_bits,
+    const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ drop,
+    const float* __restrict__ partial, int rows, int rows_alloc, float* __restrict__ dbeta_out,
+    float* __restrict__ dgamma_out, uint32_t hw, int cvn_log2, uint32_t totalv, float inv_count,
+    T* __restrict__ dx, T* __restrict__ dres) {
+  constexpr int V = VecIO<T>::V;
+  typedef BnBwdElem<T, MASK, DROP> Elem;
+  extern __shared__ __attribute__((aligned(16))) float sums[];   // [2][c]
+  const uint32_t cvn = 1u << cvn_log2;
+  const int c = (int)cvn * V;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBwdSlices; ++sl) {
+      a1 += (double)partial[((long)0 * rows_alloc + rows + sl) * c + ch];
+      a2 += (double)partial[((long)1 * rows_alloc + rows + sl) * c + ch];
+    }
+    sums[ch] = (float)a1;
+    sums[c + ch] = (float)a2;
+    if (blockIdx.x == 0) {
+      dbeta_out[ch] = (float)a1;
+      dgamma_out[ch] = (float)a2;
+    }
+  }
+  __syncthreads();
+  const uint32_t stride = gridDim.x * kThreads;
+  uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t cv = i & (cvn - 1), dpix = stride >> cvn_log2;
+  uint32_t pix = i >> cvn_log2;
+  float ga[V], is[V], mu[V], db[V], dg[V];
+  ldf<V>(gamma + cv * V, ga);
+  ldf<V>(invstd + cv * V, is);
+  if constexpr (TRAIN) {
+    ldf<V>(mean + cv * V, mu);
+    ldf<V>(sums + cv * V, db);
+    ldf<V>(sums + c + cv * V, dg);
+  }
+  auto use = [&](const Elem& e, uint32_t idx) {
+    float g[V], gres[V], o[V];
+    bn_bwd_grad<T, MASK, DROP>(e, idx, g, gres);
+    if (dres) VecIO<T>::store(dres + (size_t)idx * V, gres);
+    if constexpr (TRAIN) {
+      float xx[V];
+      VecIO<T>::cvt(e.x, xx);
+#pragma unroll
+      for (int k = 0; k < V; ++k)
+        o[k] = bn_dx_train(g[k], xx[k], mu[k], is[k], bn_mul(ga[k], is[k]), db[k], dg[k], inv_count);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] = bn_mul(bn_mul(g[k], ga[k]), is[k]);
+    }
+    VecIO<T>::store(dx + (size_t)idx * V, o);
+  };
+  for (; i + stride < totalv; i += 2 * stride, pix += 2 * dpix) {
+    Elem e0, e1;
+    bn_bwd_issue<T, MASK, DROP>(e0, dy, y, mask_bits, x, drop, i, pix, hw, cvn, cv, TRAIN);
+    bn_bwd_issue<T, MASK, DROP>(e1, dy, y, mask_bits, x, drop, i + stride, pix + dpix, hw, cvn, cv, TRAIN);
+    use(e0, i);
+    use(e1, i + stride);
+  }
+  if (i < totalv) {
+    Elem e0;
+    bn_bwd_issue<T, MASK, DROP>(e0, dy, y, mask_bits, x, drop, i, pix, hw, cvn, cv, TRAIN);
+    use(e0, i);
   }
 }
 
@@ -2152,6 +2472,21 @@ extern "C" int emsa_bn_fold(const float* gamma, const float* beta, const float* 
 extern "C" int64_t emsa_relu_mask_words(int64_t elements) {
   return ((elements / 4 + 63) / 64) * 4 + 8;
 }
+// fast forms of the BatchNorm passes (bn_act_fwd_fast_kernel): log2 of the channel-vector count when
+// it is a power of two <= 256 and the indices fit 32 bits, else -1 (general kernels).
+// EMSA_BN_FAST=0: always the general kernels (A/B runs)
+static bool bn_fast_on() {
+  static const bool on = [] {
+    const char* e = getenv("EMSA_BN_FAST");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+static int bn_fast_log2(int cvn, long totalv, long hw) {
+  if (!bn_fast_on() || cvn < 1 || cvn > kThreads || (cvn & (cvn - 1)) != 0) return -1;
+  if (totalv < 1 || totalv >= (1L << 31) || hw < 1 || hw >= (1L << 31)) return -1;
+  return __builtin_ctz((unsigned)cvn);
+}
 // channel count admissible for the vectorised BatchNorm passes of storage type T
 template <typename T> static bool cv_ok(int c) { return c4_ok(c) && c % VecIO<T>::V == 0; }
 
@@ -2161,6 +2496,21 @@ static int bn_act_fwd_impl(const T* x, T* y, const float* scale, const float* sh
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   constexpr int V = VecIO<T>::V;
   const long totalv = (long)n_img * hw * (c / V);
+  const int lg = bn_fast_log2(c / V, totalv, hw);
+  if (lg >= 0) {
+    const dim3 grid(grid_for(totalv)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define EMSA_FWD_FAST(D, R)                                                                        \
+  hipLaunchKernelGGL((bn_act_fwd_fast_kernel<T, D, R>), grid, block, 0, st, x, y, scale, shift,   \
+                     drop, residual, (uint32_t)hw, lg, (uint32_t)totalv, act, mask_bits)
+    if (drop) {
+      if (residual) EMSA_FWD_FAST(true, true); else EMSA_FWD_FAST(true, false);
+    } else {
+      if (residual) EMSA_FWD_FAST(false, true); else EMSA_FWD_FAST(false, false);
+    }
+#undef EMSA_FWD_FAST
+    return emsa_launch_status();
+  }
   hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(grid_for(totalv)), dim3(kThreads), 0,
                      (hipStream_t)stream, x, y, scale, shift, drop, residual, (long)hw, c / V,
                      totalv, act, mask_bits);
@@ -2202,6 +2552,22 @@ static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits
   const int rows = bn_bwd_rows_for(pixels, c);
   const int cvn = c / VecIO<T>::V, lanes = kThreads / cvn;
   const size_t lds = (size_t)2 * lanes * c * sizeof(float);
+  if (bn_fast_on() && cvn <= kThreads && pixels * cvn < (1L << 31) && hw < (1L << 31)) {
+    const dim3 grid(rows), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    const int mask = act == EMSA_ACT_RELU ? (mask_bits ? 1 : 2) : 0;
+#define EMSA_RED_FAST(M, D)                                                                        \
+  hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<T, M, D>), grid, block, lds, st, dy, y, mask_bits, \
+                     x, save_mean, save_invstd, drop, (uint32_t)pixels, (uint32_t)hw, cvn,        \
+                     rows + kBwdSlices, partial)
+    if (drop) {
+      if (mask == 1) EMSA_RED_FAST(1, true); else if (mask == 2) EMSA_RED_FAST(2, true); else EMSA_RED_FAST(0, true);
+    } else {
+      if (mask == 1) EMSA_RED_FAST(1, false); else if (mask == 2) EMSA_RED_FAST(2, false); else EMSA_RED_FAST(0, false);
+    }
+#undef EMSA_RED_FAST
+    return emsa_launch_status();
+  }
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
                      dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, cvn, act,
                      rows + kBwdSlices, partial);
@@ -2238,6 +2604,30 @@ static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits,
   // four workgroups per CU (the other streaming kernels: eight): measured -0.3 ms per step
   int ap_grid = grid_for(totalv);
   if (ap_grid > 256 * 4) ap_grid = 256 * 4;
+  const int lg = bn_fast_log2(c / V, totalv, hw);
+  if (lg >= 0) {
+    const dim3 grid(ap_grid), block(kThreads);
+    const size_t lds = (size_t)2 * c * sizeof(float);
+    const int mask = act == EMSA_ACT_RELU ? (mask_bits ? 1 : 2) : 0;
+    const float inv_count = 1.0f / (float)pixels;
+#define EMSA_APP_FAST(M, D, TR)                                                                     \
+  hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, M, D, TR>), grid, block, lds, st, dy, y,         \
+                     mask_bits, x, gamma, save_mean, save_invstd, drop, partial, rows, rows_alloc,  \
+                     dbeta, dgamma, (uint32_t)hw, lg, (uint32_t)totalv, inv_count, dx, dres)
+#define EMSA_APP_FAST_M(D, TR)                                                                      \
+  do {                                                                                              \
+    if (mask == 1) EMSA_APP_FAST(1, D, TR); else if (mask == 2) EMSA_APP_FAST(2, D, TR);            \
+    else EMSA_APP_FAST(0, D, TR);                                                                   \
+  } while (0)
+    if (drop) {
+      if (train) EMSA_APP_FAST_M(true, true); else EMSA_APP_FAST_M(true, false);
+    } else {
+      if (train) EMSA_APP_FAST_M(false, true); else EMSA_APP_FAST_M(false, false);
+    }
+#undef EMSA_APP_FAST_M
+#undef EMSA_APP_FAST
+    return emsa_launch_status();
+  }
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ap_grid), dim3(kThreads),
                      (size_t)2 * c * sizeof(float), st, dy, y, mask_bits, x, gamma, save_mean,
                      save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / V, totalv,

@@ -463,3 +463,67 @@ def test_head_act_bwd_gather_is_copy_plus_bwd(dtype, n_norm):
         got = Fn.head_act_bwd_gather(grads, sizes, y, 1, 2, n_norm, x=xg if n_norm else None, dtype=dtype)
         torch.cuda.synchronize()
         assert got is not None and got.dtype == dtype and torch.equal(got, ref), (dtype, n_norm, drop)
+
+
+_BN_FAST_CODE = '''
+import sys, torch
+sys.path.insert(0, "tests")
+from util import DEV, rnd
+from emsanet_amd import functional as Fn
+
+def run(dtype, n, c, h, w):
+    def act(seed):
+        g = torch.Generator().manual_seed(seed)
+        t = torch.randn(n, h, w, c, generator=g).to(dtype).to(DEV)
+        return t.permute(0, 3, 1, 2)
+    x, res, dy = act(1), act(2), act(3)
+    sc, sh = (rnd(c, seed=4).abs() + 0.5).to(DEV), rnd(c, seed=5).to(DEV)
+    mean, inv = rnd(c, seed=6).to(DEV), (rnd(c, seed=7).abs() + 0.5).to(DEV)
+    drop = ((rnd(n, c, seed=8) > -0.5).float() * 1.25).to(DEV)
+    out = []
+    for d, r in ((None, None), (drop, res), (None, res), (drop, None)):
+        y, bits = Fn.bn_act(x, sc, sh, d, r, Fn.ACT_RELU, want_mask=True)
+        out += [y, bits[:(y.numel() // 64)]]
+        for mask in (bits, y):
+            for train in (True, False):
+                out += [t for t in Fn.bn_bwd(dy, mask, x, sc, mean, inv, d, Fn.ACT_RELU, train, r is not None)
+                        if t is not None]
+    y = Fn.bn_act(x, sc, sh, None, None, Fn.ACT_NONE)
+    out += [y] + [t for t in Fn.bn_bwd(dy, None, x, sc, mean, inv, None, Fn.ACT_NONE, True, False)
+                  if t is not None]
+    torch.cuda.synchronize()
+    return [t.cpu() for t in out]
+
+res = {}
+for name, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+    # several grid strides per thread (pair loop + tail), a ragged end, c = 512 (64 / 128 vectors)
+    for shp in ((8, 64, 120, 160), (3, 128, 37, 41), (2, 512, 15, 20), (5, 64, 9, 7)):
+        res[name + str(shp)] = run(dtype, *shp)
+torch.save(res, sys.argv[1])
+print("BN_DUMP_OK")
+'''
+
+
+def test_bn_fast_kernels_are_bit_identical_to_the_general_ones(tmp_path):
+    """round 5: the BatchNorm passes run on `*_fast_kernel` forms (fixed channel vector per thread,
+    all loads of an iteration issued first, csrc/pointwise.hip); EMSA_BN_FAST=0 selects the general
+    loops they replace -- same arithmetic in the same order, so every output must be bit-identical"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ('1', '0'):
+        path = str(tmp_path / f'bn_{flag}.pt')
+        env = dict(os.environ, EMSA_BN_FAST=flag)
+        r = subprocess.run([sys.executable, '-c', _BN_FAST_CODE, path], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert 'BN_DUMP_OK' in r.stdout, r.stderr[-3000:]
+        outs[flag] = torch.load(path)
+    assert outs['1'].keys() == outs['0'].keys()
+    for k in outs['1']:
+        a, b = outs['1'][k], outs['0'][k]
+        assert len(a) == len(b) and len(a) > 20
+        for i, (ta, tb) in enumerate(zip(a, b)):
+            assert ta.dtype == tb.dtype and ta.shape == tb.shape
+            assert torch.equal(ta, tb), (k, i, (ta.float() - tb.float()).abs().max().item())
