@@ -978,18 +978,20 @@ __global__ void dropout2d_mask_batch_kernel(float* __restrict__ masks,
 // ------------------------------------------------------------------------------------------
 // max pool 3x3 s2 p1
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// I: index type (uint32_t when every element index fits 31 bits -- idx32_ok: a 64-bit division costs
+// ~120 instructions, a 32-bit one ~25, and these loops decompose their index per element)
+template <typename T, typename I = long>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                    int8_t* __restrict__ idx, int n, int h, int w, int c4n) {
   const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;
-  const long total = (long)n * oh_n * ow_n * c4n;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long r = i / c4n;
-    const int ow = (int)(r % ow_n); r /= ow_n;
-    const int oh = (int)(r % oh_n);
-    const int img = (int)(r / oh_n);
+  const I total = (I)n * oh_n * ow_n * c4n;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total;
+       i += (I)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (I)c4n);
+    I r = i / (I)c4n;
+    const int ow = (int)(r % (I)ow_n); r /= (I)ow_n;
+    const int oh = (int)(r % (I)oh_n);
+    const int img = (int)(r / (I)oh_n);
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int bi[4] = {0, 0, 0, 0};
     bool first = true;
@@ -999,7 +1001,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
         if (ih < 0 || ih >= h || iw < 0 || iw >= w) continue;
-        const float4 v = emsa_ld4(x + (((long)img * h + ih) * w + iw) * c4n * 4 + c4 * 4);
+        const float4 v = emsa_ld4(x + (size_t)(((((I)img * h + ih) * w + iw) * c4n + c4) * 4));
         const int t = kh * 3 + kw;
         if (first || v.x > best.x) { best.x = v.x; bi[0] = t; }
         if (first || v.y > best.y) { best.y = v.y; bi[1] = t; }
@@ -1007,8 +1009,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
         if (first || v.w > best.w) { best.w = v.w; bi[3] = t; }
         first = false;
       }
-    emsa_st4(y + i * 4, best);
-    *reinterpret_cast<char4*>(idx + i * 4) = make_char4(bi[0], bi[1], bi[2], bi[3]);
+    emsa_st4(y + (size_t)i * 4, best);
+    *reinterpret_cast<char4*>(idx + (size_t)i * 4) = make_char4(bi[0], bi[1], bi[2], bi[3]);
   }
 }
 
@@ -1016,19 +1018,19 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
 // under exactly the four windows (qh..qh+1, qw..qw+1), so four (dy, argmax) pairs are read for four
 // stores -- the pixel-per-thread form read 2.25 windows per pixel (4.5 loads per store) and moved
 // 2.4 TB/s.  Window (oh, ow) covers rows 2oh-1 .. 2oh+1: tap index kh = ih - 2oh + 1.
-template <typename T>
+template <typename T, typename I = long>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __restrict__ idx,
                                    T* __restrict__ dx, int n, int h, int w, int cvn) {
   constexpr int V = VecIO<T>::V;
   const int oh_n = (h + 1) / 2, ow_n = (w + 1) / 2;      // also the number of quads per direction
-  const long total = (long)n * oh_n * ow_n * cvn;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % cvn);
-    long r = i / cvn;
-    const int qw = (int)(r % ow_n); r /= ow_n;
-    const int qh = (int)(r % oh_n);
-    const int img = (int)(r / oh_n);
+  const I total = (I)n * oh_n * ow_n * cvn;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total;
+       i += (I)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % (I)cvn);
+    I r = i / (I)cvn;
+    const int qw = (int)(r % (I)ow_n); r /= (I)ow_n;
+    const int qh = (int)(r % (I)oh_n);
+    const int img = (int)(r / (I)oh_n);
     float acc[2][2][V];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1042,7 +1044,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __res
       for (int dw = 0; dw < 2; ++dw) {
         const int oh = qh + dh, ow = qw + dw;
         if (oh >= oh_n || ow >= ow_n) continue;
-        const long o = ((((long)img * oh_n + oh) * ow_n + ow) * cvn + cv) * V;
+        const size_t o = (size_t)(((((I)img * oh_n + oh) * ow_n + ow) * cvn + cv) * V);
         float g[V];
         VecIO<T>::load(dy + o, g);
         int8_t kk[V];
@@ -1079,7 +1081,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __res
       for (int b2 = 0; b2 < 2; ++b2) {
         const int ih = 2 * qh + a, iw = 2 * qw + b2;
         if (ih < h && iw < w)
-          VecIO<T>::store(dx + ((((long)img * h + ih) * w + iw) * cvn + cv) * V, acc[a][b2]);
+          VecIO<T>::store(dx + (size_t)(((((I)img * h + ih) * w + iw) * cvn + cv) * V), acc[a][b2]);
       }
   }
 }
@@ -1381,55 +1383,71 @@ __global__ void se_mlp_bwd_kernel(const float* __restrict__ gap, const float* __
   }
 }
 
-template <typename T>
+// HAS_B / HAS_E: the optional second operand is a template parameter -- all loads of an element are
+// issued before the first is used (as a run-time `if (b)` the loads sat behind a branch and the
+// element took two memory round trips); I: index type, see maxpool_fwd_kernel
+template <typename T, bool HAS_B, typename I>
 __global__ void se_scale_add_fwd_kernel(const T* __restrict__ a, const float* __restrict__ sa,
                                         const T* __restrict__ b, const float* __restrict__ sb,
-                                        T* __restrict__ out, long hw, int cvn, long totalv) {
+                                        T* __restrict__ out, I hw, int cvn, I totalv) {
   constexpr int V = VecIO<T>::V;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalv;
-       i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % cvn);
-    const long img = (i / cvn) / hw;
+  typedef typename VecIO<T>::raw Raw;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < totalv;
+       i += (I)gridDim.x * blockDim.x) {
+    const I pix = i / (I)cvn;
+    const int cv = (int)(i - pix * (I)cvn);
+    const I img = pix / hw;
+    const size_t so = (size_t)(img * (I)cvn + cv) * V;
+    const Raw ra = VecIO<T>::load_raw(a + (size_t)i * V);
+    Raw rb = ra;
+    if constexpr (HAS_B) rb = VecIO<T>::load_raw(b + (size_t)i * V);
     float va[V], ka[V], o[V];
-    VecIO<T>::load(a + i * V, va);
-    ldf<V>(sa + (img * cvn + cv) * V, ka);
+    ldf<V>(sa + so, ka);
+    float kb[V];
+    if constexpr (HAS_B) ldf<V>(sb + so, kb);
+    VecIO<T>::cvt(ra, va);
 #pragma unroll
     for (int k = 0; k < V; ++k) o[k] = va[k] * ka[k];
-    if (b) {
-      float vb[V], kb[V];
-      VecIO<T>::load(b + i * V, vb);
-      ldf<V>(sb + (img * cvn + cv) * V, kb);
+    if constexpr (HAS_B) {
+      float vb[V];
+      VecIO<T>::cvt(rb, vb);
 #pragma unroll
       for (int k = 0; k < V; ++k) o[k] += vb[k] * kb[k];
     }
-    VecIO<T>::store(out + i * V, o);
+    VecIO<T>::store(out + (size_t)i * V, o);
   }
 }
 
-template <typename T>
+template <typename T, bool HAS_E, typename I>
 __global__ void se_scale_bwd_apply_kernel(const T* __restrict__ dout,
                                           const float* __restrict__ s,
                                           const float* __restrict__ dgap,
                                           const T* __restrict__ extra, T* __restrict__ dx,
-                                          long hw, int cvn, long totalv, float inv_hw) {
+                                          I hw, int cvn, I totalv, float inv_hw) {
   constexpr int V = VecIO<T>::V;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalv;
-       i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % cvn);
-    const long img = (i / cvn) / hw;
+  typedef typename VecIO<T>::raw Raw;
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < totalv;
+       i += (I)gridDim.x * blockDim.x) {
+    const I pix = i / (I)cvn;
+    const int cv = (int)(i - pix * (I)cvn);
+    const I img = pix / hw;
+    const size_t so = (size_t)(img * (I)cvn + cv) * V;
+    const Raw rg = VecIO<T>::load_raw(dout + (size_t)i * V);
+    Raw re = rg;
+    if constexpr (HAS_E) re = VecIO<T>::load_raw(extra + (size_t)i * V);
     float g[V], k_[V], dg[V], o[V];
-    VecIO<T>::load(dout + i * V, g);
-    ldf<V>(s + (img * cvn + cv) * V, k_);
-    ldf<V>(dgap + (img * cvn + cv) * V, dg);
+    ldf<V>(s + so, k_);
+    ldf<V>(dgap + so, dg);
+    VecIO<T>::cvt(rg, g);
 #pragma unroll
     for (int k = 0; k < V; ++k) o[k] = g[k] * k_[k] + dg[k] * inv_hw;
-    if (extra) {
+    if constexpr (HAS_E) {
       float e[V];
-      VecIO<T>::load(extra + i * V, e);
+      VecIO<T>::cvt(re, e);
 #pragma unroll
       for (int k = 0; k < V; ++k) o[k] += e[k];
     }
-    VecIO<T>::store(dx + i * V, o);
+    VecIO<T>::store(dx + (size_t)i * V, o);
   }
 }
 
@@ -1450,7 +1468,7 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 // model's fp32 output straight from 16-bit features)
 // NT: the output goes out with non-temporal stores (a pure write stream of up to 1.57 GB that no
 // later kernel finds in a cache anyway)
-template <typename T, typename TO, bool NT = false>
+template <typename T, typename TO, bool NT = false, typename I = long>
 __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const T* __restrict__ skip,
                                    TO* __restrict__ y, int n, int h, int w, int c4n,
@@ -1470,15 +1488,15 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
   const int C = c4n * 4;
   for (int j = threadIdx.x; j < 9 * C; j += blockDim.x) wl[(j % 9) * C + j / 9] = wdw[j];
   __syncthreads();
-  const long total = (long)n * h * w * c4n;
+  const I total = (I)n * h * w * c4n;
   const int ow_n = 2 * w;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % c4n);
-    long r = i / c4n;
-    const int iw = (int)(r % w); r /= w;
-    const int ih = (int)(r % h);
-    const int img = (int)(r / h);
+  for (I i = blockIdx.x * (I)blockDim.x + threadIdx.x; i < total;
+       i += (I)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (I)c4n);
+    I r = i / (I)c4n;
+    const int iw = (int)(r % (I)w); r /= (I)w;
+    const int ih = (int)(r % (I)h);
+    const int img = (int)(r / (I)h);
     float4 nb[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -1486,7 +1504,7 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
       for (int b = 0; b < 3; ++b) {
         const int hh = ih - 1 + a, ww = iw - 1 + b;
         nb[a][b] = (hh >= 0 && hh < h && ww >= 0 && ww < w)
-                       ? emsa_ld4(x + ((((long)img * h + hh) * w + ww) * c4n + c4) * 4)
+                       ? emsa_ld4(x + (size_t)(((((I)img * h + hh) * w + ww) * c4n + c4) * 4))
                        : emsa_zero4();
       }
     float4 k[9];
@@ -1509,7 +1527,7 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
             const float4 kk = k[kh * 3 + kw];
             acc.x += v.x * kk.x; acc.y += v.y * kk.y; acc.z += v.z * kk.z; acc.w += v.w * kk.w;
           }
-        const long o = ((((long)img * 2 * h + 2 * ih + a) * ow_n + 2 * iw + b) * c4n + c4) * 4;
+        const size_t o = (size_t)(((((I)img * 2 * h + 2 * ih + a) * ow_n + 2 * iw + b) * c4n + c4) * 4);
         if (skip) {
           const float4 sk = emsa_ld4(skip + o);
           acc.x += sk.x; acc.y += sk.y; acc.z += sk.z; acc.w += sk.w;
@@ -2472,6 +2490,15 @@ extern "C" int emsa_bn_fold(const float* gamma, const float* beta, const float* 
 extern "C" int64_t emsa_relu_mask_words(int64_t elements) {
   return ((elements / 4 + 63) / 64) * 4 + 8;
 }
+// 32-bit element indices (maxpool_fwd_kernel's `I`): the largest tensor of the launch has < 2^31
+// elements (index + one grid stride cannot wrap)
+static bool idx32_ok(long max_elements) {
+  static const bool on = [] {                     // EMSA_IDX32=0: 64-bit indices everywhere (A/B runs)
+    const char* e = getenv("EMSA_IDX32");
+    return !e || atoi(e) != 0;
+  }();
+  return on && max_elements > 0 && max_elements < (1L << 31);
+}
 // fast forms of the BatchNorm passes (bn_act_fwd_fast_kernel): log2 of the channel-vector count when
 // it is a power of two <= 256 and the indices fit 32 bits, else -1 (general kernels).
 // EMSA_BN_FAST=0: always the general kernels (A/B runs)
@@ -2696,8 +2723,12 @@ static int maxpool3x3s2_fwd_impl(const T* x, T* y, int8_t* idx, int32_t n, int32
   if (!x || !y || !idx) return EMSA_E_ARG;
   if (!c4_ok(c)) return EMSA_E_SHAPE;
   const long total = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / 4);
-  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, y, idx, n, h, w, c / 4);
+  if (idx32_ok((long)n * h * w * c))
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T, uint32_t>), dim3(grid_for(total)), dim3(kThreads), 0,
+                       (hipStream_t)stream, x, y, idx, n, h, w, c / 4);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T, long>), dim3(grid_for(total)), dim3(kThreads), 0,
+                       (hipStream_t)stream, x, y, idx, n, h, w, c / 4);
   return emsa_launch_status();
 }
 extern "C" int emsa_maxpool3x3s2_fwd(const float* x, float* y, int8_t* idx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
@@ -2717,8 +2748,12 @@ static int maxpool3x3s2_bwd_impl(const T* dy, const int8_t* idx, T* dx, int32_t 
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   constexpr int V = VecIO<T>::V;
   const long total = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / V);
-  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dy, idx, dx, n, h, w, c / V);
+  if (idx32_ok((long)n * h * w * c))
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T, uint32_t>), dim3(grid_for(total)), dim3(kThreads), 0,
+                       (hipStream_t)stream, dy, idx, dx, n, h, w, c / V);
+  else
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T, long>), dim3(grid_for(total)), dim3(kThreads), 0,
+                       (hipStream_t)stream, dy, idx, dx, n, h, w, c / V);
   return emsa_launch_status();
 }
 extern "C" int emsa_maxpool3x3s2_bwd(const float* dy, const int8_t* idx, float* dx, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
@@ -2876,8 +2911,18 @@ static int se_scale_add_fwd_impl(const T* a, const float* sa, const T* b, const 
   if (!a || !sa || !out || ((b == nullptr) != (sb == nullptr))) return EMSA_E_ARG;
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const long totalv = (long)n * hw * (c / VecIO<T>::V);
-  hipLaunchKernelGGL((se_scale_add_fwd_kernel<T>), dim3(grid_for(totalv)), dim3(kThreads), 0,
-                     (hipStream_t)stream, a, sa, b, sb, out, (long)hw, c / VecIO<T>::V, totalv);
+  const dim3 grid(grid_for(totalv)), block(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  const int cvn = c / VecIO<T>::V;
+#define EMSA_SE_FWD(B, I)                                                                          \
+  hipLaunchKernelGGL((se_scale_add_fwd_kernel<T, B, I>), grid, block, 0, st, a, sa, b, sb, out,   \
+                     (I)hw, cvn, (I)totalv)
+  if (idx32_ok((long)n * hw * c)) {
+    if (b) EMSA_SE_FWD(true, uint32_t); else EMSA_SE_FWD(false, uint32_t);
+  } else {
+    if (b) EMSA_SE_FWD(true, long); else EMSA_SE_FWD(false, long);
+  }
+#undef EMSA_SE_FWD
   return emsa_launch_status();
 }
 extern "C" int emsa_se_scale_add_fwd(const float* a, const float* sa, const float* b, const float* sb, float* out, int32_t n, int64_t hw, int32_t c, void* stream) {
@@ -2896,9 +2941,19 @@ static int se_scale_bwd_apply_impl(const T* dout, const float* s, const float* d
   if (!dout || !s || !dgap || !dx) return EMSA_E_ARG;
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const long totalv = (long)n * hw * (c / VecIO<T>::V);
-  hipLaunchKernelGGL((se_scale_bwd_apply_kernel<T>), dim3(grid_for(totalv)), dim3(kThreads), 0,
-                     (hipStream_t)stream, dout, s, dgap, dx_extra, dx, (long)hw, c / VecIO<T>::V,
-                     totalv, 1.0f / (float)hw);
+  const dim3 grid(grid_for(totalv)), block(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  const int cvn = c / VecIO<T>::V;
+  const float inv_hw = 1.0f / (float)hw;
+#define EMSA_SE_BWD(E, I)                                                                          \
+  hipLaunchKernelGGL((se_scale_bwd_apply_kernel<T, E, I>), grid, block, 0, st, dout, s, dgap,     \
+                     dx_extra, dx, (I)hw, cvn, (I)totalv, inv_hw)
+  if (idx32_ok((long)n * hw * c)) {
+    if (dx_extra) EMSA_SE_BWD(true, uint32_t); else EMSA_SE_BWD(false, uint32_t);
+  } else {
+    if (dx_extra) EMSA_SE_BWD(true, long); else EMSA_SE_BWD(false, long);
+  }
+#undef EMSA_SE_BWD
   return emsa_launch_status();
 }
 extern "C" int emsa_se_scale_bwd_apply(const float* dout, const float* s, const float* dgap, const float* dx_extra, float* dx, int32_t n, int64_t hw, int32_t c, void* stream) {
@@ -2926,14 +2981,19 @@ static int up2x_dw3x3_fwd_impl(const T* x, const float* wdw, const float* bias, 
     return e ? (e[0] == '1' ? 1 : 0) : -1;
   }();
   const bool nt = nt_env >= 0 ? nt_env == 1 : c >= 32;
-  if (nt && std::is_same<TO, float>::value)
-    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO, true>), dim3(grid_for(total)), dim3(kThreads),
-                       (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
-                       h, w, c / 4);
-  else
-    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO>), dim3(grid_for(total)), dim3(kThreads),
-                       (size_t)9 * c * sizeof(float), (hipStream_t)stream, x, wdw, bias, skip, y, n,
-                       h, w, c / 4);
+  const dim3 grid(grid_for(total)), block(kThreads);
+  const size_t lds = (size_t)9 * c * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define EMSA_UP_FWD(NTF, I)                                                                         \
+  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO, NTF, I>), grid, block, lds, st, x, wdw, bias, skip, \
+                     y, n, h, w, c / 4)
+  const bool i32 = idx32_ok((long)n * 4 * h * w * c);
+  if (nt && std::is_same<TO, float>::value) {
+    if (i32) EMSA_UP_FWD(true, uint32_t); else EMSA_UP_FWD(true, long);
+  } else {
+    if (i32) EMSA_UP_FWD(false, uint32_t); else EMSA_UP_FWD(false, long);
+  }
+#undef EMSA_UP_FWD
   return emsa_launch_status();
 }
 // Twin launch of emsa_up2x_dw3x3_fwd_t (16-bit storage in, same type out): the learned x2 up-sampling
@@ -2943,9 +3003,14 @@ static int up2x_pair_impl(const T* x0, const T* x1, const float* w0, const float
                           const float* b1, const T* s0, const T* s1, T* y0, T* y1, int n, int h,
                           int w, int c, hipStream_t st) {
   const long total = (long)n * 4 * h * w * (c / 4);
-  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T>), dim3(grid_for(total), 2), dim3(kThreads),
-                     (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w, c / 4, x1, w1, b1,
-                     s1, y1);
+  if (idx32_ok((long)n * 4 * h * w * c))
+    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T, false, uint32_t>), dim3(grid_for(total), 2),
+                       dim3(kThreads), (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w,
+                       c / 4, x1, w1, b1, s1, y1);
+  else
+    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T, false, long>), dim3(grid_for(total), 2),
+                       dim3(kThreads), (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w,
+                       c / 4, x1, w1, b1, s1, y1);
   return emsa_launch_status();
 }
 extern "C" int emsa_up2x_dw3x3_fwd_pair_t(int32_t dtype, const void* x0, const void* x1,
