@@ -272,24 +272,30 @@ __global__ __launch_bounds__(4 * RG) void bn_finalize_rows_kernel(const float* _
     const bool ok = nbf > 0.f;
     n += ok ? nb : 0.0;
     s1 += ok ? sb : 0.0;
-    q += ok ? (double)m2f + sb * sb / (ok ? nb : 1.0) : 0.0;
+    // 1 / nb: the float reciprocal of the (integer) count + one Newton step in fp64 (relative error
+    // ~1e-14) instead of an fp64 division (~25 instructions, up to 19 per thread in the wide form)
+    const double r0 = (double)(1.0f / (ok ? nbf : 1.f));
+    const double rn = r0 * (2.0 - (ok ? nb : 1.0) * r0);
+    q += ok ? (double)m2f + sb * sb * rn : 0.0;
   }
-  sh[0][rg][cl] = n; sh[1][rg][cl] = s1; sh[2][rg][cl] = q;
+  // second level: the 16 row groups of a wave meet through lane shuffles (xor 4, 8, 16, 32: lanes
+  // with the same channel), the waves through LDS -- a fixed tree, so the result does not depend on
+  // the run.  (One thread summing the 64 / 256 row groups from LDS was a serial chain of 64 dependent
+  // fp64 additions: ~3 of the launch's 7-10 us.)
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) {
+    n += __shfl_xor(n, off);
+    s1 += __shfl_xor(s1, off);
+    q += __shfl_xor(q, off);
+  }
+  constexpr int NW = 4 * RG / 64;                  // waves of the workgroup
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 4) { sh[0][wv][cl] = n; sh[1][wv][cl] = s1; sh[2][wv][cl] = q; }
   __syncthreads();
-  if constexpr (RG > 64) {
-    // second level in two steps: 16 threads per channel sum RG / 16 groups each, one thread the 16
-    // (a 256-step serial sum by one thread would be the tail of the wide form)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    if (rg < 16)
-      for (int k = rg; k < RG; k += 16) { a0 += sh[0][k][cl]; a1 += sh[1][k][cl]; a2 += sh[2][k][cl]; }
-    __syncthreads();
-    if (rg < 16) { sh[0][rg][cl] = a0; sh[1][rg][cl] = a1; sh[2][rg][cl] = a2; }
-    __syncthreads();
-  }
   if (rg != 0 || ch >= c) return;
   n = s1 = q = 0.0;
-  constexpr int kLast = RG > 64 ? 16 : RG;
-  for (int k = 0; k < kLast; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) { n += sh[0][k][cl]; s1 += sh[1][k][cl]; q += sh[2][k][cl]; }
   const double mean = n > 0.0 ? s1 / n : 0.0;
   double m2 = q - s1 * mean;
   if (m2 < 0.0) m2 = 0.0;
@@ -678,6 +684,7 @@ __global__ void bn_bwd_sum_kernel(float* __restrict__ partial, int rows, int row
   const int r0 = sl * per, r1 = min(rows, r0 + per);
   double a1 = 0.0, a2 = 0.0;
   if (ch < c) {
+#pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 8) {
       a1 += (double)partial[((long)0 * rows_alloc + r) * c + ch];
       a2 += (double)partial[((long)1 * rows_alloc + r) * c + ch];
