@@ -3135,7 +3135,18 @@ static int up2x_dw3x3_bwd_launch(const TO* dy, const T* x, const float* wdw, T* 
   }
   const int nchunks = (c + CC - 1) / CC;
   const long ntiles = (long)n * ((h + kUpTH - 1) / kUpTH) * ((w + TW - 1) / TW);
-  long bpc = 1024 / nchunks;
+  // workgroups of the launch (each walks its share of the tiles of one channel chunk): 512 = the two
+  // per CU that are resident at once.  Round 5 sweep (tools/up2x_bwd_bench.py, profiles/
+  // r05_p_up2x_bwd_wgs.txt; 13 decoder shapes, sum of the launch times): 128 / 256 / 384 / 512 / 768 /
+  // 1024 / 2048 workgroups -> 6.97 / 3.93 / 3.20 / 2.94 / 3.57 / 3.70 / 4.74 ms -- the 1024 of rounds
+  // 3-4 ran a second, half-empty round whose prologue / first-tile latency / 640 atomics per
+  // workgroup nothing hid (512-channel map at /32: 117 -> 56 us).  EMSA_UP2X_BWD_WGS: tuning runs
+  static const int wgs = [] {
+    const char* e = getenv("EMSA_UP2X_BWD_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 64 ? v : 512;
+  }();
+  long bpc = wgs / nchunks;
   if (bpc > ntiles) bpc = ntiles;
   if (bpc < 1) bpc = 1;
   hipLaunchKernelGGL((up2x_dw_bwd_fused_kernel<T, TO, CC, TW>), dim3((unsigned)(bpc * nchunks)),
