@@ -1699,6 +1699,11 @@ __global__ void up2x_dw_bwd_weight_kernel(const TO* __restrict__ dy, const T* __
 //     are loop invariants the compiler keeps in registers across the tile loop.
 constexpr int kUpTH = 4;
 __device__ const uint4 kUpZeroPage = {0u, 0u, 0u, 0u};
+// tile buffers of up2x_dw_bwd_fused_kernel: a third one (two tiles of loads in flight per workgroup)
+// where buffers + collapsed taps of TWO workgroups still fit a CU's 160 KB
+constexpr int up2x_nbuf(int stage_bytes, int cc) {
+  return 3 * stage_bytes + 16 * cc * 4 <= 80 * 1024 ? 3 : 2;
+}
 
 template <typename E>
 __device__ __forceinline__ float4 up_lds4(const E* p) {       // 4 consecutive channels from LDS
@@ -1714,7 +1719,7 @@ __device__ __forceinline__ void up_dma16(const void* src, void* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, typename TO, int CC, int TW>
+template <typename T, typename TO, int CC, int TW, typename I = long>
 __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
     const TO* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ wdw,
     T* __restrict__ dx, float* __restrict__ dwt, float* __restrict__ db, int n, int h, int w,
@@ -1727,22 +1732,32 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
   constexpr int kDyBytes = DH * DW * CC * (int)sizeof(TO);
   constexpr int kXBytes = XH * XW * CC * (int)sizeof(T);
   constexpr int kStage = kDyBytes + kXBytes;  // one tile buffer (multiple of 16)
+  constexpr int NBUF = up2x_nbuf(kStage, CC); // tile buffers: 3 where two workgroups per CU still fit
   constexpr int dy_upp = CC * (int)sizeof(TO) / 16, x_upp = CC * (int)sizeof(T) / 16;   // 16-B units per pixel
   constexpr int dy_units = DH * DW * dy_upp, x_units = XH * XW * x_upp;
-  float* wc = reinterpret_cast<float*>(upsm + 2 * kStage);     // [16][CC] collapsed taps (data gradient)
+  float* wc = reinterpret_cast<float*>(upsm + NBUF * kStage);  // [16][CC] collapsed taps (data gradient)
   const int chunk = blockIdx.x / bpc, bic = blockIdx.x % bpc;
   const int c0 = chunk * CC;                  // (C is CC or a multiple of it: every chunk is full)
-  for (int j = tid; j < 16 * CC; j += kThreads) {
-    const int c = j % CC, pq = j / CC, pp = pq >> 2, qq = pq & 3;
-    float a = 0.f;
-    for (int kh = 0; kh < 3; ++kh) {
-      if (kh != 2 - pp && kh != 3 - pp) continue;
-      for (int kw = 0; kw < 3; ++kw) {
-        if (kw != 2 - qq && kw != 3 - qq) continue;
-        a += wdw[(c0 + c) * 9 + kh * 3 + kw];
+  // (the chunk's 9 * CC weights go through LDS first: summed straight from global memory the up to
+  //  four taps of an entry were four dependent round trips -- `s_waitcnt vmcnt(0)` behind every load --
+  //  times four entries per thread, ~10 us before the first tile)
+  {
+    float* wraw = reinterpret_cast<float*>(upsm);              // [CC][9], overlays tile buffer 0
+    for (int j = tid; j < 9 * CC; j += kThreads) wraw[j] = wdw[c0 * 9 + j];
+    __syncthreads();
+    for (int j = tid; j < 16 * CC; j += kThreads) {
+      const int c = j % CC, pq = j / CC, pp = pq >> 2, qq = pq & 3;
+      float a = 0.f;
+      for (int kh = 0; kh < 3; ++kh) {
+        if (kh != 2 - pp && kh != 3 - pp) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          if (kw != 2 - qq && kw != 3 - qq) continue;
+          a += wraw[c * 9 + kh * 3 + kw];
+        }
       }
+      wc[j] = a;
     }
-    wc[j] = a;
+    __syncthreads();                                           // (the first DMA overwrites wraw)
   }
   const bool active = tid < npx * tpp;
   const int c4 = tid % tpp, pl = tid / tpp, lw = pl % TW, lh = pl / TW;
@@ -1750,15 +1765,17 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = emsa_zero4();
   const int tiles_w = (w + TW - 1) / TW, tiles_h = (h + kUpTH - 1) / kUpTH;
-  const long ntiles = (long)n * tiles_h * tiles_w;
+  // (tile indices are 32-bit: their decomposition is SCALAR code, and as 64-bit divisions it was
+  //  ~1,000 scalar instructions per tile and wave -- the CU's one scalar unit bounded the kernel)
+  const int ntiles = n * tiles_h * tiles_w;
   const int OH = 2 * h, OW = 2 * w;
   const int wave_u0 = tid & ~63;              // first unit of this wave within a 256-unit round
 
   // issue the DMA of tile t into buffer `buf`: unit u = (pixel of the patch, 16-byte piece)
-  auto issue = [&](long t, int buf) {
-    const int tw_i = (int)(t % tiles_w);
-    const long r = t / tiles_w;
-    const int th_i = (int)(r % tiles_h), img = (int)(r / tiles_h);
+  auto issue = [&](int t, int buf) {
+    const int r = t / tiles_w;
+    const int tw_i = t - r * tiles_w;
+    const int img = r / tiles_h, th_i = r - img * tiles_h;
     const int h0 = th_i * kUpTH, w0 = tw_i * TW;
     unsigned char* sdy = upsm + buf * kStage;
     unsigned char* sx = sdy + kDyBytes;
@@ -1770,7 +1787,7 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
         const int oh = 2 * h0 - 1 + row, ow = 2 * w0 - 1 + col;
         const bool in = oh >= 0 && oh < OH && ow >= 0 && ow < OW;
         const void* src = in ? (const void*)(reinterpret_cast<const unsigned char*>(
-                                                 dy + (((long)img * OH + oh) * OW + ow) * C + c0) +
+                                                 dy + (size_t)((((I)img * OH + oh) * OW + ow) * C + c0)) +
                                              cu * 16)
                              : (const void*)&kUpZeroPage;
         up_dma16(src, sdy + (u0 + wave_u0) * 16);
@@ -1784,7 +1801,7 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
         const int hh = h0 - 1 + row, ww = w0 - 1 + col;
         const bool in = hh >= 0 && hh < h && ww >= 0 && ww < w;
         const void* src = in ? (const void*)(reinterpret_cast<const unsigned char*>(
-                                                 x + (((long)img * h + hh) * w + ww) * C + c0) +
+                                                 x + (size_t)((((I)img * h + hh) * w + ww) * C + c0)) +
                                              cu * 16)
                              : (const void*)&kUpZeroPage;
         up_dma16(src, sx + (u0 + wave_u0) * 16);
@@ -1792,17 +1809,30 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
     }
   };
 
-  if (bic < ntiles) issue(bic, 0);
+#pragma unroll
+  for (int k = 0; k < NBUF - 1; ++k)
+    if (bic + k * bpc < ntiles) issue(bic + k * bpc, k);
+  // NBUF = 3: tile t + 1 may still be in flight while tile t is consumed.  vmcnt counts this wave's
+  // loads AND stores; loads return in order among themselves, so "at most kInFlight operations
+  // outstanding" proves tile t has landed as long as tile t + 1 was issued behind it with at least
+  // kInFlight DMA instructions in this wave (the FULL 256-unit rounds of a tile: every wave issues
+  // those) -- whatever the dx stores in between do
+  constexpr int kInFlight = dy_units / kThreads + x_units / kThreads;
+  static_assert(NBUF == 2 || (kInFlight >= 1 && kInFlight <= 15), "counted wait out of range");
   int buf = 0;
-  for (long t = bic; t < ntiles; t += bpc, buf ^= 1) {
+  for (int t = bic; t < ntiles; t += bpc, buf = buf + 1 == NBUF ? 0 : buf + 1) {
     // this wave's pieces of tile t have landed; after the barrier everybody's have, and everybody
-    // is done reading the other buffer (tile t - bpc) -> refill it while tile t is consumed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // is done reading the buffer of tile t - bpc -> refill it while tile t is consumed
+    if (NBUF == 3 && t + bpc < ntiles)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF == 3 ? kInFlight : 0) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + bpc < ntiles) issue(t + bpc, buf ^ 1);
-    const int tw_i = (int)(t % tiles_w);
-    const long r = t / tiles_w;
-    const int th_i = (int)(r % tiles_h), img = (int)(r / tiles_h);
+    if (t + (NBUF - 1) * bpc < ntiles)
+      issue(t + (NBUF - 1) * bpc, buf + NBUF - 1 >= NBUF ? buf - 1 : buf + NBUF - 1);
+    const int r = t / tiles_w;
+    const int tw_i = t - r * tiles_w;
+    const int img = r / tiles_h, th_i = r - img * tiles_h;
     const int h0 = th_i * kUpTH, w0 = tw_i * TW;
     const TO* dyt = reinterpret_cast<const TO*>(upsm + buf * kStage);
     const T* xt = reinterpret_cast<const T*>(upsm + buf * kStage + kDyBytes);
@@ -1819,7 +1849,7 @@ __global__ __launch_bounds__(kThreads, 2) void up2x_dw_bwd_fused_kernel(
         }
       const int ih = h0 + lh, iw = w0 + lw;
       if (dx != nullptr && ih < h && iw < w)
-        emsa_st4(dx + (((long)img * h + ih) * w + iw) * C + c0 + c4 * 4, d);
+        emsa_st4(dx + (size_t)((((I)img * h + ih) * w + iw) * C + c0 + c4 * 4), d);
       // weight gradient: the pixel's own 2x2 output quad stays in registers, the 3x3 x
       // neighbourhood is streamed (entry (r, s) meets the taps with ((a+kh+1)>>1, (b+kw+1)>>1) ==
       // (r, s); all conditions fold at compile time)
@@ -3124,12 +3154,14 @@ static int up2x_dw3x3_bwd_launch(const TO* dy, const T* x, const float* wdw, T* 
   constexpr int npx = kUpTH * TW;
   constexpr int stage = (2 * kUpTH + 2) * (2 * TW + 2) * CC * (int)sizeof(TO) +
                         (kUpTH + 2) * (TW + 2) * CC * (int)sizeof(T);
-  constexpr int tiles = 2 * stage + 16 * CC * (int)sizeof(float);
+  constexpr int tiles = up2x_nbuf(stage, CC) * stage + 16 * CC * (int)sizeof(float);
   constexpr int red = npx * 5 * CC * (int)sizeof(float);
   constexpr size_t lds = (size_t)(tiles > red ? tiles : red);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_fused_kernel<T, TO, CC, TW>,
+    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_fused_kernel<T, TO, CC, TW, long>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)up2x_dw_bwd_fused_kernel<T, TO, CC, TW, uint32_t>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
@@ -3146,12 +3178,18 @@ static int up2x_dw3x3_bwd_launch(const TO* dy, const T* x, const float* wdw, T* 
     const int v = e ? atoi(e) : 0;
     return v >= 64 ? v : 512;
   }();
+  if (ntiles >= (1L << 30)) return EMSA_E_SHAPE;     // (32-bit tile indices in the kernel)
   long bpc = wgs / nchunks;
   if (bpc > ntiles) bpc = ntiles;
   if (bpc < 1) bpc = 1;
-  hipLaunchKernelGGL((up2x_dw_bwd_fused_kernel<T, TO, CC, TW>), dim3((unsigned)(bpc * nchunks)),
-                     dim3(kThreads), lds, (hipStream_t)stream, dy, x, wdw, dx, dw, db, n, h, w, c,
-                     (int)bpc);
+  if (idx32_ok((long)n * 4 * h * w * c))
+    hipLaunchKernelGGL((up2x_dw_bwd_fused_kernel<T, TO, CC, TW, uint32_t>),
+                       dim3((unsigned)(bpc * nchunks)), dim3(kThreads), lds, (hipStream_t)stream, dy, x,
+                       wdw, dx, dw, db, n, h, w, c, (int)bpc);
+  else
+    hipLaunchKernelGGL((up2x_dw_bwd_fused_kernel<T, TO, CC, TW, long>),
+                       dim3((unsigned)(bpc * nchunks)), dim3(kThreads), lds, (hipStream_t)stream, dy, x,
+                       wdw, dx, dw, db, n, h, w, c, (int)bpc);
   return emsa_launch_status();
 }
 template <typename T, typename TO>
