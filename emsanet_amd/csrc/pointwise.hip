@@ -1475,7 +1475,11 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 // model's fp32 output straight from 16-bit features)
 // NT: the output goes out with non-temporal stores (a pure write stream of up to 1.57 GB that no
 // later kernel finds in a cache anyway)
-template <typename T, typename TO, bool NT = false, typename I = long>
+// (round 5: SKIP is a template parameter and every load of an element -- the 3x3 input neighbourhood
+//  at CLAMPED coordinates, zeroed by a select, and the four skip values -- is issued before the first
+//  is used.  The border tests used to be branches around the loads: nine `s_waitcnt vmcnt(0)` in a row,
+//  then four more behind the stores -- 13 serialised memory round trips per thread and iteration.)
+template <typename T, typename TO, bool NT = false, typename I = long, bool SKIP = false>
 __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const T* __restrict__ skip,
                                    TO* __restrict__ y, int n, int h, int w, int c4n,
@@ -1510,9 +1514,25 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         const int hh = ih - 1 + a, ww = iw - 1 + b;
-        nb[a][b] = (hh >= 0 && hh < h && ww >= 0 && ww < w)
-                       ? emsa_ld4(x + (size_t)(((((I)img * h + hh) * w + ww) * c4n + c4) * 4))
-                       : emsa_zero4();
+        const int hc = min(max(hh, 0), h - 1), wc_ = min(max(ww, 0), w - 1);
+        nb[a][b] = emsa_ld4(x + (size_t)(((((I)img * h + hc) * w + wc_) * c4n + c4) * 4));
+      }
+    float4 sk[2][2];
+    if constexpr (SKIP) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          sk[a][b] = emsa_ld4(skip + (size_t)(((((I)img * 2 * h + 2 * ih + a) * ow_n + 2 * iw + b) * c4n + c4) * 4));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int hh = ih - 1 + a, ww = iw - 1 + b;
+        const bool in = hh >= 0 && hh < h && ww >= 0 && ww < w;
+        nb[a][b].x = in ? nb[a][b].x : 0.f; nb[a][b].y = in ? nb[a][b].y : 0.f;
+        nb[a][b].z = in ? nb[a][b].z : 0.f; nb[a][b].w = in ? nb[a][b].w : 0.f;
       }
     float4 k[9];
 #pragma unroll
@@ -1535,9 +1555,8 @@ __global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restr
             acc.x += v.x * kk.x; acc.y += v.y * kk.y; acc.z += v.z * kk.z; acc.w += v.w * kk.w;
           }
         const size_t o = (size_t)(((((I)img * 2 * h + 2 * ih + a) * ow_n + 2 * iw + b) * c4n + c4) * 4);
-        if (skip) {
-          const float4 sk = emsa_ld4(skip + o);
-          acc.x += sk.x; acc.y += sk.y; acc.z += sk.z; acc.w += sk.w;
+        if constexpr (SKIP) {
+          acc.x += sk[a][b].x; acc.y += sk[a][b].y; acc.z += sk[a][b].z; acc.w += sk[a][b].w;
         }
         if constexpr (NT && std::is_same<TO, float>::value) {
           const f32x4 v = {acc.x, acc.y, acc.z, acc.w};
@@ -2599,7 +2618,12 @@ static int bn_bwd_rows_for(long pixels, int c) {
   long r = (pixels * c + 8191) / 8192;
   if (r > pixels) r = pixels;
   if (r < 1) r = 1;
-  if (r > 1024) r = 1024;
+  static const long cap = [] {                    // EMSA_BN_REDUCE_ROWS: tuning runs (<= 1024)
+    const char* e = getenv("EMSA_BN_REDUCE_ROWS");
+    const long v = e ? atol(e) : 0;
+    return v >= 16 && v <= 1024 ? v : 1024L;
+  }();
+  if (r > cap) r = cap;
   return (int)r;
 }
 // rows to ALLOCATE: the per-workgroup partial rows plus kBwdSlices rows of level-1 slice sums
@@ -2666,8 +2690,13 @@ static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits,
   constexpr int V = VecIO<T>::V;
   const long totalv = pixels * (c / V);
   // four workgroups per CU (the other streaming kernels: eight): measured -0.3 ms per step
+  static const int ap_cap = [] {                  // EMSA_BN_APPLY_WGS: tuning runs
+    const char* e = getenv("EMSA_BN_APPLY_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 64 ? v : 256 * 4;
+  }();
   int ap_grid = grid_for(totalv);
-  if (ap_grid > 256 * 4) ap_grid = 256 * 4;
+  if (ap_grid > ap_cap) ap_grid = ap_cap;
   const int lg = bn_fast_log2(c / V, totalv, hw);
   if (lg >= 0) {
     const dim3 grid(ap_grid), block(kThreads);
@@ -3022,8 +3051,14 @@ static int up2x_dw3x3_fwd_impl(const T* x, const float* wdw, const float* bias, 
   const size_t lds = (size_t)9 * c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
 #define EMSA_UP_FWD(NTF, I)                                                                         \
-  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO, NTF, I>), grid, block, lds, st, x, wdw, bias, skip, \
-                     y, n, h, w, c / 4)
+  do {                                                                                              \
+    if (skip)                                                                                       \
+      hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO, NTF, I, true>), grid, block, lds, st, x, wdw,   \
+                         bias, skip, y, n, h, w, c / 4);                                            \
+    else                                                                                            \
+      hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, TO, NTF, I, false>), grid, block, lds, st, x, wdw,  \
+                         bias, skip, y, n, h, w, c / 4);                                            \
+  } while (0)
   const bool i32 = idx32_ok((long)n * 4 * h * w * c);
   if (nt && std::is_same<TO, float>::value) {
     if (i32) EMSA_UP_FWD(true, uint32_t); else EMSA_UP_FWD(true, long);
@@ -3040,14 +3075,17 @@ static int up2x_pair_impl(const T* x0, const T* x1, const float* w0, const float
                           const float* b1, const T* s0, const T* s1, T* y0, T* y1, int n, int h,
                           int w, int c, hipStream_t st) {
   const long total = (long)n * 4 * h * w * (c / 4);
-  if (idx32_ok((long)n * 4 * h * w * c))
-    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T, false, uint32_t>), dim3(grid_for(total), 2),
-                       dim3(kThreads), (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w,
-                       c / 4, x1, w1, b1, s1, y1);
-  else
-    hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T, false, long>), dim3(grid_for(total), 2),
-                       dim3(kThreads), (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w,
-                       c / 4, x1, w1, b1, s1, y1);
+  if ((s0 == nullptr) != (s1 == nullptr)) return EMSA_E_ARG;        // (SKIP is one template flag)
+#define EMSA_UP_PAIR(I, SK)                                                                         \
+  hipLaunchKernelGGL((up2x_dw_fwd_kernel<T, T, false, I, SK>), dim3(grid_for(total), 2),            \
+                     dim3(kThreads), (size_t)9 * c * sizeof(float), st, x0, w0, b0, s0, y0, n, h, w, \
+                     c / 4, x1, w1, b1, s1, y1)
+  if (idx32_ok((long)n * 4 * h * w * c)) {
+    if (s0) EMSA_UP_PAIR(uint32_t, true); else EMSA_UP_PAIR(uint32_t, false);
+  } else {
+    if (s0) EMSA_UP_PAIR(long, true); else EMSA_UP_PAIR(long, false);
+  }
+#undef EMSA_UP_PAIR
   return emsa_launch_status();
 }
 extern "C" int emsa_up2x_dw3x3_fwd_pair_t(int32_t dtype, const void* x0, const void* x1,
