@@ -1002,19 +1002,29 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int bi[4] = {0, 0, 0, 0};
     bool first = true;
+    // all nine taps are loaded first, at clamped coordinates (a window's out-of-range taps used to be
+    // skipped by a branch around the load: nine dependent memory round trips per output)
+    float4 tap[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = min(max(oh * 2 - 1 + kh, 0), h - 1), iw = min(max(ow * 2 - 1 + kw, 0), w - 1);
+        tap[kh * 3 + kw] = emsa_ld4(x + (size_t)(((((I)img * h + ih) * w + iw) * c4n + c4) * 4));
+      }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-        if (ih < 0 || ih >= h || iw < 0 || iw >= w) continue;
-        const float4 v = emsa_ld4(x + (size_t)(((((I)img * h + ih) * w + iw) * c4n + c4) * 4));
+        const bool in = ih >= 0 && ih < h && iw >= 0 && iw < w;
+        const float4 v = tap[kh * 3 + kw];
         const int t = kh * 3 + kw;
-        if (first || v.x > best.x) { best.x = v.x; bi[0] = t; }
-        if (first || v.y > best.y) { best.y = v.y; bi[1] = t; }
-        if (first || v.z > best.z) { best.z = v.z; bi[2] = t; }
-        if (first || v.w > best.w) { best.w = v.w; bi[3] = t; }
-        first = false;
+        if (in && (first || v.x > best.x)) { best.x = v.x; bi[0] = t; }
+        if (in && (first || v.y > best.y)) { best.y = v.y; bi[1] = t; }
+        if (in && (first || v.z > best.z)) { best.z = v.z; bi[2] = t; }
+        if (in && (first || v.w > best.w)) { best.w = v.w; bi[3] = t; }
+        first = first && !in;
       }
     emsa_st4(y + (size_t)i * 4, best);
     *reinterpret_cast<char4*>(idx + (size_t)i * 4) = make_char4(bi[0], bi[1], bi[2], bi[3]);
