@@ -1111,7 +1111,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const int8_t* __res
 // run-to-run noise there flips ReLU masks downstream)
 // nblk_a: the first nblk_a workgroups reduce `a`, the ones behind them `a2` (b == NULL): the two
 // squeeze inputs of an SE-add fusion in ONE launch (emsa_se_pair_fwd_t)
-template <typename T>
+template <typename T, bool HAS_B>
 __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                    float* __restrict__ ws, long hw, int cvn, int splits,
                                    const T* __restrict__ a2 = nullptr, int nblk_a = 0x7fffffff) {
@@ -1131,22 +1131,42 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict_
     float acc[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[k] = 0.f;
-    // (unrolled: four independent 16-byte loads per tensor in flight per thread -- one at a time the
-    //  /2 and /4 maps moved 2-3 TB/s; the additions keep their order, results are bit-identical)
-#pragma unroll 4
-    for (long p = p0 + rl; p < p1; p += lanes) {
-      const long i = (p * cvn + cv) * V;
+    // Four pixels per iteration, their loads issued together (HAS_B is a template flag: with a
+    // run-time `if (b)` inside the loop every load was followed by `s_waitcnt vmcnt(0)` whatever the
+    // unroll pragma said -- one 16-byte load in flight per thread); the additions keep their order.
+    typedef typename VecIO<T>::raw Raw;
+    auto term = [&](const Raw& ra, const Raw& rb) {
       float va[V];
-      VecIO<T>::load(a + i, va);
-      if (b) {
+      VecIO<T>::cvt(ra, va);
+      if constexpr (HAS_B) {
         float vb[V];
-        VecIO<T>::load(b + i, vb);
+        VecIO<T>::cvt(rb, vb);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] += va[k] * vb[k];
       } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] += va[k];
       }
+    };
+    long p = p0 + rl;
+    for (; p + 3 * lanes < p1; p += 4 * lanes) {
+      Raw ra[4], rb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = ((p + u * lanes) * cvn + cv) * V;
+        ra[u] = VecIO<T>::load_raw(a + i);
+        rb[u] = ra[u];
+        if constexpr (HAS_B) rb[u] = VecIO<T>::load_raw(b + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) term(ra[u], rb[u]);
+    }
+    for (; p < p1; p += lanes) {
+      const long i = (p * cvn + cv) * V;
+      const Raw ra = VecIO<T>::load_raw(a + i);
+      Raw rb = ra;
+      if constexpr (HAS_B) rb = VecIO<T>::load_raw(b + i);
+      term(ra, rb);
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) cred[rl * c + cv * V + k] = acc[k];
@@ -2881,8 +2901,12 @@ static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, lon
   if (cvn > kThreads) return EMSA_E_SHAPE;
   const int lanes = kThreads / cvn;
   const size_t lds = (size_t)lanes * c * sizeof(float);
-  hipLaunchKernelGGL((channel_dot_kernel<T>), dim3(n * splits), dim3(kThreads), lds, st, a, b, ws,
-                     hw, cvn, splits);
+  if (b)
+    hipLaunchKernelGGL((channel_dot_kernel<T, true>), dim3(n * splits), dim3(kThreads), lds, st, a, b,
+                       ws, hw, cvn, splits);
+  else
+    hipLaunchKernelGGL((channel_dot_kernel<T, false>), dim3(n * splits), dim3(kThreads), lds, st, a, b,
+                       ws, hw, cvn, splits);
   hipLaunchKernelGGL(channel_dot_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, ws,
                      out, n, c, splits, scale);
   return emsa_launch_status();
@@ -2936,7 +2960,7 @@ static int se_pair_fwd(const T* xa, const T* xb, float* ws, const float* const* 
   if (cvn > kThreads) return EMSA_E_SHAPE;
   const int lanes = kThreads / cvn;
   const size_t lds = (size_t)lanes * c * sizeof(float);
-  hipLaunchKernelGGL((channel_dot_kernel<T>), dim3(2 * n * splits), dim3(kThreads), lds, st, xa,
+  hipLaunchKernelGGL((channel_dot_kernel<T, false>), dim3(2 * n * splits), dim3(kThreads), lds, st, xa,
                      (const T*)nullptr, ws, hw, cvn, splits, xb, n * splits);
   hipLaunchKernelGGL(se_mlp_pair_fwd_kernel, dim3(2 * n), dim3(256),
                      (size_t)(c + cr) * sizeof(float), st, ws, splits, 1.0f / (float)hw, wts[0],
