@@ -1510,7 +1510,7 @@ __device__ __forceinline__ float4 dw_weight4(const float* __restrict__ w, int c,
 //  is used.  The border tests used to be branches around the loads: nine `s_waitcnt vmcnt(0)` in a row,
 //  then four more behind the stores -- 13 serialised memory round trips per thread and iteration.)
 template <typename T, typename TO, bool NT = false, typename I = long, bool SKIP = false>
-__global__ void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
+__global__ __launch_bounds__(kThreads) void up2x_dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
                                    const float* __restrict__ bias, const T* __restrict__ skip,
                                    TO* __restrict__ y, int n, int h, int w, int c4n,
                                    const T* __restrict__ x2 = nullptr,
