@@ -97,8 +97,10 @@ def parse():
                          '--warmup (reference: 20) + --steps (80) runs, FPS = mean(1/t) +- std; '
                          'reported as `reference_protocol` beside the resident value')
     ap.add_argument('--eager', action='store_true',
-                    help='N > 1 only: keep the hook-driven eager step (default for N > 1 is the '
-                         'segmented-hipGraph step: the eager 16-bit step is host-bound)')
+                    help='launch the training step kernel by kernel from the host instead of replaying it '
+                         'from a hipGraph (the hipGraph step is the default for 16-bit training at N = 1 '
+                         'and for every N > 1 -- the eager 16-bit step is host-bound; fp32 at N = 1 is '
+                         'eager unless --graph is given)')
     return ap.parse_args()
 
 
@@ -385,8 +387,16 @@ def run(args):
     # several ranks: the default is the segmented-hipGraph step (one graph per backward segment,
     # all-reduce issued eagerly in between) -- the hook-driven eager step costs 16 % in bf16 before a
     # byte crosses xGMI; --eager / --torch-optimizer / --h2d keep the eager path
-    if world > 1 and not args.eval and not args.eager and not args.torch_optimizer and not args.h2d:
+    # one rank (round 5): the 16-bit step as ONE hipGraph by default as well -- bf16 955 vs 793-806
+    # images/s, its eager step is host-bound; a refused capture falls back to the eager step below
+    # (graph_auto).  The fp32 step stays eager by default: GPU-bound either way (331.5 vs 329.9 images/s
+    # on one box, 319.0 vs 317.3 on another: profiles/r05_aa_*, r05_ab_*), and per-launch HIP events
+    # inside the timed region only exist for the eager step
+    graph_auto = False
+    if not args.eval and not args.eager and not args.torch_optimizer and not args.h2d and not args.graph \
+            and (world > 1 or args.dtype != 'f32'):
         args.graph = True
+        graph_auto = world == 1 and not args.force_dist
     segmented = bool(args.graph and not args.eval and dist_on)
     if segmented:
         # multi-rank step under hipGraphs: one graph per backward segment, the buckets of a segment
@@ -485,6 +495,7 @@ def run(args):
             memory_format=torch.channels_last if t.dim() == 4 else torch.contiguous_format)
             for t in flat0]
         del flat0
+        kernel_timing_off = args.no_kernel_timing
         args.no_kernel_timing = True
         cls = SegmentedGraphedTrainStep if segmented else GraphedTrainStep
         # N > 1 (the default there is the segmented graph, which no multi-GPU node has run yet): a
@@ -493,11 +504,22 @@ def run(args):
         kw = {'eager_fallback': True} if (segmented and world > 1 and not args.force_dist) else {}
         if segmented:
             kw['decoder_cut'] = True       # the decoder segment's buckets leave in two steps (nn.CutPlan)
-        if crit is not None:
-            train_graph = cls(model, batch, buckets, opt, loss_fn=lambda out: crit(out, targets)[0], **kw)
-        else:
-            train_graph = cls(model, batch, buckets, opt, cotangents=cots, **kw)
-        graph_fallback = getattr(train_graph, 'capture_error', None)
+        try:
+            if crit is not None:
+                train_graph = cls(model, batch, buckets, opt, loss_fn=lambda out: crit(out, targets)[0], **kw)
+            else:
+                train_graph = cls(model, batch, buckets, opt, cotangents=cots, **kw)
+        except Exception as e:                  # noqa: BLE001
+            if not graph_auto:
+                raise
+            # the graph was this script's own choice, not the caller's: run the eager step instead
+            print(f'[bench] hipGraph capture of the training step failed ({type(e).__name__}: {e}); '
+                  'eager step', file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            train_graph, args.graph, args.no_kernel_timing = None, False, kernel_timing_off
+            graph_fallback = f'{type(e).__name__}: {e}'
+        if train_graph is not None:
+            graph_fallback = getattr(train_graph, 'capture_error', None)
         if graph_fallback:
             print(f'[bench] rank {rank}: hipGraph capture failed ({graph_fallback}); eager segmented step',
                   file=sys.stderr, flush=True)

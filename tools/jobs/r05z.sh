@@ -23,7 +23,8 @@ tools/pmc_traffic2.sh bf16 --dtype bf16 > $O/pmc_bf16.log 2>&1; EMSA_PMC_BENCH_A
 rm -rf gpurun_out/pmc_f32/FETCH_SIZE gpurun_out/pmc_f32/WRITE_SIZE gpurun_out/pmc_bf16/FETCH_SIZE gpurun_out/pmc_bf16/WRITE_SIZE
 cp $O/r05_pmc_traffic.json $O/r05_pmc_traffic_bf16.json profiles/ 2>/dev/null
 run bench_driver_cmd_f32 --gpus 1 --steps 20 --warmup 5
-run bench_bf16 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline
+run bench_f32_eager --gpus 1 --eager --steps 20 --warmup 5 --no-cpu-baseline
+run bench_bf16 --dtype bf16 --eager --steps 20 --warmup 5 --no-cpu-baseline
 run bench_bf16_graph --dtype bf16 --graph --steps 20 --warmup 5 --no-cpu-baseline
 EMSA_WGRAD_MULTI=0 run bench_bf16_graph_wgrad_multi_off --dtype bf16 --graph --steps 20 --warmup 5 --no-cpu-baseline
 EMSA_RS_CUS=224 run bench_bf16_graph_rs_cus_224 --dtype bf16 --graph --steps 20 --warmup 5 --no-cpu-baseline
@@ -39,8 +40,8 @@ run config3_r101_960x736_bs16_bf16 --dtype bf16 --backbone resnet101 --height 73
 run eval_bs32_f32 --eval --steps 20 --warmup 5 --no-cpu-baseline
 run eval_bs32_bf16 --dtype bf16 --eval --steps 20 --warmup 5 --no-cpu-baseline
 cd /tmp && export TMPDIR=/tmp
-EMSA_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof_f32_one_stream -o p --output-format csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_f32_one.log 2>&1; echo "prof f32 one stream rc=$?"
-EMSA_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof_bf16_one_stream -o p --output-format csv -- python $R/bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_bf16_one.log 2>&1; echo "prof bf16 one stream rc=$?"
+EMSA_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof_f32_one_stream -o p --output-format csv -- python $R/bench.py --gpus 1 --eager --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_f32_one.log 2>&1; echo "prof f32 one stream rc=$?"
+EMSA_DUAL_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof_bf16_one_stream -o p --output-format csv -- python $R/bench.py --dtype bf16 --eager --steps 20 --warmup 5 --no-cpu-baseline > $R/$O/prof_bf16_one.log 2>&1; echo "prof bf16 one stream rc=$?"
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof_eval_bs1_f16 -o p --output-format csv -- python $R/bench.py --eval --graph --batch-size 1 --dtype f16 --steps 100 --warmup 10 --no-cpu-baseline > $R/$O/prof_eval.log 2>&1; echo "prof eval rc=$?"
 cd $R
 f=$(ls $O/prof_eval_bs1_f16/*kernel_trace.csv 2>/dev/null | head -1)
