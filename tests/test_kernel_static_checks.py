@@ -49,3 +49,33 @@ def test_wgrad16_kernels_use_the_lds_instructions_their_layouts_are_built_for():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_wgrad16_isa.py')],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'wgrad16 isa check: ok' in r.stdout, r.stdout + r.stderr
+
+
+@needs_hipcc
+def test_streaming_kernels_issue_their_loads_together():
+    """csrc/pointwise.hip (round 5): the BatchNorm passes, the up-sampling / max-pool
+    forward, the SE scale kernels and channel_dot must not wait for a load before the next one is
+    issued -- an optional operand behind a run-time branch, or a border test around a load, puts
+    `s_waitcnt vmcnt(0)` behind every load (one memory round trip each: the round-4 forms had 3-13
+    per element).  tools/isa_audit.py counts those load -> wait pairs per kernel."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'isa_audit.py'),
+                        os.path.join(ROOT, 'emsanet_amd', 'csrc', 'pointwise.hip'), '--min-ser', '0'],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    watched = ('bn_act_fwd_fast_kernel', 'bn_bwd_reduce_fast_kernel', 'bn_bwd_apply_fast_kernel',
+               'up2x_dw_fwd_kernel', 'maxpool_fwd_kernel', 'se_scale_add_fwd_kernel',
+               'se_scale_bwd_apply_kernel', 'channel_dot_kernel')
+    seen, bad = set(), []
+    for line in r.stdout.splitlines()[1:]:
+        f = line.split()
+        if len(f) < 5:
+            continue
+        kname = ' '.join(f[4:])
+        for w in watched:
+            if w in kname:
+                seen.add(w)
+                # (<= 3: the prologue of bn_bwd_apply -- the slice-sum merge -- and single tail loads)
+                if int(f[0]) > 3:
+                    bad.append(line)
+    assert seen == set(watched), set(watched) - seen
+    assert not bad, '\n'.join(bad)

@@ -24,12 +24,14 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 LOAD = re.compile(r'\b(global_load|buffer_load|flat_load)')
 
 
+_CXXFILT = next((c for c in ('/opt/rocm/lib/llvm/bin/llvm-cxxfilt', '/usr/bin/c++filt') if os.path.exists(c)), None)
+
+
 def demangle(name):
-    try:
-        r = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name], capture_output=True, text=True)
-        return r.stdout.strip() or name
-    except OSError:
+    if _CXXFILT is None:
         return name
+    r = subprocess.run([_CXXFILT, name], capture_output=True, text=True)
+    return r.stdout.strip() or name
 
 
 def audit(path, tmp):
@@ -37,11 +39,12 @@ def audit(path, tmp):
     subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-S',
                     '--cuda-device-only', f'-I{CSRC}', f'-I{ROOT}/include', path, '-o', out],
                    check=True, stderr=subprocess.DEVNULL)
-    text = open(out).read()
     rows = []
-    for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)\.end_amdhsa_kernel', text, re.S | re.M):
-        name, body = m.group(1), m.group(2)
-        lines = [x for x in body.split('\n') if x.strip() and not x.strip().startswith(';')]
+    name, lines = None, []
+
+    def close():
+        if name is None:
+            return
         ser = 0
         for i, line in enumerate(lines):
             if not LOAD.search(line):
@@ -52,8 +55,24 @@ def audit(path, tmp):
                 if 's_waitcnt vmcnt(0)' in nxt:
                     ser += 1
                     break
+        body = '\n'.join(lines)
         rows.append((ser, len(re.findall(r'v_rcp_(iflag_)?f32', body)), body.count('s_mul_hi_u32'),
                      os.path.basename(path), name))
+    with open(out) as f:                       # one linear pass (the .s of pointwise.hip is 10 MB)
+        for raw in f:
+            m = re.match(r'^(_Z\w+):', raw)
+            if m:
+                name, lines = m.group(1), []
+                continue
+            if name is None:
+                continue
+            if '.end_amdhsa_kernel' in raw:
+                close()
+                name = None
+                continue
+            t = raw.strip()
+            if t and not t.startswith(';'):
+                lines.append(t)
     return rows
 
 
