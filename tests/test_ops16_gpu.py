@@ -527,3 +527,64 @@ def test_bn_fast_kernels_are_bit_identical_to_the_general_ones(tmp_path):
         for i, (ta, tb) in enumerate(zip(a, b)):
             assert ta.dtype == tb.dtype and ta.shape == tb.shape
             assert torch.equal(ta, tb), (k, i, (ta.float() - tb.float()).abs().max().item())
+
+
+_IDX_CODE = '''
+import sys, torch
+sys.path.insert(0, "tests")
+from util import DEV, rnd
+from emsanet_amd import functional as Fn
+
+def run(dtype, n, c, h, w):
+    def act(seed, hh=h, ww=w):
+        g = torch.Generator().manual_seed(seed)
+        return torch.randn(n, hh, ww, c, generator=g).to(dtype).to(DEV).permute(0, 3, 1, 2)
+    x, b = act(1), act(2)
+    out = []
+    y, idx = Fn.maxpool_fwd(x)
+    out += [y, idx, Fn.maxpool_bwd(act(3, (h + 1) // 2, (w + 1) // 2), idx, (h, w))]
+    sa, sb = (rnd(n, c, seed=4).abs() + 0.1).to(DEV), (rnd(n, c, seed=5).abs() + 0.1).to(DEV)
+    out += [Fn.se_scale_add(x, sa), Fn.se_scale_add(x, sa, b, sb)]
+    out += [Fn.se_scale_bwd_apply(x, sa, sb), Fn.se_scale_bwd_apply(x, sa, sb, b)]
+    wdw, bias = rnd(c, 1, 3, 3, seed=6).to(DEV), rnd(c, seed=7).to(DEV)
+    skip = act(8, 2 * h, 2 * w)
+    out += [Fn.up2x_dw_fwd(x, wdw, bias), Fn.up2x_dw_fwd(x, wdw, bias, skip)]
+    if dtype != torch.float32:
+        out += [Fn.up2x_dw_fwd(x, wdw, bias, None, out_f32=True)]
+    dx, dw, db = Fn.up2x_dw_bwd(skip, x, wdw)
+    out += [dx]                                 # (dw / db: fp32 atomics, compared by tolerance elsewhere)
+    torch.cuda.synchronize()
+    return [t.cpu() for t in out]
+
+res = {}
+for name, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+    for shp in ((2, 64, 23, 30), (3, 40, 9, 7), (1, 128, 16, 20)):
+        if dtype != torch.float32 and shp[1] % 8:
+            continue
+        res[name + str(shp)] = run(dtype, *shp)
+torch.save(res, sys.argv[1])
+print("IDX_DUMP_OK")
+'''
+
+
+def test_index_width_variants_are_bit_identical(tmp_path):
+    """round 5: max-pool, SE scale and up-sampling kernels run on 32-bit element indices whenever the
+    tensors have < 2^31 elements (every shape of every test); EMSA_IDX32=0 forces the 64-bit
+    instantiations that larger tensors take -- they must produce the same bits"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ('1', '0'):
+        path = str(tmp_path / f'idx_{flag}.pt')
+        r = subprocess.run([sys.executable, '-c', _IDX_CODE, path], cwd=root,
+                           env=dict(os.environ, EMSA_IDX32=flag), capture_output=True, text=True,
+                           timeout=600)
+        assert 'IDX_DUMP_OK' in r.stdout, r.stderr[-3000:]
+        outs[flag] = torch.load(path)
+    assert outs['1'].keys() == outs['0'].keys() and len(outs['1']) >= 5
+    for k in outs['1']:
+        for i, (ta, tb) in enumerate(zip(outs['1'][k], outs['0'][k])):
+            assert ta.dtype == tb.dtype and ta.shape == tb.shape
+            assert torch.equal(ta, tb), (k, i)
