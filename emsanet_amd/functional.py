@@ -221,6 +221,12 @@ def rs_eligible(spec):
             and spec.sw == 1 and spec.cin == spec.cout and spec.cin in (64, 128, 256, 512))
 
 
+def _resolve(w):
+    """packed weights, or a callable that packs them on demand (ops.ConvRT hands the [tap][n][k] form of
+    a conv_rs-capable conv over lazily: where conv_rs takes the geometry nobody reads it)"""
+    return w() if callable(w) else w
+
+
 def rs_supported(code, g):
     """the kernel takes this geometry (cached on the geometry object: a plan per shape)"""
     if not CONV_RS or code == 0:
@@ -404,6 +410,7 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
               'emsa_conv1d_rs_t')
     elif code != 0 and not want_stats and _splitk_ws_bytes(code, g) > 0:
         # few output tiles, long K (the decoders' 3x3 convs at batch 1): tap-split + finish pass
+        wp = _resolve(wp)
         if wp is None or wp.dtype != x.dtype:
             raise _lib.EmsaError("conv weights are not packed in the activations' dtype")
         ws = _empty((_splitk_ws_bytes(code, g) // 4,), x.device)
@@ -411,6 +418,7 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
                                          _p(shift), _p(residual), lr, act, _p(ws), _stream()),
               'emsa_conv_igemm_splitk_t')
     else:
+        wp = _resolve(wp)
         if wp is None or wp.dtype != x.dtype:
             raise _lib.EmsaError(f"conv weights packed as {None if wp is None else wp.dtype} for "
                                  f"{x.dtype} activations")
@@ -630,6 +638,8 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
     lr = ld_of(residual) if residual is not None else 0
     if code != 0:
         wino_u = None
+    if wino_u is None and (spec.sh > 1 or spec.sw > 1):
+        wpd = _resolve(wpd)
     if wino_u is None and (spec.sh > 1 or spec.sw > 1) and dgrad_phases(dy.dtype) \
             and wpd is not None and wpd.dtype == dy.dtype:
         r = _conv_dgrad_phased(dy, wpd, spec, in_hw, mask_src, residual, out)
@@ -648,6 +658,7 @@ def conv_dgrad(dy, wpd, spec, in_hw, mask_src=None, residual=None, out=None, win
                                  _p(residual), lr, _p(mask_src), lm, ACT_NONE, _stream()),
               'emsa_conv1d_rs_t(dgrad)')
     else:
+        wpd = _resolve(wpd)
         if wpd is None or wpd.dtype != dy.dtype:
             raise _lib.EmsaError("data-gradient weights are not packed in the gradient's dtype")
         lm = ld_of(mask_src) if mask_src is not None else 0
@@ -745,6 +756,7 @@ def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invs
                                      _p(bn_invstd), _p(partial), rows + 16, _stream()),
               'emsa_conv1d_rs_bnb_t')
     else:
+        wpd = _resolve(wpd)
         if wpd is None or wpd.dtype != dy.dtype:
             raise _lib.EmsaError("data-gradient weights are not packed in the gradient's dtype")
         check(L.emsa_conv_igemm_bnb_t(code, g, _p(dy), _p(wpd), _p(out), _p(residual), lr, _p(t),

@@ -91,6 +91,7 @@ class ConvRT:
         # streaming kernel (conv_rs.hip) with fragment-ordered weights, where it takes the geometry
         self.rs = Fn.rs_eligible(self.spec)
         self._hf = {}             # fragment-ordered 16-bit packs: dtype -> [key, fwd, key_d, dgrad]
+        self.plain_asked = 0      # times the [tap][n][k] 16-bit operand of an rs conv was read (PackPlan)
 
     def spec_key(self):
         s = self.spec
@@ -107,7 +108,8 @@ class ConvRT:
     def forward(self, x, **kw):
         """conv forward through the best kernel for this layer (fused-epilogue kwargs of conv_fwd)"""
         if x.dtype != torch.float32:
-            return Fn.conv_fwd(x, self.packed(x.dtype), self.spec, wfrag=self.frag(x.dtype), **kw)
+            wf = self.frag(x.dtype)
+            return Fn.conv_fwd(x, self._plain(x.dtype, wf, self.packed), self.spec, wfrag=wf, **kw)
         if self.wino:
             return Fn.conv_fwd(x, None, self.spec, wino_u=self._wino_weights()[0], **kw)
         return Fn.conv_fwd(x, self.packed(), self.spec, **kw)
@@ -122,8 +124,9 @@ class ConvRT:
         """mask_bits: the ReLU mask of the producing layer as bits (conv_fwd(want_relu_bits));
         used by the Winograd kernel, otherwise the float `mask_src` applies"""
         if dy.dtype != torch.float32:
-            return Fn.conv_dgrad(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw,
-                                 wfrag=self.frag_dgrad(dy.dtype), **kw)
+            wf = self.frag_dgrad(dy.dtype)
+            return Fn.conv_dgrad(dy, self._plain(dy.dtype, wf, self.packed_dgrad), self.spec, in_hw,
+                                 wfrag=wf, **kw)
         if self.wino:
             u, ud = self._wino_weights()
             if ud is None:
@@ -140,9 +143,9 @@ class ConvRT:
             return None
         scale, shift = affine
         if dy.dtype != torch.float32:
-            return Fn.conv_dgrad_bnb(dy, self.packed_dgrad(dy.dtype), self.spec, in_hw, t, scale,
-                                     shift, mean, invstd, residual=residual,
-                                     wfrag=self.frag_dgrad(dy.dtype))
+            wf = self.frag_dgrad(dy.dtype)
+            return Fn.conv_dgrad_bnb(dy, self._plain(dy.dtype, wf, self.packed_dgrad), self.spec, in_hw,
+                                     t, scale, shift, mean, invstd, residual=residual, wfrag=wf)
         if not self.wino:
             return None
         u, ud = self._wino_weights()
@@ -150,6 +153,16 @@ class ConvRT:
             ud = Fn.pack_wino(self.conv.weight.detach(), fwd=False, dgrad=True)[1]
         return Fn.conv_dgrad_bnb(dy, None, self.spec, in_hw, t, scale, shift, mean, invstd,
                                  residual=residual, wino_u=ud)
+
+    def _plain(self, dtype, wfrag, getter):
+        """the [tap][n][k] operand of the implicit GEMM: at once for a conv without fragment-ordered
+        weights, ON DEMAND for a conv_rs-capable one -- where conv_rs takes the geometry (every NBt1D
+        conv of a training step) nobody reads it, and PackPlan stops packing it (`plain_asked`
+        tells it when somebody did)"""
+        if wfrag is None:
+            return getter(dtype)
+
+        return lambda: getter(dtype)
 
     def frag(self, dtype):
         """fragment-ordered forward weights for conv_rs.hip (None: not that kind of conv)"""
@@ -180,6 +193,7 @@ class ConvRT:
         w = self.conv.weight
         key = (w._version, w.data_ptr())
         if dtype != torch.float32:
+            self.plain_asked += 1
             ent = self._h.setdefault(dtype, [None, None, None, None])
             if ent[0] != key:
                 ent[1], d = Fn.pack_weight_t(w.detach(), dtype, fwd=True, dgrad=w.requires_grad)
@@ -201,6 +215,7 @@ class ConvRT:
         w = self.conv.weight
         key = (w._version, w.data_ptr())
         if dtype != torch.float32:
+            self.plain_asked += 1
             ent = self._h.setdefault(dtype, [None, None, None, None])
             if ent[2] != key:
                 ent[3] = Fn.pack_weight_t(w.detach(), dtype, fwd=False, dgrad=True)[1]
@@ -210,6 +225,10 @@ class ConvRT:
             self._wpd = Fn.pack_weight(w.detach(), 'dgrad')
             self._keyd = key
         return self._wpd
+
+
+# EMSA_PACK_LEAN=0: always pack both 16-bit operand forms of the conv_rs-capable convs (A/B runs)
+PACK_LEAN = os.environ.get('EMSA_PACK_LEAN', '1') != '0'
 
 
 class PackPlan:
@@ -234,8 +253,20 @@ class PackPlan:
         self._arena = None
         self._views = None
         self._dtype = None
+        # lean: the conv_rs-capable convs get their fragment-ordered 16-bit operands only -- their
+        # [tap][n][k] form (half of the 16-bit pack launch: 188 convs of the full model) is read only
+        # where conv_rs refuses a geometry.  Decided from what the previous step asked for
+        # (ConvRT.plain_asked): full table first, lean once a whole step went by without a reader,
+        # full again as soon as one turns up (who meanwhile packs per layer, ConvRT.packed)
+        self._lean = False
+        self._asked_seen = None
+        self._refreshes = 0
 
-    def _build(self, dev, dtype):
+    def _asked(self):
+        return sum(rt.plain_asked for rt in self.rts if rt.rs)
+
+    def _build(self, dev, dtype, lean=False):
+        self._lean = lean
         n = len(self.rts)
         n_multi = sum(len(m.placements) + sum(1 for q, _, _ in m.placements if q.bias is not None)
                       for m in self.multi)
@@ -243,6 +274,8 @@ class PackPlan:
         # the stride-1 3-tap 1-D convs additionally get the fragment-ordered operands of conv_rs.hip
         # (pack kinds 5 / 6) -- the [tap][n][k] form stays for geometries that kernel refuses
         frag_rts = [rt for rt in self.rts if half and rt.rs and Fn.CONV_RS]
+        lean = self._lean = bool(lean and frag_rts)
+        skip = set(id(rt) for rt in frag_rts) if lean else set()
         jobs = (_lib.EmsaPackJob * (n + n_multi + len(frag_rts)))()
         esz = 2 if half else 4
         sizes = []
@@ -251,7 +284,10 @@ class PackPlan:
             numel = w.numel()
             per = numel if half else (numel * 4 // 3 if rt.wino else numel)   # U: 4 comps per 3 taps
             per_b = (per * esz + 15) // 16 * 16            # every pack starts 16-byte aligned
-            sizes.append((per, per_b, per_b if w.requires_grad else 0))
+            if id(rt) in skip:
+                sizes.append((0, 0, 0))
+            else:
+                sizes.append((per, per_b, per_b if w.requires_grad else 0))
         fsizes = [((rt.conv.weight.numel() * esz + 15) // 16 * 16) * (2 if rt.conv.weight.requires_grad else 1)
                   for rt in frag_rts]
         arena = torch.empty(sum(a + b for _, a, b in sizes) + sum(fsizes), device=dev,
@@ -259,6 +295,12 @@ class PackPlan:
         views, off, blk = [], 0, 0
         for j, (rt, (per, a, b)) in enumerate(zip(self.rts, sizes)):
             w = rt.conv.weight
+            if id(rt) in skip:
+                # lean: no [tap][n][k] operand for this conv -- an empty job keeps the table's indexing
+                views.append((None, None))
+                jobs[j] = _lib.EmsaPackJob(w.data_ptr(), w.data_ptr(), None, 0, 1, 1, 1, 4, blk)
+                blk += 1
+                continue
             v0 = arena[off:off + per * esz].view(dtype)
             v1 = arena[off + a:off + a + per * esz].view(dtype) if b else None
             off += a + b
@@ -331,8 +373,18 @@ class PackPlan:
         mptrs = tuple(q.weight.data_ptr() for m in self.multi for q, _, _ in m.placements)
         if self._dtype != dtype or self._ptrs != tuple(w.data_ptr() for w in ws) or \
                 getattr(self, '_mptrs', None) != mptrs or \
-                any((v1 is None) == w.requires_grad for (_, v1), w in zip(self._views or [], ws)):
-            self._build(ws[0].device, dtype)
+                any(v0 is not None and (v1 is None) == w.requires_grad
+                    for (v0, v1), w in zip(self._views or [], ws)):
+            self._build(ws[0].device, dtype, self._lean)
+        # lean / full job table, from what the step behind us read (never switched inside a capture:
+        # _build uploads the table)
+        asked = self._asked()
+        if PACK_LEAN and dtype != torch.float32 and not torch.cuda.is_current_stream_capturing():
+            if self._lean and asked != self._asked_seen:
+                self._build(ws[0].device, dtype, False)
+            elif not self._lean and self._asked_seen is not None and asked == self._asked_seen:
+                self._build(ws[0].device, dtype, True)
+        self._asked_seen = asked
         check(_lib.lib().emsa_pack_batch(self._jobs.data_ptr(), self._n_jobs, self._n_blocks,
                                          Fn._stream()), 'emsa_pack_batch')
         for m, mk, (d0, d1, bias, wino) in zip(self.multi, mkeys, self._mviews):
@@ -351,6 +403,8 @@ class PackPlan:
             rt._hf[dtype] = [k, f0, k if f1 is not None else None, f1]
         for rt, (v0, v1), w in zip(self.rts, self._views, ws):
             k = (w._version, w.data_ptr())
+            if v0 is None:
+                continue                       # lean: ConvRT.packed packs this one itself if asked
             if dtype != torch.float32:
                 rt._h[dtype] = [k, v0, k if v1 is not None else None, v1]
             elif rt.wino:
