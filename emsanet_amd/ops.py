@@ -261,11 +261,27 @@ class PackPlan:
         self._lean = False
         self._asked_seen = None
         self._refreshes = 0
+        # a hipGraph that captured `emsa_pack_batch` holds RAW pointers to the job table, the arena
+        # and the merged-head operands.  Once a refresh ran under capture the lean / full state is
+        # frozen (the table a replay reads must stay the one it recorded) and whatever a later
+        # rebuild supersedes (new dtype, moved parameters) is kept alive in `_retired` instead of
+        # going back to the allocator, where a replay would scribble over someone else's memory
+        # (ADVICE r5).  `thaw()` drops both when the graphs are gone.
+        self._captured = False
+        self._retired = []
+
+    def thaw(self):
+        """no captured graph replays this plan's pack launch any more: allow lean / full switches
+        again and release the superseded tables"""
+        self._captured = False
+        self._retired.clear()
 
     def _asked(self):
         return sum(rt.plain_asked for rt in self.rts if rt.rs)
 
     def _build(self, dev, dtype, lean=False):
+        if self._captured and self._jobs is not None:
+            self._retired.append((self._jobs, self._arena, self._views, self._frag, self._mviews))
         self._lean = lean
         n = len(self.rts)
         n_multi = sum(len(m.placements) + sum(1 for q, _, _ in m.placements if q.bias is not None)
@@ -379,7 +395,9 @@ class PackPlan:
         # lean / full job table, from what the step behind us read (never switched inside a capture:
         # _build uploads the table)
         asked = self._asked()
-        if PACK_LEAN and dtype != torch.float32 and not torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
+        if PACK_LEAN and dtype != torch.float32 and not self._captured:
             if self._lean and asked != self._asked_seen:
                 self._build(ws[0].device, dtype, False)
             elif not self._lean and self._asked_seen is not None and asked == self._asked_seen:

@@ -788,3 +788,103 @@ def test_twin_launches_match_separate_launches(dtype, shape, monkeypatch):
     assert 'instance_predicted_centers' in keys and 'instance_segmentation_idx' in keys
     for k in keys:
         assert torch.equal(r0[k], r1[k]), k
+
+
+def _bf16_train_setup(lr=0.0):
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from emsanet_amd.optim import FusedSGD
+    from emsanet_amd.parallel import GradientBuckets
+    args = full_args(input_height=96, input_width=128, compute_dtype='bfloat16')
+    torch.manual_seed(0)
+    m = EMSANet(args, nyuv2_config()).to(DEV).train()
+    m.dropout_seed = 7
+    b = GradientBuckets([p for p in m.parameters() if p.requires_grad])
+    o = FusedSGD(b, lr=lr, momentum=0.9, weight_decay=0.0)
+    return m, b, o
+
+
+@pytest.mark.parametrize('warmup', [1, 3])
+def test_pack_table_is_frozen_once_a_train_graph_captured_it(warmup):
+    """the captured step holds raw pointers to PackPlan's job table and arena.
+    warmup=1 captures the FULL table; the first eager forward afterwards used to find a quiet step
+    behind it and rebuild to LEAN -- freeing the table the next replay reads.  warmup=3 captures a
+    lean table; an eager reader of a plain operand used to rebuild to full.  Now: the table, the
+    arena and the lean flag do not change after a capture, and replay / eager eval / replay gives
+    the losses of replay / replay."""
+    from emsanet_amd.graph import GraphedTrainStep
+    from oracle.emsanet_oracle import synthetic_batch
+    batches = [{k: v.to(DEV) for k, v in synthetic_batch(2, 96, 128, seed=s).items()}
+               for s in (1, 2, 3)]
+
+    def loss_of(out):
+        return sum((t * t).mean() for t in _flatten(out))
+
+    def run(disturb):
+        m, b, o = _bf16_train_setup()
+        g = GraphedTrainStep(m, batches[0], b, o, loss_fn=loss_of, warmup=warmup)
+        plan = m._pack_plan
+        assert plan._captured
+        ident = (plan._jobs.data_ptr(), plan._arena.data_ptr(), plan._lean)
+        losses = [float(g.replay(batches[1])[0])]
+        if disturb:
+            m.eval()
+            with torch.no_grad():
+                m(batches[2])                      # quiet step behind it -> would have gone lean
+                for rt in plan.rts:                # a plain-operand reader -> would have gone full
+                    if rt.rs:
+                        rt.packed(torch.bfloat16)
+                        break
+                m(batches[2])
+            m.train()
+            assert (plan._jobs.data_ptr(), plan._arena.data_ptr(), plan._lean) == ident
+        losses.append(float(g.replay(batches[2])[0]))
+        torch.cuda.synchronize()
+        return losses, ident[2]
+    la, lean_a = run(False)
+    lb, lean_b = run(True)
+    assert lean_a == lean_b == (warmup >= 2)
+    assert la == lb, (la, lb)
+    assert all(x == x for x in la)
+
+
+def test_lean_pack_table_round_trip_matches_full(monkeypatch):
+    """the lean 16-bit pack table (conv_rs convs keep only their fragment-ordered
+    operands) against EMSA_PACK_LEAN=0 -- eager steps go full -> lean after a quiet step, a reader of
+    a plain operand sends the table back to full, a quiet step back to lean; the forward outputs are
+    bit-identical to the always-full plan's throughout."""
+    from emsanet_amd import ops
+    from oracle.emsanet_oracle import synthetic_batch
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(2, 96, 128, seed=5).items()}
+
+    def outs(lean):
+        monkeypatch.setattr(ops, 'PACK_LEAN', lean)
+        m, _, _ = _bf16_train_setup()
+        m.eval()
+        plan = m._pack_plan
+        res, states = [], []
+        with torch.no_grad():
+            for i in range(6):
+                if i == 3:
+                    rt = next(rt for rt in plan.rts if rt.rs)
+                    rt.packed(torch.bfloat16)
+                # a new weight version makes refresh() run its lean / full decision
+                torch.autograd.graph.increment_version(plan.rts[0].conv.weight)
+                res.append([t.clone() for t in _flatten_eval(m(batch))])
+                states.append(plan._lean)
+        return res, states
+    full, s_full = outs(False)
+    lean, s_lean = outs(True)
+    assert not any(s_full)
+    # full first, lean after a quiet step, a reader before pass 3 -> full, quiet again -> lean
+    assert s_lean == [False, True, True, False, True, True], s_lean
+    for a, b in zip(full, lean):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def _flatten_eval(outs):
+    flat = []
+    for o, sides in outs:
+        flat += list(o) if isinstance(o, tuple) else [o]
+    return flat
