@@ -51,6 +51,7 @@ _GP = POINTER(EmsaConvGeom)
 SIGNATURES = {
     'emsa_arch': (c_char_p, []),
     'emsa_version': (c_int, []),
+    'emsa_set_batch_invariant': (c_int, [c_int]),
     'emsa_conv_igemm': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, c_int32, _P]),
     'emsa_conv_stats_rows': (c_int, [_GP]),
     'emsa_conv1d_wino_supported': (c_int, [_GP]),

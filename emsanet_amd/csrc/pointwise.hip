@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -2068,6 +2069,12 @@ __device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, in
 template <typename T>
 __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n,
                                     int ih, int iw, int oh, int ow, int c, int ld_y) {
+  // no fma contraction: the compiler contracted the interpolation differently in the peeled first
+  // iteration and in the steady-state body of the grid-stride loop, so an element's last bit depended
+  // on how many iterations its thread ran, i.e. on the batch size (found by
+  // tools/batch_invariance_probe.py: the only batch-dependent rounding left in the eval forward once
+  // the channel reductions are partitioned by map size, emsa_set_batch_invariant)
+#pragma clang fp contract(off)
   const long total = (long)n * oh * ow * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
@@ -2088,28 +2095,44 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
   }
 }
 
-// dx is ALWAYS fp32 (scattered atomics; a few KB at the /32 pyramid-pooling resolution)
+// dx is ALWAYS fp32.  GATHER form (round 6): one thread per dx element walks the output rows / columns
+// whose two source taps include its own row / column and sums their contributions in a fixed
+// order -- no atomics, no zero-fill, bit-reproducible.  (The scatter form with fp32 atomics was the one
+// non-reproducible link of the ACTIVATION-gradient chain: in 16-bit storage its 1e-7 jitter flips
+// a few roundings of the pyramid-pooling branch gradients, and 30 blocks of bf16 rounding further
+// up the encoder those few flips have grown into a different 1.5 % noise realisation of every
+// encoder gradient, run to run -- tools/grad_repeat_probe.py.)
 template <typename T>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dx, int n,
                                     int ih, int iw, int oh, int ow, int c, int ld_dy) {
-  const long total = (long)n * oh * ow * c;
+#pragma clang fp contract(off)
+  const long total = (long)n * ih * iw * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % c);
     long r = i / c;
-    const int xo = (int)(r % ow); r /= ow;
-    const int yo = (int)(r % oh);
-    const int img = (int)(r / oh);
-    int h0, h1, w0, w1;
-    float lh, lw;
-    bilinear_src(yo, ih, oh, h0, h1, lh);
-    bilinear_src(xo, iw, ow, w0, w1, lw);
-    const float g = emsa_ld1(dy + (((long)img * oh + yo) * ow + xo) * ld_dy + ch);
-    float* b = dx + (long)img * ih * iw * c + ch;
-    unsafeAtomicAdd(b + ((long)h0 * iw + w0) * c, g * (1.f - lh) * (1.f - lw));
-    unsafeAtomicAdd(b + ((long)h0 * iw + w1) * c, g * (1.f - lh) * lw);
-    unsafeAtomicAdd(b + ((long)h1 * iw + w0) * c, g * lh * (1.f - lw));
-    unsafeAtomicAdd(b + ((long)h1 * iw + w1) * c, g * lh * lw);
+    const int xi = (int)(r % iw); r /= iw;
+    const int yi = (int)(r % ih);
+    const int img = (int)(r / ih);
+    const T* b = dy + (long)img * oh * ow * ld_dy + ch;
+    float a = 0.f;
+    for (int yo = 0; yo < oh; ++yo) {
+      int h0, h1;
+      float lh;
+      bilinear_src(yo, ih, oh, h0, h1, lh);
+      // (h0 == h1 at the clamped border: both taps land on the same row, as in the scatter form)
+      const float wy = (h0 == yi ? 1.f - lh : 0.f) + (h1 == yi ? lh : 0.f);
+      if (h0 != yi && h1 != yi) continue;
+      for (int xo = 0; xo < ow; ++xo) {
+        int w0, w1;
+        float lw;
+        bilinear_src(xo, iw, ow, w0, w1, lw);
+        if (w0 != xi && w1 != xi) continue;
+        const float wx = (w0 == xi ? 1.f - lw : 0.f) + (w1 == xi ? lw : 0.f);
+        a += emsa_ld1(b + ((long)yo * ow + xo) * ld_dy) * (wy * wx);
+      }
+    }
+    dx[i] = a;
   }
 }
 
@@ -2879,15 +2902,25 @@ extern "C" int emsa_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const int8
 // /16 sums of the training shapes too, and the bf16 train-mode gates of tests/test_model16_gpu.py,
 // which sit on one draw of a chaotic system, moved: an SE hidden unit flipped against the oracle's.
 // Those partitions stay what they were)
+// emsa_set_batch_invariant(1): the partition becomes a function of the map size alone (always the
+// 512-pixel rule), so a sample's sums -- and with them its whole eval forward -- are the same bits
+// whatever batch it sits in; opt-in (slower at batch 1), used by tests/test_timed_size_gpu.py to
+// compare the gradients of one bs-32 step with the sum over four bs-8 steps on identical ReLU
+// decisions.
+static std::atomic<int> g_batch_invariant{0};
 static int channel_splits(long hw, int n) {
   int splits = (int)((hw + 511) / 512);
   if (splits > 64) splits = 64;
-  if ((long)n * splits <= 64) {
+  if ((long)n * splits <= 64 && !g_batch_invariant.load(std::memory_order_relaxed)) {
     splits = (int)((hw + 63) / 64);
     if (splits > 256) splits = 256;
   }
   if (splits < 1) splits = 1;
   return splits;
+}
+
+extern "C" int emsa_set_batch_invariant(int on) {
+  return g_batch_invariant.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
 
 template <typename T>
@@ -3365,8 +3398,7 @@ template <typename T>
 static int bilinear_bwd_impl(const T* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
   if (!dy || !dx) return EMSA_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  emsa_zero_async(dx, (size_t)n * ih * iw * c * sizeof(float), st);
-  const long total = (long)n * oh * ow * c;
+  const long total = (long)n * ih * iw * c;
   hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, dy, dx, n,
                      ih, iw, oh, ow, c, ld_dy);
   return emsa_launch_status();

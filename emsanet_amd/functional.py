@@ -1295,11 +1295,11 @@ def bilinear_fwd(x, out):
 
 
 def bilinear_bwd(dy, in_hw):
-    """scattered fp32 atomics into a zeroed fp32 dx (a few KB at the pyramid-pooling resolution),
-    returned in the dtype of dy"""
+    """gather-form backward (one thread per dx element, fixed summation order: bit-reproducible) into
+    an fp32 dx, returned in the dtype of dy"""
     n, c, oh, ow = dy.shape
     ih, iw = in_hw
-    dx = act_zeros(n, c, ih, iw, dy.device)
+    dx = act_empty(n, c, ih, iw, dy.device)
     check(call_t('emsa_bilinear_bwd', dt(dy), _p(dy), _p(dx), n, ih, iw, oh, ow, c, ld_of(dy),
                  _stream()), 'emsa_bilinear_bwd')
     if dy.dtype != torch.float32:

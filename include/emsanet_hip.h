@@ -46,6 +46,11 @@ extern "C" {
 /* library identity: returns the gfx arch string the kernels were compiled for ("gfx950") */
 const char* emsa_arch(void);
 int emsa_version(void);
+/* batch-invariant reductions (default off): with 1 the per-image pixel partition of the SE / channel
+ * reductions depends on the map size only, so a sample's forward does not depend on the batch it sits
+ * in (the default rule re-partitions small launches for latency).  Returns the previous setting.
+ * No reference counterpart: ATen makes no such promise (emsanet/model.py:192-233 runs eager ATen). */
+int emsa_set_batch_invariant(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA (v_mfma_f32_32x32x2_f32).
@@ -357,7 +362,9 @@ int emsa_up2x_dw3x3_bwd(const float* dy, const float* x, const float* wdw, float
 int emsa_up2x_dw3x3_bwd_supported(int32_t c, int32_t esize);
 
 /* pyramid pooling ('ppm', emsanet/args.py:243-256): adaptive average pool to bins x bins and
- * bilinear (align_corners=False) upsampling back, written into a channel slice (ld_y)        */
+ * bilinear (align_corners=False) upsampling back, written into a channel slice (ld_y).
+ * emsa_bilinear_bwd WRITES every element of dx (gather form, fixed summation order: reproducible;
+ * no zero-fill needed).                                                                       */
 int emsa_adaptive_avgpool_fwd(const float* x, float* y, int32_t n, int32_t h, int32_t w,
                               int32_t c, int32_t bins, void* stream);
 int emsa_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t n, int32_t h, int32_t w,
@@ -641,7 +648,7 @@ int emsa_pack_weight_frag_t(int32_t dtype, const float* w_oihw, void* wf_fwd, vo
  * boundary take `out_f32`: the tensors on the OUTPUT side of the op (y of a forward kernel, dy / y
  * of its backward kernels) are fp32 while the features are 16-bit -- the last up-sampling of a head
  * and the head activations write the model's fp32 outputs directly.  emsa_bilinear_bwd_t always
- * accumulates into an fp32 dx (scattered atomics at the /32 pyramid resolution).
+ * writes an fp32 dx (gather form: every element written, reproducible).
  * emsa_cast_channels: strided channel-slice copy with conversion between storage types.
  * ------------------------------------------------------------------------------------------ */
 int emsa_bn_act_fwd_t(int32_t dtype, const void* x, void* y, const float* scale, const float*

@@ -15,10 +15,11 @@ text of any reference file.
 
 Expected outputs come from the build's oracle (oracle/emsanet_oracle.py, parity unpinned w.r.t.
 upstream): deterministic weights (seed 0), BatchNorm running statistics recalibrated on
-this frame (one train-mode pass with momentum 1 and Dropout2d seed 2024 over a batch of TWO: the
-frame and an augmented twin -- mirrored, colour channels reversed, depth halved -- because the PPM's
-1x1 bin needs two distinct values per channel for a variance; frozen statistics that do not belong
-to the weights leave the eval forward un-normalised), then the eval forward of the frame alone.
+this frame (one train-mode pass with momentum 1 and Dropout2d seed 2024 over a batch of SIX: the
+frame and five augmented twins -- mirrored / flipped, colour channels permuted, depth scaled --
+because the PPM's 1x1 bin needs several distinct values per channel for a usable variance; frozen
+statistics that do not belong to the weights leave the eval forward un-normalised), then the eval
+forward of the frame alone.
 Stored: semantic arg-max map (uint8), logits sampled with stride 8, centre / offset / orientation with 4,
 scene logits, fp64 checksums of every raw output.
 """
@@ -53,14 +54,23 @@ def normalise(rgb_u8, depth_u16):
 
 
 def calibration_batch(rgb_u8, depth_u16):
-    twin_rgb = rgb_u8[:, ::-1, ::-1].copy()
-    twin_depth = (depth_u16[:, ::-1] // 2).astype(np.uint16)
-    a, b = normalise(rgb_u8, depth_u16), normalise(twin_rgb, twin_depth)
-    return torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
+    """the frame and five augmented twins (mirrored / flipped, colour channels permuted, depth scaled):
+    six samples per channel for the 1x1 bin of the pyramid pooling, whose BatchNorm otherwise sees a
+    near-zero variance and amplifies every rounding of its branch by 1/sqrt(eps)"""
+    variants = [
+        (rgb_u8, depth_u16),
+        (rgb_u8[:, ::-1, ::-1], depth_u16[:, ::-1] // 2),
+        (rgb_u8[::-1, :, [1, 2, 0]], (depth_u16[::-1].astype(np.uint32) * 3 // 4).astype(np.uint16)),
+        (rgb_u8[::-1, ::-1, [2, 0, 1]], np.minimum(depth_u16[::-1, ::-1].astype(np.uint32) * 5 // 4, 65535).astype(np.uint16)),
+        (255 - rgb_u8, depth_u16 // 3),
+        (np.roll(rgb_u8, 213, axis=1)[:, :, ::-1], np.roll(depth_u16, 213, axis=1)),
+    ]
+    parts = [normalise(np.ascontiguousarray(r), np.ascontiguousarray(d)) for r, d in variants]
+    return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
 
 
 def recalibrated_oracle(rgb, depth, dtype=torch.float32, **arg_overrides):
-    """rgb / depth: the normalised calibration batch (2, C, H, W)"""
+    """rgb / depth: the normalised calibration batch (6, C, H, W)"""
     from emsanet_amd import full_args, nyuv2_config
     from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict
     oracle = EMSANetOracle(full_args(input_height=H, input_width=W, **arg_overrides), nyuv2_config())

@@ -62,11 +62,16 @@ def _engine_on_sample(dtype, do_postprocessing=False, enable_panoptic=False):
     from emsanet_amd.model import EMSANet
     from emsanet_amd.staging import BatchStager
     fx = _fixture()
-    oracle = SP.recalibrated_oracle(*SP.calibration_batch(fx['rgb_u8'], fx['depth_u16']),
-                                    enable_panoptic=enable_panoptic)
+    oracle = SP.recalibrated_oracle(*SP.calibration_batch(fx['rgb_u8'], fx['depth_u16']))
     model = EMSANet(full_args(input_height=480, input_width=640, enable_panoptic=enable_panoptic),
                     nyuv2_config())
-    model.load_state_dict(oracle.state_dict())
+    sd = oracle.state_dict()
+    if enable_panoptic:
+        # (the oracle has no PanopticHelper wrapper: same decoders one level down)
+        sd = {k.replace('decoders.semantic_decoder.', 'decoders.panoptic_helper.semantic_decoder.')
+               .replace('decoders.instance_decoder.', 'decoders.panoptic_helper.instance_decoder.'): v
+              for k, v in sd.items()}
+    model.load_state_dict(sd)
     model.to(DEV).eval()
     if dtype != torch.float32:
         model.set_compute_dtype(dtype)
@@ -103,18 +108,37 @@ def test_real_sample_fp32_engine_vs_oracle():
     assert same >= 0.9999, same
 
 
+# 16-bit storage on the REAL frame, measured (r06b): semantic logits rel-L2 vs the fp32 oracle 1.2e-2 (fp16) /
+# 6.8e-2 (bf16) -- 3-4x the error on uniform noise (4e-3 / 3e-2 gates of tests/test_model16_gpu.py): flat
+# image regions give feature maps with a large common mode, which costs mantissa bits of the stored
+# values.  What decides whether that is the ENGINE or 16-bit storage is the oracle that rounds where
+# the engine rounds (Spec.STORAGE): the engine must sit on it at the tolerance of the noise tests.
+REAL_OUT_TOL = {torch.float16: 3e-2, torch.bfloat16: 1.5e-1}
+REAL_EMU_TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2}
+REAL_AGREE = {torch.float16: 0.99, torch.bfloat16: 0.95}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
-def test_real_sample_16bit_engine_vs_oracle(dtype):
-    from test_model16_gpu import AGREE, OUT_TOL, _argmax_gate, _rel_l2
+def test_real_sample_16bit_engine_vs_oracle(dtype, monkeypatch):
+    from oracle import emsanet_oracle as O
+    from test_model16_gpu import _rel_l2
     fx, oracle, model, batch, out, (x_rgb, x_depth) = _engine_on_sample(dtype)
+    got = SP.flat_eval(out)
     with torch.no_grad():
         ref = SP.flat_eval(oracle({'rgb': x_rgb, 'depth': x_depth}))
-    got = SP.flat_eval(out)
-    for n, a, b in zip(NAMES, got, ref):
-        e = _rel_l2(a, b)
-        assert e <= OUT_TOL[dtype], f"{n}: rel-L2 {e:.3e}"
-    _argmax_gate(got[0], ref[0], 'semantic (real sample)', AGREE[dtype])
+        monkeypatch.setattr(O.Spec, 'STORAGE', dtype)
+        emu = SP.flat_eval(oracle.double()({'rgb': x_rgb.double(), 'depth': x_depth.double()}))
+    e_ref = [_rel_l2(a, b) for a, b in zip(got, ref)]
+    e_emu = [_rel_l2(a, b) for a, b in zip(got, emu)]
+    same = float((got[0].argmax(1).cpu() == ref[0].argmax(1)).float().mean())
+    same_emu = float((got[0].argmax(1).cpu() == emu[0].argmax(1)).float().mean())
+    print(f"real sample {dtype}: rel-L2 vs fp32 oracle " + ' '.join(f'{e:.1e}' for e in e_ref) +
+          " | vs storage-emulating oracle " + ' '.join(f'{e:.1e}' for e in e_emu) +
+          f" | semantic arg-max agreement {same:.4f} (fp32 oracle) {same_emu:.4f} (emulating)")
+    assert max(e_emu) <= REAL_EMU_TOL[dtype], e_emu
+    assert max(e_ref) <= REAL_OUT_TOL[dtype], e_ref
+    assert same >= REAL_AGREE[dtype] and same_emu >= same - 0.01, (same, same_emu)
 
 
 @pytest.mark.gpu
