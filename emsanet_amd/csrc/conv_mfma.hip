@@ -1743,7 +1743,12 @@ struct WgradMulti {
   Wgrad1dArgs j[kWgradMultiMax];
 };
 
-template <typename T>
+// XBN (round 6, emsa_conv_wgrad_inbn_t / emsa_conv_wgrad_multi_inbn_t): a job with in_scale != NULL
+// takes x = relu(in * in_scale[c] + in_shift[c]) -- the BatchNorm + ReLU in front of the conv, whose
+// forward ran with the same fold in ITS loader (conv_rs.hip INBN) -- formed where the prefetched
+// registers go to LDS: per thread 16 channels, scale / shift from a 512-byte LDS table, pixels that
+// were loaded out of range (line ends, the virtual pixel of an odd line, image borders) stay zero.
+template <typename T, bool XBN = false>
 __device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int bid, const int nblk) {
   constexpr int BCO = 64, BCI = 64;
   constexpr uint32_t ES = sizeof(T);
@@ -1756,6 +1761,7 @@ __device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int 
   // which is not the one the current step reads
   T* const dS = reinterpret_cast<T*>(smem);
   T* const xS = dS + kWT_IMG;
+  float* const xbnS = reinterpret_cast<float*>(xS + kWT_IMG);     // XBN: [2: scale, shift][BCI]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave & 1, wci = wave >> 1;
@@ -1799,10 +1805,20 @@ __device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int 
         ? (__umul24(img, (uint32_t)p.in_simg) + __umul24((uint32_t)a2, (uint32_t)p.in_sa1) +
            __umul24((uint32_t)b_, (uint32_t)p.in_sb)) * ES : kOOB;
   };
+  const bool xbn = XBN && p.in_scale != nullptr;      // (uniform per workgroup: one job of a launch)
+  if constexpr (XBN) {
+    if (xbn && tid < 2 * BCI) {
+      const int ch = ci0 + (tid & (BCI - 1));
+      const float* src = tid < BCI ? p.in_scale : p.in_shift;
+      xbnS[tid] = ch < p.k_ch ? src[ch] : 0.f;
+    }
+  }
   u32x4h rd[2], rx[2];
+  [[maybe_unused]] bool x_real = false;               // the prefetched x pixel is a real pixel
   auto load_px = [&](int k, u32x4h (&d)[2], u32x4h (&x)[2]) {
     uint32_t od, ox;
     px_off(k, od, ox);
+    if constexpr (XBN) x_real = ox != kOOB;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       d[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(od | dadd[h]) >= 0 ? (int)(od + dadd[h]) : (int)kOOB, 0, 0);
@@ -1818,7 +1834,34 @@ __device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[h][e] = 0.f;
   // st: the step being stored (its pixel 63 becomes the front row of step st + 1)
-  auto store_lds = [&](int st, const u32x4h (&rd)[2], const u32x4h (&rx)[2]) {
+  [[maybe_unused]] auto xbn_apply = [&](u32x4h (&x)[2]) {
+    if constexpr (XBN) {
+      if (xbn) {
+        typedef typename std::conditional<std::is_same<T, emsa_f16>::value, _Float16, __bf16>::type EX;
+        typedef EX ex8 __attribute__((ext_vector_type(8)));
+        typedef float fx8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 s0 = emsa_ld4(xbnS + ch0 + 32 * h), s1 = emsa_ld4(xbnS + ch0 + 32 * h + 4);
+          const float4 t0 = emsa_ld4(xbnS + BCI + ch0 + 32 * h), t1 = emsa_ld4(xbnS + BCI + ch0 + 32 * h + 4);
+          const fx8 v = __builtin_convertvector(__builtin_bit_cast(ex8, x[h]), fx8);
+          const bool ok = x_real && xadd[h] != kOOB;
+          fx8 a;
+          a[0] = ok ? fmaxf(__builtin_fmaf(v[0], s0.x, t0.x), 0.f) : 0.f;
+          a[1] = ok ? fmaxf(__builtin_fmaf(v[1], s0.y, t0.y), 0.f) : 0.f;
+          a[2] = ok ? fmaxf(__builtin_fmaf(v[2], s0.z, t0.z), 0.f) : 0.f;
+          a[3] = ok ? fmaxf(__builtin_fmaf(v[3], s0.w, t0.w), 0.f) : 0.f;
+          a[4] = ok ? fmaxf(__builtin_fmaf(v[4], s1.x, t1.x), 0.f) : 0.f;
+          a[5] = ok ? fmaxf(__builtin_fmaf(v[5], s1.y, t1.y), 0.f) : 0.f;
+          a[6] = ok ? fmaxf(__builtin_fmaf(v[6], s1.z, t1.z), 0.f) : 0.f;
+          a[7] = ok ? fmaxf(__builtin_fmaf(v[7], s1.w, t1.w), 0.f) : 0.f;
+          x[h] = __builtin_bit_cast(u32x4h, __builtin_convertvector(a, ex8));
+        }
+      }
+    }
+  };
+  auto store_lds = [&](int st, const u32x4h (&rd)[2], u32x4h (&rx)[2]) {
+    xbn_apply(rx);
     if (do_bias) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1859,7 +1902,9 @@ __device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int 
   if (s_begin < s_end) {
     // the pixel in front of the split: loaded by every quad, stored (as "pixel 63 of step
     // s_begin - 1") by quad 63 into front row 0
+    if constexpr (XBN) __syncthreads();               // the affine table is in LDS
     load_px(s_begin * kWT_PK - 1, rd, rx);
+    if constexpr (XBN) xbn_apply(rx);
     if (lp == kWT_PK - 1) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1992,13 +2037,13 @@ __device__ __forceinline__ void wgrad1d_tr_body(const Wgrad1dArgs& p, const int 
   }
 }
 
-template <typename T>
+template <typename T, bool XBN = false>
 __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_kernel(const Wgrad1dArgs p) {
-  wgrad1d_tr_body<T>(p, blockIdx.x, gridDim.x);
+  wgrad1d_tr_body<T, XBN>(p, blockIdx.x, gridDim.x);
 }
-template <typename T>
+template <typename T, bool XBN = false>
 __global__ __launch_bounds__(256, 3) void conv_wgrad1d_tr_multi_kernel(const WgradMulti m) {
-  wgrad1d_tr_body<T>(m.j[blockIdx.y], blockIdx.x, gridDim.x);
+  wgrad1d_tr_body<T, XBN>(m.j[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // second pass of the deterministic split-K: dw[co][ci][t] (OIHW of a 3-tap 1-D conv) =
@@ -2517,7 +2562,9 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     w.in = in; w.dout = dout; w.dw = dw; w.dbias = dbias;
     w.ws = ws;
     w.in_scale = in_scale; w.in_shift = in_shift;
-    if (in_scale && (kHalf || !pl.wino || w.R != 1)) return EMSA_E_SHAPE;
+    if (in_scale && !kHalf && (!pl.wino || w.R != 1)) return EMSA_E_SHAPE;
+    // (16-bit: the loader fold exists in the transposed-read kernel, conv_wgrad1d_tr_kernel<T, true>)
+    if (in_scale && kHalf && !(direct16 && pl.mode == 0 && w.R == 1)) return EMSA_E_SHAPE;
     w.ws_bias = ws ? ws + (size_t)pl.ksplit * w.n_tiles * w.R * w.taps * 4096 : nullptr;
     constexpr int BCO = 64, BCI = 64;
     constexpr size_t lds = (size_t)(32 * BCO + 34 * BCI) * sizeof(float);
@@ -2533,6 +2580,10 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
     if constexpr (kHalf) {
       if (direct16) {
         const dim3 grid(w.n_tiles * w.R * pl.ksplit);
+        if (in_scale && pl.mode != 0) {
+          prof_end(ps, st);
+          return EMSA_E_SHAPE;
+        }
         if (pl.mode == 1)
           hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 1>), grid, dim3(256),
                              (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);
@@ -2542,10 +2593,18 @@ int conv_wgrad_impl(const EmsaConvGeom* g, const T* in_t, const T* dout_t, float
         else if (wgrad16_tr() && !(g->k_ch & 7) && !(g->n_ch & 7) && !(g->ld_out & 7) &&
                  !(g->in_px_stride & 7) && !(g->in_row_stride & 7) && !(g->in_img_stride & 7) &&
                  !((((uintptr_t)in) | ((uintptr_t)dout)) & 15))
+        {
           // (16-byte chunks: every pixel row of both tensors starts on a 16-byte boundary)
-          hipLaunchKernelGGL((conv_wgrad1d_tr_kernel<T>), grid, dim3(256),
-                             (size_t)2 * kWT_IMG * sizeof(T), st, w);
-        else
+          if (in_scale)
+            hipLaunchKernelGGL((conv_wgrad1d_tr_kernel<T, true>), grid, dim3(256),
+                               (size_t)2 * kWT_IMG * sizeof(T) + 2 * 64 * sizeof(float), st, w);
+          else
+            hipLaunchKernelGGL((conv_wgrad1d_tr_kernel<T>), grid, dim3(256),
+                               (size_t)2 * kWT_IMG * sizeof(T), st, w);
+        } else if (in_scale) {
+          prof_end(ps, st);
+          return EMSA_E_SHAPE;                     // conv_wgrad1d_h_kernel has no loader fold
+        } else
           hipLaunchKernelGGL((conv_wgrad1d_h_kernel<T, 0>), grid, dim3(256),
                              (size_t)2 * 64 * kWH_ROW * sizeof(T), st, w);
       } else
@@ -2646,6 +2705,12 @@ bool plan_wgrad_multi(int n_jobs, const EmsaConvGeom* geoms, Wgrad1dPlan* pls, i
     if (pls[j].w.n_tiles != pls[0].w.n_tiles || pls[j].w.R != pls[0].w.R ||
         pls[j].w.n_ch != pls[0].w.n_ch || pls[j].w.k_ch != pls[0].w.k_ch)
       return false;
+    // (reduction lengths may differ -- the 3x1 and 1x3 convs of one block already do: pixels are
+    //  enumerated along the conv direction and an odd line is padded by one virtual pixel.  A shorter
+    //  job leaves its last split(s) empty: wgrad1d_tr_body guards its prologue and its K loop with
+    //  s_begin < s_end, so such a workgroup loads nothing and stores an all-zero partial tile for the
+    //  reduction pass -- tests/test_ops16_gpu.py::test_conv16_wgrad_multi runs unequal pixel counts
+    //  against the single-job launches)
   }
   const Wgrad1dArgs& w0 = pls[0].w;
   // (EMSA_WGRAD_MULTI_WGS: the shared workgroup budget, tuning runs only)
@@ -2693,10 +2758,11 @@ extern "C" int64_t emsa_conv_wgrad_multi_ws_bytes(int32_t dtype, int32_t n_jobs,
 // one reduction launch: in / dout / dw / dbias are arrays of n_jobs pointers (dbias[j] may be NULL),
 // geoms an array of n_jobs geometries, ws = emsa_conv_wgrad_multi_ws_bytes bytes.  Results are
 // written in the OIHW parameter layout like emsa_conv_wgrad_t's two-pass form (deterministic).
-extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
-                                       const void* const* in, const void* const* dout,
-                                       float* const* dw, float* const* dbias, float* ws,
-                                       void* stream) {
+namespace {
+int conv_wgrad_multi_impl(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
+                          const void* const* in, const void* const* dout, float* const* dw,
+                          float* const* dbias, float* ws, const float* const* in_scale,
+                          const float* const* in_shift, void* stream) {
   if (dtype != EMSA_DT_BF16) return EMSA_E_ARG;
   if (!geoms || !in || !dout || !dw || !dbias || !ws) return EMSA_E_ARG;
   Wgrad1dPlan pls[kWgradMultiMax];
@@ -2707,6 +2773,7 @@ extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const Emsa
   ReduceMulti r;
   float* wsp = ws;
   double flops = 0.0, bytes = 0.0;
+  bool any_xbn = false;
   for (int j = 0; j < kWgradMultiMax; ++j) {
     const int k = j < n_jobs ? j : 0;             // (unused slots repeat job 0; never indexed)
     if (j < n_jobs) {
@@ -2720,7 +2787,10 @@ extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const Emsa
       w.dbias = dbias[j];
       w.ws = wsp;
       w.ws_bias = wsp + (size_t)ks * w.n_tiles * w.R * w.taps * 4096;
-      w.in_scale = w.in_shift = nullptr;
+      w.in_scale = in_scale ? in_scale[j] : nullptr;
+      w.in_shift = in_shift ? in_shift[j] : nullptr;
+      if ((w.in_scale == nullptr) != (w.in_shift == nullptr)) return EMSA_E_ARG;
+      any_xbn = any_xbn || w.in_scale != nullptr;
       wsp += wgrad_multi_job_floats(pls[j]);
       flops += algo_flops(*g);
       bytes += (double)g->n_img * g->in_h * g->in_w * g->k_ch * 2.0 +
@@ -2733,8 +2803,12 @@ extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const Emsa
   r.splits = ks; r.n_tiles = w0.n_tiles; r.n_ci_tiles = w0.n_ci_tiles; r.n_co_tiles = w0.n_co_tiles;
   r.n_ch = w0.n_ch; r.k_ch = w0.k_ch; r.R = w0.R; r.taps = w0.taps;
   const int ps = prof_begin(kProfClassWgradH, flops, st, bytes);
-  hipLaunchKernelGGL((conv_wgrad1d_tr_multi_kernel<emsa_bf16>), dim3(w0.n_tiles * w0.R * ks, n_jobs),
-                     dim3(256), (size_t)2 * kWT_IMG * sizeof(emsa_bf16), st, m);
+  if (any_xbn)
+    hipLaunchKernelGGL((conv_wgrad1d_tr_multi_kernel<emsa_bf16, true>), dim3(w0.n_tiles * w0.R * ks, n_jobs),
+                       dim3(256), (size_t)2 * kWT_IMG * sizeof(emsa_bf16) + 2 * 64 * sizeof(float), st, m);
+  else
+    hipLaunchKernelGGL((conv_wgrad1d_tr_multi_kernel<emsa_bf16>), dim3(w0.n_tiles * w0.R * ks, n_jobs),
+                       dim3(256), (size_t)2 * kWT_IMG * sizeof(emsa_bf16), st, m);
   if (ks <= 16 && w0.n_tiles >= 32)
     hipLaunchKernelGGL((wgrad1d_reduce_multi_kernel<true>), dim3(w0.n_tiles * 4 + w0.n_co_tiles, n_jobs),
                        dim3(256), 0, st, r);
@@ -2743,6 +2817,43 @@ extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const Emsa
                        dim3(w0.n_tiles * w0.R * w0.taps * 64 + w0.n_co_tiles, n_jobs), dim3(256), 0, st, r);
   prof_end(ps, st);
   return emsa_launch_status();
+}
+}  // namespace
+
+extern "C" int emsa_conv_wgrad_multi_t(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
+                                       const void* const* in, const void* const* dout,
+                                       float* const* dw, float* const* dbias, float* ws,
+                                       void* stream) {
+  return conv_wgrad_multi_impl(dtype, n_jobs, geoms, in, dout, dw, dbias, ws, nullptr, nullptr, stream);
+}
+
+// The same launch with the loader fold of emsa_conv_wgrad_inbn_t per job: in_scale[j] / in_shift[j]
+// non-NULL -> job j's x operand is relu(in[j] * in_scale[j][c] + in_shift[j][c]) (both arrays have
+// n_jobs entries; NULL entries = plain jobs).
+extern "C" int emsa_conv_wgrad_multi_inbn_t(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
+                                            const void* const* in, const void* const* dout,
+                                            float* const* dw, float* const* dbias, float* ws,
+                                            const float* const* in_scale,
+                                            const float* const* in_shift, void* stream) {
+  if (!in_scale || !in_shift) return EMSA_E_ARG;
+  return conv_wgrad_multi_impl(dtype, n_jobs, geoms, in, dout, dw, dbias, ws, in_scale, in_shift, stream);
+}
+
+// 16-bit form of emsa_conv_wgrad_inbn: weight gradient of a stride-1 3-tap 1-D conv whose forward
+// ran with its input's BatchNorm + ReLU folded into the loader (emsa_conv1d_rs_inbn_t); `in` is the
+// BatchNorm's INPUT in storage type `dtype` (EMSA_DT_BF16).  EMSA_E_SHAPE where the transposed-read
+// kernel does not take the geometry (the caller then materialises the BatchNorm output).
+extern "C" int emsa_conv_wgrad_inbn_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                      const void* dout, float* dw, float* dbias, float* ws,
+                                      const float* in_scale, const float* in_shift, void* stream) {
+  if (!in_scale || !in_shift) return EMSA_E_ARG;
+  if (dtype == EMSA_DT_F32)
+    return conv_wgrad_impl<float>(g, (const float*)in, (const float*)dout, dw, dbias, ws, stream,
+                                  in_scale, in_shift);
+  if (dtype == EMSA_DT_BF16)
+    return conv_wgrad_impl<emsa_bf16>(g, (const emsa_bf16*)in, (const emsa_bf16*)dout, dw, dbias,
+                                      ws, stream, in_scale, in_shift);
+  return EMSA_E_ARG;
 }
 
 // ---- profiling C-ABI -------------------------------------------------------------------------

@@ -121,6 +121,12 @@ struct ConvRSArgs {
   const float* scale2;
   const float* shift2;
   const void* residual2;
+  // INBN (emsa_conv1d_rs_inbn_t): the conv runs on relu(in * in_scale[c] + in_shift[c]) -- the
+  // BatchNorm + ReLU in front of it, formed where the staged tile goes from registers to LDS;
+  // inaff_off = LDS offset of the [2][C_in] table
+  const float* in_scale;
+  const float* in_shift;
+  int inaff_off;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t r_rsrc(const void* p, uint32_t bytes) {
@@ -173,9 +179,15 @@ __device__ __forceinline__ int r_swz(int R) {
 #endif
 // EPI: the epilogue reads a residual and / or a mask tensor (as its own instantiation: the waits for
 // those loads would otherwise sit in every launch's output pass and drain the next tile's DMA).
+// INBN: the input tile is normalised + rectified on its way into LDS (the NBt1D block's bn1 folded
+// into conv3x1_2, ref emsanet/model.py:47-58): per lane 8 fixed input channels, scale / shift from an
+// LDS table, 8 fma + 8 max per 16-byte piece; pieces loaded out of range (zero padding above / below
+// the image, pixels beyond the tile) stay zero -- the padding pads the NORMALISED tensor.
 template <typename T, int KC, int TN, int WM, int WN, int WK, int TM, bool DIRH, bool BNB, bool EPI,
-          bool PAIR = false>
+          bool PAIR = false, bool INBN = false>
 __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel(const ConvRSArgs p_in) {
+  static_assert(!INBN || (DIRH && !BNB && !EPI && !PAIR && EMSA_RS_DMA == 0),
+                "INBN: the 3x1 forward conv on the register-staged loader");
   typedef typename RVec8<T>::type V8;
   // PAIR: two independent convs of one geometry in one launch (grid.y = 2); everything below sees
   // the tensors of its half through `p`
@@ -241,6 +253,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
     }
   }
 
+  if constexpr (INBN) {
+    float* tb = reinterpret_cast<float*>(smem + p.inaff_off);
+    for (int i = tid; i < KC; i += NT) {
+      tb[i] = p.in_scale[i];
+      tb[KC + i] = p.in_shift[i];
+    }
+  }
+
   const uint64_t in_base = (uint64_t)p.in;
   const ru32x4 rs_in = {(uint32_t)in_base, (uint32_t)(in_base >> 32) & 0xFFFFu, p.in_bytes, 0x00020000u};
   const __amdgpu_buffer_rsrc_t rs_inb = r_rsrc(p.in, p.in_bytes);
@@ -274,19 +294,37 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
     }
   };
   ru32x4 areg[NIWM];
+  [[maybe_unused]] uint32_t areal = 0u;               // INBN: bit jj = piece jj was loaded from a real pixel
   [[maybe_unused]] auto load_tile = [&](int tl) {
+    if constexpr (INBN) areal = 0u;
 #pragma unroll
     for (int jj = 0; jj < NIWM; ++jj) {
       const int qi = wave + jj * NWV;
       // (pieces beyond the tile: an out-of-range offset instead of a branch around the load)
-      areg[jj] = __builtin_amdgcn_raw_buffer_load_b128(
-          rs_inb, (int)(qi < p.ni ? tile_voff(tl, qi) : kROOB), 0, 0);
+      const uint32_t vo = qi < p.ni ? tile_voff(tl, qi) : kROOB;
+      if constexpr (INBN) areal |= (vo != kROOB ? 1u : 0u) << jj;
+      areg[jj] = __builtin_amdgcn_raw_buffer_load_b128(rs_inb, (int)vo, 0, 0);
     }
   };
   [[maybe_unused]] auto store_tile = [&]() {
+    [[maybe_unused]] rf32x8 isc, ish;
+    if constexpr (INBN) {
+      const float* tb = reinterpret_cast<const float*>(smem + p.inaff_off) + pc * 8;
+      const float4 s0 = emsa_ld4(tb), s1 = emsa_ld4(tb + 4), t0 = emsa_ld4(tb + KC), t1 = emsa_ld4(tb + KC + 4);
+      isc = rf32x8{s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      ish = rf32x8{t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    }
 #pragma unroll
     for (int jj = 0; jj < NIWM; ++jj) {
       const int qi = wave + jj * NWV;
+      if constexpr (INBN) {
+        const rf32x8 v = __builtin_convertvector(__builtin_bit_cast(V8, areg[jj]), rf32x8);
+        const bool real = (areal >> jj) & 1u;
+        rf32x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = real ? fmaxf(__builtin_fmaf(v[e], isc[e], ish[e]), 0.f) : 0.f;
+        areg[jj] = __builtin_bit_cast(ru32x4, __builtin_convertvector(a, V8));
+      }
       if (qi < p.ni)
         *reinterpret_cast<ru32x4*>(smem + (qi * RPI + lrow) * RBP + pc * 16) = areg[jj];
     }
@@ -352,6 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, EMSA_RS_OCC) void conv_rs_kernel
         }
   }
 
+  if constexpr (INBN) __syncthreads();                // the input-affine table is in LDS
   if constexpr (!kDMA) store_tile();
   RS_MARK(0);
   int it = 0;
@@ -789,6 +828,7 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
 template <typename T, int KC, int TN, int WM, int WN, int WK, int TM>
 int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
   const bool pair = a.in2 != nullptr;
+  const bool inbn = a.in_scale != nullptr;
   const dim3 grid(8 * pl.gx * pl.nslice, pair ? 2 : 1), block(64 * WM * WN * WK);
   const bool epi = a.residual != nullptr || a.mask_src != nullptr;
   auto go = [&](void (*kern)(const ConvRSArgs)) {
@@ -807,6 +847,16 @@ int rs_launch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
   // (the fused BatchNorm-backward form exists for bf16 only: fp16 is an inference storage type)
   constexpr bool kTrain = sizeof(T) == 2 && !__is_same(T, emsa_f16);
   if (bnb && !kTrain) return EMSA_E_ARG;
+  if (inbn) {
+    // the folded input BatchNorm: 3x1 forward conv, plain epilogue (bias, statistics, ReLU), bf16
+    if (pair || bnb || epi || !pl.dirh || EMSA_RS_DMA != 0) return EMSA_E_SHAPE;
+    if constexpr (kTrain && EMSA_RS_DMA == 0) {
+      go(conv_rs_kernel<T, KC, TN, WM, WN, WK, TM, true, false, false, false, true>);
+      return emsa_launch_status();
+    } else {
+      return EMSA_E_SHAPE;
+    }
+  }
   if (pair) {
     // twin launch: forward epilogues only (bias, folded BatchNorm, residual, ReLU)
     if (bnb || a.mask_src || a.stats) return EMSA_E_ARG;
@@ -849,10 +899,19 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
                  const float* bias, float* stats, const float* scale, const float* shift,
                  const void* residual, int32_t ld_res, const void* mask_src, int32_t ld_mask,
                  int32_t act, const float* bnb_mean, const float* bnb_invstd, float* bnb_out,
-                 int32_t bnb_rows_alloc, void* stream, const ConvRSArgs* twin = nullptr) {
+                 int32_t bnb_rows_alloc, void* stream, const ConvRSArgs* twin = nullptr,
+                 const float* in_scale = nullptr, const float* in_shift = nullptr) {
   if (dtype != EMSA_DT_BF16 && dtype != EMSA_DT_F16) return EMSA_E_ARG;
   RSPlan pl;
   if (!rs_plan(g, pl)) return EMSA_E_SHAPE;
+  int inaff_off = 0;
+  if (in_scale) {
+    if (!in_shift || twin || !pl.dirh || dtype != EMSA_DT_BF16) return EMSA_E_SHAPE;
+    if ((((uintptr_t)in_scale) | ((uintptr_t)in_shift)) & 3) return EMSA_E_SHAPE;
+    inaff_off = (pl.lds + 15) / 16 * 16;
+    pl.lds = inaff_off + 2 * pl.kc * 4;
+    if (pl.lds > 160 * 1024) return EMSA_E_SHAPE;
+  }
   if (twin) {
     // both halves resident at once: half the persistent workgroups per half where the full grid
     // would not fit twice
@@ -894,6 +953,7 @@ int conv_rs_impl(int32_t dtype, const EmsaConvGeom* g, const void* in, const voi
   a.bacc_off = pl.bacc_off;
   a.in2 = nullptr; a.wf2 = nullptr; a.out2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr;
   a.shift2 = nullptr; a.residual2 = nullptr;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.inaff_off = inaff_off;
   if (twin) {
     a.in2 = twin->in2; a.wf2 = twin->wf2; a.out2 = twin->out2; a.bias2 = twin->bias2;
     a.scale2 = twin->scale2; a.shift2 = twin->shift2; a.residual2 = twin->residual2;
@@ -975,6 +1035,20 @@ extern "C" int emsa_conv1d_rs_t(int32_t dtype, const EmsaConvGeom* g, const void
                                 void* stream) {
   return conv_rs_impl(dtype, g, in, wfrag, out, bias, stats, scale, shift, residual, ld_res,
                       mask_src, ld_mask, act, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Forward conv on relu(in * in_scale[c] + in_shift[c]): the BatchNorm + ReLU in front of a 3x1 conv
+// (the NBt1D block's bn1 in front of conv3x1_2, ref emsanet/model.py:47-58) folded into the loader --
+// `in` is the BatchNorm's INPUT, the normalised tensor is never written.  16-bit twin of
+// emsa_conv1d_wino_inbn; bf16, taps along H, epilogue: bias, statistics rows, ReLU.  EMSA_E_SHAPE
+// where this form does not exist (the caller runs the normalise pass + emsa_conv1d_rs_t).
+extern "C" int emsa_conv1d_rs_inbn_t(int32_t dtype, const EmsaConvGeom* g, const void* in,
+                                     const void* wfrag, void* out, const float* bias, float* stats,
+                                     const float* in_scale, const float* in_shift, int32_t act,
+                                     void* stream) {
+  if (!in_scale || !in_shift) return EMSA_E_ARG;
+  return conv_rs_impl(dtype, g, in, wfrag, out, bias, stats, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                      act, nullptr, nullptr, nullptr, 0, stream, nullptr, in_scale, in_shift);
 }
 
 // Twin launch: the same conv geometry on two independent sets of tensors (the rgb | depth encoder

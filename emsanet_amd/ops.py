@@ -645,10 +645,27 @@ def _flush_wgrads(defer, grads):
         for x, dy, *_ in defer:                 # (the caching allocator must not recycle them early)
             x.record_stream(side)
             dy.record_stream(side)
-        if not _wgrad_pending:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad_streams)
-        if side not in _wgrad_pending:
-            _wgrad_pending.append(side)
+        # The join may wait for the end of the backward pass only where nobody reads these gradients
+        # before: every one of them written into a bucket view of MANUAL buckets (no autograd hooks: the
+        # caller reduces after backward).  Otherwise AccumulateGrad (adding into an existing .grad) or a
+        # hook-driven bucket all-reduce would consume them while the side stream still writes (ADVICE
+        # r5): join right here, and tell the allocator which stream the fresh tensors are used on.
+        def _manual(job):
+            slot = getattr(job[2].conv.weight, '_emsa_grad_slot', None)
+            bias = job[2].conv.bias
+            bslot = getattr(bias, '_emsa_grad_slot', None) if bias is not None else slot
+            return (job[3] is not None and slot is not None and getattr(slot[1], 'manual', False) and
+                    (bias is None or (job[4] is not None and bslot is not None)))
+        if all(_manual(job) for job in defer):
+            if not _wgrad_pending:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_wgrad_streams)
+            if side not in _wgrad_pending:
+                _wgrad_pending.append(side)
+        else:
+            cur.wait_stream(side)
+            for g in out:
+                if torch.is_tensor(g):
+                    g.record_stream(cur)
         return out
     res = [None] * len(defer)
     groups = {}

@@ -44,6 +44,11 @@ TRAIN_OUT_TOL, TRAIN_COS = 0.5, 0.95
 # exp(-|x|), so the 4-6 % forward deviation of these outputs becomes 10 % in their derivative; the
 # orientation conv beside them (no saturating activation) sits at 0.9975 / 1.0000.
 EVAL_GRAD_OUT_TOL, EVAL_GRAD_COS_MEDIAN, EVAL_GRAD_COS_MIN = 0.1, 0.999, 0.95
+# per-tensor norm-ratio bands of that test for the tensors whose scale the train-mode test cannot gate.
+# Measured (r06i, gpurun_out/grad_ratio_bf16_evalbn_480x640.txt): squeeze-excite linears 0.982 .. 1.037,
+# tensors of < 1024 elements 0.967 .. 1.053, the one-element centre bias 1.124 (round 5: 1.54 -- it sums
+# the derivative of a partly saturated sigmoid over all pixels); all 742 tensors inside 0.967 .. 1.124.
+SE_RATIO, SMALL_RATIO, SMALL_RATIO_CENTRE = (0.93, 1.07), (0.9, 1.12), (0.6, 1.7)
 
 
 def _flatten(outs):
@@ -267,8 +272,10 @@ def test_train_bf16_pinned_gradients(shape, monkeypatch):
     # error in one small tensor).  Measured over the 666 gradient tensors of this configuration:
     # cosine min 0.934 (p1 0.949), norm ratio p1..p99 0.96..1.12, extremes 0.68 / 1.27 on eight
     # tiny tensors (side-head biases, SE fc.0 of the first fusion, the 9-tap upsampling weights).
-    # A sign error gives cosine -1, a dropped term or factor of two a ratio of 0.5 / 2 -- every
-    # tensor has to clear both bounds, and 97 % of them the tight ratio band.
+    # A sign error gives cosine -1 (every tensor clears the cosine bound); a dropped term or factor of
+    # two gives a ratio of 0.5 / 2, which the ratio band below catches on the tensors of >= 1024
+    # elements outside the SE MLPs (97 % of all tensors inside the tight band) -- for the loose class see
+    # the note at the ratio gate.
     # (tensors of < 1024 elements and the squeeze-excite linears form the loose class, as for the norm
     #  ratio below: 0.862 on decoders.instance_decoder.side_output_heads.2.task_convs.1.bias -- two
     #  elements, each a nearly cancelling sum over all pixels -- on one build of round 5; >= 0.7 there
@@ -307,23 +314,22 @@ def test_train_bf16_pinned_gradients(shape, monkeypatch):
     for k in CHECKPOINTS:
         if k in eng and k in ctrl:
             assert abs(eng[k] - ctrl[k]) <= 0.04, (k, eng[k], ctrl[k])
-    # extremes: [0.6, 1.4] for every tensor of >= 1024 elements; the tiny ones (SE fc biases of 4-32
-    # elements, one-element head biases: sums over 8 samples / all pixels that nearly cancel) get
-    # [0.25, 4] -- measured at 640x480 bs 8: 1.51 on encoder.fusion_modules.2.se_depth.fc.0.bias, 0.77
-    # on a side head's centre bias, everything else inside [0.84, 1.23]; the cosine gate above (>= 0.9,
-    # >= 0.7 for the tiny ones) is what catches a sign error there
-    # (the squeeze-excite linears belong to the loose class whatever their size: their gradients
-    #  are sums over 8 samples of pooled signals -- 1.47 on encoder.fusion_modules.2.se_depth.fc.0.weight
-    #  on a second box, 0.40 on ...se_depth.fc.0.bias on a build whose BatchNorm statistics merge
-    #  sums in another order: the draw of a chaotic system moves with every last-bit change.  The
-    #  loose band is [0.25, 4]: these tensors' kernels -- SE MLP backward, head biases -- are pinned
-    #  by the operator tests at 2e-4, what this gate adds for them is the cosine)
-    for sel, (rlo, rhi) in ((big, (0.6, 1.4)), (~big, (0.25, 4.0))):
-        r_ = ratio[sel]
-        nm = [k for k, b_ in zip(names, sel.tolist()) if b_]
-        lo, hi = int(r_.argmin()), int(r_.argmax())
-        assert r_.min().item() >= rlo and r_.max().item() <= rhi, \
-            (nm[lo], r_.min().item(), nm[hi], r_.max().item())
+    # extremes: [0.6, 1.4] for every tensor of >= 1024 elements outside the squeeze-excite MLPs.  The
+    # loose class (tensors of < 1024 elements -- SE fc biases of 4-32 elements, one-element head biases:
+    # sums over 8 samples / all pixels that nearly cancel -- and the SE linears whatever their size) has
+    # NO ratio gate in this train-mode test any more: its ratios are one draw of a chaotic system that
+    # moves with every last-bit change of any kernel upstream (measured on encoder.fusion_modules.2.
+    # se_depth.fc.0.bias over the builds of rounds 4-6: 1.51, 1.47, 0.40, 0.24), so a band wide enough
+    # to hold them ([0.25, 4] in round 5) no longer separated a factor of two.  What pins the
+    # SCALE of those tensors instead: the frozen-BatchNorm test below (tight per-tensor bands for the SE
+    # linears and the small tensors), tests/test_timed_size_gpu.py (every gradient of the bs-32 step
+    # against the sum over two bs-16 steps at 1e-4) and the operator tests of the SE MLP backward /
+    # head biases at 2e-4; here they keep the cosine gate above (>= 0.7: a sign error gives -1).
+    r_ = ratio[big]
+    nm = [k for k, b_ in zip(names, big.tolist()) if b_]
+    lo, hi = int(r_.argmin()), int(r_.argmax())
+    assert r_.min().item() >= 0.6 and r_.max().item() <= 1.4, \
+        (nm[lo], r_.min().item(), nm[hi], r_.max().item())
     assert ((ratio - 1.0).abs() <= 0.15).float().mean().item() >= 0.97
 
 
@@ -414,6 +420,17 @@ def test_eval_bn_bf16_pinned_gradients_baseline_resolution(monkeypatch):
     assert ((ratio - 1.0).abs() <= 0.05).float().mean().item() >= 0.97, \
         (names[lo], ratio.min().item(), names[hi], ratio.max().item())
     assert cos.min().item() >= EVAL_GRAD_COS_MIN, (names[wc], cos.min().item())
+    # the tensors the train-mode test above cannot gate on scale: every squeeze-excite
+    # linear and every tensor of < 1024 elements, here without batch statistics -> no chaos
+    for k, r_, c_ in zip(names, ratio.tolist(), cos.tolist()):
+        small = mp[k].numel() < 1024
+        if '.se_' in k:
+            assert SE_RATIO[0] <= r_ <= SE_RATIO[1], (k, r_)
+        elif small and k.endswith('task_convs.0.bias'):
+            # one element, the derivative of a (partly saturated) sigmoid summed over all pixels
+            assert SMALL_RATIO_CENTRE[0] <= r_ <= SMALL_RATIO_CENTRE[1] and c_ > 0.0, (k, r_, c_)
+        elif small:
+            assert SMALL_RATIO[0] <= r_ <= SMALL_RATIO[1], (k, r_)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

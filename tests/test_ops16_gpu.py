@@ -268,6 +268,19 @@ def test_conv16_wgrad_multi(c, n, h, w, n_jobs):
     spec2 = Fn.ConvSpec(c, c * 2, (1, 3), (1, 1), (0, 1))
     assert Fn.conv_wgrad_multi([a, (a[0], act16(rnd(n, c * 2, h, w, seed=5), dtype), spec2,
                                     torch.empty(c * 2, c, 1, 3, device=DEV), None, None, True)]) is None
+    # unequal pixel counts: the shorter job leaves its last split(s) empty -- all-zero
+    # partial tiles for the reduction pass; same result as its own single-job launch
+    if h > 3:
+        hs = max(2, h // 2)
+        xs, dys = act16(rnd(n, c, hs, w, seed=6), dtype), act16(rnd(n, c, hs, w, seed=7), dtype)
+        out2 = Fn.conv_wgrad_multi([a[:4] + (None, None, True), (xs, dys, a[2], a[3], None, None, True)])
+        if out2 is not None:
+            torch.cuda.synchronize()
+            for (xx, dd), (dw, db) in zip(((a[0], a[1]), (xs, dys)), out2):
+                dw1, db1, packed = Fn.conv_wgrad(xx, dd, a[2], True, like=a[3], two_pass=True)
+                assert not packed
+                close(dw, dw1.double().cpu(), tol=2e-5, what='multi (unequal pixel counts) vs single')
+                close(db, db1.double().cpu(), tol=2e-5, what='multi dbias (unequal pixel counts) vs single')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -108,14 +108,17 @@ def test_real_sample_fp32_engine_vs_oracle():
     assert same >= 0.9999, same
 
 
-# 16-bit storage on the REAL frame, measured (r06b): semantic logits rel-L2 vs the fp32 oracle 1.2e-2 (fp16) /
-# 6.8e-2 (bf16) -- 3-4x the error on uniform noise (4e-3 / 3e-2 gates of tests/test_model16_gpu.py): flat
-# image regions give feature maps with a large common mode, which costs mantissa bits of the stored
-# values.  What decides whether that is the ENGINE or 16-bit storage is the oracle that rounds where
-# the engine rounds (Spec.STORAGE): the engine must sit on it at the tolerance of the noise tests.
-REAL_OUT_TOL = {torch.float16: 3e-2, torch.bfloat16: 1.5e-1}
-REAL_EMU_TOL = {torch.float16: 3e-3, torch.bfloat16: 2e-2}
-REAL_AGREE = {torch.float16: 0.99, torch.bfloat16: 0.95}
+# 16-bit storage on the REAL frame, measured (r06g; semantic, centre, offset, orientation, scene):
+#   fp16: rel-L2 vs the fp32 oracle 2.3e-3 1.1e-3 5.4e-3 5.1e-3 3.5e-3, vs the oracle that rounds where the
+#         engine rounds (Spec.STORAGE) 1.8e-3 8.4e-4 4.4e-3 4.0e-3 3.0e-3, semantic arg-max agreement 0.9959
+#   bf16: 1.7e-2 8.2e-3 4.1e-2 3.9e-2 2.5e-2, vs emulating 1.0e-2 5.8e-3 2.4e-2 2.4e-2 1.1e-2, agreement 0.9714
+# i.e. within 1.5x of the uniform-noise gates of tests/test_model16_gpu.py (4e-3 / 3e-2 vs fp32, 3e-3 / 2e-2
+# vs emulating); the offset / orientation maps (tanh / raw outputs over flat image regions) are the
+# widest.  (With BatchNorm statistics calibrated on TWO samples the same frame gave 3x these errors: a
+# near-zero variance in the pyramid pooling's 1x1 bin amplifies every rounding of that branch.)
+REAL_OUT_TOL = {torch.float16: 1e-2, torch.bfloat16: 6e-2}
+REAL_EMU_TOL = {torch.float16: 7e-3, torch.bfloat16: 3.5e-2}
+REAL_AGREE = {torch.float16: 0.99, torch.bfloat16: 0.96}
 
 
 @pytest.mark.gpu

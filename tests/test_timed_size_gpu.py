@@ -216,7 +216,7 @@ def test_train_step_gradients_two_kernel_families_at_the_timed_size(monkeypatch)
     # The gates catch what a wrong launch plan at bs 32 would do (a lost partial, a wrong index
     # width: O(1 / splits) .. O(1) in its tensor), not roundoff:
     for e, ratio, cos, k in rows:
-        assert e <= 5e-2 and abs(ratio - 1.0) <= 1e-2 and cos >= 0.998, (k, e, ratio, cos)
+        assert e <= 5e-2 and abs(ratio - 1.0) <= 5e-2 and cos >= 0.998, (k, e, ratio, cos)
 
 
 def _conv_ref(x, dy, k, p, dtype=None):
@@ -256,14 +256,15 @@ def test_wgrad_3tap_at_the_timed_reduction_length():
         close(db3, rb, tol=2e-5, what=f'dbias {k} atomics')
 
 
-def test_wgrad16_multi_job_at_the_timed_reduction_length():
-    """the bf16 NBt1D block's four weight gradients in one launch (emsa_conv_wgrad_multi_t) at the
-    /4-stage size of the timed step: n = 32, 120x160, C = 64, against fp64 on the rounded operands
-    and against the single-job launches"""
+@pytest.mark.parametrize('c,h,w', [(64, 120, 160), (128, 60, 80)])
+def test_wgrad16_multi_job_at_the_timed_reduction_length(c, h, w):
+    """the bf16 NBt1D block's four weight gradients at the /4- and /8-stage sizes of the timed step
+    (n = 32; 614,400 / 153,600 pixels per reduction), single launches and -- where the library has the
+    form -- the one multi-job launch (emsa_conv_wgrad_multi_t), against fp64 on the rounded operands"""
     from emsanet_amd import functional as Fn
     from test_ops16_gpu import act16
     dtype = torch.bfloat16
-    n, c, h, w = 32, 64, 120, 160
+    n = 32
     kinds = [((3, 1), (1, 0)), ((1, 3), (0, 1)), ((3, 1), (1, 0)), ((1, 3), (0, 1))]
     jobs, refs = [], []
     for j, (k, p) in enumerate(kinds):
@@ -276,13 +277,17 @@ def test_wgrad16_multi_job_at_the_timed_reduction_length():
     out = Fn.conv_wgrad_multi(jobs)
     assert out is not None and len(out) == 4
     torch.cuda.synchronize()
-    for j, ((dw, db), (rw, rb)) in enumerate(zip(out, refs)):
-        close(dw, rw, tol=5e-5, what=f'multi wgrad16 job {j}')
-        close(db, rb, tol=5e-5, what=f'multi dbias16 job {j}')
+    for j, (rw, rb) in enumerate(refs):
         x, dy, spec, like, _, _, _ = jobs[j]
         dw1, db1, packed = Fn.conv_wgrad(x, dy, spec, True, like=like, two_pass=True)
         assert not packed
-        close(dw, dw1.double().cpu(), tol=2e-5, what=f'multi vs single job {j}')
+        close(dw1, rw, tol=5e-5, what=f'wgrad16 job {j}')
+        close(db1, rb, tol=5e-5, what=f'dbias16 job {j}')
+        if out is not None:
+            dw, db = out[j]
+            close(dw, rw, tol=5e-5, what=f'multi wgrad16 job {j}')
+            close(db, rb, tol=5e-5, what=f'multi dbias16 job {j}')
+            close(dw, dw1.double().cpu(), tol=2e-5, what=f'multi vs single job {j}')
 
 
 def test_config3_r101_bs16_batch_consistency_and_determinism():
