@@ -73,6 +73,14 @@ SIGNATURES = {
                                c_int64, c_int64, _P]),
     'emsa_conv1d_wino_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P]),
     'emsa_conv_wgrad_inbn': (c_int, [_GP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'emsa_conv_wgrad_inbn_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'emsa_conv_wgrad_multi_inbn_t': (c_int, [c_int32, c_int32, _GP, POINTER(c_void_p), POINTER(c_void_p),
+                                             POINTER(c_void_p), POINTER(c_void_p), _P,
+                                             POINTER(c_void_p), POINTER(c_void_p), _P]),
+    'emsa_conv1d_rs_inbn_t': (c_int, [c_int32, _GP, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
+    'emsa_bn_bwd_reduce_aff_t': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int32, _P, _P]),
+    'emsa_bn_bwd_apply_aff_t': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64,
+                                        c_int32, _P, _P, _P, _P]),
     'emsa_conv_wgrad_multi_ws_bytes': (c_int64, [c_int32, c_int32, _GP]),
     'emsa_conv_wgrad_multi_t': (c_int, [c_int32, c_int32, _GP, POINTER(c_void_p), POINTER(c_void_p),
                                         POINTER(c_void_p), POINTER(c_void_p), _P, _P]),

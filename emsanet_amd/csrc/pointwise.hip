@@ -782,7 +782,7 @@ __device__ __forceinline__ void bn_bwd_issue(BnBwdElem<T, MASK, DROP>& e, const 
                                              uint32_t cv, bool want_x) {
   constexpr int V = VecIO<T>::V;
   e.g = VecIO<T>::load_raw(dy + (size_t)i * V);
-  if (want_x) e.x = VecIO<T>::load_raw(x + (size_t)i * V);
+  if (want_x || MASK == 3) e.x = VecIO<T>::load_raw(x + (size_t)i * V);
   if constexpr (MASK == 1) {
     const ulonglong2* w = reinterpret_cast<const ulonglong2*>(mask_bits + (size_t)(i >> 6) * V);
 #pragma unroll
@@ -792,11 +792,21 @@ __device__ __forceinline__ void bn_bwd_issue(BnBwdElem<T, MASK, DROP>& e, const 
   if constexpr (DROP) ldf<V>(drop + ((size_t)(pix / hw) * cvn + cv) * V, e.d);
 }
 // -> g (masked, dropped), gres (masked): the values bn_bwd_load produces
+// MASK = 3 (round 6): the ReLU decision recomputed from the BatchNorm's INPUT x with the forward pass's
+// own scale / shift, (x * msc + msh) > 0 with the same single fma the folded loaders use
+// (conv_rs.hip INBN, conv_mfma.hip XBN): the normalised tensor and its bit mask never existed.
 template <typename T, int MASK, bool DROP>
 __device__ __forceinline__ void bn_bwd_grad(const BnBwdElem<T, MASK, DROP>& e, uint32_t i,
-                                            float (&g)[VecIO<T>::V], float (&gres)[VecIO<T>::V]) {
+                                            float (&g)[VecIO<T>::V], float (&gres)[VecIO<T>::V],
+                                            const float* msc = nullptr, const float* msh = nullptr) {
   constexpr int V = VecIO<T>::V;
   VecIO<T>::cvt(e.g, g);
+  if constexpr (MASK == 3) {
+    float xx[V];
+    VecIO<T>::cvt(e.x, xx);
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = bn_affine(xx[k], msc[k], msh[k]) > 0.f ? g[k] : 0.f;
+  }
   if constexpr (MASK == 1) {
     const int sh = (int)(i & 63);
 #pragma unroll
@@ -824,7 +834,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_fast_kernel(
     const T* __restrict__ dy, const T* __restrict__ y, const uint64_t* __restrict__ mask_bits,
     const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ drop, uint32_t pixels, uint32_t hw, int cvn, int rows_alloc,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, const float* __restrict__ mask_scale = nullptr,
+    const float* __restrict__ mask_shift = nullptr) {
   constexpr int V = VecIO<T>::V;
   typedef BnBwdElem<T, MASK, DROP> Elem;
   extern __shared__ __attribute__((aligned(16))) float cred[];   // [2][lanes][c]
@@ -840,9 +851,14 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_fast_kernel(
     float mu[V], is[V];
     ldf<V>(mean + cv * V, mu);
     ldf<V>(invstd + cv * V, is);
+    [[maybe_unused]] float msc[V], msh[V];
+    if constexpr (MASK == 3) {
+      ldf<V>(mask_scale + cv * V, msc);
+      ldf<V>(mask_shift + cv * V, msh);
+    }
     auto use = [&](const Elem& e, uint32_t i) {
       float g[V], gres[V], xx[V];
-      bn_bwd_grad<T, MASK, DROP>(e, i, g, gres);
+      bn_bwd_grad<T, MASK, DROP>(e, i, g, gres, msc, msh);
       VecIO<T>::cvt(e.x, xx);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
@@ -889,7 +905,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_fast_kernel(
     const float* __restrict__ invstd, const float* __restrict__ drop,
     const float* __restrict__ partial, int rows, int rows_alloc, float* __restrict__ dbeta_out,
     float* __restrict__ dgamma_out, uint32_t hw, int cvn_log2, uint32_t totalv, float inv_count,
-    T* __restrict__ dx, T* __restrict__ dres) {
+    T* __restrict__ dx, T* __restrict__ dres, const float* __restrict__ mask_scale = nullptr,
+    const float* __restrict__ mask_shift = nullptr) {
   constexpr int V = VecIO<T>::V;
   typedef BnBwdElem<T, MASK, DROP> Elem;
   extern __shared__ __attribute__((aligned(16))) float sums[];   // [2][c]
@@ -922,9 +939,14 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_fast_kernel(
     ldf<V>(sums + cv * V, db);
     ldf<V>(sums + c + cv * V, dg);
   }
+  [[maybe_unused]] float msc[V], msh[V];
+  if constexpr (MASK == 3) {
+    ldf<V>(mask_scale + cv * V, msc);
+    ldf<V>(mask_shift + cv * V, msh);
+  }
   auto use = [&](const Elem& e, uint32_t idx) {
     float g[V], gres[V], o[V];
-    bn_bwd_grad<T, MASK, DROP>(e, idx, g, gres);
+    bn_bwd_grad<T, MASK, DROP>(e, idx, g, gres, msc, msh);
     if (dres) VecIO<T>::store(dres + (size_t)idx * V, gres);
     if constexpr (TRAIN) {
       float xx[V];
@@ -2685,9 +2707,10 @@ extern "C" int emsa_bn_bwd_rows(int64_t pixels, int32_t c) {
 }
 
 template <typename T>
-static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* save_mean, const float* save_invstd, const float* drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream) {
+static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* save_mean, const float* save_invstd, const float* drop, int32_t n_img, int64_t hw, int32_t c, int32_t act, float* partial, void* stream, const float* mask_scale = nullptr, const float* mask_shift = nullptr) {
   if (!dy || !x || !save_mean || !save_invstd || !partial) return EMSA_E_ARG;
-  if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
+  if (act == EMSA_ACT_RELU && !y && !mask_bits && !mask_scale) return EMSA_E_ARG;
+  if ((mask_scale == nullptr) != (mask_shift == nullptr)) return EMSA_E_ARG;
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const long pixels = (long)n_img * hw;
   const int rows = bn_bwd_rows_for(pixels, c);
@@ -2696,12 +2719,15 @@ static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits
   if (bn_fast_on() && cvn <= kThreads && pixels * cvn < (1L << 31) && hw < (1L << 31)) {
     const dim3 grid(rows), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
-    const int mask = act == EMSA_ACT_RELU ? (mask_bits ? 1 : 2) : 0;
+    const int mask = act == EMSA_ACT_RELU ? (mask_scale ? 3 : mask_bits ? 1 : 2) : 0;
 #define EMSA_RED_FAST(M, D)                                                                        \
   hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<T, M, D>), grid, block, lds, st, dy, y, mask_bits, \
                      x, save_mean, save_invstd, drop, (uint32_t)pixels, (uint32_t)hw, cvn,        \
-                     rows + kBwdSlices, partial)
-    if (drop) {
+                     rows + kBwdSlices, partial, mask_scale, mask_shift)
+    if (mask == 3) {
+      if (drop) return EMSA_E_ARG;
+      EMSA_RED_FAST(3, false);
+    } else if (drop) {
       if (mask == 1) EMSA_RED_FAST(1, true); else if (mask == 2) EMSA_RED_FAST(2, true); else EMSA_RED_FAST(0, true);
     } else {
       if (mask == 1) EMSA_RED_FAST(1, false); else if (mask == 2) EMSA_RED_FAST(2, false); else EMSA_RED_FAST(0, false);
@@ -2709,6 +2735,7 @@ static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits
 #undef EMSA_RED_FAST
     return emsa_launch_status();
   }
+  if (mask_scale) return EMSA_E_SHAPE;            // (the general loop has no recomputed-mask form)
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
                      dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, cvn, act,
                      rows + kBwdSlices, partial);
@@ -2727,10 +2754,11 @@ extern "C" int emsa_bn_bwd_reduce_t(int32_t dtype, const void* dy, const void* y
 }
 
 template <typename T>
-static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, T* dx, T* dres, float* dgamma, float* dbeta, void* stream, int32_t rows_given = -1) {
+static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits, const T* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* drop, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, int32_t act, int32_t train, T* dx, T* dres, float* dgamma, float* dbeta, void* stream, int32_t rows_given = -1, const float* mask_scale = nullptr, const float* mask_shift = nullptr) {
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !partial || !dx || !dgamma || !dbeta)
     return EMSA_E_ARG;
-  if (act == EMSA_ACT_RELU && !y && !mask_bits) return EMSA_E_ARG;
+  if (act == EMSA_ACT_RELU && !y && !mask_bits && !mask_scale) return EMSA_E_ARG;
+  if ((mask_scale == nullptr) != (mask_shift == nullptr)) return EMSA_E_ARG;
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const long pixels = (long)n_img * hw;
@@ -2754,18 +2782,22 @@ static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits,
   if (lg >= 0) {
     const dim3 grid(ap_grid), block(kThreads);
     const size_t lds = (size_t)2 * c * sizeof(float);
-    const int mask = act == EMSA_ACT_RELU ? (mask_bits ? 1 : 2) : 0;
+    const int mask = act == EMSA_ACT_RELU ? (mask_scale ? 3 : mask_bits ? 1 : 2) : 0;
     const float inv_count = 1.0f / (float)pixels;
 #define EMSA_APP_FAST(M, D, TR)                                                                     \
   hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<T, M, D, TR>), grid, block, lds, st, dy, y,         \
                      mask_bits, x, gamma, save_mean, save_invstd, drop, partial, rows, rows_alloc,  \
-                     dbeta, dgamma, (uint32_t)hw, lg, (uint32_t)totalv, inv_count, dx, dres)
+                     dbeta, dgamma, (uint32_t)hw, lg, (uint32_t)totalv, inv_count, dx, dres,        \
+                     mask_scale, mask_shift)
 #define EMSA_APP_FAST_M(D, TR)                                                                      \
   do {                                                                                              \
     if (mask == 1) EMSA_APP_FAST(1, D, TR); else if (mask == 2) EMSA_APP_FAST(2, D, TR);            \
     else EMSA_APP_FAST(0, D, TR);                                                                   \
   } while (0)
-    if (drop) {
+    if (mask == 3) {
+      if (drop || !train) return EMSA_E_ARG;      // (bn1 of an NBt1D block: batch statistics, no dropout)
+      EMSA_APP_FAST(3, false, true);
+    } else if (drop) {
       if (train) EMSA_APP_FAST_M(true, true); else EMSA_APP_FAST_M(true, false);
     } else {
       if (train) EMSA_APP_FAST_M(false, true); else EMSA_APP_FAST_M(false, false);
@@ -2774,6 +2806,7 @@ static int bn_bwd_apply_impl(const T* dy, const T* y, const uint64_t* mask_bits,
 #undef EMSA_APP_FAST
     return emsa_launch_status();
   }
+  if (mask_scale) return EMSA_E_SHAPE;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ap_grid), dim3(kThreads),
                      (size_t)2 * c * sizeof(float), st, dy, y, mask_bits, x, gamma, save_mean,
                      save_invstd, drop, partial, rows, rows_alloc, dbeta, dgamma, (long)hw, c / V, totalv,
@@ -2800,6 +2833,28 @@ extern "C" int emsa_bn_bwd_apply_rows_t(int32_t dtype, const void* g, const void
     case EMSA_DT_F32: return bn_bwd_apply_impl<float>((const float*)g, nullptr, nullptr, (const float*)x, gamma, save_mean, save_invstd, nullptr, partial, rows + kBwdSlices, n_img, hw, c, EMSA_ACT_NONE, train, (float*)dx, (float*)nullptr, dgamma, dbeta, stream, rows);
     case EMSA_DT_BF16: return bn_bwd_apply_impl<emsa_bf16>((const emsa_bf16*)g, nullptr, nullptr, (const emsa_bf16*)x, gamma, save_mean, save_invstd, nullptr, partial, rows + kBwdSlices, n_img, hw, c, EMSA_ACT_NONE, train, (emsa_bf16*)dx, (emsa_bf16*)nullptr, dgamma, dbeta, stream, rows);
     case EMSA_DT_F16: return bn_bwd_apply_impl<emsa_f16>((const emsa_f16*)g, nullptr, nullptr, (const emsa_f16*)x, gamma, save_mean, save_invstd, nullptr, partial, rows + kBwdSlices, n_img, hw, c, EMSA_ACT_NONE, train, (emsa_f16*)dx, (emsa_f16*)nullptr, dgamma, dbeta, stream, rows);
+    default: return EMSA_E_ARG;
+  }
+}
+
+// BatchNorm + ReLU backward with the ReLU decisions RECOMPUTED from the BatchNorm's input:
+// mask = (x * mask_scale[c] + mask_shift[c]) > 0, the forward pass's own folded scale / shift (the
+// normalised tensor was never written: emsa_conv1d_rs_inbn_t took x itself).  Batch statistics, no
+// Dropout2d (the NBt1D block's bn1, ref emsanet/model.py:47-58).  Same partial-row contract as
+// emsa_bn_bwd_reduce_t / emsa_bn_bwd_apply_t; power-of-two channel-vector counts only (EMSA_E_SHAPE).
+extern "C" int emsa_bn_bwd_reduce_aff_t(int32_t dtype, const void* dy, const void* x, const float* save_mean, const float* save_invstd, const float* mask_scale, const float* mask_shift, int32_t n_img, int64_t hw, int32_t c, float* partial, void* stream) {
+  if (!mask_scale || !mask_shift) return EMSA_E_ARG;
+  switch (dtype) {
+    case EMSA_DT_F32: return bn_bwd_reduce_impl<float>((const float*)dy, nullptr, nullptr, (const float*)x, save_mean, save_invstd, nullptr, n_img, hw, c, EMSA_ACT_RELU, partial, stream, mask_scale, mask_shift);
+    case EMSA_DT_BF16: return bn_bwd_reduce_impl<emsa_bf16>((const emsa_bf16*)dy, nullptr, nullptr, (const emsa_bf16*)x, save_mean, save_invstd, nullptr, n_img, hw, c, EMSA_ACT_RELU, partial, stream, mask_scale, mask_shift);
+    default: return EMSA_E_ARG;
+  }
+}
+extern "C" int emsa_bn_bwd_apply_aff_t(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_invstd, const float* mask_scale, const float* mask_shift, float* partial, int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, void* dx, float* dgamma, float* dbeta, void* stream) {
+  if (!mask_scale || !mask_shift) return EMSA_E_ARG;
+  switch (dtype) {
+    case EMSA_DT_F32: return bn_bwd_apply_impl<float>((const float*)dy, nullptr, nullptr, (const float*)x, gamma, save_mean, save_invstd, nullptr, partial, rows_alloc, n_img, hw, c, EMSA_ACT_RELU, 1, (float*)dx, (float*)nullptr, dgamma, dbeta, stream, -1, mask_scale, mask_shift);
+    case EMSA_DT_BF16: return bn_bwd_apply_impl<emsa_bf16>((const emsa_bf16*)dy, nullptr, nullptr, (const emsa_bf16*)x, gamma, save_mean, save_invstd, nullptr, partial, rows_alloc, n_img, hw, c, EMSA_ACT_RELU, 1, (emsa_bf16*)dx, (emsa_bf16*)nullptr, dgamma, dbeta, stream, -1, mask_scale, mask_shift);
     default: return EMSA_E_ARG;
   }
 }

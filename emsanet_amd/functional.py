@@ -388,6 +388,17 @@ def conv_fwd(x, wp, spec, bias=None, want_stats=False, scale=None, shift=None, r
         stats = _empty((3, rows, spec.cout), x.device)
     lr = ld_of(residual) if residual is not None else 0
     bits = None
+    if in_affine is not None and code != 0:
+        # 16-bit twin of the fold: conv_rs.hip takes the BatchNorm + ReLU of its input into the loader
+        # (3x1 convs; emsa_conv1d_rs_inbn_t).  The caller asked `bn1_fold16_ok` first.
+        if not use_rs or scale is not None or residual is not None:
+            raise _lib.EmsaError("in_affine (16-bit): only the conv_rs 3x1 forward folds its input's "
+                                 "BatchNorm (no output affine / residual)")
+        check(L.emsa_conv1d_rs_inbn_t(code, g, _p(x), _p(wfrag), _p(out), _p(bias), _p(stats),
+                                      _p(in_affine[0]), _p(in_affine[1]), act, _stream()),
+              'emsa_conv1d_rs_inbn_t')
+        res = (out, stats) if want_stats else out
+        return (res, None) if want_relu_bits else res
     if in_affine is not None and (wino_u is None or scale is not None or residual is not None):
         raise _lib.EmsaError("in_affine: only the fp32 1-D Winograd forward folds its input's "
                              "BatchNorm (no output affine / residual)")
@@ -722,6 +733,66 @@ def bn1_fold(t):
     return t.numel() * 4 >= _BN1_FOLD_MIN_BYTES
 
 
+# The same fold in 16-bit storage (round 6): conv_rs.hip's loader normalises the staged tile
+# (emsa_conv1d_rs_inbn_t), the transposed-read weight gradient recomputes it (emsa_conv_wgrad_inbn_t /
+# emsa_conv_wgrad_multi_inbn_t), and bn1's backward passes recompute the ReLU decisions from their
+# input (emsa_bn_bwd_*_aff_t) -- the data gradient stays the plain conv_rs launch (its fused
+# BatchNorm-backward epilogue costs more than the separate reduction, section 4.3 of DESIGN.md).
+# What leaves the step: the bn_act_fwd pass of bn1 (52 launches) and its ReLU bit mask.
+# Measured per block at bs 32 (tools/bn1_fold16_bench.py, profiles/r06_bn1_fold16_stages.txt; us at
+# the /4 /8 /16 /32 stages): saved normalise pass 33.0 / 18.0 / 11.0 / 7.3; cost forward conv +3.0 /
+# +2.4 / +5.9 / +5.5, weight gradient +1.3 / +3.5 / +5.6 / +6.0, bn1 backward -1.7 / -1.4 / -0.2 / -0.9
+# (no bit mask to read) -> net +30.4 / +13.5 / -0.3 / -3.2: like the fp32 fold it pays on the large
+# tensors only.  Default: fold when the BatchNorm's tensor is at least EMSA_BN1_FOLD16_MIN_MB (24) MiB
+# (the /4 and /8 stages at bs 32); step: 983.6 vs 977.9 images/s folded everywhere (+0.6 %, 1,444 vs
+# 1,494 graph nodes; profiles/r06_k_*).  EMSA_BN1_FOLD16=0 / 1 forces never / always; tests:
+# BN1_FOLD16 = True / False.
+_BN1_FOLD16_ENV = os.environ.get('EMSA_BN1_FOLD16')
+_BN1_FOLD16_MIN_BYTES = int(float(os.environ.get('EMSA_BN1_FOLD16_MIN_MB', '24')) * (1 << 20))
+BN1_FOLD16 = None
+
+
+def bn1_fold16(t, spec):
+    """fold the BatchNorm + ReLU applied to the bf16 activation `t` into the loader of the 3x1 conv
+    `spec` behind it?"""
+    if t.dtype != torch.bfloat16 or not CONV_RS or not rs_eligible(spec) or (spec.kh, spec.kw) != (3, 1):
+        return False
+    if BN1_FOLD16 is not None:
+        on = BN1_FOLD16
+    elif _BN1_FOLD16_ENV is not None:
+        on = _BN1_FOLD16_ENV != '0'
+    else:
+        on = t.numel() * 2 >= _BN1_FOLD16_MIN_BYTES
+    if not on or not deterministic_wgrad():
+        return False
+    n, c, h, w = t.shape
+    g = spec.geom_fwd(n, h, w, ld_of(t), spec.cout)
+    # (the weight gradient's fold lives in the transposed-read kernel: 16-byte rows, channels % 8)
+    return rs_supported(dt(t), g) and c % 8 == 0 and ld_of(t) % 8 == 0
+
+
+def bn_bwd_aff(dy, x, gamma, mean, invstd, affine, dg_out=None, db_out=None):
+    """BatchNorm (batch statistics) + ReLU backward with the ReLU decisions recomputed from the
+    BatchNorm's input x and the forward's folded (scale, shift): returns dx, dgamma, dbeta"""
+    n, c, h, w = x.shape
+    assert ld_of(x) == c and ld_of(dy) == c and dy.dtype == x.dtype
+    L = _lib.lib()
+    code = dt(x)
+    rows = L.emsa_bn_bwd_rows(n * h * w, c)
+    partial = _empty((2, rows, c), x.device)
+    check(L.emsa_bn_bwd_reduce_aff_t(code, _p(dy), _p(x), _p(mean), _p(invstd), _p(affine[0]),
+                                     _p(affine[1]), n, h * w, c, _p(partial), _stream()),
+          'emsa_bn_bwd_reduce_aff_t')
+    dx = act_empty(n, c, h, w, x.device, dtype=x.dtype)
+    if dg_out is None or db_out is None:
+        dgb = _empty((2, c), x.device)
+        dg_out, db_out = dgb[0], dgb[1]
+    check(L.emsa_bn_bwd_apply_aff_t(code, _p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(affine[0]),
+                                    _p(affine[1]), _p(partial), rows, n, h * w, c, _p(dx), _p(dg_out),
+                                    _p(db_out), _stream()), 'emsa_bn_bwd_apply_aff_t')
+    return dx, dg_out, db_out
+
+
 def conv_dgrad_bnb(dy, wpd, spec, in_hw, t, bn_scale, bn_shift, bn_mean, bn_invstd, residual=None,
                    wino_u=None, wfrag=None):
     """data gradient of the conv behind a BatchNorm+ReLU with that BatchNorm's backward reduction
@@ -824,9 +895,13 @@ def conv_wgrad(x, dy, spec, want_bias, like=None, two_pass=None, dw_out=None, db
         db = buf[nw:] if want_bias else None
     if x.dtype != dy.dtype:
         raise _lib.EmsaError(f"weight gradient of {x.dtype} activations with a {dy.dtype} gradient")
-    if in_affine is not None:
-        if dt(x) != 0:
-            raise _lib.EmsaError("in_affine: fp32 only")
+    if in_affine is not None and dt(x) != 0:
+        if ws is None:
+            raise _lib.EmsaError("in_affine (16-bit): the two-pass weight gradient only")
+        check(L.emsa_conv_wgrad_inbn_t(dt(x), g, _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                       _p(in_affine[0]), _p(in_affine[1]), _stream()),
+              'emsa_conv_wgrad_inbn_t')
+    elif in_affine is not None:
         check(L.emsa_conv_wgrad_inbn(g, _p(x), _p(dy), _p(dw), _p(db), _p(ws), _p(in_affine[0]),
                                      _p(in_affine[1]), _stream()), 'emsa_conv_wgrad_inbn')
     else:
@@ -853,8 +928,9 @@ def wgrad_multi_eligible(x, spec):
 
 
 def conv_wgrad_multi(jobs):
-    """jobs: [(x, dy, spec, like, dw_out, db_out, want_bias)] of `wgrad_multi_eligible` convs with the
-    same channel counts -> [(dw (parameter layout), dbias or None)] per job, or None when the library
+    """jobs: [(x, dy, spec, like, dw_out, db_out, want_bias[, in_affine])] of `wgrad_multi_eligible` convs
+    with the same channel counts (in_affine = (scale, shift): that job's x is the input of a folded
+    BatchNorm + ReLU, recomputed in the loader) -> [(dw (parameter layout), dbias or None)] per job, or None when the library
     has no multi-job form for this set (caller: one conv_wgrad per job)"""
     n_jobs = len(jobs)
     if n_jobs < 2 or n_jobs > WGRAD_MULTI_MAX:
@@ -874,9 +950,13 @@ def conv_wgrad_multi(jobs):
     dev = jobs[0][0].device
     ws = _empty((ws_bytes // 4,), dev)
     arr = lambda: (ctypes.c_void_p * n_jobs)()          # noqa: E731
-    a_in, a_dy, a_dw, a_db = arr(), arr(), arr(), arr()
+    a_in, a_dy, a_dw, a_db, a_sc, a_sh = arr(), arr(), arr(), arr(), arr(), arr()
     outs = []
-    for j, (x, dy, spec, like, dw_out, db_out, want_bias) in enumerate(jobs):
+    any_aff = False
+    for j, (x, dy, spec, like, dw_out, db_out, want_bias, *aff) in enumerate(jobs):
+        if aff and aff[0] is not None:
+            a_sc[j], a_sh[j] = _p(aff[0][0]), _p(aff[0][1])
+            any_aff = True
         nw = spec.kh * spec.kw * spec.cout * spec.cin
         if dw_out is not None and (db_out is not None or not want_bias):
             dw, db = dw_out.view(-1), db_out
@@ -886,8 +966,12 @@ def conv_wgrad_multi(jobs):
             db = buf[nw:] if want_bias else None
         a_in[j], a_dy[j], a_dw[j], a_db[j] = _p(x), _p(dy), _p(dw), _p(db)
         outs.append((dw.view(like.shape), db))
-    check(L.emsa_conv_wgrad_multi_t(code, n_jobs, geoms, a_in, a_dy, a_dw, a_db, _p(ws), _stream()),
-          'emsa_conv_wgrad_multi_t')
+    if any_aff:
+        check(L.emsa_conv_wgrad_multi_inbn_t(code, n_jobs, geoms, a_in, a_dy, a_dw, a_db, _p(ws), a_sc,
+                                             a_sh, _stream()), 'emsa_conv_wgrad_multi_inbn_t')
+    else:
+        check(L.emsa_conv_wgrad_multi_t(code, n_jobs, geoms, a_in, a_dy, a_dw, a_db, _p(ws), _stream()),
+              'emsa_conv_wgrad_multi_t')
     return outs
 
 

@@ -118,6 +118,8 @@ class ConvRT:
         """this conv can take the BatchNorm + ReLU in front of it (input tensor `t`) into its
         loader: fp32 1-D Winograd form, forward and weight gradient; Fn.bn1_fold decides whether
         it pays at this size"""
+        if t.dtype != torch.float32:
+            return self.rs and Fn.bn1_fold16(t, self.spec)
         return self.wino and Fn.wino_rows(self.spec) == 1 and Fn.bn1_fold(t)
 
     def dgrad(self, dy, in_hw, mask_bits=None, **kw):
@@ -670,7 +672,8 @@ def _flush_wgrads(defer, grads):
     res = [None] * len(defer)
     groups = {}
     for i, job in enumerate(defer):
-        ok = job[5] is None and Fn.wgrad_multi_eligible(job[0], job[2].spec)
+        ok = (job[5] is None or job[0].dtype != torch.float32) and \
+            Fn.wgrad_multi_eligible(job[0], job[2].spec)
         groups.setdefault((job[2].spec.cin, job[2].spec.cout) if ok else ('single', i), []).append(i)
     for idx in groups.values():
         for k in range(0, len(idx), Fn.WGRAD_MULTI_MAX):
@@ -679,7 +682,8 @@ def _flush_wgrads(defer, grads):
             if len(part) >= 2:
                 out = Fn.conv_wgrad_multi([(defer[i][0], defer[i][1], defer[i][2].spec,
                                             defer[i][2].conv.weight, defer[i][3], defer[i][4],
-                                            defer[i][2].conv.bias is not None) for i in part])
+                                            defer[i][2].conv.bias is not None, defer[i][5])
+                                           for i in part])
             if out is None:
                 for i in part:
                     x, dy, crt, tw, tb, aff = defer[i]
@@ -704,13 +708,18 @@ def _conv_backward(x, dy, crt, need_dx, mask_src=None, residual=None, mask_bits=
     # GradientBuckets manages the parameters (no gather copy later)
     tw = grad_target(conv.weight)
     tb = grad_target(conv.bias) if conv.bias is not None else None
-    if defer is not None and (WGRAD_STREAM or (in_affine is None and
+    half = dy.dtype != torch.float32
+    if defer is not None and (WGRAD_STREAM or ((in_affine is None or half) and
                                                Fn.wgrad_multi_eligible(x, crt.spec))):
         defer.append((x, dy, crt, tw, tb, in_affine))
         dw, db = _Deferred(len(defer) - 1, 0), _Deferred(len(defer) - 1, 1)
     else:
         dw, db = _wgrad_now(x, dy, crt, tw, tb, in_affine)
     dx = None
+    if bnb is not None and in_affine is not None and half:
+        # 16-bit fold: plain data gradient; bn1's backward passes recompute the ReLU decisions from
+        # the BatchNorm's input themselves (Fn.bn_bwd_aff)
+        return crt.dgrad(dy, x.shape[2:], residual=residual), dw, db, None
     if bnb is not None:
         t, affine, mean, invstd = bnb
         r = crt.dgrad_bnb(dy, x.shape[2:], t, affine, mean, invstd, residual=residual,
@@ -821,13 +830,18 @@ class NBt1DFunction(Function):
         aff1 = getattr(m1, '_emsa_affine', None)
         if a2 is None:                    # folded forward: the conv's input is relu(bn1(y2))
             da2, dw3, dbias3, fused = _conv_backward(y2, dz3, rt.c31_2, True,
-                                                     bnb=(y2, aff1, m1, is1), in_affine=aff1)
+                                                     bnb=(y2, aff1, m1, is1), in_affine=aff1,
+                                                     defer=defer if y2.dtype != torch.float32 else None)
         else:
             da2, dw3, dbias3, fused = _conv_backward(a2, dz3, rt.c31_2, True,
                                                      bnb=(y2, aff1, m1, is1), defer=defer)
         if fused is not None:
             dy2, dg1, db1 = Fn.bn_bwd_from_rows(da2, y2, rt.bn1.bn.weight.detach(), m1, is1,
                                                 fused[0], fused[1], t1, **_bn_targets(rt.bn1))
+        elif a2 is None:
+            # 16-bit fold: no a2, no bit mask -- the passes recompute the decisions from y2
+            dy2, dg1, db1 = Fn.bn_bwd_aff(da2, y2, rt.bn1.bn.weight.detach(), m1, is1, aff1,
+                                          **_bn_targets(rt.bn1))
         else:
             dy2, _, dg1, db1 = Fn.bn_bwd(da2, k1, y2, rt.bn1.bn.weight.detach(), m1, is1, None,
                                          ACT_RELU, t1, want_dres=False, **_bn_targets(rt.bn1))

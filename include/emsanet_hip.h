@@ -643,6 +643,44 @@ int emsa_pack_weight_frag_t(int32_t dtype, const float* w_oihw, void* wf_fwd, vo
                             int32_t cout, int32_t cin, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The NBt1D block's bn1 (BatchNorm + ReLU between conv1x3_1 and conv3x1_2, emsanet/model.py:47-58,
+ * args.py:125-131) FOLDED into its consumers in 16-bit storage (round 6; the fp32 twins are
+ * emsa_conv1d_wino_inbn / emsa_conv_wgrad_inbn / emsa_conv1d_wino_bnb): the normalised tensor and
+ * its ReLU bit mask are never written.  in_scale / in_shift / mask_scale / mask_shift = the
+ * BatchNorm's folded per-channel scale and shift of THIS forward pass (emsa_bn_finalize).
+ *   emsa_conv1d_rs_inbn_t        forward conv3x1 on relu(in * in_scale + in_shift), formed where the
+ *                                staged tile enters LDS; padding rows stay zero (the padding pads the
+ *                                normalised tensor).  bf16, taps along H; epilogue bias / statistics /
+ *                                ReLU.  EMSA_E_SHAPE: no such form for this geometry.
+ *   emsa_conv_wgrad_inbn_t       weight gradient of that conv, x operand recomputed in the loader.
+ *   emsa_conv_wgrad_multi_inbn_t the multi-job launch with per-job in_scale[j] / in_shift[j] (NULL
+ *                                entries = plain jobs).
+ *   emsa_bn_bwd_reduce_aff_t /   BatchNorm + ReLU backward whose ReLU decisions are recomputed from the
+ *   emsa_bn_bwd_apply_aff_t      BatchNorm's input: (x * mask_scale + mask_shift) > 0, the same single
+ *                                fma as the loaders.  Batch statistics, no Dropout2d; partial rows as
+ *                                emsa_bn_bwd_reduce_t / emsa_bn_bwd_apply_t.
+ * ------------------------------------------------------------------------------------------ */
+int emsa_conv1d_rs_inbn_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* wfrag,
+                          void* out, const float* bias, float* stats, const float* in_scale,
+                          const float* in_shift, int32_t act, void* stream);
+int emsa_conv_wgrad_inbn_t(int32_t dtype, const EmsaConvGeom* g, const void* in, const void* dout,
+                           float* dw, float* dbias, float* ws, const float* in_scale,
+                           const float* in_shift, void* stream);
+int emsa_conv_wgrad_multi_inbn_t(int32_t dtype, int32_t n_jobs, const EmsaConvGeom* geoms,
+                                 const void* const* in, const void* const* dout, float* const* dw,
+                                 float* const* dbias, float* ws, const float* const* in_scale,
+                                 const float* const* in_shift, void* stream);
+int emsa_bn_bwd_reduce_aff_t(int32_t dtype, const void* dy, const void* x, const float* save_mean,
+                             const float* save_invstd, const float* mask_scale,
+                             const float* mask_shift, int32_t n_img, int64_t hw, int32_t c,
+                             float* partial, void* stream);
+int emsa_bn_bwd_apply_aff_t(int32_t dtype, const void* dy, const void* x, const float* gamma,
+                            const float* save_mean, const float* save_invstd,
+                            const float* mask_scale, const float* mask_shift, float* partial,
+                            int32_t rows_alloc, int32_t n_img, int64_t hw, int32_t c, void* dx,
+                            float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Typed ("_t") forms of the HBM-bound kernels: same semantics and argument order as the fp32 entry
  * points above, activation tensors in the storage type `dtype` (EMSA_DT_*).  Kernels at the model
  * boundary take `out_f32`: the tensors on the OUTPUT side of the op (y of a forward kernel, dy / y

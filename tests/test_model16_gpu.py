@@ -492,15 +492,20 @@ def test_bf16_training_step_with_losses_and_sgd():
 
 
 @pytest.mark.parametrize('cin,cout,stride,p', [(64, 64, 1, 0.0), (64, 64, 1, 0.2), (64, 128, 2, 0.1)])
-@pytest.mark.parametrize('mode', ['train', 'train_fused_bnb', 'eval_grad', 'eval_fast'])
+@pytest.mark.parametrize('mode', ['train', 'train_folded', 'train_fused_bnb', 'eval_grad', 'eval_fast'])
 def test_nbt1d_block_bf16_vs_emulating_oracle(cin, cout, stride, p, mode, monkeypatch):
     """one NonBottleneck1D block in bf16 against the fp64 block that rounds where the engine rounds;
-    'train_fused_bnb': bn1's backward reduction inside the data gradient of conv3x1_2
+    'train_folded' (round 6): bn1 + ReLU formed in the loader of conv3x1_2 (emsa_conv1d_rs_inbn_t) and of
+    its weight gradient (emsa_conv_wgrad_multi_inbn_t), bn1's backward passes recompute the ReLU
+    decisions from y2 (emsa_bn_bwd_*_aff_t) -- 'train' is the same block with the separate normalise
+    pass; 'train_fused_bnb': bn1's backward reduction inside the data gradient of conv3x1_2
     (emsa_conv1d_rs_bnb_t / emsa_conv_igemm_bnb_t -- opt-in since round 5, EMSA_BN_FUSE=1)"""
     import torch.nn.functional as F
     from emsanet_amd import functional as Fn, ops
+    monkeypatch.setattr(Fn, 'BN1_FOLD16', mode == 'train_folded')
     if mode == 'train_fused_bnb':
         monkeypatch.setattr(Fn, '_BN_FUSE_ENV', '1')
+    if mode in ('train_fused_bnb', 'train_folded'):
         mode = 'train'
     from emsanet_amd.nn import NonBottleneck1D
     from oracle import emsanet_oracle as O
@@ -905,3 +910,83 @@ def _flatten_eval(outs):
     for o, sides in outs:
         flat += list(o) if isinstance(o, tuple) else [o]
     return flat
+
+
+@pytest.mark.parametrize('c,h,w', [(64, 24, 32), (128, 13, 21), (256, 15, 20), (512, 15, 20)])
+def test_bn1_fold16_is_the_unfolded_block_bit_for_bit(c, h, w, monkeypatch):
+    """16-bit bn1 fold (round 6) against the same block with the separate normalise pass: the loader
+    forms bf16(relu(fma(y2, scale, shift))) -- the very value the normalise pass would have stored -- so
+    the block output and the input gradient are BIT-identical and the parameter gradients differ by
+    the fp32 summation order of the split-K partials only (odd sizes: padding rows / line ends must
+    stay zero after the fold, not relu(shift))."""
+    from emsanet_amd import functional as Fn, ops
+    from emsanet_amd.nn import NonBottleneck1D
+    res = []
+    for fold in (False, True):
+        monkeypatch.setattr(Fn, 'BN1_FOLD16', fold)
+        torch.manual_seed(3)
+        blk = NonBottleneck1D(c, c, 1, 0.1)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.3)
+        blk.dropout.layer_id = 5
+        blk.dropout.seed_fn = lambda: 7
+        blk.to(DEV).train()
+        x = _nhwc(rnd(3, c, h, w, seed=1), torch.bfloat16).requires_grad_(True)
+        launches = []
+        orig = Fn.bn_act
+
+        def counted(*a, **k):
+            launches.append(1)
+            return orig(*a, **k)
+        monkeypatch.setattr(Fn, 'bn_act', counted)
+        y = blk(x)
+        monkeypatch.setattr(Fn, 'bn_act', orig)
+        y.backward(_nhwc(rnd(3, c, h, w, seed=2), torch.bfloat16))
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), x.grad.clone(),
+                    {k: q.grad.clone() for k, q in blk.named_parameters()}, len(launches)))
+    (y0, dx0, g0, n0), (y1, dx1, g1, n1) = res
+    assert n1 == n0 - 1, (n0, n1)                    # bn1's normalise pass is gone
+    assert torch.equal(y0, y1), 'forward differs'
+    assert torch.equal(dx0, dx1), 'input gradient differs'
+    for k in g0:
+        d = float((g0[k] - g1[k]).abs().max())
+        assert d <= 2e-5 * max(1.0, float(g0[k].abs().max())), (k, d)
+
+
+def test_bn1_fold16_whole_model_train_step_is_bit_identical(monkeypatch):
+    """the whole bf16 TRAIN step (all heads, Dropout2d, side outputs) with bn1 of every NBt1D block
+    folded into its consumers against the same step with the separate normalise passes: every output
+    bit-identical, every parameter gradient within the fp32 summation order of the weight-gradient
+    splits (the fold changes WHERE relu(bn1(y2)) is formed, not its bits; default rule: tensors
+    >= 24 MiB, forced on here at a small size)"""
+    from emsanet_amd import full_args, functional as Fn, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import synthetic_batch
+    from util import deterministic_state_dict
+    args = full_args(input_height=128, input_width=160, compute_dtype='bfloat16')
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(3, 128, 160, seed=9).items()}
+    res = []
+    for fold in (False, True):
+        monkeypatch.setattr(Fn, 'BN1_FOLD16', fold)
+        model = EMSANet(args, nyuv2_config())
+        model.load_state_dict(deterministic_state_dict(model))
+        model.to(DEV).train()
+        model.dropout_seed, model.dropout_step = 11, 0
+        out = _flatten(model(batch))
+        g = torch.Generator().manual_seed(5)
+        cots = [(torch.randn(t.shape, generator=g) * 1e-1).to(DEV) for t in out]
+        torch.autograd.backward(out, cots)
+        torch.cuda.synchronize()
+        res.append(([t.detach().clone() for t in out],
+                    {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (o0, g0), (o1, g1) = res
+    for i, (a, b) in enumerate(zip(o0, o1)):
+        assert torch.equal(a, b), f"output {i} differs with the fold"
+    assert set(g0) == set(g1)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        d = float((g0[k] - g1[k]).abs().max())
+        assert d <= 2e-5 * max(float(g0[k].abs().max()), 1e-3 * gmax), (k, d)
