@@ -180,7 +180,9 @@ class GradientBuckets:
                 if self.active and not manual:
                     p.register_post_accumulate_grad_hook(self._hook)
         self.rs_cu_budget = None
-        if self.world > 1 and params and params[0].is_cuda:
+        # (force_collectives: the one-rank rehearsal of the multi-rank step -- the collective kernels
+        #  are resident there too, so the budget engages and the evidence file shows it)
+        if self.active and params and params[0].is_cuda:
             self.rs_cu_budget = reserve_cus_for_collectives()
         self.reset()
 
