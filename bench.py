@@ -882,8 +882,8 @@ def run(args):
     roofline = None
     traffic, traffic_src = None, None
     pmc, pmc_file = None, None
-    pmc_names = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json') \
-        if args.dtype == 'f32' else (f'r05_pmc_traffic_{args.dtype}.json', f'r04_pmc_traffic_{args.dtype}.json')
+    pmc_names = ('r06_pmc_traffic.json', 'r05_pmc_traffic.json') \
+        if args.dtype == 'f32' else (f'r06_pmc_traffic_{args.dtype}.json', f'r05_pmc_traffic_{args.dtype}.json')
     pmc_stale = None
     for name in pmc_names:                                             # newest measurement first
         try:
