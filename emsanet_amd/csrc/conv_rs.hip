@@ -177,6 +177,21 @@ __device__ __forceinline__ int r_swz(int R) {
 #ifndef EMSA_RS_OCC
 #define EMSA_RS_OCC 2
 #endif
+// Wave-tile variants (round 6 A/B builds): 1 = every wave owns TWO 32-channel output tiles (TN = 2) of
+// a smaller K range -- one ds_read_b128 of the A operand then feeds two MFMAs (half the LDS read
+// volume of the MFMA loop) at the price of a K split twice as deep (2x the fp32 stage).
+//   V128: <TN 1, WN 4, WK 1, TM 2> (64-pixel tiles)  ->  <TN 2, WN 2, WK 2, TM 1> (32-pixel tiles)
+//   V256: <TN 1, WN 2, WK 2>                         ->  <TN 2, WN 1, WK 4>
+//   V512: <TN 1, WN 2, WK 4, TM 1|2>                 ->  <TN 2, WN 1, WK 8, TM 1>
+#ifndef EMSA_RS_V128
+#define EMSA_RS_V128 0
+#endif
+#ifndef EMSA_RS_V256
+#define EMSA_RS_V256 0
+#endif
+#ifndef EMSA_RS_V512
+#define EMSA_RS_V512 0
+#endif
 // EPI: the epilogue reads a residual and / or a mask tensor (as its own instantiation: the waits for
 // those loads would otherwise sit in every launch's output pass and drain the next tile's DMA).
 // INBN: the input tile is normalised + rectified on its way into LDS (the NBt1D block's bn1 folded
@@ -759,12 +774,15 @@ bool rs_plan(const EmsaConvGeom* g, RSPlan& pl) {
   pl.rpi = 1024 / (pl.kc * 2);
   switch (pl.kc) {
     case 64: pl.bm = (EMSA_RS_W8 & 1) ? 256 : 128; pl.nwg = 64; pl.nwv = (EMSA_RS_W8 & 1) ? 8 : 4; pl.wk = 1; break;
-    case 128: pl.bm = (EMSA_RS_W8 & 2) ? 128 : 64; pl.nwg = 128; pl.nwv = (EMSA_RS_W8 & 2) ? 8 : 4; pl.wk = 1; break;
-    case 256: pl.tm = EMSA_RS_TM256; pl.nwg = 64; pl.nwv = (EMSA_RS_W8 & 4) ? 8 : 4; pl.wk = 2; break;
+    case 128:
+      if (EMSA_RS_V128) { pl.bm = 32; pl.nwg = 128; pl.nwv = 4; pl.wk = 2; break; }
+      pl.bm = (EMSA_RS_W8 & 2) ? 128 : 64; pl.nwg = 128; pl.nwv = (EMSA_RS_W8 & 2) ? 8 : 4; pl.wk = 1; break;
+    case 256: pl.tm = EMSA_RS_TM256; pl.nwg = 64; pl.nwv = (EMSA_RS_W8 & 4) ? 8 : 4; pl.wk = EMSA_RS_V256 ? 4 : 2; break;
     default:
       // 64-pixel tiles at 512 channels once there are enough pixels to give every workgroup a
       // few of them; small maps (batch-1 inference: 300 pixels at /32) keep 32-pixel tiles
-      pl.tm = (EMSA_RS_TM512 == 2 && M >= 4096) ? 2 : 1; pl.nwg = 64; pl.nwv = 8; pl.wk = 4; break;
+      pl.tm = (EMSA_RS_TM512 == 2 && M >= 4096 && !EMSA_RS_V512) ? 2 : 1; pl.nwg = 64; pl.nwv = 8;
+      pl.wk = EMSA_RS_V512 ? 8 : 4; break;
   }
   if (pl.kc >= 256) {
     pl.bm = 32 * pl.tm * ((pl.kc == 256 && (EMSA_RS_W8 & 4)) ? 2 : 1);
@@ -887,11 +905,23 @@ template <typename T>
 int rs_dispatch(const ConvRSArgs& a, const RSPlan& pl, bool bnb, hipStream_t st) {
   switch (pl.kc) {
     case 64: return rs_launch<T, 64, 2, (EMSA_RS_W8 & 1) ? 8 : 4, 1, 1, 1>(a, pl, bnb, st);
+#if EMSA_RS_V128
+    case 128: return rs_launch<T, 128, 2, 1, 2, 2, 1>(a, pl, bnb, st);
+#else
     case 128: return rs_launch<T, 128, 1, (EMSA_RS_W8 & 2) ? 2 : 1, 4, 1, 2>(a, pl, bnb, st);
+#endif
+#if EMSA_RS_V256
+    case 256: return rs_launch<T, 256, 2, (EMSA_RS_W8 & 4) ? 2 : 1, 1, 4, EMSA_RS_TM256>(a, pl, bnb, st);
+#else
     case 256: return rs_launch<T, 256, 1, (EMSA_RS_W8 & 4) ? 2 : 1, 2, 2, EMSA_RS_TM256>(a, pl, bnb, st);
+#endif
     default:
+#if EMSA_RS_V512
+      return rs_launch<T, 512, 2, 1, 1, 8, 1>(a, pl, bnb, st);
+#else
       if (pl.tm == 2) return rs_launch<T, 512, 1, 1, 2, 4, 2>(a, pl, bnb, st);
       return rs_launch<T, 512, 1, 1, 2, 4, 1>(a, pl, bnb, st);
+#endif
   }
 }
 

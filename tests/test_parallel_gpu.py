@@ -390,9 +390,8 @@ def test_bench_self_launch_two_ranks_gloo():
 def test_segmented_step_capture_and_fallback_leave_identical_parameters(monkeypatch):
     """the N > 1 code path of bench.py (segmented step, cuts (3, 2, 1) + decoder cut, manual buckets,
     fused SGD at lr > 0) once with its hipGraphs captured and once with the capture REFUSED (eager
-    twin through `eager_fallback`): after two steps on two batches both models hold the same
-    parameters and BatchNorm statistics, to the fp32-atomics jitter of a few weight gradients
-    (VERDICT r5 item 6)."""
+    twin through `eager_fallback`): after a step both models hold the same parameters and BatchNorm
+    statistics, to the fp32-atomics jitter of a few weight gradients."""
     sys.path.insert(0, ROOT)
     from emsanet_amd import full_args, graph as G, nyuv2_config
     from emsanet_amd.model import EMSANet
@@ -426,15 +425,23 @@ def test_segmented_step_capture_and_fallback_leave_identical_parameters(monkeypa
             step = G.SegmentedGraphedTrainStep(model, batches[0], buckets, opt, loss_fn=loss_of,
                                                cut_stages=(3, 2, 1), decoder_cut=True)
             assert step.graphs is not None and len(step.graphs) == 7
-        for b in batches[1:]:
-            step.replay(b)
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        step.replay(batches[1])
         torch.cuda.synchronize()
-        return {k: v.detach().clone() for k, v in model.state_dict().items()}
-    a, b = run(False), run(True)
+        return before, {k: v.detach().clone() for k, v in model.state_dict().items()}
+    (b0, a), (b1, b) = run(False), run(True)
     assert set(a) == set(b)
+    moved = 0.0
     for k in a:
+        assert torch.equal(b0[k], b1[k]), f"{k}: building the step changed the state"
         if a[k].dtype.is_floating_point:
+            upd = float((a[k] - b0[k]).abs().max())
+            moved = max(moved, upd)
             d = float((a[k] - b[k]).abs().max())
-            assert d <= 1e-5 * max(1.0, float(b[k].abs().max())), (k, d)
+            # ONE step (a second one would compound the chaos of train-mode BatchNorm on this tiny
+            # configuration, cf. test_hipgraph_train_step_matches_eager): 1e-3 of the update + one fp32
+            # ulp of the tensor -- the weight gradients of heads / 1x1 / strided convs carry atomics jitter
+            assert d <= 1e-3 * upd + 2.5e-7 * float(b[k].abs().max()) + 1e-9, (k, d, upd)
         else:
             assert torch.equal(a[k], b[k]), k
+    assert moved > 0.0
