@@ -2138,14 +2138,27 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, float* __restrict_
     const int img = (int)(r / ih);
     const T* b = dy + (long)img * oh * ow * ld_dy + ch;
     float a = 0.f;
-    for (int yo = 0; yo < oh; ++yo) {
+    // output rows / columns that can touch input row yi / column xi: source coordinate in
+    // (yi - 1, yi + 1), i.e. |o - (yi + 0.5) * oh / ih + 0.5| < oh / ih; one output row of margin on
+    // both sides, the membership test below decides (the window only bounds the walk: a 640-wide
+    // map would otherwise cost 640 source computations per element and row)
+    const float ry = (float)oh / (float)ih, rx = (float)ow / (float)iw;
+    int y_lo = (int)(((float)yi - 1.f) * ry) - 2, y_hi = (int)(((float)yi + 2.f) * ry) + 2;
+    int x_lo = (int)(((float)xi - 1.f) * rx) - 2, x_hi = (int)(((float)xi + 2.f) * rx) + 2;
+    if (yi == 0) y_lo = 0;                             // (clamped border: everything above maps here)
+    if (yi == ih - 1) y_hi = oh - 1;
+    if (xi == 0) x_lo = 0;
+    if (xi == iw - 1) x_hi = ow - 1;
+    y_lo = y_lo < 0 ? 0 : y_lo; y_hi = y_hi > oh - 1 ? oh - 1 : y_hi;
+    x_lo = x_lo < 0 ? 0 : x_lo; x_hi = x_hi > ow - 1 ? ow - 1 : x_hi;
+    for (int yo = y_lo; yo <= y_hi; ++yo) {
       int h0, h1;
       float lh;
       bilinear_src(yo, ih, oh, h0, h1, lh);
       // (h0 == h1 at the clamped border: both taps land on the same row, as in the scatter form)
       const float wy = (h0 == yi ? 1.f - lh : 0.f) + (h1 == yi ? lh : 0.f);
       if (h0 != yi && h1 != yi) continue;
-      for (int xo = 0; xo < ow; ++xo) {
+      for (int xo = x_lo; xo <= x_hi; ++xo) {
         int w0, w1;
         float lw;
         bilinear_src(xo, iw, ow, w0, w1, lw);

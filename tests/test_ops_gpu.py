@@ -597,6 +597,26 @@ def test_ppm_pieces():
     close(y5g.grad, y5.grad, what='ppm dy5')
 
 
+@pytest.mark.parametrize('ih,iw,oh,ow', [(5, 5, 15, 20), (1, 1, 15, 20), (7, 9, 30, 41), (30, 40, 15, 20),
+                                         (15, 20, 480, 640), (3, 640, 6, 640)])
+def test_bilinear_bwd_gather(ih, iw, oh, ow):
+    """the gather-form bilinear backward (round 6: one thread per dx element over a WINDOW of output
+    rows / columns, fixed summation order) against torch autograd, up- and down-sampling, clamped
+    borders, a one-pixel source, a large map; and bit-reproducible run to run"""
+    Fn = _fn()
+    n, c = 2, 8
+    x = rnd(n, c, ih, iw, seed=1).double().requires_grad_(True)
+    y = F.interpolate(x, (oh, ow), mode='bilinear', align_corners=False)
+    dy = rnd(n, c, oh, ow, seed=2)
+    y.backward(dy.double())
+    got = Fn.bilinear_bwd(to_act(dy), (ih, iw))
+    close(got, x.grad, tol=2e-5, what='bilinear bwd')
+    again = Fn.bilinear_bwd(to_act(dy), (ih, iw))
+    assert torch.equal(got, again)
+    out = Fn.act_empty(n, c, oh, ow, DEV)
+    close(Fn.bilinear_fwd(to_act(x.detach().float()), out), y, what='bilinear fwd')
+
+
 def test_head_act():
     from emsanet_amd import ops
     x = rnd(2, 8, 6, 7, seed=1).double().requires_grad_(True)
