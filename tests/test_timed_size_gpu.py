@@ -363,11 +363,17 @@ def test_train_step_gradients_are_reproducible_run_to_run(dtype):
     for a, b in zip(o0, o1):
         assert torch.equal(a, b), 'train-mode forward is not bit-reproducible'
     worst, n_diff = 0.0, 0
+    gmax = max(float(v.abs().max()) for v in g0.values())
     for k, a in g0.items():
         b = g1[k]
         if torch.equal(a, b):
             continue
         n_diff += 1
+        # (a conv bias in front of a train-mode BatchNorm has a mathematically ZERO gradient: what the
+        #  atomics form returns for it is a cancelled sum, roundoff-sized and different every run --
+        #  measured 0.15 relative on layer2.0.conv1x3_1.bias at 1e-7 of the largest gradient)
+        if float((a - b).abs().max()) <= 1e-6 * gmax and float(b.abs().max()) <= 1e-4 * gmax:
+            continue
         e = float((a - b).norm() / max(float(b.norm()), 1e-30))
         worst = max(worst, e)
         assert e <= 1e-5, f"{k}: run-to-run rel-L2 {e:.3e}"
