@@ -912,8 +912,10 @@ def _flatten_eval(outs):
     return flat
 
 
-@pytest.mark.parametrize('c,h,w', [(64, 24, 32), (128, 13, 21), (256, 15, 20), (512, 15, 20)])
-def test_bn1_fold16_is_the_unfolded_block_bit_for_bit(c, h, w, monkeypatch):
+@pytest.mark.parametrize('multi', [True, False])
+@pytest.mark.parametrize('c,h,w', [(64, 24, 32), (128, 13, 21), (256, 15, 20), (512, 15, 20), (64, 23, 30),
+                                   (128, 61, 79), (256, 7, 9), (512, 3, 5)])
+def test_bn1_fold16_is_the_unfolded_block_bit_for_bit(c, h, w, multi, monkeypatch):
     """16-bit bn1 fold (round 6) against the same block with the separate normalise pass: the loader
     forms bf16(relu(fma(y2, scale, shift))) -- the very value the normalise pass would have stored -- so
     the block output and the input gradient are BIT-identical and the parameter gradients differ by
@@ -921,6 +923,9 @@ def test_bn1_fold16_is_the_unfolded_block_bit_for_bit(c, h, w, monkeypatch):
     stay zero after the fold, not relu(shift))."""
     from emsanet_amd import functional as Fn, ops
     from emsanet_amd.nn import NonBottleneck1D
+    # (multi = False: the block's weight gradients as single launches -- emsa_conv_wgrad_inbn_t instead of
+    #  the per-job in_scale of emsa_conv_wgrad_multi_inbn_t)
+    monkeypatch.setattr(Fn, 'WGRAD_MULTI', multi)
     res = []
     for fold in (False, True):
         monkeypatch.setattr(Fn, 'BN1_FOLD16', fold)
