@@ -24,6 +24,10 @@
 //     exceeds the main loop's.
 #include <cstdlib>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "common.h"
 #include "prof.h"
 
@@ -155,10 +159,12 @@ __device__ __forceinline__ uint32_t h_gather(const HGather& q, int img_off, int 
 // instantiation (its accumulators and channel vectors spilled in the common kernel).
 template <int BM, int BN, int WM, int WN, typename T, int PF, bool BNB = false, int HK = 64,
           bool PAIR = false>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? ((PF == 2 || BNB) && BM * BN > 64 * 64 ? 3 : 4) : 2)
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 1 : (BM * BN <= 128 * 64) ? ((PF == 2 || BNB) && BM * BN > 64 * 64 ? 3 : 4) : 2)
 void conv_h_kernel(
     const ConvHArgs p_in) {
-  static_assert(WM * WN == 4, "4 waves");
+  // 4 waves (256 threads), or 8 (round 6: the 256 x 128 tile of the dense 3x3 convs -- half the L2
+  // operand traffic per FLOP of 128 x 128, one workgroup per CU)
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   // PAIR: two independent convs of one geometry in one launch (grid.y = 2)
   ConvHArgs p = p_in;
   if constexpr (PAIR) {
@@ -172,8 +178,8 @@ void conv_h_kernel(
   constexpr int kHLD = kHK + 8;         // padded LDS row of the register-staged variants (elements)
   constexpr int kHRowLanes = kHK / 8;   // lanes (16 B each) per staged row
   typedef typename Vec8<T>::type V8;
-  constexpr int NT = 256;
-  constexpr int kRowsPerPass = NT / kHRowLanes;                   // 32
+  constexpr int NT = 64 * WM * WN;
+  constexpr int kRowsPerPass = NT / kHRowLanes;                   // 32 (4 waves, 64-channel steps)
   static_assert(BM % kRowsPerPass == 0 && BN % kRowsPerPass == 0, "loader mapping");
   constexpr int AR = BM / kRowsPerPass, BR = BN / kRowsPerPass;   // 16-byte loads per thread
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -656,11 +662,12 @@ __global__ void conv_h_splitk_finish_kernel(const float* __restrict__ ws, int ks
   }
 }
 
-enum HTile { HT_128x64 = 0, HT_128x128, HT_64x64, HT_COUNT };
-int ht_bm(HTile t) { return t == HT_64x64 ? 64 : 128; }
-int ht_bn(HTile t) { return t == HT_128x128 ? 128 : 64; }
+enum HTile { HT_128x64 = 0, HT_128x128, HT_64x64, HT_256x128, HT_COUNT };
+int ht_bm(HTile t) { return t == HT_64x64 ? 64 : (t == HT_256x128 ? 256 : 128); }
+int ht_bn(HTile t) { return (t == HT_128x128 || t == HT_256x128) ? 128 : 64; }
 
-// EMSA_CONVH_TILE=0..2 forces a tile configuration (tests / tuning)
+// EMSA_CONVH_TILE=0..3 forces a tile configuration (tests / tuning; 3 = 256 x 128 on eight waves: measured
+// slower on every 3x3 shape, profiles/r06_p_conv_h_tile_256x128.txt -- the rule below never picks it)
 HTile pick_htile(long M, int n_ch) {
   const char* e = getenv("EMSA_CONVH_TILE");
   const int f = (e && *e) ? atoi(e) : -1;
@@ -758,23 +765,38 @@ int launch_h(const ConvHArgs& a_in, hipStream_t st) {
     // twin launch: the LDS-DMA forward kernel only (no statistics / mask / BatchNorm-backward form)
     if (a.bnb_out || a.stats || a.mask_src || convh_pf() != 0) return EMSA_E_SHAPE;
     const int ps2 = emsa_prof_begin(kProfClassConvH, 2.0 * flops, st, 2.0 * bytes);
-    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, HK, true>), dim3(grid, 2), dim3(256),
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, HK, true>), dim3(grid, 2), dim3(64 * WM * WN),
                        lds, st, a);
     emsa_prof_end(ps2, st);
     return emsa_launch_status();
   }
+  if constexpr (lds > 64 * 1024) {
+    // (the 256 x 128 tile: 96 KB of LDS-DMA buffers -- more than 64 KB has to be asked for, once per
+    //  kernel instantiation and device)
+    static std::mutex mu;
+    static std::set<std::pair<int, int>> seen;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen.insert({dev, HK}).second) {
+      (void)hipFuncSetAttribute((const void*)conv_h_kernel<BM, BN, WM, WN, T, 0, false, HK>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)conv_h_kernel<BM, BN, WM, WN, T, 1, false, HK>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+  }
   const int ps = emsa_prof_begin(kProfClassConvH, flops, st, bytes);
   if constexpr (HK == 32) {
-    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, 32>), dim3(grid), dim3(256), lds,
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0, false, 32>), dim3(grid), dim3(64 * WM * WN), lds,
                        st, a);
   } else if (a.bnb_out)
-    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1, true>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1, true>), dim3(grid), dim3(64 * WM * WN), lds, st, a);
   else if (convh_pf() == 0)
-    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 0>), dim3(grid), dim3(64 * WM * WN), lds, st, a);
   else if (convh_pf() == 2)
-    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 2>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 2>), dim3(grid), dim3(64 * WM * WN), lds, st, a);
   else
-    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_h_kernel<BM, BN, WM, WN, T, 1>), dim3(grid), dim3(64 * WM * WN), lds, st, a);
   emsa_prof_end(ps, st);
   return emsa_launch_status();
 }
@@ -783,6 +805,7 @@ template <typename T>
 int conv_h_dispatch(const ConvHArgs& a, HTile t, hipStream_t st) {
   switch (t) {
     case HT_128x128: return launch_h<128, 128, 2, 2, T>(a, st);
+    case HT_256x128: return launch_h<256, 128, 4, 2, T>(a, st);
     case HT_64x64: return launch_h<64, 64, 2, 2, T>(a, st);
     default: return launch_h<128, 64, 2, 2, T>(a, st);
   }
