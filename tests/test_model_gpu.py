@@ -495,7 +495,7 @@ class _PinnedRelu:
 
 
 def _pinned_grad_parity(args, bs, seed, monkeypatch, tol_out, tol_grad, oracle_dtype=torch.float64,
-                        check_buffers=True):
+                        check_buffers=True, cfg=None):
     """train-mode forward + backward of the engine vs the oracle on the engine's ReLU branch:
     every raw output within tol_out, EVERY parameter gradient within tol_grad (relative L2;
     gradients that are mathematically ~0 are compared against the global scale)"""
@@ -503,7 +503,7 @@ def _pinned_grad_parity(args, bs, seed, monkeypatch, tol_out, tol_grad, oracle_d
     from emsanet_amd import nyuv2_config, ops
     from emsanet_amd.model import EMSANet
     from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
-    cfg = nyuv2_config()
+    cfg = cfg if cfg is not None else nyuv2_config()
     oracle = EMSANetOracle(args, cfg)
     sd = deterministic_state_dict(oracle, 0)
     oracle.load_state_dict(sd)
@@ -619,6 +619,19 @@ def test_pinned_gradients_other_resnet_blocks(backbone, block, monkeypatch):
         out = model({k: v.to(DEV) for k, v in batch.items()})
     for i, (a, b) in enumerate(zip(_flatten(out), _flatten(ref))):
         assert _rel(a, b) <= TOL, f"eval output {i}: {_rel(a, b):.3e}"
+
+
+@pytest.mark.parametrize('n_sem,n_scene', [(37, 21), (19, 5), (41, 3)])
+def test_pinned_gradients_other_class_counts(n_sem, n_scene, monkeypatch):
+    """the reference's other datasets change the head widths only (`dataset_config.semantic_label_list_
+    without_void`, /root/reference/emsanet/model.py:39-43: SUNRGB-D 37 classes, Cityscapes 19, ...): the
+    semantic head is then a channel-PADDED conv (37 -> 40, 19 -> 24, 41 -> 48) and its two learned
+    up-samplings run on channel counts without a fused backward tile -- outputs and every gradient vs
+    the fp64 oracle, as for NYUv2's 40"""
+    from emsanet_amd import full_args
+    from emsanet_amd.data import DatasetConfig
+    _pinned_grad_parity(full_args(input_height=96, input_width=128), 3, 55, monkeypatch, tol_out=TOL,
+                        tol_grad=2e-3, cfg=DatasetConfig(n_sem, n_scene))
 
 
 def test_pinned_gradients_baseline_resolution(monkeypatch):
