@@ -634,6 +634,37 @@ def test_pinned_gradients_other_class_counts(n_sem, n_scene, monkeypatch):
                         tol_grad=2e-3, cfg=DatasetConfig(n_sem, n_scene))
 
 
+def test_cityscapes_like_geometry(monkeypatch):
+    """a wide frame with 19 classes (the reference trains Cityscapes at 512x1024,
+    /root/reference/README.md): eval forward at 512x1024 bs 1 vs the fp32 / fp64 oracle at north_star's
+    1e-3 (other tile tails: 128 / 64 / 32 / 16 rows of 256 ... 32 pixels), then a train step at 256x512
+    bs 2 with every gradient against the fp64 oracle on the engine's ReLU branch"""
+    from emsanet_amd import full_args
+    from emsanet_amd.data import DatasetConfig
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
+    cfg = DatasetConfig(19, 3)
+    args = full_args(input_height=512, input_width=1024)
+    o32 = EMSANetOracle(args, cfg)
+    sd = deterministic_state_dict(o32, 0)
+    o32.load_state_dict(sd)
+    model = EMSANet(args, cfg)
+    model.load_state_dict(sd)
+    model.to(DEV).eval()
+    o32.eval()
+    batch = synthetic_batch(1, 512, 1024)
+    with torch.no_grad():
+        ref = _flatten(o32(batch))
+        out = _flatten(model({k: v.to(DEV) for k, v in batch.items()}))
+    assert out[0].shape == (1, 19, 512, 1024)
+    for i, (a, b) in enumerate(zip(out, ref)):
+        close(a, b, tol=TOL, what=f'output {i}')
+    _argmax_check(out[0], ref[0].double(), 'semantic (512x1024)')
+    del model, o32
+    _pinned_grad_parity(full_args(input_height=256, input_width=512), 2, 8, monkeypatch, tol_out=TOL,
+                        tol_grad=2e-3, cfg=cfg)
+
+
 def test_pinned_gradients_baseline_resolution(monkeypatch):
     """BASELINE configs[1] shape: 640x480 RGB-D, all heads, train mode, bs=2 (what the fp64 CPU
     oracle finishes in seconds): every output and every one of the 742 gradients vs fp64; bn1 folded
