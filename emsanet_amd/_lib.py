@@ -173,6 +173,8 @@ SIGNATURES = {
     'emsa_adaptive_avgpool_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_bilinear_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_bilinear_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_nearest_fwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'emsa_nearest_bwd_t': (c_int, [c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_head_act_fwd_t': (c_int, [c_int32, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'emsa_head_act_bwd_gather_t': (c_int, [c_int32, _P, c_int32, c_int32, _P, c_int32, c_int32, _P, c_int32,
                                            c_int32, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32,

@@ -2171,6 +2171,60 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, float* __restrict_
   }
 }
 
+// 'nearest' up-sampling of the pyramid-pooling branches (`--upsampling-context-module nearest`,
+// /root/reference/emsanet/args.py:250-256; torch.nn.functional.interpolate(mode='nearest'): source index
+// floor(dst * in / out) in float arithmetic, clamped).  Backward: gather, one thread per dx element over
+// the window of outputs that map to it, fixed order.
+__device__ __forceinline__ int nearest_src(int o, int in, int out) {
+  const float scale = (float)in / (float)out;
+  const int i = (int)floorf((float)o * scale);
+  return i < in - 1 ? i : in - 1;
+}
+template <typename T>
+__global__ void nearest_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int ih, int iw,
+                                   int oh, int ow, int c, int ld_y) {
+  const long total = (long)n * oh * ow * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int xo = (int)(r % ow); r /= ow;
+    const int yo = (int)(r % oh);
+    const int img = (int)(r / oh);
+    const int yi = nearest_src(yo, ih, oh), xi = nearest_src(xo, iw, ow);
+    emsa_st1(y + (((long)img * oh + yo) * ow + xo) * ld_y + ch,
+             emsa_ld1(x + (((long)img * ih + yi) * iw + xi) * c + ch));
+  }
+}
+template <typename T>
+__global__ void nearest_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dx, int n, int ih,
+                                   int iw, int oh, int ow, int c, int ld_dy) {
+  const long total = (long)n * ih * iw * c;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int xi = (int)(r % iw); r /= iw;
+    const int yi = (int)(r % ih);
+    const int img = (int)(r / ih);
+    const T* b = dy + (long)img * oh * ow * ld_dy + ch;
+    // outputs o with nearest_src(o) == yi lie in [yi * oh / ih, (yi + 1) * oh / ih) up to float
+    // rounding: one output of margin on both sides, the membership test decides
+    const float ry = (float)oh / (float)ih, rx = (float)ow / (float)iw;
+    int y_lo = (int)((float)yi * ry) - 1, y_hi = (int)((float)(yi + 1) * ry) + 1;
+    int x_lo = (int)((float)xi * rx) - 1, x_hi = (int)((float)(xi + 1) * rx) + 1;
+    y_lo = y_lo < 0 ? 0 : y_lo; y_hi = y_hi > oh - 1 ? oh - 1 : y_hi;
+    x_lo = x_lo < 0 ? 0 : x_lo; x_hi = x_hi > ow - 1 ? ow - 1 : x_hi;
+    float a = 0.f;
+    for (int yo = y_lo; yo <= y_hi; ++yo) {
+      if (nearest_src(yo, ih, oh) != yi) continue;
+      for (int xo = x_lo; xo <= x_hi; ++xo)
+        if (nearest_src(xo, iw, ow) == xi) a += emsa_ld1(b + ((long)yo * ow + xo) * ld_dy);
+    }
+    dx[i] = a;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // head activations, copies
 // ------------------------------------------------------------------------------------------
@@ -3459,6 +3513,40 @@ extern "C" int emsa_bilinear_fwd_t(int32_t dtype, const void* x, void* y, int32_
     case EMSA_DT_F32: { return bilinear_fwd_impl<float>((const float*)x, (float*)y, n, ih, iw, oh, ow, c, ld_y, stream); }
     case EMSA_DT_BF16: { return bilinear_fwd_impl<emsa_bf16>((const emsa_bf16*)x, (emsa_bf16*)y, n, ih, iw, oh, ow, c, ld_y, stream); }
     case EMSA_DT_F16: { return bilinear_fwd_impl<emsa_f16>((const emsa_f16*)x, (emsa_f16*)y, n, ih, iw, oh, ow, c, ld_y, stream); }
+    default: return EMSA_E_ARG;
+  }
+}
+template <typename T>
+static int nearest_fwd_impl(const T* x, T* y, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
+  if (!x || !y) return EMSA_E_ARG;
+  if (n < 1 || ih < 1 || iw < 1 || oh < 1 || ow < 1 || c < 1 || ld_y < c) return EMSA_E_SHAPE;
+  const long total = (long)n * oh * ow * c;
+  hipLaunchKernelGGL((nearest_fwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, y, n, ih, iw, oh, ow, c, ld_y);
+  return emsa_launch_status();
+}
+template <typename T>
+static int nearest_bwd_impl(const T* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
+  if (!dy || !dx) return EMSA_E_ARG;
+  if (n < 1 || ih < 1 || iw < 1 || oh < 1 || ow < 1 || c < 1 || ld_dy < c) return EMSA_E_SHAPE;
+  const long total = (long)n * ih * iw * c;
+  hipLaunchKernelGGL((nearest_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
+                     (hipStream_t)stream, dy, dx, n, ih, iw, oh, ow, c, ld_dy);
+  return emsa_launch_status();
+}
+extern "C" int emsa_nearest_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: return nearest_fwd_impl<float>((const float*)x, (float*)y, n, ih, iw, oh, ow, c, ld_y, stream);
+    case EMSA_DT_BF16: return nearest_fwd_impl<emsa_bf16>((const emsa_bf16*)x, (emsa_bf16*)y, n, ih, iw, oh, ow, c, ld_y, stream);
+    case EMSA_DT_F16: return nearest_fwd_impl<emsa_f16>((const emsa_f16*)x, (emsa_f16*)y, n, ih, iw, oh, ow, c, ld_y, stream);
+    default: return EMSA_E_ARG;
+  }
+}
+extern "C" int emsa_nearest_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream) {
+  switch (dtype) {
+    case EMSA_DT_F32: return nearest_bwd_impl<float>((const float*)dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream);
+    case EMSA_DT_BF16: return nearest_bwd_impl<emsa_bf16>((const emsa_bf16*)dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream);
+    case EMSA_DT_F16: return nearest_bwd_impl<emsa_f16>((const emsa_f16*)dy, dx, n, ih, iw, oh, ow, c, ld_dy, stream);
     default: return EMSA_E_ARG;
   }
 }

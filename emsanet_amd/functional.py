@@ -1391,6 +1391,28 @@ def bilinear_bwd(dy, in_hw):
     return dx
 
 
+def nearest_fwd(x, out):
+    """x (N,C,ih,iw) dense -> out (N,C,oh,ow) possibly a channel slice: F.interpolate(mode='nearest')"""
+    n, c, ih, iw = x.shape
+    oh, ow = out.shape[2:]
+    assert ld_of(x) == c and out.dtype == x.dtype
+    check(_lib.lib().emsa_nearest_fwd_t(dt(x), _p(x), _p(out), n, ih, iw, oh, ow, c, ld_of(out),
+                                        _stream()), 'emsa_nearest_fwd_t')
+    return out
+
+
+def nearest_bwd(dy, in_hw):
+    """gather-form backward of `nearest_fwd` into an fp32 dx, returned in the dtype of dy"""
+    n, c, oh, ow = dy.shape
+    ih, iw = in_hw
+    dx = act_empty(n, c, ih, iw, dy.device)
+    check(_lib.lib().emsa_nearest_bwd_t(dt(dy), _p(dy), _p(dx), n, ih, iw, oh, ow, c, ld_of(dy),
+                                        _stream()), 'emsa_nearest_bwd_t')
+    if dy.dtype != torch.float32:
+        dx = cast(dx, dy.dtype)
+    return dx
+
+
 def head_act_fwd(x, n_sig, n_tanh, n_norm=0, norm_off=3):
     """16-bit features -> fp32 outputs (the model's instance outputs), fp32 -> fp32"""
     n, c, h, w = x.shape

@@ -58,7 +58,8 @@ class EMSANet(nn.Module):
         if args.context_module != 'ppm':
             raise NotImplementedError(f"context module '{args.context_module}'")
         self.context_module = PyramidPoolingModule(
-            c_enc, c_enc, (args.input_height // ds_enc, args.input_width // ds_enc))
+            c_enc, c_enc, (args.input_height // ds_enc, args.input_width // ds_enc),
+            upsampling=getattr(args, 'upsampling_context_module', 'bilinear'))   # (model.py:109-119)
 
         # --- decoders (model.py:122-160) ----------------------------------------------------------
         # offset encoding -> (normalised by the image size?, tanh on the head?)

@@ -458,8 +458,11 @@ class FusedEncoder(nn.Module):
 class PyramidPoolingModule(nn.Module):
     """'ppm' context module (/root/reference/emsanet/args.py:243-256)."""
 
-    def __init__(self, cin, cout, input_size):
+    def __init__(self, cin, cout, input_size, upsampling='bilinear'):
         super().__init__()
+        if upsampling not in ('bilinear', 'nearest'):       # (args.py:250-256: the two choices)
+            raise NotImplementedError(f"upsampling_context_module='{upsampling}'")
+        self.upsampling = upsampling
         bins = Spec.PPM_BINS
         self.bins = bins
         self.n_channels_reduction = cin // len(bins)
@@ -473,7 +476,7 @@ class PyramidPoolingModule(nn.Module):
         feats = []
         for b, f in zip(self.bins, self.features):
             feats.append(f[1](ops.AdaptiveAvgPoolFunction.apply(x, b)))
-        cat = ops.PPMConcatFunction.apply(x, *feats)
+        cat = ops.PPMConcatFunction.apply(x, *feats, self.upsampling)
         return self.final_conv(cat), tuple(feats)
 
 

@@ -1413,10 +1413,21 @@ class AdaptiveAvgPoolFunction(Function):
 
 
 class PPMConcatFunction(Function):
-    """cat([x, bilinear(y_i) ...], dim=1) written straight into one NHWC buffer."""
+    """cat([x, up(y_i) ...], dim=1) written straight into one NHWC buffer; up = bilinear
+    (align_corners=False) or -- a trailing 'nearest' argument -- nearest, the two choices of
+    `--upsampling-context-module` (/root/reference/emsanet/args.py:250-256)."""
 
     @staticmethod
     def forward(ctx, x, *ys):
+        mode = 'bilinear'
+        if ys and isinstance(ys[-1], str):
+            mode, ys = ys[-1], ys[:-1]
+            ctx.has_mode = True
+        else:
+            ctx.has_mode = False
+        if mode not in ('bilinear', 'nearest'):
+            raise NotImplementedError(f"upsampling_context_module='{mode}'")
+        up = Fn.bilinear_fwd if mode == 'bilinear' else Fn.nearest_fwd
         x = Fn.as_act(x)
         ys = [Fn.as_act(y, dense=True) for y in ys]
         n, c, h, w = x.shape
@@ -1425,9 +1436,9 @@ class PPMConcatFunction(Function):
         Fn.copy_channels(x, buf[:, :c])
         off = c
         for y in ys:
-            Fn.bilinear_fwd(y, buf[:, off:off + y.shape[1]])
+            up(y, buf[:, off:off + y.shape[1]])
             off += y.shape[1]
-        ctx.meta = (c, [tuple(y.shape) for y in ys])
+        ctx.meta = (c, [tuple(y.shape) for y in ys], mode)
         return buf
 
     @staticmethod
@@ -1435,15 +1446,16 @@ class PPMConcatFunction(Function):
     @_traced
     def backward(ctx, dbuf):
         dbuf = Fn.as_act(dbuf)
-        c, yshapes = ctx.meta
+        c, yshapes, mode = ctx.meta
+        down = Fn.bilinear_bwd if mode == 'bilinear' else Fn.nearest_bwd
         n, _, h, w = dbuf.shape
         dx = Fn.act_empty(n, c, h, w, dbuf.device, dtype=dbuf.dtype)
         Fn.copy_channels(dbuf[:, :c], dx)
         off, dys = c, []
         for ys in yshapes:
-            dys.append(Fn.bilinear_bwd(dbuf[:, off:off + ys[1]], ys[2:]))
+            dys.append(down(dbuf[:, off:off + ys[1]], ys[2:]))
             off += ys[1]
-        return (dx,) + tuple(dys)
+        return (dx,) + tuple(dys) + ((None,) if ctx.has_mode else ())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -734,6 +734,14 @@ int emsa_bilinear_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_
     iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream);
 int emsa_bilinear_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int32_t ih, int32_t
     iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream);
+/* 'nearest' up-sampling of the pyramid-pooling branches (`--upsampling-context-module nearest`,
+ * emsanet/args.py:250-256, passed on at emsanet/model.py:109-119): source index floor(dst * in / out) as
+ * torch.nn.functional.interpolate(mode='nearest'); y may be a channel slice (ld_y).  The backward pass
+ * writes every element of an fp32 dx (gather, fixed order). */
+int emsa_nearest_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t ih, int32_t iw,
+    int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream);
+int emsa_nearest_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int32_t ih, int32_t iw,
+    int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream);
 int emsa_head_act_fwd_t(int32_t dtype, int32_t out_f32, const void* x, void* y, int64_t pixels,
     int32_t c, int32_t n_sig, int32_t n_tanh, int32_t norm_off, int32_t n_norm, void* stream);
 /* emsa_head_act_bwd over the 8-channel (padded) instance head with the three task gradients (centre,

@@ -359,8 +359,10 @@ class FusedEncoder(nn.Module):
 class PyramidPoolingModule(nn.Module):
     """'ppm' (args.py:243-256): bins (1,5), 1x1 conv+BN+ReLU per bin, bilinear up, concat, 1x1."""
 
-    def __init__(self, cin, cout, input_size):
+    def __init__(self, cin, cout, input_size, upsampling='bilinear'):
         super().__init__()
+        assert upsampling in ('bilinear', 'nearest')       # --upsampling-context-module, args.py:250-256
+        self.upsampling = upsampling
         bins = Spec.PPM_BINS
         self.n_channels_reduction = cin // len(bins)
         self.features = nn.ModuleList([
@@ -374,7 +376,10 @@ class PyramidPoolingModule(nn.Module):
         for f in self.features:
             y = f[1](store(f[0](x)))
             feats.append(y)
-            outs.append(store(F.interpolate(y, (h, w), mode='bilinear', align_corners=False)))
+            if self.upsampling == 'nearest':
+                outs.append(store(F.interpolate(y, (h, w), mode='nearest')))
+            else:
+                outs.append(store(F.interpolate(y, (h, w), mode='bilinear', align_corners=False)))
         return self.final_conv(torch.cat(outs, 1)), tuple(feats)
 
 
@@ -615,7 +620,8 @@ class EMSANetOracle(nn.Module):
         assert args.context_module == 'ppm'
         c_enc = self.encoder.n_channels_out
         self.context_module = PyramidPoolingModule(
-            c_enc, c_enc, (args.input_height // 32, args.input_width // 32))
+            c_enc, c_enc, (args.input_height // 32, args.input_width // 32),
+            upsampling=getattr(args, 'upsampling_context_module', 'bilinear'))      # (model.py:109-119)
 
         fus_c = self.encoder.skips_n_channels[::-1]
         fus_d = tuple(args.encoder_decoder_skip_downsamplings)[::-1]

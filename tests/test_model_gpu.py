@@ -634,6 +634,31 @@ def test_pinned_gradients_other_class_counts(n_sem, n_scene, monkeypatch):
                         tol_grad=2e-3, cfg=DatasetConfig(n_sem, n_scene))
 
 
+def test_pinned_gradients_nearest_context_upsampling(monkeypatch):
+    """`--upsampling-context-module nearest` (/root/reference/emsanet/args.py:250-256, handed to the
+    context module at model.py:109-119; the engine used to ignore the argument): outputs and every
+    gradient vs the fp64 oracle, which up-samples with F.interpolate(mode='nearest')"""
+    from emsanet_amd import full_args
+    args = full_args(input_height=96, input_width=128, upsampling_context_module='nearest')
+    _pinned_grad_parity(args, 3, 21, monkeypatch, tol_out=TOL, tol_grad=2e-3)
+    # and the two modes differ (the argument is honoured)
+    from emsanet_amd import nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from util import deterministic_state_dict
+    outs = []
+    for mode in ('bilinear', 'nearest'):
+        m = EMSANet(full_args(input_height=96, input_width=128, upsampling_context_module=mode),
+                    nyuv2_config())
+        m.load_state_dict(deterministic_state_dict(m))
+        m.to(DEV).eval()
+        g = torch.Generator().manual_seed(1)
+        b = {'rgb': torch.randn(1, 3, 96, 128, generator=g).to(DEV),
+             'depth': torch.randn(1, 1, 96, 128, generator=g).to(DEV)}
+        with torch.no_grad():
+            outs.append(m(b)[0][0].clone())
+    assert not torch.equal(outs[0], outs[1])
+
+
 def test_cityscapes_like_geometry(monkeypatch):
     """a wide frame with 19 classes (the reference trains Cityscapes at 512x1024,
     /root/reference/README.md): eval forward at 512x1024 bs 1 vs the fp32 / fp64 oracle at north_star's

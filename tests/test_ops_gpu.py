@@ -617,6 +617,21 @@ def test_bilinear_bwd_gather(ih, iw, oh, ow):
     close(Fn.bilinear_fwd(to_act(x.detach().float()), out), y, what='bilinear fwd')
 
 
+@pytest.mark.parametrize('ih,iw,oh,ow', [(5, 5, 15, 20), (1, 1, 15, 20), (7, 9, 30, 41), (30, 40, 15, 20), (3, 5, 23, 31)])
+def test_nearest_up(ih, iw, oh, ow):
+    """'nearest' up-sampling of the pyramid-pooling branches (--upsampling-context-module nearest,
+    /root/reference/emsanet/args.py:250-256) and its gather-form backward vs torch"""
+    Fn = _fn()
+    n, c = 2, 8
+    x = rnd(n, c, ih, iw, seed=1).double().requires_grad_(True)
+    y = F.interpolate(x, (oh, ow), mode='nearest')
+    dy = rnd(n, c, oh, ow, seed=2)
+    y.backward(dy.double())
+    out = Fn.act_empty(n, c, oh, ow, DEV)
+    close(Fn.nearest_fwd(to_act(x.detach().float()), out), y, tol=0.0, what='nearest fwd')
+    close(Fn.nearest_bwd(to_act(dy), (ih, iw)), x.grad, tol=2e-6, what='nearest bwd')
+
+
 def test_head_act():
     from emsanet_amd import ops
     x = rnd(2, 8, 6, 7, seed=1).double().requires_grad_(True)
