@@ -382,6 +382,13 @@ def get_decoders(
         if getattr(args, a, 'learned-3x3-zeropad') != 'learned-3x3-zeropad':
             raise NotImplementedError(f"{a}={getattr(args, a)} (only learned-3x3-zeropad)")
 
+    # the decoder modules run at /16, /8, /4 (`*_decoder_downsamplings`, /root/reference/emsanet/decoder.py:
+    # 67,99,166; default (16, 8, 4)): another schedule is refused, not silently replaced
+    for task in ('semantic', 'instance', 'normal'):
+        ds = getattr(args, f'{task}_decoder_downsamplings', (16, 8, 4))
+        if task in args.tasks and tuple(ds) != (16, 8, 4):
+            raise NotImplementedError(f"{task}_decoder_downsamplings={tuple(ds)} (only (16, 8, 4))")
+
     decoders = OrderedDict()
     if 'semantic' in args.tasks:
         if args.semantic_decoder.lower() != 'emsanet':

@@ -41,6 +41,9 @@ class EMSANet(nn.Module):
         # --- encoders (model.py:46-106): one NBt1D ResNet per modality, SE-add fusion ----------
         if getattr(args, 'activation', 'relu') != 'relu':
             raise NotImplementedError("only the default 'relu' activation has kernels")
+        if getattr(args, 'encoder_normalization', 'batchnorm') not in ('batchnorm', 'bn'):
+            # (model.py:47-74 hands it to the backbones: refused, not silently replaced)
+            raise NotImplementedError(f"encoder_normalization='{args.encoder_normalization}' (only batchnorm)")
         nets = {}
         for modality, n_in in (('rgb', 3), ('depth', 1), ('rgbd', 3 + 1)):
             if modality not in args.input_modalities:

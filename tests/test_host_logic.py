@@ -132,6 +132,17 @@ def test_unsupported_configurations_raise():
         _model(full_args(semantic_decoder='segformermlp'))
     with pytest.raises(NotImplementedError):
         _model(full_args(instance_offset_encoding='bogus'))
+    # arguments the reference hands on to its factories and the engine has ONE implementation for:
+    # refused loudly, never silently replaced (round 6: `upsampling_context_module` used to be ignored)
+    with pytest.raises(NotImplementedError):
+        _model(full_args(encoder_normalization='layernorm'))
+    with pytest.raises(NotImplementedError):
+        _model(full_args(semantic_decoder_downsamplings=(8, 4, 2)))
+    with pytest.raises(NotImplementedError):
+        _model(full_args(upsampling_context_module='bicubic'))
+    with pytest.raises(NotImplementedError):
+        _model(full_args(activation='swish'))
+    assert _model(full_args(upsampling_context_module='nearest')).context_module.upsampling == 'nearest'
     with pytest.raises(KeyError):
         default_args(not_a_field=1)
     a = default_args(input_modalities=('rgb',))
