@@ -52,6 +52,23 @@ class EMSANet(nn.Module):
             block = getattr(args, f'{modality}_encoder_backbone_resnet_block')
             nets[modality] = ResNetNBt1D(getattr(args, f'{modality}_encoder_backbone'), n_in,
                                          args.dropout_p, block=block)
+        # pretrained backbones (model.py:58-59,72-73,88-89: `pretrained=not args.no_pretrained_backbone,
+        # pretrained_filepath=...`): the reference's library downloads ImageNet weights when no file is
+        # named; there is no such source here -- a file is loaded, its absence is an error, never a
+        # silent random initialisation
+        if not getattr(args, 'no_pretrained_backbone', False):
+            from .weights import load_backbone_weights
+            for modality, net in nets.items():
+                if net is None:
+                    continue
+                fp = getattr(args, f'{modality}_encoder_backbone_pretrained_weights_filepath', None)
+                if not fp:
+                    raise NotImplementedError(
+                        f"pretrained '{modality}' backbone requested (no_pretrained_backbone is False) "
+                        f"without --{modality}-encoder-backbone-pretrained-weights-filepath: the reference "
+                        "downloads ImageNet weights through nicr_mt_scene_analysis, this engine loads a "
+                        "file or starts from scratch with --no-pretrained-backbone")
+                load_backbone_weights(net, fp, modality, verbose=bool(getattr(args, 'debug', False)))
         self.encoder = FusedEncoder(nets['rgb'], nets['depth'], args.encoder_fusion,
                                     args.encoder_decoder_skip_downsamplings,
                                     backbone_rgbd=nets['rgbd'])

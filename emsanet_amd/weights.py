@@ -111,3 +111,46 @@ def load_weights(args, model, state_dict, verbose=True, scannet_mapping=None):
 
     model.load_state_dict(sd, strict=True)
     return model
+
+
+def load_backbone_weights(backbone, filepath, modality, verbose=True):
+    """`get_backbone(..., pretrained=True, pretrained_filepath=...)` of the reference
+    (/root/reference/emsanet/model.py:47-74, args.py:119-123,174,207,232): the ImageNet-pretrained
+    ResNet-NBt1D weights of ONE backbone from a checkpoint file.  The loader of the reference lives in
+    the un-vendored nicr_mt_scene_analysis, so the file layout is [U]; accepted here: a plain state
+    dict or one under 'state_dict' / 'model', keys optionally prefixed ('module.', 'backbone.',
+    'encoder.backbone_<modality>.'), with the backbone's own key names.  A 3-channel
+    stem in front of a 1-channel (depth) backbone is summed over its input channels, a 1- or
+    3-channel stem in front of the 4-channel rgbd stem is refused.  Classifier keys (`fc.*`) are
+    dropped.  Everything else must match: a file that fills less than the whole backbone raises."""
+    import torch
+    log = print if verbose else (lambda *a, **k: None)
+    sd = torch.load(filepath, map_location='cpu')
+    for wrap in ('state_dict', 'model'):
+        if isinstance(sd, dict) and wrap in sd and isinstance(sd[wrap], dict):
+            sd = sd[wrap]
+    own = backbone.state_dict()
+    clean = {}
+    for k, v in sd.items():
+        for pre in ('module.', f'encoder.backbone_{modality}.', 'backbone.'):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        if k.startswith('fc.') or k not in own:
+            continue
+        if k == 'conv1.weight' and v.shape[1] != own[k].shape[1]:
+            if v.shape[1] == 3 and own[k].shape[1] == 1:
+                log(f"backbone '{modality}': summing the pretrained 3-channel stem over its input channels")
+                v = v.sum(1, keepdim=True)
+            else:
+                raise NotImplementedError(f"pretrained stem with {v.shape[1]} input channels for a "
+                                          f"{own[k].shape[1]}-channel '{modality}' backbone")
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise RuntimeError(f"{filepath}: '{k}' has shape {tuple(v.shape)}, the backbone {tuple(own[k].shape)}")
+        clean[k] = v
+    missing = [k for k in own if k not in clean and not k.endswith('num_batches_tracked')]
+    if missing:
+        raise RuntimeError(f"{filepath}: {len(missing)} of {len(own)} backbone tensors missing "
+                           f"(first: {missing[0]}) -- not a ResNet-NBt1D checkpoint of this layout")
+    backbone.load_state_dict(clean, strict=False)
+    log(f"backbone '{modality}': loaded {len(clean)} pretrained tensors from {filepath}")
+    return backbone

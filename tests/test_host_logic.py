@@ -554,3 +554,35 @@ def test_cut_plan_dry_run(fake_lib, monkeypatch):
     model._cut_plan = None
     assert [g for _, _, _, g in plan.records].count(CutPlan.DECODER_MID) == 2
     assert plan.late_stages == {3, 4}
+
+
+def test_pretrained_backbone_argument_is_honoured(tmp_path):
+    """`no_pretrained_backbone=False` (the reference's default, /root/reference/emsanet/args.py:119-123;
+    handed to `get_backbone` at model.py:58-59,72-73): with a weights file the backbones carry its
+    tensors (a 3-channel stem summed for the depth backbone), without one the constructor refuses --
+    it used to build a randomly initialised model without a word"""
+    from emsanet_amd import full_args
+    from emsanet_amd.nn import ResNetNBt1D
+    with pytest.raises(NotImplementedError, match='pretrained'):
+        _model(full_args(no_pretrained_backbone=False))
+    torch.manual_seed(3)
+    src = ResNetNBt1D('resnet34', 3, 0.1)
+    sd = {('module.' + k): v.clone() for k, v in src.state_dict().items()}
+    sd['module.fc.weight'] = torch.zeros(1000, 512)
+    fp = str(tmp_path / 'r34_nbt1d.pth')
+    torch.save({'state_dict': sd}, fp)
+    m = _model(full_args(no_pretrained_backbone=False,
+                         rgb_encoder_backbone_pretrained_weights_filepath=fp,
+                         depth_encoder_backbone_pretrained_weights_filepath=fp))
+    own = src.state_dict()
+    for k, v in m.encoder.backbone_rgb.state_dict().items():
+        assert torch.equal(v, own[k]), k
+    d = m.encoder.backbone_depth.state_dict()
+    assert torch.equal(d['conv1.weight'], own['conv1.weight'].sum(1, keepdim=True))
+    assert torch.equal(d['layer3.2.conv1x3_2.weight'], own['layer3.2.conv1x3_2.weight'])
+    bad = str(tmp_path / 'bad.pth')
+    torch.save({k: v for k, v in list(sd.items())[:10]}, bad)
+    with pytest.raises(RuntimeError, match='missing'):
+        _model(full_args(no_pretrained_backbone=False,
+                         rgb_encoder_backbone_pretrained_weights_filepath=bad,
+                         depth_encoder_backbone_pretrained_weights_filepath=bad))
