@@ -295,10 +295,21 @@ class InstanceDecoder(DecoderBody):
         if self.with_orientation:
             r['instance_orientation'] = out[2]
         if not self.training and self.postprocessing is not None:
-            # centre NMS / top-k and pixel grouping; the foreground comes from the batch when the
-            # reference's ground-truth-foreground key is present
-            fg = None if batch is None else batch.get('instance_segmentation_gt_foreground')
-            r.update(self.postprocessing(out[0], out[1], fg))
+            # centre NMS / top-k and pixel grouping.  The pure instance task groups inside the GROUND-TRUTH
+            # foreground: the dataset hands it over as batch['instance_foreground'] ((N,1,H,W) or (N,H,W)
+            # bool: /root/reference/emsanet/tests/test_interface_model.py:60-65, visualization.py:643) and
+            # the consumers read the result as 'instance_segmentation_gt_foreground'
+            # (visualization.py:607-620).  (Until round 6 the mask was looked up under
+            # the OUTPUT key, i.e. never found.)
+            fg = None
+            if batch is not None:
+                fg = batch.get('instance_foreground', batch.get('instance_segmentation_gt_foreground'))
+            if fg is not None and fg.dim() == 4:
+                fg = fg[:, 0]
+            res = self.postprocessing(out[0], out[1], fg)
+            r.update(res)
+            if fg is not None:
+                r['instance_segmentation_gt_foreground'] = res['instance_segmentation_idx']
         return r
 
 

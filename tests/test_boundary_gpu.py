@@ -234,6 +234,10 @@ def test_model_interface_reference_inputs(tasks, modalities, training, do_postpr
         assert outputs['semantic_output'].shape == (bs, 40, H, W)
         if not training:
             assert outputs['semantic_segmentation_idx'].shape == (bs, H, W)
+            if 'instance' in tasks:
+                # the key the reference's consumers read (visualization.py:607-620), grouped inside
+                # batch['instance_foreground']
+                assert outputs['instance_segmentation_gt_foreground'].shape == (bs, H, W)
     else:
         assert isinstance(outputs, list) and outputs
         assert len(outputs) == len(tasks) - ('orientation' in tasks)

@@ -193,3 +193,34 @@ def test_model_panoptic_postprocessing():
     pan, ps, pi = (r['panoptic_segmentation_deeplab'], r['panoptic_segmentation_deeplab_semantic_idx'],
                    r['panoptic_segmentation_deeplab_instance_idx'])
     assert torch.equal(pan, torch.where(ps < 0, torch.zeros_like(pan), (ps + 1) * 1000 + pi.long()))
+
+
+def test_instance_postprocessing_uses_the_batch_foreground():
+    """pure instance task, eval + do_postprocessing: pixels outside batch['instance_foreground'] get no
+    instance and the result is published under 'instance_segmentation_gt_foreground' -- the key
+    /root/reference/emsanet/visualization.py:607-620 reads; the mask arrives under the INPUT key of
+    /root/reference/emsanet/tests/test_interface_model.py:60-65"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    model = EMSANet(full_args(input_height=64, input_width=96), nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    fg = torch.zeros(2, 1, 64, 96, dtype=torch.bool, device=DEV)
+    fg[:, :, 16:48, 24:72] = True
+    with torch.no_grad():
+        free = model(batch, do_postprocessing=True)
+        masked = model({**batch, 'instance_foreground': fg}, do_postprocessing=True)
+    assert 'instance_segmentation_gt_foreground' not in free
+    ids = masked['instance_segmentation_gt_foreground']
+    assert ids.shape == (2, 64, 96)
+    assert int(ids[~fg[:, 0]].abs().max()) == 0               # nothing outside the ground-truth foreground
+    assert int(free['instance_segmentation_idx'][~fg[:, 0]].abs().max()) > 0
+    inside = fg[:, 0]
+    assert torch.equal(ids[inside] > 0, torch.ones_like(ids[inside], dtype=torch.bool)) or int((ids[inside] > 0).sum()) > 0
