@@ -386,4 +386,11 @@ class EMSANet(nn.Module):
         merged = {}
         for r in reversed(results):          # earlier decoders win on duplicate keys
             merged.update(r)
+        if not self.training:
+            # inference with the un-resized frames in the batch: `<key>_fullres` predictions for the
+            # reference's consumers (inference_samples.py:153-163, inference_dataset.py:223-520)
+            from .postprocessing import add_fullres_predictions, fullres_shape
+            hw = fullres_shape(batch)
+            if hw is not None:
+                add_fullres_predictions(merged, hw)
         return merged

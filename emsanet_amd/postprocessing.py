@@ -215,3 +215,62 @@ class PanopticPostprocessing:
         r['panoptic_segmentation_deeplab_semantic_idx'] = m['semantic']
         r['panoptic_segmentation_deeplab_instance_idx'] = m['instance']
         return r
+
+
+# ---------------------------------------------------------------------------------------------
+# full-resolution predictions
+# ---------------------------------------------------------------------------------------------
+_FULLRES_LABEL_KEYS = ('instance_segmentation_idx', 'instance_segmentation_gt_foreground',
+                       'panoptic_foreground_mask', 'panoptic_segmentation_deeplab',
+                       'panoptic_segmentation_deeplab_semantic_idx',
+                       'panoptic_segmentation_deeplab_instance_idx', 'scene_class_idx')
+
+
+def fullres_shape(batch):
+    """(H, W) of the full-resolution frames the batch carries (`rgb_fullres` / `depth_fullres`,
+    /root/reference/emsanet/tests/test_interface_model.py:86-91), or None"""
+    for k in ('rgb_fullres', 'depth_fullres', 'rgbd_fullres'):
+        t = batch.get(k) if batch is not None else None
+        if torch.is_tensor(t) and t.dim() >= 2:
+            return int(t.shape[-2]), int(t.shape[-1])
+    return None
+
+
+def add_fullres_predictions(r, hw):
+    """`<key>_fullres` entries of the post-processed dict -- what the reference's consumers read through
+    `get_fullres(prediction, key)` (/root/reference/inference_dataset.py:223-225,284,298,411,468-520;
+    inference_samples.py:153-163): predictions at the resolution of the un-resized input frames.
+    How the un-vendored library resamples is [U]; here: the semantic LOGITS are up-sampled bilinearly
+    (align_corners=False, `emsa_bilinear_fwd_t`) and arg-max / softmax score are taken at full
+    resolution (`emsa_softmax_argmax`); label maps (instance / panoptic ids, masks) are resampled with
+    nearest neighbour (`emsa_nearest_fwd_t` on their exact fp32 image: ids < 2^24).  Equal shapes: the
+    plain entries are aliased."""
+    hf, wf = hw
+    out = {}
+    logits = r.get('semantic_output')
+    if logits is not None and 'semantic_segmentation_idx' in r:
+        n, c, h, w = logits.shape
+        if (h, w) == (hf, wf):
+            out['semantic_segmentation_idx_fullres'] = r['semantic_segmentation_idx']
+            out['semantic_segmentation_score_fullres'] = r['semantic_segmentation_score']
+        else:
+            x = Fn.as_act(logits.float() if logits.dtype != torch.float32 else logits, dense=True)
+            big = Fn.act_empty(n, c, hf, wf, x.device)
+            Fn.bilinear_fwd(x, big)
+            score, idx = softmax_argmax(big)
+            out['semantic_segmentation_idx_fullres'] = idx
+            out['semantic_segmentation_score_fullres'] = score
+    for k in _FULLRES_LABEL_KEYS:
+        t = r.get(k)
+        if not torch.is_tensor(t) or t.dim() != 3:
+            continue
+        n, h, w = t.shape
+        if (h, w) == (hf, wf):
+            out[k + '_fullres'] = t
+            continue
+        x = Fn.as_act(t.to(torch.float32).unsqueeze(1), dense=True)
+        big = Fn.act_empty(n, 1, hf, wf, x.device)
+        Fn.nearest_fwd(x, big)
+        out[k + '_fullres'] = big[:, 0].to(t.dtype)
+    r.update(out)
+    return r

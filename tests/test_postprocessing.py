@@ -224,3 +224,46 @@ def test_instance_postprocessing_uses_the_batch_foreground():
     assert int(free['instance_segmentation_idx'][~fg[:, 0]].abs().max()) > 0
     inside = fg[:, 0]
     assert torch.equal(ids[inside] > 0, torch.ones_like(ids[inside], dtype=torch.bool)) or int((ids[inside] > 0).sum()) > 0
+
+
+def test_fullres_predictions():
+    """eval + do_postprocessing with the un-resized frames in the batch (`rgb_fullres`,
+    /root/reference/emsanet/tests/test_interface_model.py:86-91): the `<key>_fullres` entries the
+    reference's scripts read (inference_samples.py:153-163, inference_dataset.py:223-520) exist at the
+    frame's resolution -- semantic arg-max of the bilinearly up-sampled logits, label maps resampled
+    with nearest neighbour -- and alias the plain entries when the resolutions are equal"""
+    import os
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    model = EMSANet(full_args(input_height=64, input_width=96, enable_panoptic=True), nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    full = torch.zeros(2, 3, 150, 201, device=DEV)
+    with torch.no_grad():
+        r = model({**batch, 'rgb_fullres': full}, do_postprocessing=True)
+        same = model({**batch, 'rgb_fullres': batch['rgb']}, do_postprocessing=True)
+        plain = model(batch, do_postprocessing=True)
+    assert not any(k.endswith('_fullres') for k in plain)
+    for k in ('semantic_segmentation_idx', 'semantic_segmentation_score', 'panoptic_segmentation_deeplab',
+              'panoptic_segmentation_deeplab_semantic_idx', 'panoptic_segmentation_deeplab_instance_idx',
+              'instance_segmentation_idx', 'panoptic_foreground_mask'):
+        assert r[k + '_fullres'].shape == (2, 150, 201), k
+        assert r[k + '_fullres'].dtype == r[k].dtype, k
+        assert same[k + '_fullres'] is same[k], k
+    logits = r['semantic_output'].float().cpu()
+    up = F.interpolate(logits, (150, 201), mode='bilinear', align_corners=False)
+    sc, ix = torch.softmax(up, 1).max(1)
+    got_ix = r['semantic_segmentation_idx_fullres'].cpu()
+    agree = (got_ix == ix).float().mean().item()
+    assert agree >= 0.999, agree                        # (ties / fp32 interpolation order)
+    assert (r['semantic_segmentation_score_fullres'].cpu() - sc).abs().max().item() <= 1e-4
+    pan = r['panoptic_segmentation_deeplab'].cpu()
+    ref = F.interpolate(pan[:, None].float(), (150, 201), mode='nearest')[:, 0].to(pan.dtype)
+    assert torch.equal(r['panoptic_segmentation_deeplab_fullres'].cpu(), ref)
