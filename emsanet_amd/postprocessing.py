@@ -201,6 +201,12 @@ class PanopticPostprocessing:
         self.is_thing = tuple(bool(t) for t in semantic_classes_is_thing)
         self.label_divisor = label_divisor
 
+    @property
+    def max_instances_per_category(self):
+        """the attribute /root/reference/inference_dataset.py:723-724 reads off
+        `model.decoders['panoptic_helper'].postprocessing`: panoptic id = (class + 1) * this + instance"""
+        return self.label_divisor
+
     def __call__(self, semantic_logits, center, offset):
         score, idx = softmax_argmax(semantic_logits)
         thing = thing_table(self.is_thing, idx.device).bool()[idx]           # (N,H,W) bool

@@ -1134,3 +1134,44 @@ def test_eval_after_stats_only_train_forward_sees_new_running_stats():
         after = blk(to_act(x0))
         close(after, ref(x0), tol=2e-4, what='eval after recalibration')
         assert float((after - before).abs().max()) > 1e-2      # (the statistics did move)
+
+
+def test_sanity_check_flow_of_main_py_leaves_running_statistics_alone():
+    """/root/reference/main.py:486-498: before training, the reference forwards one batch in TRAIN mode
+    with `track_running_stats = False` on every module that has the attribute, then switches it back on.
+    The engine never calls nn.BatchNorm2d.forward, so it has to honour the flag itself: no running
+    statistic and no step counter moves while it is off, batch statistics are still used (outputs ==
+    the tracked pass's), and tracking resumes afterwards."""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from util import deterministic_state_dict
+    model = EMSANet(full_args(input_height=64, input_width=96), nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).train()
+    model.dropout_seed = 3
+    g = torch.Generator().manual_seed(9)
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    for m in model.modules():
+        if hasattr(m, 'track_running_stats'):
+            m.track_running_stats = False
+    model.dropout_step = 0
+    with torch.no_grad():
+        out_off = [t.clone() for t in _flatten(model(batch))]
+    after = model.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), f"{k} moved with track_running_stats = False"
+    for m in model.modules():
+        if hasattr(m, 'track_running_stats'):
+            m.track_running_stats = True
+    model.dropout_step = 0
+    with torch.no_grad():
+        out_on = _flatten(model(batch))
+    for a, b in zip(out_off, out_on):
+        assert torch.equal(a, b)                       # batch statistics either way
+    after = model.state_dict()
+    moved = [k for k in before if 'running_mean' in k and not torch.equal(before[k], after[k])]
+    assert len(moved) > 100
+    k = next(k for k in after if k.endswith('num_batches_tracked'))
+    assert int(after[k]) == int(before[k]) + 1

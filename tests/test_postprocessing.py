@@ -193,6 +193,8 @@ def test_model_panoptic_postprocessing():
     pan, ps, pi = (r['panoptic_segmentation_deeplab'], r['panoptic_segmentation_deeplab_semantic_idx'],
                    r['panoptic_segmentation_deeplab_instance_idx'])
     assert torch.equal(pan, torch.where(ps < 0, torch.zeros_like(pan), (ps + 1) * 1000 + pi.long()))
+    # (the attribute /root/reference/inference_dataset.py:723-724 reads)
+    assert model.decoders['panoptic_helper'].postprocessing.max_instances_per_category == 1000
 
 
 def test_instance_postprocessing_uses_the_batch_foreground():
