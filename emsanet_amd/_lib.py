@@ -148,6 +148,10 @@ SIGNATURES = {
                                      _P, c_int32, _P, c_float, _P, _P]),
     'emsa_panoptic_merge': (c_int, [_P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_int32, _P, _P,
                                     _P, _P, _P, _P]),
+    'emsa_instance_stats': (c_int, [_P, _P, _P, c_int32, c_int64, c_int32, _P, _P, _P]),
+    'emsa_panoptic_scores': (c_int, [_P, _P, _P, _P, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P,
+                                     _P, _P]),
+    'emsa_instance_orientation': (c_int, [_P, c_int32, _P, _P, c_int32, c_int64, c_int32, _P, _P, _P]),
     'emsa_normalize_rgb': (c_int, [_P, _P, c_int32, c_int32, c_int32, c_float, _P, _P, _P]),
     'emsa_normalize_depth': (c_int, [_P, _P, c_int64, c_float, c_float, c_int32, _P]),
     'emsa_sgd_nesterov': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,

@@ -267,7 +267,9 @@ __global__ void panoptic_class_kernel(const int32_t* __restrict__ votes, int n_c
 }
 
 // per pixel: thing pixel with an instance -> (instance class, id); stuff pixel -> (class, 0);
-// thing pixel without an instance -> void.  panoptic id = (class + 1) * label_divisor + id, 0 = void
+// thing pixel without an instance -> void.  panoptic id = (class + 1) * label_divisor + id, 0 = void;
+// the semantic part is published in the label list WITH void, like the id: class + 1, 0 = void
+// (/root/reference/inference_dataset.py:298-304 "already has void class", visualization.py:726-727)
 __global__ void panoptic_merge_kernel(const int64_t* __restrict__ sem, const int32_t* __restrict__ ids,
                                       const uint8_t* __restrict__ is_thing,
                                       const int32_t* __restrict__ cls, long hw, long total,
@@ -288,10 +290,161 @@ __global__ void panoptic_merge_kernel(const int64_t* __restrict__ sem, const int
         if (k >= 0) { oc = k; oi = id; }
       }
     }
-    pan_sem[i] = oc;
+    pan_sem[i] = oc + 1;                      // WITH void: 0 = void, class c -> c + 1 (see emsa_panoptic_merge)
     pan_inst[i] = oi;
     pan_id[i] = oc < 0 ? 0 : (int64_t)(oc + 1) * label_divisor + oi;
   }
+}
+
+// ---- per-instance statistics, scores, orientations -------------------------------------------
+// Sums are taken in FIXED POINT with integer atomics, so they do not depend on the order the
+// pixels arrive in: the scores and angles derived from them are bit-reproducible and the numpy
+// oracle reproduces them exactly.
+constexpr int kStatSlotsLds = 1024;              // per-workgroup LDS histogram up to this many ids
+constexpr double kScoreOne = 1073741824.0;       // 2^30: scores in [0, 1]
+constexpr double kVecOne = 16777216.0;           // 2^24: orientation components, clamped to +-2^14
+
+__device__ __forceinline__ unsigned long long score_fixed(float v) {
+  if (!(v > 0.f)) return 0ull;                   // also NaN
+  if (v > 1.f) v = 1.f;
+  return (unsigned long long)((double)v * kScoreOne + 0.5);
+}
+
+__device__ __forceinline__ long long vec_fixed(float v) {
+  if (!(v == v)) return 0ll;
+  if (v > 16384.f) v = 16384.f;
+  if (v < -16384.f) v = -16384.f;
+  return __double2ll_rn((double)v * kVecOne);
+}
+
+// grid = (blocks per image, images).  area[n][slots] += 1 and sum[n][slots] += fixed(value) for every
+// pixel with 0 < id < slots (and mask != 0)
+template <bool LDS>
+__global__ void instance_stats_kernel(const int32_t* __restrict__ ids, const float* __restrict__ value,
+                                      const uint8_t* __restrict__ mask, long hw, int slots,
+                                      unsigned long long* __restrict__ sum, int32_t* __restrict__ area) {
+  __shared__ unsigned long long s_sum[LDS ? kStatSlotsLds : 1];
+  __shared__ int s_area[LDS ? kStatSlotsLds : 1];
+  const long img = blockIdx.y;
+  if (LDS) {
+    for (int k = threadIdx.x; k < slots; k += blockDim.x) { s_sum[k] = 0ull; s_area[k] = 0; }
+    __syncthreads();
+  }
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < hw;
+       q += (long)gridDim.x * blockDim.x) {
+    const long i = img * hw + q;
+    const int id = ids[i];
+    if (id <= 0 || id >= slots || (mask && !mask[i])) continue;
+    if (LDS) {
+      atomicAdd(s_area + id, 1);
+      if (value) atomicAdd(s_sum + id, score_fixed(value[i]));
+    } else {
+      atomicAdd(area + img * slots + id, 1);
+      if (value) atomicAdd(sum + img * slots + id, score_fixed(value[i]));
+    }
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < slots; k += blockDim.x)
+      if (s_area[k]) {
+        atomicAdd(area + img * slots + k, s_area[k]);
+        if (value) atomicAdd(sum + img * slots + k, s_sum[k]);
+      }
+  }
+}
+
+// vec[n][slots][2] += fixed(orientation[pixel][0..1]), count[n][slots] += 1
+template <bool LDS>
+__global__ void instance_orientation_kernel(const float* __restrict__ ori, int ld,
+                                            const int32_t* __restrict__ ids,
+                                            const uint8_t* __restrict__ mask, long hw, int slots,
+                                            long long* __restrict__ vec, int32_t* __restrict__ count) {
+  __shared__ unsigned long long s_vec[LDS ? 2 * kStatSlotsLds : 1];
+  __shared__ int s_cnt[LDS ? kStatSlotsLds : 1];
+  const long img = blockIdx.y;
+  if (LDS) {
+    for (int k = threadIdx.x; k < slots; k += blockDim.x) {
+      s_vec[2 * k] = 0ull; s_vec[2 * k + 1] = 0ull; s_cnt[k] = 0;
+    }
+    __syncthreads();
+  }
+  unsigned long long* gv = (unsigned long long*)vec;     // two's complement: wrap-around adds
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < hw;
+       q += (long)gridDim.x * blockDim.x) {
+    const long i = img * hw + q;
+    const int id = ids[i];
+    if (id <= 0 || id >= slots || (mask && !mask[i])) continue;
+    const unsigned long long a = (unsigned long long)vec_fixed(ori[i * ld]);
+    const unsigned long long b = (unsigned long long)vec_fixed(ori[i * ld + 1]);
+    if (LDS) {
+      atomicAdd(s_vec + 2 * id, a);
+      atomicAdd(s_vec + 2 * id + 1, b);
+      atomicAdd(s_cnt + id, 1);
+    } else {
+      atomicAdd(gv + (img * slots + id) * 2, a);
+      atomicAdd(gv + (img * slots + id) * 2 + 1, b);
+      atomicAdd(count + img * slots + id, 1);
+    }
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < slots; k += blockDim.x)
+      if (s_cnt[k]) {
+        atomicAdd(gv + (img * slots + k) * 2, s_vec[2 * k]);
+        atomicAdd(gv + (img * slots + k) * 2 + 1, s_vec[2 * k + 1]);
+        atomicAdd(count + img * slots + k, s_cnt[k]);
+      }
+  }
+}
+
+// per instance: mean semantic score of its pixels, and centre score x that mean
+__global__ void panoptic_instance_scores_kernel(const unsigned long long* __restrict__ sum,
+                                                const int32_t* __restrict__ area,
+                                                const float* __restrict__ center_scores, int slots,
+                                                int top_k, int total, float* __restrict__ inst_sem,
+                                                float* __restrict__ inst_pan) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int a = area[i];
+  const float mean = a > 0 ? (float)((double)sum[i] / (double)a / kScoreOne) : 0.f;
+  const int id = i % slots;
+  const float cs = id >= 1 ? center_scores[(long)(i / slots) * top_k + id - 1] : 0.f;
+  inst_sem[i] = mean;
+  inst_pan[i] = __fmul_rn(cs, mean);
+}
+
+// per pixel: instance pixel -> (mean semantic score, centre score, product) of its instance;
+// stuff pixel -> (own semantic score, 0, own semantic score); void -> 0
+__global__ void panoptic_pixel_scores_kernel(const float* __restrict__ sem_score,
+                                             const int32_t* __restrict__ pan_inst,
+                                             const int64_t* __restrict__ pan_sem,
+                                             const float* __restrict__ center_scores,
+                                             const float* __restrict__ inst_sem,
+                                             const float* __restrict__ inst_pan, long hw, long total,
+                                             int slots, int top_k, float* __restrict__ o_sem,
+                                             float* __restrict__ o_inst, float* __restrict__ o_pan) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int id = pan_inst[i];
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (id > 0 && id < slots) {
+      const long img = i / hw;
+      a = inst_sem[img * slots + id];
+      b = center_scores[img * top_k + id - 1];
+      c = inst_pan[img * slots + id];
+    } else if (pan_sem[i] > 0) {
+      a = sem_score[i];
+      c = a;
+    }
+    o_sem[i] = a;
+    o_inst[i] = b;
+    o_pan[i] = c;
+  }
+}
+
+inline int stats_grid(long hw) {
+  long b = (hw + 1023) / 1024;                   // >= 4 pixels per thread: few LDS flushes
+  return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
 }
 
 inline int grid1d(long items) {
@@ -415,5 +568,69 @@ extern "C" int emsa_panoptic_merge(const int64_t* semantic_idx, const int32_t* i
   hipLaunchKernelGGL(panoptic_merge_kernel, dim3(grid1d(total)), dim3(256), 0, st, semantic_idx,
                      instance_ids, class_is_thing, ws_class, (long)hw, total, n_classes, slots,
                      label_divisor, pan_semantic, pan_instance, pan_id);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_instance_stats(const int32_t* ids, const float* value, const uint8_t* mask,
+                                   int32_t n, int64_t hw, int32_t slots, int64_t* sum,
+                                   int32_t* area, void* stream) {
+  if (!ids || !area || (value && !sum)) return EMSA_E_ARG;
+  if (n < 1 || hw < 1 || slots < 2) return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  emsa_zero_async(area, (size_t)n * slots * sizeof(int32_t), st);
+  if (value) emsa_zero_async(sum, (size_t)n * slots * sizeof(int64_t), st);
+  const dim3 grid(stats_grid(hw), n);
+  if (slots <= kStatSlotsLds)
+    hipLaunchKernelGGL(instance_stats_kernel<true>, grid, dim3(256), 0, st, ids, value, mask,
+                       (long)hw, slots, (unsigned long long*)sum, area);
+  else
+    hipLaunchKernelGGL(instance_stats_kernel<false>, grid, dim3(256), 0, st, ids, value, mask,
+                       (long)hw, slots, (unsigned long long*)sum, area);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_panoptic_scores(const float* semantic_score, const int32_t* pan_instance,
+                                    const int64_t* pan_semantic, const float* center_scores,
+                                    int32_t n, int64_t hw, int32_t top_k, int64_t* ws_sum,
+                                    int32_t* inst_area, float* inst_semantic_score,
+                                    float* inst_panoptic_score, float* semantic_score_out,
+                                    float* instance_score_out, float* panoptic_score_out,
+                                    void* stream) {
+  if (!semantic_score || !pan_instance || !pan_semantic || !center_scores || !ws_sum ||
+      !inst_area || !inst_semantic_score || !inst_panoptic_score || !semantic_score_out ||
+      !instance_score_out || !panoptic_score_out)
+    return EMSA_E_ARG;
+  if (n < 1 || hw < 1 || top_k < 1 || top_k > kMaxTopK) return EMSA_E_SHAPE;
+  const int slots = top_k + 1;
+  const int rc = emsa_instance_stats(pan_instance, semantic_score, nullptr, n, hw, slots, ws_sum,
+                                     inst_area, stream);
+  if (rc != EMSA_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(panoptic_instance_scores_kernel, dim3((n * slots + 255) / 256), dim3(256), 0,
+                     st, (const unsigned long long*)ws_sum, inst_area, center_scores, slots, top_k,
+                     n * slots, inst_semantic_score, inst_panoptic_score);
+  const long total = (long)n * hw;
+  hipLaunchKernelGGL(panoptic_pixel_scores_kernel, dim3(grid1d(total)), dim3(256), 0, st,
+                     semantic_score, pan_instance, pan_semantic, center_scores, inst_semantic_score,
+                     inst_panoptic_score, (long)hw, total, slots, top_k, semantic_score_out,
+                     instance_score_out, panoptic_score_out);
+  return emsa_launch_status();
+}
+
+extern "C" int emsa_instance_orientation(const float* orientation, int32_t ld, const int32_t* ids,
+                                         const uint8_t* mask, int32_t n, int64_t hw, int32_t slots,
+                                         int64_t* vec_sum, int32_t* count, void* stream) {
+  if (!orientation || !ids || !vec_sum || !count) return EMSA_E_ARG;
+  if (n < 1 || hw < 1 || ld < 2 || slots < 2) return EMSA_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  emsa_zero_async(vec_sum, (size_t)n * slots * 2 * sizeof(int64_t), st);
+  emsa_zero_async(count, (size_t)n * slots * sizeof(int32_t), st);
+  const dim3 grid(stats_grid(hw), n);
+  if (slots <= kStatSlotsLds)
+    hipLaunchKernelGGL(instance_orientation_kernel<true>, grid, dim3(256), 0, st, orientation, ld, ids,
+                       mask, (long)hw, slots, (long long*)vec_sum, count);
+  else
+    hipLaunchKernelGGL(instance_orientation_kernel<false>, grid, dim3(256), 0, st, orientation, ld,
+                       ids, mask, (long)hw, slots, (long long*)vec_sum, count);
   return emsa_launch_status();
 }

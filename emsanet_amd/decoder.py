@@ -20,7 +20,8 @@ from . import functional as Fn
 from . import ops
 from .nn import (ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt,
                  plain_conv)
-from .postprocessing import InstancePostprocessing, PanopticPostprocessing, softmax_argmax
+from .postprocessing import (InstancePostprocessing, PanopticPostprocessing, gt_instance_orientations,
+                             softmax_argmax)
 
 _FUSIONS = ('add-rgb', 'add-depth', 'add-rgbd', 'add')     # encoder -> decoder skip fusions built here
 
@@ -306,10 +307,15 @@ class InstanceDecoder(DecoderBody):
                 fg = batch.get('instance_foreground', batch.get('instance_segmentation_gt_foreground'))
             if fg is not None and fg.dim() == 4:
                 fg = fg[:, 0]
-            res = self.postprocessing(out[0], out[1], fg)
+            res = self.postprocessing(out[0], out[1], fg, with_meta=True)
             r.update(res)
             if fg is not None:
                 r['instance_segmentation_gt_foreground'] = res['instance_segmentation_idx']
+                r['instance_segmentation_gt_meta'] = res['instance_segmentation_meta']
+            if len(out) > 2:
+                o = gt_instance_orientations(out[2], batch)
+                if o is not None:
+                    r['orientations_gt_instance_gt_orientation_foreground'] = o
         return r
 
 
@@ -320,13 +326,15 @@ class PanopticHelper(nn.Module):
     ((semantic logits, instance outputs), (semantic side outputs, instance side outputs))
     (inference_time_whole_model.py:324-333), eval post-processing = Panoptic-DeepLab merge."""
 
-    def __init__(self, semantic_decoder, instance_decoder, classes_is_thing):
+    def __init__(self, semantic_decoder, instance_decoder, classes_is_thing, class_has_orientation=None):
         super().__init__()
         self.semantic_decoder = semantic_decoder
         self.instance_decoder = instance_decoder
         self.side_output_downscales = semantic_decoder.side_output_downscales
-        self.postprocessing = PanopticPostprocessing(instance_decoder.postprocessing,
-                                                     classes_is_thing)
+        # (`compute_scores=True`: /root/reference/emsanet/decoder.py:152)
+        self.postprocessing = PanopticPostprocessing(
+            instance_decoder.postprocessing, classes_is_thing,
+            semantic_class_has_orientation=class_has_orientation, compute_scores=True)
 
     def forward(self, x, skips, batch=None, do_postprocessing=False):
         sem, sem_side = self.semantic_decoder(x, skips, batch, do_postprocessing=False)
@@ -339,7 +347,11 @@ class PanopticHelper(nn.Module):
         if len(inst) > 2:
             r['instance_orientation'] = inst[2]
         if not self.training:
-            r.update(self.postprocessing(sem, inst[0], inst[1]))
+            r.update(self.postprocessing(sem, inst[0], inst[1], inst[2] if len(inst) > 2 else None))
+            if len(inst) > 2:
+                o = gt_instance_orientations(inst[2], batch)
+                if o is not None:
+                    r['orientations_gt_instance_gt_orientation_foreground'] = o
         return r
 
 
@@ -443,7 +455,7 @@ def get_decoders(
         if 'semantic_decoder' not in decoders or 'instance_decoder' not in decoders:
             raise ValueError("enable_panoptic needs the semantic and the instance task")
         helper = PanopticHelper(decoders.pop('semantic_decoder'), decoders.pop('instance_decoder'),
-                                panoptic_semantic_classes_is_thing)
+                                panoptic_semantic_classes_is_thing, panoptic_has_orientation)
         decoders = OrderedDict([('panoptic_helper', helper)] + list(decoders.items()))
     if 'normal' in args.tasks:
         # /root/reference/emsanet/decoder.py:160-189

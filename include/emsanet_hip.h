@@ -475,14 +475,43 @@ int emsa_instance_assign(const float* offset, int32_t ld, int32_t n, int32_t h, 
                          float max_distance, int32_t* ids, void* stream);
 /* panoptic merge: every instance (ids from emsa_instance_assign on the thing pixels) takes the
  * majority semantic class of its pixels; stuff pixels keep their class; thing pixels without an
- * instance become void.  pan_semantic (-1 = void), pan_instance, pan_id = (class+1)*label_divisor
- * + instance (0 = void).  class_is_thing uint8[n_classes] (DEVICE); ws_votes int32[n*(top_k+1)*
- * n_classes], ws_class int32[n*(top_k+1)] scratch.                                              */
+ * instance become void.  pan_semantic is in the label list WITH void (0 = void, class c -> c + 1:
+ * /root/reference/inference_dataset.py:298-304, emsanet/visualization.py:726-727; until round 6
+ * it was c with -1 = void), pan_instance, pan_id = pan_semantic * label_divisor + instance
+ * (0 = void; emsanet/tests/test_metrics_with_model.py:113-131).  class_is_thing uint8[n_classes]
+ * (DEVICE); ws_votes int32[n*(top_k+1)*n_classes] scratch; ws_class int32[n*(top_k+1)]: on return
+ * the class (WITHOUT void, -1 = no pixel) of every instance slot.                               */
 int emsa_panoptic_merge(const int64_t* semantic_idx, const int32_t* instance_ids,
                         const uint8_t* class_is_thing, int32_t n, int64_t hw, int32_t n_classes,
                         int32_t top_k, int32_t label_divisor, int32_t* ws_votes,
                         int32_t* ws_class, int64_t* pan_semantic, int32_t* pan_instance,
                         int64_t* pan_id, void* stream);
+/* per-instance pixel count and (value != NULL) fixed-point sum of a [0, 1] score map:
+ * area[n][slots] = #pixels with that id (0 < id < slots, mask NULL or != 0), sum[n][slots] =
+ * sum of floor(value * 2^30 + 0.5) -- integer atomics: independent of the pixel order.           */
+int emsa_instance_stats(const int32_t* ids, const float* value, const uint8_t* mask, int32_t n,
+                        int64_t hw, int32_t slots, int64_t* sum, int32_t* area, void* stream);
+/* the score maps / per-instance scores the reference's panoptic post-processing is built with
+ * (`compute_scores=True`, /root/reference/emsanet/decoder.py:152; consumers:
+ * inference_dataset.py:420-437,486-523): per instance the mean semantic score of its pixels and
+ * "score_instance_center * (mean_semantic_score_of_instance)" (inference_dataset.py:506-507); per
+ * pixel (semantic, instance, panoptic) score = those of its instance; stuff pixels: (own semantic
+ * score, 0, own semantic score); void: 0.  pan_instance / pan_semantic from emsa_panoptic_merge,
+ * center_scores float[n][top_k] from emsa_instance_centers; ws_sum int64[n*(top_k+1)] scratch;
+ * inst_* [n][top_k+1].                                                                         */
+int emsa_panoptic_scores(const float* semantic_score, const int32_t* pan_instance,
+                         const int64_t* pan_semantic, const float* center_scores, int32_t n,
+                         int64_t hw, int32_t top_k, int64_t* ws_sum, int32_t* inst_area,
+                         float* inst_semantic_score, float* inst_panoptic_score,
+                         float* semantic_score_out, float* instance_score_out,
+                         float* panoptic_score_out, void* stream);
+/* per-instance sum of the two orientation channels (pixel-major, row stride ld) in fixed point
+ * (round(v * 2^24), |v| clamped to 2^14): vec_sum int64[n][slots][2], count int32[n][slots]; the
+ * instance's angle is atan2 of the two sums (the `orientations_*` dictionaries of
+ * /root/reference/emsanet/visualization.py:752-813).                                            */
+int emsa_instance_orientation(const float* orientation, int32_t ld, const int32_t* ids,
+                              const uint8_t* mask, int32_t n, int64_t hw, int32_t slots,
+                              int64_t* vec_sum, int32_t* count, void* stream);
 int emsa_normalize_rgb(const uint8_t* rgb_hwc, float* out_chw, int32_t n, int32_t h, int32_t w,
                        float scale, const float* mean3, const float* std3, void* stream);
 int emsa_normalize_depth(const uint16_t* depth, float* out, int64_t total, float mean, float std,

@@ -164,7 +164,76 @@ def test_panoptic_merge_vs_oracle():
     ref = O.panoptic_merge(sem, ids, is_thing)
     for key in ('semantic', 'instance', 'panoptic'):
         assert torch.equal(got[key].cpu(), ref[key].to(got[key].dtype)), key
-    assert (got['semantic'] == -1).any() and (got['instance'] > 0).any()
+    assert (got['semantic'] == 0).any() and (got['instance'] > 0).any()     # 0 = void: WITH-void ids
+    assert int(got['semantic'].max()) <= nc
+
+
+def test_panoptic_scores_and_meta_vs_oracle():
+    """score maps + per-instance meta of `compute_scores=True` (/root/reference/emsanet/decoder.py:152;
+    consumers inference_dataset.py:412-437,486-533): bit-equal to the oracle (integer sums: no
+    dependence on the order of the atomics), twice in a row"""
+    from emsanet_amd.postprocessing import instance_meta, panoptic_merge, panoptic_scores
+    from oracle import postprocessing_oracle as O
+    g = torch.Generator().manual_seed(12)
+    n, h, w, nc, k = 2, 48, 64, 40, 16
+    is_thing = [bool(i % 3) for i in range(nc)]
+    sem = torch.randint(0, nc, (n, h // 4, w // 4), generator=g).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    ids = torch.randint(0, 9, (n, h // 8, w // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    ids = ids.to(torch.int32)
+    score = torch.rand(n, h, w, generator=g)
+    cscore = torch.rand(n, k, generator=g)
+    centers = torch.rand(n, k, 2, generator=g) * 40
+    ncen = torch.tensor([9, 8], dtype=torch.int32)
+    m = panoptic_merge(sem.to(DEV), ids.to(DEV), is_thing, top_k=k)
+    ref_m = O.panoptic_merge(sem, ids, is_thing)
+    rs, ri, rp, per = O.panoptic_scores(score, ref_m['instance'], ref_m['semantic'], list(cscore))
+    for _ in range(2):
+        got = panoptic_scores(score.to(DEV), m['instance'], m['semantic'], cscore.to(DEV))
+        assert torch.equal(got['semantic_score'].cpu(), rs)
+        assert torch.equal(got['instance_score'].cpu(), ri)
+        assert torch.equal(got['panoptic_score'].cpu(), rp)
+    meta = instance_meta(centers.to(DEV), cscore.to(DEV), ncen.to(DEV), got['area'], m['instance_class'],
+                         got['instance_semantic_score'], got['instance_panoptic_score'])
+    assert len(meta) == n
+    import copy
+    import json
+    json.dumps(list(copy.deepcopy(meta)))                    # what inference_dataset.py:541-542 does
+    seen = 0
+    for i in range(n):
+        assert sorted(meta[i]) == list(range(1, int(ncen[i]) + 1))
+        for j, e in meta[i].items():
+            if j in per[i]:
+                area, mean, pan = per[i][j]
+                cls = int(ref_m['semantic'][i][ref_m['instance'][i] == j][0])
+                assert (e['area'], e['semantic_idx']) == (area, cls)
+                assert e['semantic_score'] == mean and e['panoptic_score'] == pan
+                assert e['score'] == float(cscore[i, j - 1])
+                seen += 1
+            else:
+                assert e['area'] == 0 and 'semantic_idx' not in e
+    assert seen > 6
+
+
+@pytest.mark.parametrize('slots', [12, 1500])
+def test_instance_orientations_vs_oracle(slots):
+    """{instance id: angle}: atan2 of the per-instance sums of the (sin, cos) prediction, with and
+    without a mask; LDS histogram (<= 1024 ids) and global-atomics variant"""
+    from emsanet_amd.postprocessing import instance_orientation_sums, orientation_dicts
+    from oracle import postprocessing_oracle as O
+    g = torch.Generator().manual_seed(13)
+    n, h, w = 2, 40, 56
+    ids = torch.randint(0, 9, (n, h // 8, w // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    if slots > 1024:
+        ids = ids * 150
+    ids = ids.to(torch.int32)
+    ori = torch.nn.functional.normalize(torch.randn(n, 2, h, w, generator=g), dim=1)
+    mask = torch.rand(n, h, w, generator=g) > 0.3
+    for mk in (None, mask):
+        vec, cnt = instance_orientation_sums(ori.to(DEV), ids.to(DEV), slots, None if mk is None else mk.to(DEV))
+        got = orientation_dicts(vec, cnt)
+        ref = O.instance_orientations(ori, ids, mk)
+        assert list(got) == ref
+        assert sum(len(d) for d in ref) > 8
 
 
 def test_model_panoptic_postprocessing():
@@ -192,7 +261,23 @@ def test_model_panoptic_postprocessing():
         assert k in r, k
     pan, ps, pi = (r['panoptic_segmentation_deeplab'], r['panoptic_segmentation_deeplab_semantic_idx'],
                    r['panoptic_segmentation_deeplab_instance_idx'])
-    assert torch.equal(pan, torch.where(ps < 0, torch.zeros_like(pan), (ps + 1) * 1000 + pi.long()))
+    # semantic part WITH void (0 = void): panoptic id = semantic * divisor + instance
+    # (/root/reference/inference_dataset.py:298-304, emsanet/tests/test_metrics_with_model.py:113-131)
+    assert int(ps.min()) >= 0 and int(ps.max()) <= 40
+    assert torch.equal(pan, ps * 1000 + pi.long())
+    assert torch.equal(ps == 0, pan == 0)
+    for k in ('panoptic_segmentation_deeplab_semantic_score', 'panoptic_segmentation_deeplab_instance_score',
+              'panoptic_segmentation_deeplab_panoptic_score'):
+        assert r[k].shape == (2, 64, 96) and r[k].dtype == torch.float32
+        assert float(r[k].min()) >= 0 and float(r[k].max()) <= 1
+    meta = r['panoptic_segmentation_deeplab_instance_meta']
+    assert len(meta) == 2
+    for i in range(2):
+        for j, e in meta[i].items():
+            assert e['area'] == int((pi[i] == j).sum())
+            if e['area']:
+                assert e['semantic_idx'] == int(ps[i][pi[i] == j][0])
+    assert len(r['orientations_panoptic_segmentation_deeplab_instance']) == 2   # full_args: with orientation
     # (the attribute /root/reference/inference_dataset.py:723-724 reads)
     assert model.decoders['panoptic_helper'].postprocessing.max_instances_per_category == 1000
 
@@ -269,3 +354,93 @@ def test_fullres_predictions():
     pan = r['panoptic_segmentation_deeplab'].cpu()
     ref = F.interpolate(pan[:, None].float(), (150, 201), mode='nearest')[:, 0].to(pan.dtype)
     assert torch.equal(r['panoptic_segmentation_deeplab_fullres'].cpu(), ref)
+
+
+@pytest.mark.parametrize('panoptic', [True, False])
+def test_model_orientation_dictionaries(panoptic):
+    """eval + do_postprocessing with the orientation task: the per-instance angle dictionaries the
+    reference's visualisation / orientation metric read (/root/reference/emsanet/visualization.py:
+    749-813,905-914) -- 'orientations_panoptic_segmentation_deeplab_instance' (panoptic instances of a
+    class that uses orientations) and 'orientations_gt_instance_gt_orientation_foreground' (ground-
+    truth instances inside batch['orientation_foreground']) -- equal to the oracle's on the engine's
+    own raw orientation output; plus 'instance_segmentation_gt_meta' for the pure instance task"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from oracle import postprocessing_oracle as O
+    cfg = nyuv2_config()
+    args = full_args(input_height=64, input_width=96, enable_panoptic=panoptic,
+                     tasks=('semantic', 'scene', 'instance', 'orientation'))
+    model = EMSANet(args, cfg)
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    gt = torch.randint(0, 6, (2, 8, 12), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    ofg = (gt > 0) & (torch.rand(2, 64, 96, generator=g) > 0.2)
+    fg = torch.zeros(2, 1, 64, 96, dtype=torch.bool)
+    fg[:, :, 8:56, 8:88] = True
+    batch = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV),
+             'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV),
+             'instance': gt.to(DEV), 'orientation_foreground': ofg.to(DEV),
+             'instance_foreground': fg.to(DEV)}
+    with torch.no_grad():
+        r = model(batch, do_postprocessing=True)
+        no_gt = model({k: batch[k] for k in ('rgb', 'depth')}, do_postprocessing=True)
+    ori = r['instance_orientation'].float().cpu()
+    assert 'orientations_gt_instance_gt_orientation_foreground' not in no_gt
+    got = r['orientations_gt_instance_gt_orientation_foreground']
+    ref = O.instance_orientations(ori, gt, ofg)
+    assert list(got) == ref and sum(len(d) for d in ref) >= 5
+    assert all(0.0 <= a < 6.2832 for d in got for a in d.values())
+    if panoptic:
+        ids = r['panoptic_segmentation_deeplab_instance_idx'].cpu()
+        sem = r['panoptic_segmentation_deeplab_semantic_idx'].cpu()
+        use = [False] + [bool(u) for u in cfg.semantic_label_list_without_void.classes_use_orientations]
+        ref = O.instance_orientations(ori, ids)
+        ref = [{j: a for j, a in d.items() if use[int(sem[i][ids[i] == j][0])]} for i, d in enumerate(ref)]
+        assert list(r['orientations_panoptic_segmentation_deeplab_instance']) == ref
+        assert 'orientations_panoptic_segmentation_deeplab_instance' in no_gt
+    else:
+        meta = r['instance_segmentation_gt_meta']
+        idx = r['instance_segmentation_gt_foreground'].cpu()
+        for i in range(2):
+            assert sorted(meta[i]) == list(range(1, int(r['instance_predicted_centers_count'][i]) + 1))
+            for j, e in meta[i].items():
+                assert e['area'] == int((idx[i] == j).sum()) and 'semantic_idx' not in e
+        assert 'instance_segmentation_gt_meta' not in no_gt
+
+
+def test_deferred_dictionaries_under_a_captured_eval_forward():
+    """`GraphedInference(..., do_postprocessing=True)` captures the post-processing: the meta /
+    orientation dictionaries must not copy to the host while capturing; read after a replay they
+    describe THAT replay's outputs (refresh())"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from util import deterministic_state_dict
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.graph import GraphedInference
+    from emsanet_amd.model import EMSANet
+    args = full_args(input_height=64, input_width=96, enable_panoptic=True,
+                     tasks=('semantic', 'scene', 'instance', 'orientation'))
+    model = EMSANet(args, nyuv2_config())
+    model.load_state_dict(deterministic_state_dict(model))
+    model.to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    b1 = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV), 'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    b2 = {'rgb': torch.randn(2, 3, 64, 96, generator=g).to(DEV), 'depth': torch.randn(2, 1, 64, 96, generator=g).to(DEV)}
+    with torch.no_grad():
+        e1 = model(b1, do_postprocessing=True)
+        e2 = model(b2, do_postprocessing=True)
+    gi = GraphedInference(model, b1, do_postprocessing=True)
+    for b, e in ((b1, e1), (b2, e2), (b1, e1)):
+        out = gi(b)
+        torch.cuda.synchronize()
+        for k in ('panoptic_segmentation_deeplab_instance_meta', 'orientations_panoptic_segmentation_deeplab_instance'):
+            assert list(out[k].refresh()) == list(e[k]), k
+        assert torch.equal(out['panoptic_segmentation_deeplab_panoptic_score'],
+                           e['panoptic_segmentation_deeplab_panoptic_score'])
+    assert list(e1['panoptic_segmentation_deeplab_instance_meta']) != list(e2['panoptic_segmentation_deeplab_instance_meta'])

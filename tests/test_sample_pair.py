@@ -172,3 +172,14 @@ def test_real_sample_postprocessing_on_a_real_heatmap():
     ref_p = O.panoptic_merge(idx.long(), got_ids.to(torch.int32), is_thing)
     assert torch.equal(r['panoptic_segmentation_deeplab'].cpu().long(), ref_p['panoptic'].long())
     assert torch.equal(r['panoptic_segmentation_deeplab_semantic_idx'].cpu().long(), ref_p['semantic'].long())
+    # score maps / meta of `compute_scores=True` (ref decoder.py:152) on the real frame: bit-equal
+    rs, ri, rp, per = O.panoptic_scores(r['semantic_segmentation_score'].cpu(), ref_p['instance'],
+                                        ref_p['semantic'],
+                                        list(r['instance_predicted_centers_scores'].cpu()))
+    assert torch.equal(r['panoptic_segmentation_deeplab_semantic_score'].cpu(), rs)
+    assert torch.equal(r['panoptic_segmentation_deeplab_instance_score'].cpu(), ri)
+    assert torch.equal(r['panoptic_segmentation_deeplab_panoptic_score'].cpu(), rp)
+    meta = r['panoptic_segmentation_deeplab_instance_meta'][0]
+    assert sorted(meta) == list(range(1, k + 1))
+    for j, (area, mean, pan) in per[0].items():
+        assert (meta[j]['area'], meta[j]['semantic_score'], meta[j]['panoptic_score']) == (area, mean, pan)
