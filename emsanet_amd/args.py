@@ -80,6 +80,13 @@ _DEFAULTS = {
     'instance_no_multiscale_supervision': (False, 757),
     'orientation_kappa': (1.0, 766),
     'scene_loss_label_smoothing': (0.1, 791),
+    # optimizer / schedule
+    'optimizer': ('sgd', 661),
+    'learning_rate': (0.01, 668),
+    'learning_rate_scheduler': ('onecycle', 676),
+    'momentum': (0.9, 684),
+    'weight_decay': (1e-4, 690),
+    'n_epochs': (500, 649),
     'he_init': (('encoder-fusion',), 626),
     'no_zero_init_decoder_residuals': (False, 640),
     'debug': (False, 1116),

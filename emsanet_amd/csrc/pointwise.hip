@@ -2489,6 +2489,86 @@ __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Adam / AdamW / RAdam over one flat bucket: the other three optimizers the reference's factory
+// builds (/root/reference/emsanet/optimizer.py:37-57: betas (0.9, 0.999), torch's eps 1e-8, weight
+// decay as L2 for adam / radam and decoupled for adamw).  The arithmetic follows torch.optim's
+// single-tensor paths:
+//   g' = g * grad_scale (+ wd * p for adam / radam);   adamw: p *= 1 - lr * wd
+//   m += (g' - m) * (1 - b1);   v = b2 * v + (1 - b2) * g'^2
+//   adam / adamw:  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+//   radam:         p -= (m / bc1) * lr * (rho_t > 5 ? sqrt(bc2) / (sqrt(v) + eps) * rect : 1)
+// hyper (double[8], host-owned): {lr, b1, b2, eps, wd, grad_scale, mode (0 adam, 1 adamw, 2 radam)}
+// state (double[8], DEVICE-owned): {t, lr / bc1, bc1, sqrt(bc2), rect, rho_t > 5} -- advanced by a
+// one-thread kernel in front of the bucket launches, so that a step captured in a hipGraph counts
+// its own replays; the step-dependent scalars are formed in double like torch's Python floats.
+// One pass: reads p, g, m, v, writes p, m, v.
+// ------------------------------------------------------------------------------------------
+__global__ void adam_advance_kernel(const double* __restrict__ hp, double* __restrict__ st) {
+  const double b1 = hp[1], b2 = hp[2];
+  const double t = st[0] + 1.0;
+  const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+  const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+  const double rho_t = rho_inf - 2.0 * t * pow(b2, t) / bc2;
+  double rect = 0.0;
+  if (rho_t > 5.0)
+    rect = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+  st[0] = t;
+  st[1] = hp[0] / bc1;
+  st[2] = bc1;
+  st[3] = sqrt(bc2);
+  st[4] = rect;
+  st[5] = rho_t > 5.0 ? 1.0 : 0.0;
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float b1,
+                                         float b2, float eps, float wd, float gs, int mode,
+                                         float step_size, float bc1, float bc2_sqrt, float rect,
+                                         bool use_rect) {
+  float gg = g * gs;
+  if (mode == 1) p = p * (1.f - lr * wd);
+  else if (wd != 0.f) gg = gg + wd * p;
+  m = m + (gg - m) * (1.f - b1);
+  v = b2 * v + (1.f - b2) * gg * gg;
+  if (mode != 2) {
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+  } else {
+    const float mh = m / bc1;
+    p = use_rect ? p - mh * lr * (bc2_sqrt / (sqrtf(v) + eps)) * rect : p - mh * lr;
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n4, long n, const double* __restrict__ hp,
+                            const double* __restrict__ st) {
+#pragma clang fp contract(off)
+  const float lr = (float)hp[0], b1 = (float)hp[1], b2 = (float)hp[2], eps = (float)hp[3];
+  const float wd = (float)hp[4], gs = (float)hp[5];
+  const int mode = (int)hp[6];
+  const float step_size = (float)st[1], bc1 = (float)st[2], bc2_sqrt = (float)st[3];
+  const float rect = (float)st[4];
+  const bool use_rect = st[5] != 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    float4 pv = emsa_ld4(p + i * 4), mv = emsa_ld4(m + i * 4), vv = emsa_ld4(v + i * 4);
+    const float4 gv = emsa_ld4(g + i * 4);
+    adam_one(pv.x, gv.x, mv.x, vv.x, lr, b1, b2, eps, wd, gs, mode, step_size, bc1, bc2_sqrt, rect, use_rect);
+    adam_one(pv.y, gv.y, mv.y, vv.y, lr, b1, b2, eps, wd, gs, mode, step_size, bc1, bc2_sqrt, rect, use_rect);
+    adam_one(pv.z, gv.z, mv.z, vv.z, lr, b1, b2, eps, wd, gs, mode, step_size, bc1, bc2_sqrt, rect, use_rect);
+    adam_one(pv.w, gv.w, mv.w, vv.w, lr, b1, b2, eps, wd, gs, mode, step_size, bc1, bc2_sqrt, rect, use_rect);
+    emsa_st4(m + i * 4, mv);
+    emsa_st4(v + i * 4, vv);
+    emsa_st4(p + i * 4, pv);
+  }
+  const long t = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t < n) {
+    float pv = p[t], mv = m[t], vv = v[t];
+    adam_one(pv, g[t], mv, vv, lr, b1, b2, eps, wd, gs, mode, step_size, bc1, bc2_sqrt, rect, use_rect);
+    m[t] = mv; v[t] = vv; p[t] = pv;
+  }
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -3742,5 +3822,21 @@ extern "C" int emsa_sgd_nesterov_dev(float* param, const float* grad, float* mom
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0,
                      (hipStream_t)stream, param, grad, momentum_buf, n4, (long)n, 0.f, 0.f, 0.f,
                      0.f, 0, hyper);
+  return emsa_launch_status();
+}
+extern "C" int emsa_adam_advance(const double* hyper, double* state, void* stream) {
+  if (!hyper || !state) return EMSA_E_ARG;
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper, state);
+  return emsa_launch_status();
+}
+extern "C" int emsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                              int64_t n, const double* hyper, const double* state, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || !state) return EMSA_E_ARG;
+  if (n < 1) return EMSA_OK;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15)
+    return EMSA_E_SHAPE;
+  const long n4 = (long)n / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0,
+                     (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4, (long)n, hyper, state);
   return emsa_launch_status();
 }

@@ -531,6 +531,16 @@ int emsa_sgd_nesterov(float* param, const float* grad, float* momentum_buf, int6
  * time (hipGraph-captured training step: the one-cycle schedule changes them between replays) */
 int emsa_sgd_nesterov_dev(float* param, const float* grad, float* momentum_buf, int64_t n,
                           const float* hyper, void* stream);
+/* Adam / AdamW / RAdam step over one flat bucket -- the other optimizers of the reference's factory
+ * (/root/reference/emsanet/optimizer.py:37-57), arithmetic of torch.optim's single-tensor paths.
+ * hyper double[8] (DEVICE, written by the host): {lr, beta1, beta2, eps, weight_decay, grad_scale,
+ * mode: 0 adam (L2 decay), 1 adamw (decoupled), 2 radam (L2)}; state double[8] (DEVICE, owned by the
+ * kernels): {step t, lr/bc1, bc1, sqrt(bc2), RAdam rectification, rho_t > 5}.  emsa_adam_advance:
+ * t += 1 and the step-dependent scalars, once per optimizer step in front of the bucket launches
+ * (a step captured in a hipGraph counts its replays).                                          */
+int emsa_adam_advance(const double* hyper, double* state, void* stream);
+int emsa_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   const double* hyper, const double* state, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 16-bit convolution family (BASELINE configs[2] bf16 mixed-precision training, configs[4] 16-bit
