@@ -238,6 +238,12 @@ def test_model_interface_reference_inputs(tasks, modalities, training, do_postpr
                 # the key the reference's consumers read (visualization.py:607-620), grouped inside
                 # batch['instance_foreground']
                 assert outputs['instance_segmentation_gt_foreground'].shape == (bs, H, W)
+                assert len(outputs['instance_segmentation_gt_meta']) == bs          # visualization.py:622-624
+            if 'orientation' in tasks:
+                # batch['instance'] all ones, (N,1,H,W) bool as the reference's test hands it over: ONE
+                # ground-truth instance per image (visualization.py:752-765 zips it with batch['instance'])
+                o = outputs['orientations_gt_instance_gt_orientation_foreground']
+                assert len(o) == bs and all(list(d) == [1] and 0.0 <= d[1] < 6.2832 for d in o)
     else:
         assert isinstance(outputs, list) and outputs
         assert len(outputs) == len(tasks) - ('orientation' in tasks)
