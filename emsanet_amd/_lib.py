@@ -156,6 +156,7 @@ SIGNATURES = {
     'emsa_normalize_depth': (c_int, [_P, _P, c_int64, c_float, c_float, c_int32, _P]),
     'emsa_sgd_nesterov': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32,
                                   _P]),
+    'emsa_add_t': (c_int, [c_int32, _P, _P, _P, c_int64, _P]),
     'emsa_adam_advance': (c_int, [_P, _P, _P]),
     'emsa_adam_step': (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P]),
     'emsa_instance_loss_blocks': (c_int, [c_int64]),

@@ -2196,6 +2196,14 @@ __global__ void nearest_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
              emsa_ld1(x + (((long)img * ih + yi) * iw + xi) * c + ch));
   }
 }
+// out = a + b (dense, same storage type; fp32 sum rounded once): the skip add behind a plain
+// 'nearest' / 'bilinear' decoder up-sampling (the learned up-sampling adds its skip in its own kernel)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x)
+    emsa_st1(y + i, emsa_ld1(a + i) + emsa_ld1(b + i));
+}
 template <typename T>
 __global__ void nearest_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dx, int n, int ih,
                                    int iw, int oh, int ow, int c, int ld_dy) {
@@ -3612,6 +3620,14 @@ static int nearest_bwd_impl(const T* dy, float* dx, int32_t n, int32_t ih, int32
   const long total = (long)n * ih * iw * c;
   hipLaunchKernelGGL((nearest_bwd_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0,
                      (hipStream_t)stream, dy, dx, n, ih, iw, oh, ow, c, ld_dy);
+  return emsa_launch_status();
+}
+extern "C" int emsa_add_t(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream) {
+  if (!a || !b || !out) return EMSA_E_ARG;
+  if (n < 1) return EMSA_OK;
+  EMSA_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for((long)n)), dim3(kThreads), 0,
+                                         (hipStream_t)stream, (const T*)a, (const T*)b, (T*)out, (long)n));
   return emsa_launch_status();
 }
 extern "C" int emsa_nearest_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream) {

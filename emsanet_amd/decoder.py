@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import ops
-from .nn import (ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt,
+from .nn import (ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt, make_upsampling,
                  plain_conv)
 from .postprocessing import (InstancePostprocessing, PanopticPostprocessing, gt_instance_orientations,
                              softmax_argmax)
@@ -64,16 +64,19 @@ class InstanceSideHead(nn.Module):
         return ops.MultiConvFunction.apply(x, self._rt, *self._rt.params())
 
 
+DEFAULT_UPSAMPLING = 'learned-3x3-zeropad'          # /root/reference/emsanet/args.py:280-298,363-372
+
+
 class DecoderModule(nn.Module):
     """conv3x3+BN+ReLU -> n_blocks x NBt1D -> [train: 1x1 side head] -> nearest x2 + DW3x3
     -> + (1x1 conv+BN+ReLU of the rgb skip)          (figure doc/EMSANet-model.png)."""
 
-    def __init__(self, cin, c, n_blocks, dropout_p, skip_c):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, upsampling=DEFAULT_UPSAMPLING):
         super().__init__()
         self.conv3x3 = ConvNormAct(cin, c, 3)
         self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
                                       for _ in range(n_blocks)])
-        self.upsampling = LearnedUpsampling(c)
+        self.upsampling = make_upsampling(upsampling, c)
         fuse = Spec.SKIP_FUSION_1X1 == 'always' or (Spec.SKIP_FUSION_1X1 and skip_c != c)
         self.skip_fusion = ConvNormAct(skip_c, c, 1) if fuse else None
 
@@ -87,12 +90,15 @@ class DecoderModule(nn.Module):
 
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
-                 fusion_downsamplings, side_head_factory, fusion='add-rgb'):
+                 fusion_downsamplings, side_head_factory, fusion='add-rgb',
+                 upsampling=DEFAULT_UPSAMPLING, prediction_upsampling=DEFAULT_UPSAMPLING):
         super().__init__()
         self.fusion = fusion
+        # `upsampling`: between the decoder modules; `prediction_upsampling`: the two x2 steps of the
+        # head (ref emsanet/decoder.py:55-57,78,123,176)
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
-            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc))
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, upsampling))
             cin = c
         self.decoder_modules = nn.ModuleList(mods)
         self.side_output_heads = nn.ModuleList([side_head_factory(c) for c in n_channels])
@@ -148,6 +154,8 @@ def twin_bodies_ok(da, db, x):
         if len(ma.blocks) != len(mb.blocks) or \
                 ma.conv3x3.conv.out_channels != mb.conv3x3.conv.out_channels:
             return False
+        if not (isinstance(ma.upsampling, LearnedUpsampling) and isinstance(mb.upsampling, LearnedUpsampling)):
+            return False               # (the twin up-sampling launch is the learned kernel's)
     return True
 
 
@@ -177,12 +185,12 @@ def twin_bodies(da, db, x, skips):
 
 
 class SemanticHead(nn.Module):
-    def __init__(self, c, n_classes):
+    def __init__(self, c, n_classes, upsampling=DEFAULT_UPSAMPLING):
         super().__init__()
         self.conv = nn.Conv2d(c, n_classes, 3, padding=1)
         cp = Fn.pad8(n_classes)
-        self.upsampling = nn.Sequential(LearnedUpsampling(n_classes, cp),
-                                        LearnedUpsampling(n_classes, cp))
+        self.upsampling = nn.Sequential(make_upsampling(upsampling, n_classes, cp),
+                                        make_upsampling(upsampling, n_classes, cp))
         self._rt = make_plain_conv_rt(self.conv)
 
     def forward(self, x):
@@ -197,7 +205,8 @@ class SemanticDecoder(DecoderBody):
     def __init__(self, n_classes, **kw):
         super().__init__(side_head_factory=lambda c: SemanticSideHead(c, n_classes), **kw)
         self.n_classes = n_classes
-        self.head = SemanticHead(kw['n_channels'][-1], n_classes)
+        self.head = SemanticHead(kw['n_channels'][-1], n_classes,
+                                 kw.get('prediction_upsampling', DEFAULT_UPSAMPLING))
 
     def forward(self, x, skips, batch=None, do_postprocessing=False):
         x, sides = self.body(x[0], skips)
@@ -235,7 +244,7 @@ class InstanceHead(nn.Module):
     block-diagonal 96->8 convolution; shared DW upsampling x2 x2
     (/root/reference/emsanet/weights.py:39-56)."""
 
-    def __init__(self, c, with_orientation, n_per_task=32):
+    def __init__(self, c, with_orientation, n_per_task=32, upsampling=DEFAULT_UPSAMPLING):
         super().__init__()
         outs = (1, 2, 2) if with_orientation else (1, 2)
         self.outs = outs
@@ -243,8 +252,8 @@ class InstanceHead(nn.Module):
         cp = Fn.pad8(self.n_out)
         self.shared_conv = ConvNormAct(c, n_per_task * len(outs), 3)
         self.task_convs = nn.ModuleList([nn.Conv2d(n_per_task, o, 3, padding=1) for o in outs])
-        self.upsampling = nn.Sequential(LearnedUpsampling(self.n_out, cp),
-                                        LearnedUpsampling(self.n_out, cp))
+        self.upsampling = nn.Sequential(make_upsampling(upsampling, self.n_out, cp),
+                                        make_upsampling(upsampling, self.n_out, cp))
         placements, co = [], 0
         for i, (conv, o) in enumerate(zip(self.task_convs, outs)):
             placements.append((conv, co, i * n_per_task))
@@ -263,7 +272,8 @@ class InstanceDecoder(DecoderBody):
     def __init__(self, with_orientation, sigmoid_for_center, tanh_for_offset, **kw):
         self.with_orientation = with_orientation
         super().__init__(side_head_factory=lambda c: InstanceSideHead(c, with_orientation), **kw)
-        self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
+        self.head = InstanceHead(kw['n_channels'][-1], with_orientation,
+                                 upsampling=kw.get('prediction_upsampling', DEFAULT_UPSAMPLING))
         self.sigmoid_for_center = sigmoid_for_center
         self.tanh_for_offset = tanh_for_offset
         self.normalize_orientation = bool(Spec.ORIENTATION_L2_NORMALIZE) and with_orientation
@@ -400,10 +410,13 @@ def get_decoders(
     fusion_downsamplings = tuple(args.encoder_decoder_skip_downsamplings)[::-1]
     if getattr(args, 'decoder_normalization', 'batchnorm') not in ('batchnorm', 'bn'):
         raise NotImplementedError("only batchnorm decoders")
-    for a in ('upsampling_prediction', 'semantic_decoder_upsampling',
-              'instance_decoder_upsampling'):
-        if getattr(args, a, 'learned-3x3-zeropad') != 'learned-3x3-zeropad':
-            raise NotImplementedError(f"{a}={getattr(args, a)} (only learned-3x3-zeropad)")
+    from .nn import UPSAMPLING_MODES
+    for a in ('upsampling_prediction', 'semantic_decoder_upsampling', 'instance_decoder_upsampling',
+              'normal_decoder_upsampling'):
+        # 'learned-3x3-zeropad' (default), 'nearest', 'bilinear'; the library's 'learned-3x3' is refused
+        if getattr(args, a, DEFAULT_UPSAMPLING) not in UPSAMPLING_MODES:
+            raise NotImplementedError(f"{a}={getattr(args, a)} (built: {', '.join(UPSAMPLING_MODES)})")
+    up_pred = getattr(args, 'upsampling_prediction', DEFAULT_UPSAMPLING)
 
     # the decoder modules run at /16, /8, /4 (`*_decoder_downsamplings`, /root/reference/emsanet/decoder.py:
     # 67,99,166; default (16, 8, 4)): another schedule is refused, not silently replaced
@@ -425,7 +438,9 @@ def get_decoders(
             dropout_p=args.semantic_decoder_block_dropout_p,
             fusion_n_channels=tuple(fusion_n_channels),
             fusion_downsamplings=fusion_downsamplings,
-            fusion=args.semantic_encoder_decoder_fusion)
+            fusion=args.semantic_encoder_decoder_fusion,
+            upsampling=getattr(args, 'semantic_decoder_upsampling', DEFAULT_UPSAMPLING),
+            prediction_upsampling=up_pred)
     if 'instance' in args.tasks:
         if args.instance_decoder.lower() != 'emsanet':
             raise NotImplementedError(f"instance decoder '{args.instance_decoder}'")
@@ -441,7 +456,9 @@ def get_decoders(
             dropout_p=args.instance_decoder_block_dropout_p,
             fusion_n_channels=tuple(fusion_n_channels),
             fusion_downsamplings=fusion_downsamplings,
-            fusion=args.instance_encoder_decoder_fusion)
+            fusion=args.instance_encoder_decoder_fusion,
+            upsampling=getattr(args, 'instance_decoder_upsampling', DEFAULT_UPSAMPLING),
+            prediction_upsampling=up_pred)
         # post-processing parameters as in /root/reference/emsanet/decoder.py:95-104
         decoders['instance_decoder'].postprocessing = InstancePostprocessing(
             heatmap_threshold=args.instance_center_heatmap_threshold,
@@ -464,15 +481,15 @@ def get_decoders(
         fusion = getattr(args, 'normal_encoder_decoder_fusion', 'add-rgb')
         if fusion not in _FUSIONS:
             raise NotImplementedError(fusion)
-        if getattr(args, 'normal_decoder_upsampling', 'learned-3x3-zeropad') != 'learned-3x3-zeropad':
-            raise NotImplementedError(f"normal_decoder_upsampling={args.normal_decoder_upsampling}")
         decoders['normal_decoder'] = NormalDecoder(
             n_classes=normal_n_channels_out, n_channels_in=n_channels_in,
             n_channels=tuple(getattr(args, 'normal_decoder_n_channels', (512, 256, 128))),
             n_blocks=getattr(args, 'normal_decoder_n_blocks', 3),
             dropout_p=getattr(args, 'normal_decoder_block_dropout_p', 0.2),
             fusion_n_channels=tuple(fusion_n_channels),
-            fusion_downsamplings=fusion_downsamplings, fusion=fusion)
+            fusion_downsamplings=fusion_downsamplings, fusion=fusion,
+            upsampling=getattr(args, 'normal_decoder_upsampling', DEFAULT_UPSAMPLING),
+            prediction_upsampling=up_pred)
     if 'scene' in args.tasks:
         decoders['scene_decoder'] = SceneClassificationDecoder(scene_n_channels_in,
                                                                scene_n_classes)

@@ -1413,6 +1413,15 @@ def nearest_bwd(dy, in_hw):
     return dx
 
 
+def add(a, b):
+    """a + b of two dense activations of one storage type (fp32 sum, rounded once)"""
+    assert a.shape == b.shape and a.dtype == b.dtype and ld_of(a) == a.shape[1] == ld_of(b)
+    n, c, h, w = a.shape
+    out = act_empty(n, c, h, w, a.device, dtype=a.dtype)
+    check(_lib.lib().emsa_add_t(dt(a), _p(a), _p(b), _p(out), a.numel(), _stream()), 'emsa_add_t')
+    return out
+
+
 def head_act_fwd(x, n_sig, n_tanh, n_norm=0, norm_off=3):
     """16-bit features -> fp32 outputs (the model's instance outputs), fp32 -> fp32"""
     n, c, h, w = x.shape

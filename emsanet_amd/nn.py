@@ -530,6 +530,33 @@ class LearnedUpsampling(nn.Module):
         return r if r is not None else (ma(xa, ska), mb(xb, skb))
 
 
+class PlainUpsampling(nn.Module):
+    """'nearest' / 'bilinear' x2 up-sampling (no parameters): the other two buildable values of
+    `--*-decoder-upsampling` / `--upsampling-prediction` (/root/reference/emsanet/args.py:280-298);
+    bilinear = align_corners False, the convention of the context module's interpolation [U]"""
+
+    def __init__(self, mode):
+        super().__init__()
+        self.mode = mode
+
+    def forward(self, x, skip=None, out_f32=False):
+        return ops.PlainUpsampleFunction.apply(x, self.mode, skip, out_f32)
+
+
+UPSAMPLING_MODES = ('learned-3x3-zeropad', 'nearest', 'bilinear')
+
+
+def make_upsampling(mode, c, c_pad=None):
+    """`get_upsampling_class(name)` of the reference's factories (emsanet/decoder.py:55-57,78,123,176)
+    for the modes this engine builds; 'learned-3x3' (the variant without zero padding) is refused: how
+    the un-vendored library pads it is [U]"""
+    if mode == 'learned-3x3-zeropad':
+        return LearnedUpsampling(c, c_pad)
+    if mode in ('nearest', 'bilinear'):
+        return PlainUpsampling(mode)
+    raise NotImplementedError(f"upsampling '{mode}' (built: {', '.join(UPSAMPLING_MODES)})")
+
+
 def make_plain_conv_rt(conv):
     """runtime for an nn.Conv2d (+bias) evaluated by the MFMA kernel with its output channels
     zero-padded to a multiple of 8 (16-byte accesses also for 16-bit storage); `plain_conv`

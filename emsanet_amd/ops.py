@@ -1391,6 +1391,45 @@ class UpsampleDWFunction(Function):
         return dx, dw.reshape(ctx.wshape), (db if has_bias else None), dskip, None
 
 
+class PlainUpsampleFunction(Function):
+    """x2 up-sampling without weights -- 'nearest' / 'bilinear' (align_corners=False) of
+    `--{semantic,instance,normal}-decoder-upsampling` / `--upsampling-prediction`
+    (/root/reference/emsanet/args.py:280-298,363-372) -- plus the optional skip add; out_f32 as in
+    UpsampleDWFunction (16-bit features -> the model's fp32 output)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, skip, out_f32=False):
+        if mode not in ('bilinear', 'nearest'):
+            raise NotImplementedError(f"upsampling '{mode}'")
+        x = Fn.as_act(x, dense=True)
+        ctx.mode, ctx.x_dtype, ctx.hw = mode, x.dtype, tuple(x.shape[2:])
+        if out_f32 and x.dtype != torch.float32:
+            x = Fn.cast(x, torch.float32)
+        n, c, h, w = x.shape
+        y = Fn.act_empty(n, c, 2 * h, 2 * w, x.device, dtype=x.dtype)
+        (Fn.bilinear_fwd if mode == 'bilinear' else Fn.nearest_fwd)(x, y)
+        ctx.has_skip = skip is not None
+        if skip is not None:
+            skip = Fn.as_act(skip, dense=True)
+            y = Fn.add(y, skip if skip.dtype == y.dtype else Fn.cast(skip, y.dtype))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    @_traced
+    def backward(ctx, dy):
+        dy = Fn.as_act(dy, dense=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (Fn.bilinear_bwd if ctx.mode == 'bilinear' else Fn.nearest_bwd)(dy, ctx.hw)
+            if dx.dtype != ctx.x_dtype:
+                dx = Fn.cast(dx, ctx.x_dtype)
+        dskip = None
+        if ctx.has_skip:
+            dskip = dy if dy.dtype == ctx.x_dtype else Fn.cast(dy, ctx.x_dtype)
+        return dx, None, dskip, None
+
+
 # ---------------------------------------------------------------------------------------------
 # pyramid pooling pieces
 # ---------------------------------------------------------------------------------------------

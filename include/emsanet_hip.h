@@ -773,6 +773,10 @@ int emsa_bilinear_fwd_t(int32_t dtype, const void* x, void* y, int32_t n, int32_
     iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_y, void* stream);
 int emsa_bilinear_bwd_t(int32_t dtype, const void* dy, float* dx, int32_t n, int32_t ih, int32_t
     iw, int32_t oh, int32_t ow, int32_t c, int32_t ld_dy, void* stream);
+/* out = a + b over n dense elements of one storage type (dtype: EMSA_DT_*): the encoder skip added
+ * behind a plain 'nearest' / 'bilinear' decoder up-sampling (`--{semantic,instance}-decoder-
+ * upsampling`, /root/reference/emsanet/args.py:280-298,363-372)                                 */
+int emsa_add_t(int32_t dtype, const void* a, const void* b, void* out, int64_t n, void* stream);
 /* 'nearest' up-sampling of the pyramid-pooling branches (`--upsampling-context-module nearest`,
  * emsanet/args.py:250-256, passed on at emsanet/model.py:109-119): source index floor(dst * in / out) as
  * torch.nn.functional.interpolate(mode='nearest'); y may be a channel slice (ld_y).  The backward pass

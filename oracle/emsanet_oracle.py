@@ -400,6 +400,25 @@ class LearnedUpsampling(nn.Module):
         return self.conv(F.interpolate(x, scale_factor=2, mode='nearest'))
 
 
+class PlainUpsampling(nn.Module):
+    """'nearest' / 'bilinear' (align_corners=False [U]) x2: the weight-free values of
+    `--*-decoder-upsampling` / `--upsampling-prediction` (args.py:280-298,363-372)"""
+
+    def __init__(self, mode):
+        super().__init__()
+        assert mode in ('nearest', 'bilinear')
+        self.mode = mode
+
+    def forward(self, x):
+        if self.mode == 'nearest':
+            return F.interpolate(x, scale_factor=2, mode='nearest')
+        return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+
+
+def make_upsampling(mode, c):
+    return LearnedUpsampling(c) if mode == 'learned-3x3-zeropad' else PlainUpsampling(mode)
+
+
 class SemanticSideHead(nn.Module):
     # key fragments ('semantic_decoder', 'head', 'conv') with shape[0] = n_classes: the only
     # semantic keys the reference's checkpoint surgery resizes (weights.py:95-119,147-160)
@@ -426,12 +445,12 @@ class InstanceSideHead(nn.Module):
 
 
 class DecoderModule(nn.Module):
-    def __init__(self, cin, c, n_blocks, dropout_p, skip_c):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, upsampling='learned-3x3-zeropad'):
         super().__init__()
         self.conv3x3 = ConvNormAct(cin, c, 3)
         self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
                                       for _ in range(n_blocks)])
-        self.upsampling = LearnedUpsampling(c)
+        self.upsampling = make_upsampling(upsampling, c)
         if Spec.SKIP_FUSION_1X1 == 'always' or (Spec.SKIP_FUSION_1X1 and skip_c != c):
             self.skip_fusion = ConvNormAct(skip_c, c, 1)
         else:
@@ -441,19 +460,22 @@ class DecoderModule(nn.Module):
         x = self.blocks(self.conv3x3(x))
         side = side_head(x) if self.training else None
         x = self.upsampling(x)
+        if isinstance(self.upsampling, PlainUpsampling):
+            x = store(x)                    # (weight-free modes: interpolation and skip add are two kernels)
         if self.skip_fusion is not None:
             skip = self.skip_fusion(skip)
-        return store(x + skip), side        # (up-sampling + skip add: one kernel, one rounding)
+        return store(x + skip), side        # (learned up-sampling + skip add: one kernel, one rounding)
 
 
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
-                 fusion_downsamplings, side_head_factory, fusion='add-rgb'):
+                 fusion_downsamplings, side_head_factory, fusion='add-rgb',
+                 upsampling='learned-3x3-zeropad', prediction_upsampling='learned-3x3-zeropad'):
         super().__init__()
         self.fusion = fusion            # 'add-<modality>', or 'add' = the only stream there is
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
-            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc))
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, upsampling))
             cin = c
         self.decoder_modules = nn.ModuleList(mods)
         self.side_output_heads = nn.ModuleList([side_head_factory(c) for c in n_channels])
@@ -475,10 +497,11 @@ class DecoderBody(nn.Module):
 
 
 class SemanticHead(nn.Module):
-    def __init__(self, c, n_classes):
+    def __init__(self, c, n_classes, upsampling='learned-3x3-zeropad'):
         super().__init__()
         self.conv = nn.Conv2d(c, n_classes, 3, padding=1)
-        self.upsampling = nn.Sequential(LearnedUpsampling(n_classes), LearnedUpsampling(n_classes))
+        self.upsampling = nn.Sequential(make_upsampling(upsampling, n_classes),
+                                        make_upsampling(upsampling, n_classes))
 
     def forward(self, x):
         # head conv and the first up-sampling are stored; the last one writes the fp32 logits
@@ -488,7 +511,8 @@ class SemanticHead(nn.Module):
 class SemanticDecoder(DecoderBody):
     def __init__(self, n_classes, **kw):
         super().__init__(side_head_factory=lambda c: SemanticSideHead(c, n_classes), **kw)
-        self.head = SemanticHead(kw['n_channels'][-1], n_classes)
+        self.head = SemanticHead(kw['n_channels'][-1], n_classes,
+                                 kw.get('prediction_upsampling', 'learned-3x3-zeropad'))
         self.side_output_downscales = (32, 16, 8)     # module order (taken before each x2)
 
     def forward(self, x, skips, batch=None, do_postprocessing=False):
@@ -521,13 +545,14 @@ class InstanceHead(nn.Module):
     """shared_conv 3x3 C->32*T (+norm+act), task_convs.{0,1,2} 3x3 32->1/2/2, shared DW
     upsampling x2 x2 over the concatenated 5 channels (weights.py:39-56)."""
 
-    def __init__(self, c, with_orientation, n_per_task=32):
+    def __init__(self, c, with_orientation, n_per_task=32, upsampling='learned-3x3-zeropad'):
         super().__init__()
         outs = (1, 2, 2) if with_orientation else (1, 2)
         self.n_per_task = n_per_task
         self.shared_conv = ConvNormAct(c, n_per_task * len(outs), 3)
         self.task_convs = nn.ModuleList([nn.Conv2d(n_per_task, o, 3, padding=1) for o in outs])
-        self.upsampling = nn.Sequential(LearnedUpsampling(sum(outs)), LearnedUpsampling(sum(outs)))
+        self.upsampling = nn.Sequential(make_upsampling(upsampling, sum(outs)),
+                                        make_upsampling(upsampling, sum(outs)))
 
     def forward(self, x):
         x = self.shared_conv(x)
@@ -541,7 +566,8 @@ class InstanceDecoder(DecoderBody):
     def __init__(self, with_orientation, sigmoid_for_center, tanh_for_offset, **kw):
         self.with_orientation = with_orientation
         super().__init__(side_head_factory=lambda c: InstanceSideHead(c, with_orientation), **kw)
-        self.head = InstanceHead(kw['n_channels'][-1], with_orientation)
+        self.head = InstanceHead(kw['n_channels'][-1], with_orientation,
+                                 upsampling=kw.get('prediction_upsampling', 'learned-3x3-zeropad'))
         self.sigmoid_for_center = sigmoid_for_center
         self.tanh_for_offset = tanh_for_offset
         self.side_output_downscales = (32, 16, 8)
@@ -633,7 +659,9 @@ class EMSANetOracle(nn.Module):
                 n_blocks=args.semantic_decoder_n_blocks,
                 dropout_p=args.semantic_decoder_block_dropout_p,
                 fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
-                fusion=args.semantic_encoder_decoder_fusion)
+                fusion=args.semantic_encoder_decoder_fusion,
+                upsampling=getattr(args, 'semantic_decoder_upsampling', 'learned-3x3-zeropad'),
+                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'))
         if 'instance' in args.tasks:
             if args.instance_offset_encoding not in ('tanh', 'relative', 'deeplab'):
                 raise NotImplementedError
@@ -646,7 +674,9 @@ class EMSANetOracle(nn.Module):
                 n_blocks=args.instance_decoder_n_blocks,
                 dropout_p=args.instance_decoder_block_dropout_p,
                 fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
-                fusion=args.instance_encoder_decoder_fusion)
+                fusion=args.instance_encoder_decoder_fusion,
+                upsampling=getattr(args, 'instance_decoder_upsampling', 'learned-3x3-zeropad'),
+                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'))
         if 'normal' in args.tasks:
             dec['normal_decoder'] = NormalDecoder(
                 n_classes=3, n_channels_in=c_enc,
@@ -654,7 +684,9 @@ class EMSANetOracle(nn.Module):
                 n_blocks=getattr(args, 'normal_decoder_n_blocks', 3),
                 dropout_p=getattr(args, 'normal_decoder_block_dropout_p', 0.2),
                 fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
-                fusion=getattr(args, 'normal_encoder_decoder_fusion', 'add-rgb'))
+                fusion=getattr(args, 'normal_encoder_decoder_fusion', 'add-rgb'),
+                upsampling=getattr(args, 'normal_decoder_upsampling', 'learned-3x3-zeropad'),
+                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'))
         if 'scene' in args.tasks:
             dec['scene_decoder'] = SceneClassificationDecoder(
                 self.context_module.n_channels_reduction, n_scene)

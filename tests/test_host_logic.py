@@ -143,6 +143,17 @@ def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         _model(full_args(activation='swish'))
     assert _model(full_args(upsampling_context_module='nearest')).context_module.upsampling == 'nearest'
+    # decoder / prediction up-sampling (args.py:280-298,363-372): the learned one and the two weight-free
+    # modes are built, the library's 'learned-3x3' (padding rule unknown) is refused by name
+    for field in ('semantic_decoder_upsampling', 'instance_decoder_upsampling', 'upsampling_prediction'):
+        with pytest.raises(NotImplementedError, match='learned-3x3'):
+            _model(full_args(**{field: 'learned-3x3'}))
+    from emsanet_amd.nn import PlainUpsampling
+    m = _model(full_args(semantic_decoder_upsampling='bilinear', upsampling_prediction='nearest'))
+    d = m.decoders['semantic_decoder']
+    assert isinstance(d.decoder_modules[0].upsampling, PlainUpsampling) and d.decoder_modules[0].upsampling.mode == 'bilinear'
+    assert [u.mode for u in d.head.upsampling] == ['nearest', 'nearest']
+    assert not isinstance(m.decoders['instance_decoder'].decoder_modules[0].upsampling, PlainUpsampling)
     with pytest.raises(KeyError):
         default_args(not_a_field=1)
     a = default_args(input_modalities=('rgb',))

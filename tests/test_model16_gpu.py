@@ -120,7 +120,7 @@ def test_eval_16bit_vs_fp32_oracle(shape, dtype):
     print(f"{dtype} eval {shape}: worst output rel-L2 {worst:.2e}, semantic arg-max agreement {fs:.5f}")
 
 
-@pytest.mark.parametrize('variant', ['rgbd', 'basicblock', 'normal'])
+@pytest.mark.parametrize('variant', ['rgbd', 'basicblock', 'normal', 'up_nearest', 'up_bilinear'])
 def test_option_space_bf16(variant):
     """the model options beyond BASELINE's configs in bf16 storage: eval forward vs the fp32 oracle
     at the eval tolerance, and a train step (forward + backward) with finite gradients everywhere"""
@@ -134,6 +134,11 @@ def test_option_space_bf16(variant):
         kw.update(rgb_encoder_backbone='resnet18', depth_encoder_backbone='resnet18',
                   rgb_encoder_backbone_resnet_block='basicblock',
                   depth_encoder_backbone_resnet_block='basicblock')
+    elif variant.startswith('up_'):
+        # weight-free decoder / prediction up-sampling (ref args.py:280-298,363-372,439-448)
+        mode = variant[3:]
+        kw.update(semantic_decoder_upsampling=mode, instance_decoder_upsampling=mode,
+                  upsampling_prediction=mode)
     else:
         kw.update(tasks=('semantic', 'instance', 'orientation', 'scene', 'normal'))
     model, oracle = _pair(full_args(**kw))
