@@ -69,8 +69,12 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='inference-only forward (not the metric)')
     ap.add_argument('--force-dist', action='store_true',
                     help='validation: RCCL process group + bucketed all-reduce path with ONE rank')
-    ap.add_argument('--backbone', default='resnet34', choices=('resnet18', 'resnet34', 'resnet101'),
-                    help='NBt1D ResNet of both encoders (BASELINE config 4: resnet101 at 960x736)')
+    ap.add_argument('--backbone', default='resnet34', choices=('resnet18', 'resnet34', 'resnet50', 'resnet101'),
+                    help='ResNet of both encoders (BASELINE config 4: resnet101 at 960x736)')
+    ap.add_argument('--resnet-block', default='nonbottleneck1d',
+                    choices=('nonbottleneck1d', 'basicblock', 'bottleneck'),
+                    help='block of both encoders (ref --*-encoder-backbone-resnet-block; every BASELINE '
+                         'config: nonbottleneck1d; resnet50 + bottleneck = inference_time.bash:8,13)')
     ap.add_argument('--torch-optimizer', action='store_true',
                     help='A/B: torch.optim.SGD (foreach) instead of the fused bucket-wise SGD kernel')
     ap.add_argument('--losses', action='store_true',
@@ -187,7 +191,9 @@ def cpu_replica_worker(args):
         pass
     torch.set_num_threads(nt)
     a = full_args(input_height=args.height, input_width=args.width,
-                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone)
+                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone,
+                  rgb_encoder_backbone_resnet_block=args.resnet_block,
+                  depth_encoder_backbone_resnet_block=args.resnet_block)
     o = EMSANetOracle(a, nyuv2_config())
     o.load_state_dict(deterministic_state_dict(o, 0))
     o.train()
@@ -254,7 +260,7 @@ def cpu_replicas(args, threads, all_cores, bs):
     start = time.time() + 45.0          # (imports + oracle construction + one warm-up step per replica)
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-replica-threads', str(threads),
            '--cpu-replica-start', repr(start), '--cpu-replica-seconds', '12', '--height', str(args.height),
-           '--width', str(args.width), '--backbone', args.backbone]
+           '--width', str(args.width), '--backbone', args.backbone, '--resnet-block', args.resnet_block]
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
                HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     procs = [subprocess.Popen(cmd + ['--cpu-replica-worker', str(i)], stdout=subprocess.PIPE,
@@ -283,7 +289,9 @@ def cpu_baseline(args):
     from oracle.emsanet_oracle import EMSANetOracle, deterministic_state_dict, synthetic_batch
     cores = torch.get_num_threads()
     a = full_args(input_height=args.height, input_width=args.width,
-                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone)
+                  rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone,
+                  rgb_encoder_backbone_resnet_block=args.resnet_block,
+                  depth_encoder_backbone_resnet_block=args.resnet_block)
     o = EMSANetOracle(a, nyuv2_config())
     o.load_state_dict(deterministic_state_dict(o, 0))
     o.train()
@@ -514,6 +522,8 @@ def run(args):
     L = _lib.lib()
     a = full_args(input_height=args.height, input_width=args.width,
                   rgb_encoder_backbone=args.backbone, depth_encoder_backbone=args.backbone,
+                  rgb_encoder_backbone_resnet_block=args.resnet_block,
+                  depth_encoder_backbone_resnet_block=args.resnet_block,
                   compute_dtype={'f32': 'float32', 'bf16': 'bfloat16', 'f16': 'float16'}[args.dtype])
     torch.manual_seed(0)
     model = EMSANet(a, nyuv2_config())
@@ -984,14 +994,18 @@ def run(args):
     conv_ms = sum(k['total_ms'] for k in kernels)
     conv_fl = sum(k['total_ms'] * k['tflops'] for k in kernels)     # ms * TFLOP/s = GFLOP
     step_gflop = (1 if args.eval else 3) * FWD_GFLOP_PER_IMAGE * bs \
-        if (args.height, args.width) == (480, 640) else None
+        if (args.height, args.width, args.backbone, args.resnet_block) == (480, 640, 'resnet34', 'nonbottleneck1d') \
+        else None
 
-    head = (f'full EMSANet RGB-D ({args.backbone}-NBt1D x2, SE-add fusion, PPM, '
+    blk = {'nonbottleneck1d': 'NBt1D', 'basicblock': 'basic', 'bottleneck': 'bottleneck'}[args.resnet_block]
+    head = (f'full EMSANet RGB-D ({args.backbone}-{blk} x2, SE-add fusion, PPM, '
             f'semantic+instance+orientation+scene heads), {args.width}x{args.height}, bs={bs}/GPU, '
             f'{args.dtype}')
     # which BASELINE.json config this run is (or that it is none of them)
     at_640 = (args.height, args.width) == (480, 640)
-    if args.backbone == 'resnet101':
+    if args.resnet_block != 'nonbottleneck1d':
+        cfg = 'not a BASELINE.json config (other encoder block)'
+    elif args.backbone == 'resnet101':
         cfg = ('BASELINE.json configs[3] (ResNet-101-NBt1D dual encoder, 960x720 rounded up to the '
                'next multiple of 32 rows, bs=16/GPU)' if (args.width, bs) == (960, 16) and args.height in (720, 736)
                else 'ResNet-101-NBt1D variant (not a BASELINE.json config)')

@@ -672,6 +672,46 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
   }
 }
 
+// the same for tensors with more channel vectors than a workgroup has threads (fp32 with C > 1024: the
+// 2048-channel stage of the bottleneck ResNets): grid = (rows, channel-vector groups), one thread per
+// channel vector walks the row chunk alone -- no LDS, fixed order
+template <typename T>
+__global__ void bn_bwd_reduce_wide_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                          const uint64_t* __restrict__ mask_bits,
+                                          const T* __restrict__ x, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd,
+                                          const float* __restrict__ drop, long pixels, long hw,
+                                          int cvn, int act, int rows_alloc,
+                                          float* __restrict__ partial) {
+  constexpr int V = VecIO<T>::V;
+  const int cv = blockIdx.y * kThreads + threadIdx.x;
+  if (cv >= cvn) return;
+  const int rows = gridDim.x, c = cvn * V;
+  const long chunk = (pixels + rows - 1) / rows;
+  const long p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, pixels);
+  float a1[V], a2[V], mu[V], is[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) a1[k] = a2[k] = 0.f;
+  ldf<V>(mean + cv * V, mu);
+  ldf<V>(invstd + cv * V, is);
+  for (long p = p0; p < p1; ++p) {
+    const long i = p * cvn + cv;
+    float g[V], gres[V], xx[V];
+    bn_bwd_load<T, V>(dy, y, mask_bits, drop, i, p, hw, cvn, cv, act, g, gres);
+    VecIO<T>::load(x + i * V, xx);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      a1[k] = bn_add(a1[k], g[k]);
+      a2[k] = bn_acc_xhat(a2[k], g[k], xx[k], mu[k], is[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    partial[((long)0 * rows_alloc + blockIdx.x) * c + cv * V + k] = a1[k];
+    partial[((long)1 * rows_alloc + blockIdx.x) * c + cv * V + k] = a2[k];
+  }
+}
+
 // partial = float[2][rows_alloc][c], rows_alloc = rows + kBwdSlices.  Level 1 (grid = channel
 // groups x kBwdSlices): slice sums of rows [0, rows) in fp64 -> rows [rows, rows_alloc).  Level 2
 // (merging the kBwdSlices slice sums) is the prologue of bn_bwd_apply_kernel.  A single-level
@@ -1204,6 +1244,42 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, const T* __restrict_
     for (int k = 0; k < lanes; ++k) t += cred[k * c + ch];
     ws[(long)blockIdx.x * c + ch] = t;
   }
+}
+
+// channel_dot_kernel for more channel vectors than threads (fp32, C > 1024): grid = (workgroups of the
+// narrow form, channel-vector groups), one thread per channel vector, pixels in order
+template <typename T, bool HAS_B>
+__global__ void channel_dot_wide_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                        float* __restrict__ ws, long hw, int cvn, int splits,
+                                        const T* __restrict__ a2 = nullptr, int nblk_a = 0x7fffffff) {
+  constexpr int V = VecIO<T>::V;
+  const int cv = blockIdx.y * kThreads + threadIdx.x;
+  if (cv >= cvn) return;
+  const bool second = (int)blockIdx.x >= nblk_a;
+  const int blk = second ? blockIdx.x - nblk_a : blockIdx.x;
+  if (second) a = a2;
+  const int img = blk / splits, sp = blk % splits;
+  const long chunk = (hw + splits - 1) / splits;
+  const long p0 = img * hw + sp * chunk, p1 = min(img * hw + (sp + 1) * chunk, (img + 1) * hw);
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
+  for (long p = p0; p < p1; ++p) {
+    const long i = (p * cvn + cv) * V;
+    float va[V];
+    VecIO<T>::load(a + i, va);
+    if constexpr (HAS_B) {
+      float vb[V];
+      VecIO<T>::load(b + i, vb);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += va[k] * vb[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += va[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < V; ++k) ws[(long)blockIdx.x * cvn * V + cv * V + k] = acc[k];
 }
 
 __global__ void channel_dot_finish_kernel(const float* __restrict__ ws, float* __restrict__ out,
@@ -2453,7 +2529,10 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, 
   }
 }
 
-inline bool c4_ok(int c) { return c >= 4 && (c & 3) == 0 && c <= 1024; }
+// channel counts the pointwise kernels take: multiples of 4 up to 4096 (the bottleneck ResNets end at
+// 2048).  Kernels that map channel vectors onto the threads of one workgroup (reductions) take
+// c / V <= kThreads on their fast paths and switch to their *_wide_kernel forms beyond.
+inline bool c4_ok(int c) { return c >= 4 && (c & 3) == 0 && c <= 4096; }
 
 
 // ------------------------------------------------------------------------------------------
@@ -2890,7 +2969,13 @@ static int bn_bwd_reduce_impl(const T* dy, const T* y, const uint64_t* mask_bits
 #undef EMSA_RED_FAST
     return emsa_launch_status();
   }
-  if (mask_scale) return EMSA_E_SHAPE;            // (the general loop has no recomputed-mask form)
+  if (mask_scale) return EMSA_E_SHAPE;            // (the general loops have no recomputed-mask form)
+  if (cvn > kThreads) {
+    hipLaunchKernelGGL((bn_bwd_reduce_wide_kernel<T>), dim3(rows, (cvn + kThreads - 1) / kThreads),
+                       dim3(kThreads), 0, (hipStream_t)stream, dy, y, mask_bits, x, save_mean,
+                       save_invstd, drop, pixels, (long)hw, cvn, act, rows + kBwdSlices, partial);
+    return emsa_launch_status();
+  }
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(rows), dim3(kThreads), lds, (hipStream_t)stream,
                      dy, y, mask_bits, x, save_mean, save_invstd, drop, pixels, (long)hw, cvn, act,
                      rows + kBwdSlices, partial);
@@ -3140,8 +3225,19 @@ static int channel_dot(const T* a, const T* b, float* out, float* ws, int n, lon
   const int splits = channel_splits(hw, n);
   const int cvn = c / VecIO<T>::V;
   // one thread column per channel vector: wider tensors (> 1024 fp32 / 2048 16-bit channels) would
-  // leave `lanes` = 0 and every sum silently zero -- refuse them
-  if (cvn > kThreads) return EMSA_E_SHAPE;
+  // leave `lanes` = 0 and every sum silently zero -- they take the wide kernel
+  if (cvn > kThreads) {
+    const dim3 grid(n * splits, (cvn + kThreads - 1) / kThreads);
+    if (b)
+      hipLaunchKernelGGL((channel_dot_wide_kernel<T, true>), grid, dim3(kThreads), 0, st, a, b, ws, hw,
+                         cvn, splits);
+    else
+      hipLaunchKernelGGL((channel_dot_wide_kernel<T, false>), grid, dim3(kThreads), 0, st, a, b, ws, hw,
+                         cvn, splits);
+    hipLaunchKernelGGL(channel_dot_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, ws,
+                       out, n, c, splits, scale);
+    return emsa_launch_status();
+  }
   const int lanes = kThreads / cvn;
   const size_t lds = (size_t)lanes * c * sizeof(float);
   if (b)
@@ -3200,11 +3296,16 @@ static int se_pair_fwd(const T* xa, const T* xb, float* ws, const float* const* 
   if (!cv_ok<T>(c)) return EMSA_E_SHAPE;
   const int splits = channel_splits(hw, n);
   const int cvn = c / VecIO<T>::V;
-  if (cvn > kThreads) return EMSA_E_SHAPE;
-  const int lanes = kThreads / cvn;
-  const size_t lds = (size_t)lanes * c * sizeof(float);
-  hipLaunchKernelGGL((channel_dot_kernel<T, false>), dim3(2 * n * splits), dim3(kThreads), lds, st, xa,
-                     (const T*)nullptr, ws, hw, cvn, splits, xb, n * splits);
+  if (cvn > kThreads) {
+    hipLaunchKernelGGL((channel_dot_wide_kernel<T, false>),
+                       dim3(2 * n * splits, (cvn + kThreads - 1) / kThreads), dim3(kThreads), 0, st, xa,
+                       (const T*)nullptr, ws, hw, cvn, splits, xb, n * splits);
+  } else {
+    const int lanes = kThreads / cvn;
+    const size_t lds = (size_t)lanes * c * sizeof(float);
+    hipLaunchKernelGGL((channel_dot_kernel<T, false>), dim3(2 * n * splits), dim3(kThreads), lds, st, xa,
+                       (const T*)nullptr, ws, hw, cvn, splits, xb, n * splits);
+  }
   hipLaunchKernelGGL(se_mlp_pair_fwd_kernel, dim3(2 * n), dim3(256),
                      (size_t)(c + cr) * sizeof(float), st, ws, splits, 1.0f / (float)hw, wts[0],
                      wts[1], wts[2], wts[3], wts[4], wts[5], wts[6], wts[7], gap, hid, s, n, c, cr);

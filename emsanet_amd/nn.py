@@ -39,7 +39,7 @@ class Spec:
     SKIP_FUSION_1X1 = True             # True: 1x1 conv+BN+ReLU on the rgb skip when the channel
     #                                    counts differ; 'always': also when they match; False: never
     ORIENTATION_L2_NORMALIZE = False   # L2-normalise the 2-channel orientation output
-    RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
+    RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet50': (3, 4, 6, 3),
                      'resnet101': (3, 4, 23, 3)}
 
 
@@ -168,9 +168,22 @@ class BasicBlock(_ResidualBlock):
         self._finish(cin, c, stride)
 
 
-# ('bottleneck' is refused: its 1024 / 2048-channel stages exceed the 1024 channels the BatchNorm /
-#  SE reduction kernels take per workgroup row, csrc/pointwise.hip c4_ok)
-RESNET_BLOCKS = {'nonbottleneck1d': None, 'basicblock': BasicBlock}
+class Bottleneck(_ResidualBlock):
+    """'bottleneck': conv1x1 -> BN -> ReLU -> conv3x3(stride) -> BN -> ReLU -> conv1x1 (x4 channels) -> BN
+    -> + identity -> ReLU; children conv1..3 / bn1..3 / downsample, the stride on the 3x3 convolution
+    (torchvision's ResNet v1.5 layout and names [U]) -- the block of `--*-encoder-backbone resnet50`
+    (/root/reference/inference_time.bash:8,13; emsanet/tests/test_interface_model.py:133)"""
+    expansion = 4
+
+    def __init__(self, cin, c, stride=1, dropout_p=0.0):
+        super().__init__()
+        self._crts = []
+        self._chain = [self._add('1', cin, c, 1), self._add('2', c, c, 3, stride),
+                       self._add('3', c, 4 * c, 1)]
+        self._finish(cin, 4 * c, stride)
+
+
+RESNET_BLOCKS = {'nonbottleneck1d': None, 'basicblock': BasicBlock, 'bottleneck': Bottleneck}
 
 
 class ResNetNBt1D(nn.Module):

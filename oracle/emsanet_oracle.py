@@ -44,7 +44,7 @@ class Spec:
     SKIP_FUSION_1X1 = True       # [U] 1x1 conv + BN + act on the rgb skip when channels differ
     #                              ('always': also when they match; False: never)
     ORIENTATION_L2_NORMALIZE = False   # [U] raw 2-ch biternion
-    RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3),
+    RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3), 'resnet50': (3, 4, 6, 3),
                      'resnet101': (3, 4, 23, 3)}
     # Storage emulation (NOT part of the reference, which computes in fp32): None = plain
     # arithmetic in the module's dtype.  torch.bfloat16 / torch.float16: every tensor the 16-bit
@@ -258,7 +258,17 @@ class BasicBlock(_ResidualBlock):
         self._make([(cin, c, 3, stride), (c, c, 3, 1)], cin, c, stride)
 
 
-RESNET_BLOCKS = {'nonbottleneck1d': NonBottleneck1D, 'basicblock': BasicBlock}
+class Bottleneck(_ResidualBlock):
+    """1x1 -> 3x3 (stride) -> 1x1 (x4), torchvision v1.5 [U]; `--*-encoder-backbone-resnet-block
+    bottleneck` (inference_time.bash:13)"""
+    expansion = 4
+
+    def __init__(self, cin, c, stride=1, dropout_p=0.0):
+        super().__init__()
+        self._make([(cin, c, 1, 1), (c, c, 3, stride), (c, 4 * c, 1, 1)], cin, 4 * c, stride)
+
+
+RESNET_BLOCKS = {'nonbottleneck1d': NonBottleneck1D, 'basicblock': BasicBlock, 'bottleneck': Bottleneck}
 
 
 class ResNetNBt1D(nn.Module):

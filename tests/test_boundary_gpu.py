@@ -252,3 +252,43 @@ def test_model_interface_reference_inputs(tasks, modalities, training, do_postpr
     for t in _flat(outputs):
         if t.is_floating_point():
             assert torch.isfinite(t).all()
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_model_interface_resnet50_bottleneck(training):
+    """the `resnet50` case of /root/reference/emsanet/tests/test_interface_model.py:133 (the block its
+    ResNet-50 comes with: bottleneck, inference_time.bash:8,13) with the reference test's inputs: bs 3,
+    480x640, all four tasks, both modalities -- list contract in train mode (+ a backward pass with
+    finite gradients everywhere), merged dict with the post-processed keys in eval mode"""
+    from emsanet_amd import default_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    tasks = ('semantic', 'instance', 'orientation', 'scene')
+    args = default_args(
+        tasks=tasks, input_modalities=('rgb', 'depth'), input_height=H, input_width=W,
+        rgb_encoder_backbone='resnet50', depth_encoder_backbone='resnet50',
+        rgb_encoder_backbone_resnet_block='bottleneck', depth_encoder_backbone_resnet_block='bottleneck',
+        no_pretrained_backbone=True)
+    torch.manual_seed(0)
+    model = EMSANet(args, nyuv2_config()).to(DEV)
+    model.train(training)
+    bs = 3
+    batch = {'rgb': torch.randn((bs, 3, H, W), device=DEV), 'depth': torch.randn((bs, 1, H, W), device=DEV),
+             'instance_foreground': torch.ones((bs, 1, H, W), dtype=torch.bool, device=DEV),
+             'instance': torch.ones((bs, 1, H, W), dtype=torch.bool, device=DEV),
+             'orientation_foreground': torch.ones((bs, 1, H, W), dtype=torch.bool, device=DEV)}
+    if training:
+        outputs = model(batch)
+        assert isinstance(outputs, list) and len(outputs) == 3
+        flat = [t for t in _flat(outputs) if t.is_floating_point()]
+        sum((t * t).mean() for t in flat).backward()
+        for k, p in model.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    else:
+        batch['rgb_fullres'] = batch['rgb'].clone()
+        with torch.no_grad():
+            r = model(batch, do_postprocessing=True)
+        assert r['semantic_segmentation_idx_fullres'].shape == (bs, H, W)
+        assert r['instance_segmentation_gt_foreground'].shape == (bs, H, W)
+        assert len(r['orientations_gt_instance_gt_orientation_foreground']) == bs
+        assert r['scene_class_idx'].shape == (bs,)
+    torch.cuda.synchronize()

@@ -120,7 +120,7 @@ def test_eval_16bit_vs_fp32_oracle(shape, dtype):
     print(f"{dtype} eval {shape}: worst output rel-L2 {worst:.2e}, semantic arg-max agreement {fs:.5f}")
 
 
-@pytest.mark.parametrize('variant', ['rgbd', 'basicblock', 'normal', 'up_nearest', 'up_bilinear'])
+@pytest.mark.parametrize('variant', ['rgbd', 'basicblock', 'bottleneck', 'normal', 'up_nearest', 'up_bilinear'])
 def test_option_space_bf16(variant):
     """the model options beyond BASELINE's configs in bf16 storage: eval forward vs the fp32 oracle
     at the eval tolerance, and a train step (forward + backward) with finite gradients everywhere"""
@@ -134,6 +134,10 @@ def test_option_space_bf16(variant):
         kw.update(rgb_encoder_backbone='resnet18', depth_encoder_backbone='resnet18',
                   rgb_encoder_backbone_resnet_block='basicblock',
                   depth_encoder_backbone_resnet_block='basicblock')
+    elif variant == 'bottleneck':
+        kw.update(rgb_encoder_backbone='resnet50', depth_encoder_backbone='resnet50',
+                  rgb_encoder_backbone_resnet_block='bottleneck',
+                  depth_encoder_backbone_resnet_block='bottleneck')
     elif variant.startswith('up_'):
         # weight-free decoder / prediction up-sampling (ref args.py:280-298,363-372,439-448)
         mode = variant[3:]
@@ -151,7 +155,9 @@ def test_option_space_bf16(variant):
         out = _flatten(model(dev_batch))
     for i, (a, b) in enumerate(zip(out, ref)):
         e = _rel_l2(a, b)
-        assert a.dtype == torch.float32 and e <= OUT_TOL[torch.bfloat16], f"{variant} output {i}: {e:.3e}"
+        # (ResNet-50 bottleneck: 50 instead of 34 rounded layers per encoder, measured 3.1e-2)
+        tol = OUT_TOL[torch.bfloat16] * (2 if variant == 'bottleneck' else 1)
+        assert a.dtype == torch.float32 and e <= tol, f"{variant} output {i}: {e:.3e}"
     model.train()
     outs = _flatten(model(dev_batch))
     sum((t * t).mean() for t in outs).backward()

@@ -308,10 +308,11 @@ def test_stem16(dtype):
             close(dw, wd.grad, tol=2e-4, what='stem16 wgrad')
 
 
+@pytest.mark.parametrize('c', [64, 2048])            # (2048: the last stage of the bottleneck ResNets)
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_bn_act_and_backward16(dtype):
+def test_bn_act_and_backward16(dtype, c):
     Fn = _fn()
-    n, c, h, w = 3, 64, 9, 7
+    n, h, w = 3, 9, 7
     x = rnd(n, c, h, w, seed=1)
     res = rnd(n, c, h, w, seed=2)
     sc, sh = rnd(c, seed=3), rnd(c, seed=4)

@@ -363,7 +363,9 @@ def test_pack_roundtrip_and_blockdiag():
     close(back, w, tol=0, what='unpack')
 
 
-@pytest.mark.parametrize('c', [64, 128, 512, 40])
+# (1024 / 2048: the widest stages of the bottleneck ResNets; fp32 with 2048 channels has more channel
+#  vectors than a workgroup has threads and takes bn_bwd_reduce_wide_kernel)
+@pytest.mark.parametrize('c', [64, 128, 512, 40, 1024, 2048])
 @pytest.mark.parametrize('act', [0, 1])
 @pytest.mark.parametrize('train', [True, False])
 def test_bn_fwd_bwd(c, act, train):
@@ -447,7 +449,7 @@ def test_maxpool(shape):
     close(dx, x.grad, tol=1e-6, what='maxpool bwd')
 
 
-@pytest.mark.parametrize('c', [64, 512])
+@pytest.mark.parametrize('c', [64, 512, 1024, 2048])       # (2048 fp32: channel_dot_wide_kernel)
 def test_se_fusion(c):
     Fn = _fn()
     from emsanet_amd import ops
