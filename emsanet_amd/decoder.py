@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from . import ops
-from .nn import (ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt, make_upsampling,
+from .nn import (BasicBlock, ConvNormAct, LearnedUpsampling, NonBottleneck1D, Spec, make_plain_conv_rt, make_upsampling,
                  plain_conv)
 from .postprocessing import (InstancePostprocessing, PanopticPostprocessing, gt_instance_orientations,
                              softmax_argmax)
@@ -64,6 +64,19 @@ class InstanceSideHead(nn.Module):
         return ops.MultiConvFunction.apply(x, self._rt, *self._rt.params())
 
 
+DECODER_BLOCKS = {'nonbottleneck1d': NonBottleneck1D, 'basicblock': BasicBlock}
+
+
+def decoder_block_class(name):
+    """`get_block_class(args.<task>_decoder_block, dropout_p=...)` of /root/reference/emsanet/decoder.py:
+    68-71,100-103,167-170 for the blocks that keep the channel count (the decoder modules chain
+    `n_blocks` of them at one width): the NBt1D block (default) and the basic block -- whose library
+    form takes no dropout [U]; 'bottleneck' (x4 channels) is refused"""
+    if name not in DECODER_BLOCKS:
+        raise NotImplementedError(f"decoder block '{name}' (built: {', '.join(DECODER_BLOCKS)})")
+    return DECODER_BLOCKS[name]
+
+
 DEFAULT_UPSAMPLING = 'learned-3x3-zeropad'          # /root/reference/emsanet/args.py:280-298,363-372
 
 
@@ -71,11 +84,12 @@ class DecoderModule(nn.Module):
     """conv3x3+BN+ReLU -> n_blocks x NBt1D -> [train: 1x1 side head] -> nearest x2 + DW3x3
     -> + (1x1 conv+BN+ReLU of the rgb skip)          (figure doc/EMSANet-model.png)."""
 
-    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, upsampling=DEFAULT_UPSAMPLING):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, upsampling=DEFAULT_UPSAMPLING,
+                 block='nonbottleneck1d'):
         super().__init__()
         self.conv3x3 = ConvNormAct(cin, c, 3)
-        self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
-                                      for _ in range(n_blocks)])
+        cls = decoder_block_class(block)
+        self.blocks = nn.Sequential(*[cls(c, c, dropout_p=dropout_p) for _ in range(n_blocks)])
         self.upsampling = make_upsampling(upsampling, c)
         fuse = Spec.SKIP_FUSION_1X1 == 'always' or (Spec.SKIP_FUSION_1X1 and skip_c != c)
         self.skip_fusion = ConvNormAct(skip_c, c, 1) if fuse else None
@@ -91,14 +105,15 @@ class DecoderModule(nn.Module):
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
                  fusion_downsamplings, side_head_factory, fusion='add-rgb',
-                 upsampling=DEFAULT_UPSAMPLING, prediction_upsampling=DEFAULT_UPSAMPLING):
+                 upsampling=DEFAULT_UPSAMPLING, prediction_upsampling=DEFAULT_UPSAMPLING,
+                 block='nonbottleneck1d'):
         super().__init__()
         self.fusion = fusion
         # `upsampling`: between the decoder modules; `prediction_upsampling`: the two x2 steps of the
         # head (ref emsanet/decoder.py:55-57,78,123,176)
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
-            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, upsampling))
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, upsampling, block))
             cin = c
         self.decoder_modules = nn.ModuleList(mods)
         self.side_output_heads = nn.ModuleList([side_head_factory(c) for c in n_channels])
@@ -156,6 +171,8 @@ def twin_bodies_ok(da, db, x):
             return False
         if not (isinstance(ma.upsampling, LearnedUpsampling) and isinstance(mb.upsampling, LearnedUpsampling)):
             return False               # (the twin up-sampling launch is the learned kernel's)
+        if not all(isinstance(b, NonBottleneck1D) for b in list(ma.blocks) + list(mb.blocks)):
+            return False               # (... and the twin block launch the NBt1D block's)
     return True
 
 
@@ -408,6 +425,12 @@ def get_decoders(
 ) -> nn.ModuleDict:
     """Same signature and defaults as /root/reference/emsanet/decoder.py:32-48."""
     fusion_downsamplings = tuple(args.encoder_decoder_skip_downsamplings)[::-1]
+    if fusion_downsamplings != (16, 8, 4):
+        # one encoder skip per decoder module at the module's output resolution; the library's handling of
+        # fewer / other skips (`--encoder-decoder-skip-downsamplings`, args.py:261-268) is [U]: refused,
+        # not silently built with fewer decoder modules
+        raise NotImplementedError(f"encoder_decoder_skip_downsamplings={tuple(args.encoder_decoder_skip_downsamplings)}"
+                                  " (only (4, 8, 16))")
     if getattr(args, 'decoder_normalization', 'batchnorm') not in ('batchnorm', 'bn'):
         raise NotImplementedError("only batchnorm decoders")
     from .nn import UPSAMPLING_MODES
@@ -424,6 +447,10 @@ def get_decoders(
         ds = getattr(args, f'{task}_decoder_downsamplings', (16, 8, 4))
         if task in args.tasks and tuple(ds) != (16, 8, 4):
             raise NotImplementedError(f"{task}_decoder_downsamplings={tuple(ds)} (only (16, 8, 4))")
+        nch = getattr(args, f'{task}_decoder_n_channels', (512, 256, 128))
+        if task in args.tasks and len(tuple(nch)) != 3:
+            # ("Length of tuple determines the number of decoder modules", args.py:353-362: one per skip)
+            raise NotImplementedError(f"{task}_decoder_n_channels={tuple(nch)} (three decoder modules)")
 
     decoders = OrderedDict()
     if 'semantic' in args.tasks:
@@ -440,7 +467,8 @@ def get_decoders(
             fusion_downsamplings=fusion_downsamplings,
             fusion=args.semantic_encoder_decoder_fusion,
             upsampling=getattr(args, 'semantic_decoder_upsampling', DEFAULT_UPSAMPLING),
-            prediction_upsampling=up_pred)
+            prediction_upsampling=up_pred,
+            block=getattr(args, 'semantic_decoder_block', 'nonbottleneck1d'))
     if 'instance' in args.tasks:
         if args.instance_decoder.lower() != 'emsanet':
             raise NotImplementedError(f"instance decoder '{args.instance_decoder}'")
@@ -458,7 +486,8 @@ def get_decoders(
             fusion_downsamplings=fusion_downsamplings,
             fusion=args.instance_encoder_decoder_fusion,
             upsampling=getattr(args, 'instance_decoder_upsampling', DEFAULT_UPSAMPLING),
-            prediction_upsampling=up_pred)
+            prediction_upsampling=up_pred,
+            block=getattr(args, 'instance_decoder_block', 'nonbottleneck1d'))
         # post-processing parameters as in /root/reference/emsanet/decoder.py:95-104
         decoders['instance_decoder'].postprocessing = InstancePostprocessing(
             heatmap_threshold=args.instance_center_heatmap_threshold,
@@ -489,7 +518,8 @@ def get_decoders(
             fusion_n_channels=tuple(fusion_n_channels),
             fusion_downsamplings=fusion_downsamplings, fusion=fusion,
             upsampling=getattr(args, 'normal_decoder_upsampling', DEFAULT_UPSAMPLING),
-            prediction_upsampling=up_pred)
+            prediction_upsampling=up_pred,
+            block=getattr(args, 'normal_decoder_block', 'nonbottleneck1d'))
     if 'scene' in args.tasks:
         decoders['scene_decoder'] = SceneClassificationDecoder(scene_n_channels_in,
                                                                scene_n_classes)

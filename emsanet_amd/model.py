@@ -129,8 +129,9 @@ class EMSANet(nn.Module):
                 raise ValueError(f"he_init part '{part}' (choices: encoder-fusion, "
                                  "encoder-decoder-fusion, context-module, decoder; args.py:626-638)")
         if not args.no_zero_init_decoder_residuals:
+            from .nn import BasicBlock
             for m in self.decoders.modules():
-                if isinstance(m, NonBottleneck1D):
+                if isinstance(m, (NonBottleneck1D, BasicBlock)):     # (the last BatchNorm of either: bn2)
                     nn.init.zeros_(m.bn2.weight)
 
         # Dropout2d bookkeeping (counter-based masks, one id per dropout layer)

@@ -455,11 +455,13 @@ class InstanceSideHead(nn.Module):
 
 
 class DecoderModule(nn.Module):
-    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, upsampling='learned-3x3-zeropad'):
+    def __init__(self, cin, c, n_blocks, dropout_p, skip_c, upsampling='learned-3x3-zeropad',
+                 block='nonbottleneck1d'):
         super().__init__()
         self.conv3x3 = ConvNormAct(cin, c, 3)
-        self.blocks = nn.Sequential(*[NonBottleneck1D(c, c, dropout_p=dropout_p)
-                                      for _ in range(n_blocks)])
+        # `get_block_class(args.<task>_decoder_block, dropout_p=...)` (decoder.py:68-71,100-103,167-170)
+        cls = {'nonbottleneck1d': NonBottleneck1D, 'basicblock': BasicBlock}[block]
+        self.blocks = nn.Sequential(*[cls(c, c, dropout_p=dropout_p) for _ in range(n_blocks)])
         self.upsampling = make_upsampling(upsampling, c)
         if Spec.SKIP_FUSION_1X1 == 'always' or (Spec.SKIP_FUSION_1X1 and skip_c != c):
             self.skip_fusion = ConvNormAct(skip_c, c, 1)
@@ -480,12 +482,13 @@ class DecoderModule(nn.Module):
 class DecoderBody(nn.Module):
     def __init__(self, n_channels_in, n_channels, n_blocks, dropout_p, fusion_n_channels,
                  fusion_downsamplings, side_head_factory, fusion='add-rgb',
-                 upsampling='learned-3x3-zeropad', prediction_upsampling='learned-3x3-zeropad'):
+                 upsampling='learned-3x3-zeropad', prediction_upsampling='learned-3x3-zeropad',
+                 block='nonbottleneck1d'):
         super().__init__()
         self.fusion = fusion            # 'add-<modality>', or 'add' = the only stream there is
         mods, cin = [], n_channels_in
         for c, sc in zip(n_channels, fusion_n_channels):
-            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, upsampling))
+            mods.append(DecoderModule(cin, c, n_blocks, dropout_p, sc, upsampling, block))
             cin = c
         self.decoder_modules = nn.ModuleList(mods)
         self.side_output_heads = nn.ModuleList([side_head_factory(c) for c in n_channels])
@@ -671,7 +674,8 @@ class EMSANetOracle(nn.Module):
                 fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
                 fusion=args.semantic_encoder_decoder_fusion,
                 upsampling=getattr(args, 'semantic_decoder_upsampling', 'learned-3x3-zeropad'),
-                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'))
+                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'),
+                block=getattr(args, 'semantic_decoder_block', 'nonbottleneck1d'))
         if 'instance' in args.tasks:
             if args.instance_offset_encoding not in ('tanh', 'relative', 'deeplab'):
                 raise NotImplementedError
@@ -686,7 +690,8 @@ class EMSANetOracle(nn.Module):
                 fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
                 fusion=args.instance_encoder_decoder_fusion,
                 upsampling=getattr(args, 'instance_decoder_upsampling', 'learned-3x3-zeropad'),
-                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'))
+                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'),
+                block=getattr(args, 'instance_decoder_block', 'nonbottleneck1d'))
         if 'normal' in args.tasks:
             dec['normal_decoder'] = NormalDecoder(
                 n_classes=3, n_channels_in=c_enc,
@@ -696,7 +701,8 @@ class EMSANetOracle(nn.Module):
                 fusion_n_channels=fus_c, fusion_downsamplings=fus_d,
                 fusion=getattr(args, 'normal_encoder_decoder_fusion', 'add-rgb'),
                 upsampling=getattr(args, 'normal_decoder_upsampling', 'learned-3x3-zeropad'),
-                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'))
+                prediction_upsampling=getattr(args, 'upsampling_prediction', 'learned-3x3-zeropad'),
+                block=getattr(args, 'normal_decoder_block', 'nonbottleneck1d'))
         if 'scene' in args.tasks:
             dec['scene_decoder'] = SceneClassificationDecoder(
                 self.context_module.n_channels_reduction, n_scene)
@@ -710,7 +716,7 @@ class EMSANetOracle(nn.Module):
                     nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
         if not args.no_zero_init_decoder_residuals:
             for m in self.decoders.modules():
-                if isinstance(m, NonBottleneck1D):
+                if isinstance(m, (NonBottleneck1D, BasicBlock)):
                     nn.init.zeros_(m.bn2.weight)
 
         # dropout bookkeeping (shared definition with the HIP engine)

@@ -143,6 +143,16 @@ def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         _model(full_args(activation='swish'))
     assert _model(full_args(upsampling_context_module='nearest')).context_module.upsampling == 'nearest'
+    with pytest.raises(NotImplementedError, match='n_channels'):
+        _model(full_args(semantic_decoder_n_channels=(512, 256)))
+    with pytest.raises(NotImplementedError, match='skip_downsamplings'):
+        _model(full_args(encoder_decoder_skip_downsamplings=(4, 8)))
+    # decoder blocks (args.py:325-331,401-407): NBt1D (default) and basic block built, the x4 bottleneck refused
+    with pytest.raises(NotImplementedError, match='decoder block'):
+        _model(full_args(semantic_decoder_block='bottleneck'))
+    from emsanet_amd.nn import BasicBlock
+    assert isinstance(_model(full_args(instance_decoder_block='basicblock'))
+                      .decoders['instance_decoder'].decoder_modules[0].blocks[0], BasicBlock)
     # decoder / prediction up-sampling (args.py:280-298,363-372): the learned one and the two weight-free
     # modes are built, the library's 'learned-3x3' (padding rule unknown) is refused by name
     for field in ('semantic_decoder_upsampling', 'instance_decoder_upsampling', 'upsampling_prediction'):

@@ -667,6 +667,23 @@ def test_pinned_gradients_weight_free_decoder_upsampling(modes, monkeypatch):
     assert not has('semantic_decoder.decoder_modules') and not has('.head.upsampling')
 
 
+def test_pinned_gradients_basicblock_decoders(monkeypatch):
+    """`--semantic-decoder-block / --instance-decoder-block basicblock` (/root/reference/emsanet/args.py:
+    325-331,401-407; `get_block_class(...)` at emsanet/decoder.py:68-71,100-103 -- the argument used to be
+    ignored): the decoder modules chain basic blocks instead of NBt1D blocks; outputs and every gradient
+    vs the fp64 oracle, and the state dict carries conv1 / bn1 / conv2 / bn2 under `decoder_modules.*.blocks`"""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    args = full_args(input_height=96, input_width=128, semantic_decoder_block='basicblock',
+                     instance_decoder_block='basicblock')
+    _pinned_grad_parity(args, 3, 29, monkeypatch, tol_out=TOL, tol_grad=2e-3)
+    m = EMSANet(args, nyuv2_config())
+    keys = [k for k in m.state_dict() if 'semantic_decoder.decoder_modules.1.blocks.0.' in k]
+    assert any(k.endswith('conv2.weight') for k in keys) and not any('conv3x1' in k for k in keys)
+    # zero_residual_initialization (ref emsanet/model.py:188-190) reaches the basic blocks' last BatchNorm
+    assert float(m.decoders['instance_decoder'].decoder_modules[2].blocks[1].bn2.weight.abs().sum()) == 0.0
+
+
 def test_pinned_gradients_nearest_context_upsampling(monkeypatch):
     """`--upsampling-context-module nearest` (/root/reference/emsanet/args.py:250-256, handed to the
     context module at model.py:109-119; the engine used to ignore the argument): outputs and every
