@@ -444,3 +444,33 @@ def test_deferred_dictionaries_under_a_captured_eval_forward():
         assert torch.equal(out['panoptic_segmentation_deeplab_panoptic_score'],
                            e['panoptic_segmentation_deeplab_panoptic_score'])
     assert list(e1['panoptic_segmentation_deeplab_instance_meta']) != list(e2['panoptic_segmentation_deeplab_instance_meta'])
+
+
+def test_panoptic_postprocessing_without_any_instance():
+    """the empty case: no centre above the threshold -> no instance ids, thing pixels void (panoptic id 0,
+    semantic 0 = void), stuff pixels keep class + 1 and their own score, empty meta / orientation
+    dictionaries (and nothing divides by an empty area)"""
+    from emsanet_amd.postprocessing import InstancePostprocessing, PanopticPostprocessing
+    g = torch.Generator().manual_seed(3)
+    n, c, h, w = 2, 6, 32, 48
+    is_thing = [False, True, False, True, True, False]
+    logits = torch.randn(n, c, h, w, generator=g).to(DEV)
+    center = torch.full((n, 1, h, w), 0.01, device=DEV)            # below the 0.1 threshold everywhere
+    offset = torch.randn(n, 2, h, w, generator=g).to(DEV) * 0.1
+    ori = torch.nn.functional.normalize(torch.randn(n, 2, h, w, generator=g), dim=1).to(DEV)
+    post = PanopticPostprocessing(InstancePostprocessing(top_k_instances=8), is_thing)
+    r = post(logits, center, offset, ori)
+    torch.cuda.synchronize()
+    assert int(r['instance_predicted_centers_count'].sum()) == 0
+    assert int(r['panoptic_segmentation_deeplab_instance_idx'].abs().max()) == 0
+    idx = r['semantic_segmentation_idx']
+    thing = torch.tensor(is_thing, device=DEV)[idx]
+    sem = r['panoptic_segmentation_deeplab_semantic_idx']
+    assert torch.equal(sem, torch.where(thing, torch.zeros_like(idx), idx + 1))
+    assert torch.equal(r['panoptic_segmentation_deeplab'], sem * 1000)
+    s = r['panoptic_segmentation_deeplab_semantic_score']
+    assert torch.equal(s, torch.where(thing, torch.zeros_like(s), r['semantic_segmentation_score']))
+    assert float(r['panoptic_segmentation_deeplab_instance_score'].abs().max()) == 0.0
+    assert torch.equal(r['panoptic_segmentation_deeplab_panoptic_score'], s)
+    assert list(r['panoptic_segmentation_deeplab_instance_meta']) == [{}, {}]
+    assert list(r['orientations_panoptic_segmentation_deeplab_instance']) == [{}, {}]
