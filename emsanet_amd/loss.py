@@ -252,8 +252,21 @@ class TrainingLosses(torch.nn.Module):
     def forward(self, outputs, targets):
         """-> (total, dict of unweighted per-task losses summed over the scales)"""
         losses = {}
+        panoptic = self.panoptic
+        if isinstance(outputs, dict):
+            # the merged dictionary of `model(batch, do_postprocessing=True)` in TRAIN mode -- what the
+            # reference's training step hands to its task helpers (`predictions_post`,
+            # /root/reference/main.py:126-141): the same tensors under '<task>_output' /
+            # '<task>_side_outputs'
+            merged, outputs, panoptic = outputs, [], False
+            if 'semantic' in self.tasks:
+                outputs.append((merged['semantic_output'], merged['semantic_side_outputs']))
+            if 'instance' in self.tasks or 'orientation' in self.tasks:
+                outputs.append((merged['instance_output'], merged['instance_side_outputs']))
+            if 'scene' in self.tasks:
+                outputs.append((merged['scene_output'],))
         outputs = list(outputs)
-        if self.panoptic:
+        if panoptic:
             # PanopticHelper: ((semantic, instance), (semantic sides, instance sides)) first
             (sem, inst), (sem_side, inst_side) = outputs[0]
             outputs = [(sem, sem_side), (inst, inst_side)] + outputs[1:]

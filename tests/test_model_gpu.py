@@ -997,6 +997,34 @@ def _train_losses(a, bs, h, w):
     return crit, targets
 
 
+@pytest.mark.parametrize('panoptic', [False, True])
+def test_losses_on_the_merged_training_dictionary(panoptic):
+    """the reference's training step hands `model(batch, do_postprocessing=True)` -- in TRAIN mode, the
+    merged dictionary -- to its task helpers (/root/reference/main.py:126-141): TrainingLosses takes that
+    dictionary as well as the raw list, same total and per-task losses bit for bit (same tensors, same
+    kernels), also under --enable-panoptic, whose raw list is nested but whose dictionary is flat"""
+    from emsanet_amd import full_args, nyuv2_config
+    from emsanet_amd.model import EMSANet
+    from oracle.emsanet_oracle import synthetic_batch
+    args = full_args(input_height=96, input_width=128, enable_panoptic=panoptic)
+    torch.manual_seed(0)
+    model = EMSANet(args, nyuv2_config()).to(DEV).train()
+    crit, targets = _train_losses(args, 2, 96, 128)
+    batch = {k: v.to(DEV) for k, v in synthetic_batch(2, 96, 128).items()}
+    model.dropout_step = 0
+    raw = model(batch)
+    t_raw, l_raw = crit(raw, targets)
+    model.dropout_step = 0
+    merged = model(batch, do_postprocessing=True)
+    assert isinstance(merged, dict) and len(merged['semantic_side_outputs']) == 3
+    t_m, l_m = crit(merged, targets)
+    assert float(t_raw) == float(t_m) and sorted(l_raw) == sorted(l_m)
+    for k in l_raw:
+        assert float(l_raw[k]) == float(l_m[k]), k
+    t_m.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 @pytest.mark.parametrize('variant', ['bf16', 'losses', 'r101_960x736'])
 def test_hipgraph_train_step_variants(variant):
     """the captured training step == the eager step beyond the fp32 96x128 case:
