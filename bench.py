@@ -119,9 +119,8 @@ def parse():
                          'repetition per box scattered 230 .. 304 FPS)')
     ap.add_argument('--eager', action='store_true',
                     help='launch the training step kernel by kernel from the host instead of replaying it '
-                         'from a hipGraph (the hipGraph step is the default for 16-bit training at N = 1 '
-                         'and for every N > 1 -- the eager 16-bit step is host-bound; fp32 at N = 1 is '
-                         'eager unless --graph is given)')
+                         'from a hipGraph (the hipGraph step is the default for training at every N: the '
+                         'eager 16-bit step is host-bound, the fp32 replay is +0.6 %% ahead of its eager step)')
     return ap.parse_args()
 
 
@@ -548,12 +547,13 @@ def run(args):
     # byte crosses xGMI; --eager / --torch-optimizer / --h2d keep the eager path
     # one rank (round 5): the 16-bit step as ONE hipGraph by default as well -- bf16 955 vs 793-806
     # images/s, its eager step is host-bound; a refused capture falls back to the eager step below
-    # (graph_auto).  The fp32 step stays eager by default: GPU-bound either way (331.5 vs 329.9 images/s
-    # on one box, 319.0 vs 317.3 on another: profiles/r05_aa_*, r05_ab_*), and per-launch HIP events
-    # inside the timed region only exist for the eager step
+    # (graph_auto).  Round 6 (last change of the round): the fp32 step too -- GPU-bound either way, but
+    # the replay is consistently ahead: 325.8 / 325.9 / 325.6 vs 324.0 / 323.5 / 323.9 images/s
+    # alternating on one box (profiles/r06_s_f32_{graph,eager}_{1,2,3}.json; round 5: 331.5 vs 329.9,
+    # 319.0 vs 317.3 on two other boxes).  What the graph costs: the per-launch HIP events INSIDE the
+    # timed region (`in_timed_region`); the roofline's own-rate pass runs behind the region either way.
     graph_auto = False
-    if not args.eval and not args.eager and not args.torch_optimizer and not args.h2d and not args.graph \
-            and (world > 1 or args.dtype != 'f32'):
+    if not args.eval and not args.eager and not args.torch_optimizer and not args.h2d and not args.graph:
         args.graph = True
         graph_auto = world == 1 and not args.force_dist
     segmented = bool(args.graph and not args.eval and dist_on)
